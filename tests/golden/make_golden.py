@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE's own modules on CPU and dumps small .npz fixtures.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports ``network.{unet,ugan,patchnce,networks}`` and ``misc.loss`` from /root/reference
+(read-only), fills them from the deterministic weight recipe in ``oracle/recipe.py`` through
+``load_state_dict`` (after asserting the recipe's key/shape tables equal the reference
+modules' own state_dict), replays the arithmetic of ``trainer/unetTrainer.py:56-85`` and
+``trainer/uganConsisTrainer.py:110-203`` with those modules (the trainer classes themselves
+need medpy/torchvision/tensorboard, absent here -- SURVEY.md 8c), and stores inputs, outputs,
+loss scalars and selected gradients.  Fixtures hold data only -- no reference source text.
+"""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SMSUT_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)
+
+# ugan.py:329 calls mlp.cuda() unconditionally: make it a no-op on this GPU-less box.
+nn.Module.cuda = lambda self, *a, **k: self
+
+from network.unet import UNet                      # noqa: E402  (reference)
+from network.ugan import UGANnce, Discriminator    # noqa: E402  (reference)
+from network.patchnce import PatchNCELoss          # noqa: E402  (reference)
+import network.networks as ref_networks            # noqa: E402  (reference)
+from misc.loss import DiceAndCrossEntropyLoss      # noqa: E402  (reference)
+
+from oracle import recipe                          # noqa: E402  (ours)
+
+torch.set_num_threads(8)
+
+
+def load(module, shapes, seed):
+    sd_ref = module.state_dict()
+    assert list(sd_ref.keys()) == list(shapes.keys()), "recipe key table != reference state_dict"
+    for k, v in sd_ref.items():
+        assert tuple(v.shape) == tuple(shapes[k]), (k, tuple(v.shape), shapes[k])
+    module.load_state_dict(recipe.fill(shapes, seed))
+    return module
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def grad_summary(module, full_keys=()):
+    out = {}
+    names, norms = [], []
+    for k, p in module.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        norms.append(float(p.grad.double().norm()))
+        if k in full_keys:
+            out["grad::" + k] = npy(p.grad)
+    out["grad_names"] = np.array(names)
+    out["grad_l2"] = np.array(norms, dtype=np.float64)
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# --------------------------------------------------------------------------------------------
+def gen_unet_small():
+    """UNet(1,3,4,'instance','lrelu') on 2x1x64x64: logits, DiceCE, grads, 2 SGD steps (unetTrainer.py:56-85)."""
+    seed, B, H, ncls, w = 11, 2, 64, 3, 4
+    net = load(UNet(1, ncls, w, norm_type="instance", act_type="lrelu"), recipe.unet_shapes(1, ncls, w), seed)
+    net.train()
+    x = recipe.synth_images((B, 1, H, H), seed + 1)
+    y = recipe.synth_labels(B, H, H, ncls, seed + 2, block=8)
+    crit = DiceAndCrossEntropyLoss(weight_ce=0.5, weight_dc=0.5, batch_dice=True)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    losses = []
+    extra = {}
+    for it in range(2):
+        out = net(x)
+        loss = crit(out, y)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            extra.update(logits=npy(out))
+            extra.update(grad_summary(net, ("encoder.pre_conv.weight", "decoder.fc.weight",
+                                            "encoder.layer1.bn1.weight", "encoder.layer1.shortcut1.weight",
+                                            "decoder.up1.up.weight", "decoder.layer4.conv1.weight")))
+        opt.step()
+        lr_ = 1e-2 * (1.0 - it / 30000) ** 0.9
+        for g in opt.param_groups:
+            g["lr"] = lr_
+        losses.append(loss.item())
+    sd = net.state_dict()
+    save("unet_small", seed=seed, B=B, H=H, ncls=ncls, w=w, x=npy(x), y=npy(y),
+         losses=np.array(losses), post_pre_conv=npy(sd["encoder.pre_conv.weight"]),
+         post_fc=npy(sd["decoder.fc.weight"]), **extra)
+
+
+def gen_unet_relu():
+    """UNet default act ('relu') with instance norm -- the constructor surface beyond lrelu."""
+    seed, B, H, ncls, w = 17, 1, 32, 2, 4
+    net = load(UNet(1, ncls, w, norm_type="instance", act_type="relu"), recipe.unet_shapes(1, ncls, w), seed)
+    x = recipe.synth_images((B, 1, H, H), seed + 1)
+    save("unet_relu", seed=seed, B=B, H=H, ncls=ncls, w=w, x=npy(x), logits=npy(net(x)))
+
+
+def gen_unet_256():
+    """Full-size UNet(1,5,16) on one 256x256 slice: strided logits + loss + per-class sums."""
+    seed, B, H, ncls, w = 23, 1, 256, 5, 16
+    net = load(UNet(1, ncls, w, norm_type="instance", act_type="lrelu"), recipe.unet_shapes(1, ncls, w), seed)
+    x = recipe.synth_images((B, 1, H, H), seed + 1)
+    y = recipe.synth_labels(B, H, H, ncls, seed + 2)
+    out = net(x)
+    loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y)
+    loss.backward()
+    save("unet_256", seed=seed, B=B, H=H, ncls=ncls, w=w, logits_s8=npy(out[:, :, ::8, ::8]),
+         logits_sum=npy(out.double().sum((0, 2, 3))), logits_abs_sum=npy(out.double().abs().sum((0, 2, 3))),
+         loss=loss.item(), **grad_summary(net, ("decoder.fc.weight",)))
+
+
+def gen_disc_small():
+    """Discriminator(64,4,4,max_width=32) on 3x1x64x64 incl. WGAN-GP double backward
+    (uganShp0Trainer.py:127-134) and the D-loss weight grads."""
+    seed, B, S, nm, w, mw = 31, 3, 64, 4, 4, 32
+    D = load(Discriminator(S, nm, w, max_width=mw), recipe.disc_shapes(S, nm, w, mw), seed)
+    D.train()
+    x = recipe.synth_images((B, 1, S, S), seed + 1)
+    xf = recipe.synth_images((B, 1, S, S), seed + 2)
+    alpha = torch.from_numpy(np.random.RandomState(seed + 3).standard_normal((B, 1, 1, 1))).float()
+    modal = torch.tensor([0, 2, 3])
+    src, cls = D(x)
+    d_real = -src.mean()
+    d_cls = F.cross_entropy(cls, modal)
+    src_f, _ = D(xf)
+    d_fake = src_f.mean()
+    x_hat = (alpha * x + (1 - alpha) * xf).requires_grad_(True)
+    src_h, _ = D(x_hat)
+    dydx = torch.autograd.grad(src_h, x_hat, torch.ones_like(src_h), retain_graph=True, create_graph=True)[0]
+    gp = torch.mean((torch.sqrt(torch.sum(dydx.view(B, -1) ** 2, dim=1)) - 1) ** 2)
+    d_loss = d_real + d_fake + 1.0 * d_cls + 10.0 * gp
+    D.zero_grad()
+    d_loss.backward()
+    save("disc_small", seed=seed, B=B, S=S, nm=nm, w=w, mw=mw, x=npy(x), xf=npy(xf), alpha=npy(alpha),
+         modal=npy(modal), out_src=npy(src), out_cls=npy(cls), dydx=npy(dydx),
+         scalars=np.array([d_real.item(), d_fake.item(), d_cls.item(), gp.item()]),
+         **grad_summary(D, ("main.0.weight", "main.0.bias", "main.2.bn1.weight", "main.3.downsample.0.weight",
+                            "conv_src.weight", "conv_cls.weight", "main.4.conv2.weight")))
+
+
+def gen_ugan_small():
+    """UGANnce(1,5,4,16) on 4x1x64x64 (netF needs base_width 16): seg, tsl, feats."""
+    seed, B, H = 41, 4, 64
+    G = load(UGANnce(1, 5, 4, 16), recipe.ugan_shapes(1, 5, 4, 16), seed)
+    G.train()
+    x = recipe.synth_images((B, 1, H, H), seed + 1)
+    m = torch.tensor([[-1., 0, 1, 0]] * 2 + [[0., 0, 0, 0]] + [[0., -1, 0, 1]])
+    ids = torch.from_numpy(np.random.RandomState(seed + 2).permutation(16)[:64].astype(np.int64))
+    seg, tsl, feats, rid = G(x, m, sample_ids=[ids])
+    seg_v, tsl_v = G(x, val_phase=True)
+    save("ugan_small", seed=seed, B=B, H=H, x=npy(x), m=npy(m), ids=npy(ids), seg=npy(seg), tsl=npy(tsl),
+         feat=npy(feats[0]), seg_val=npy(seg_v), tsl_val=npy(tsl_v))
+
+
+def gen_losses():
+    """misc/loss.py, network/patchnce.py, networks.Normalize on random tensors."""
+    rs = np.random.RandomState(53)
+    logits = torch.from_numpy(rs.standard_normal((3, 5, 16, 16)) * 2).float()
+    labels = torch.from_numpy(rs.randint(0, 5, size=(3, 16, 16)).astype(np.int64))
+    l_bd = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(logits, labels).item()
+    l_sd = DiceAndCrossEntropyLoss(1.0, 1.0, batch_dice=False)(logits, labels).item()
+    q = torch.from_numpy(rs.standard_normal((64, 32))).float()
+    k = torch.from_numpy(rs.standard_normal((64, 32))).float()
+    qn, kn = ref_networks.Normalize(2)(q), ref_networks.Normalize(2)(k)
+    nce = PatchNCELoss(2)(qn, kn)
+    save("losses", logits=npy(logits), labels=npy(labels), dicece_batch=l_bd, dicece_sample=l_sd,
+         q=npy(q), k=npy(k), qn=npy(qn), nce=npy(nce))
+
+
+def gen_iter_small():
+    """Two uganConsis iterations (uganConsisTrainer.py:110-203) at 64x64, B = 2 labeled + 2 unlabeled,
+    PatchNCELoss(2) fed B=4 (the reference's batch_size/B mismatch), iter >= 1000 so the
+    consistency branch runs; all 10 scalars per iteration + post-step weight slices."""
+    seed, bs, H, nm = 61, 2, 64, 4
+    B = 2 * bs
+    G = load(UGANnce(1, 5, nm, 16), recipe.ugan_shapes(1, 5, nm, 16), seed)
+    D = load(Discriminator(H, nm, 16, max_width=256), recipe.disc_shapes(H, nm, 16, 256), seed + 1)
+    G.train(); D.train()
+    crit = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)
+    nce = PatchNCELoss(bs)
+    g_opt = torch.optim.SGD(G.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    d_opt = torch.optim.Adam(D.parameters(), 1e-2, [0.9, 0.999], weight_decay=1e-3)
+    lam = dict(cls=1.0, rec=10.0, gp=10.0, seg=10.0)
+    epoch, it0 = 100, 15000
+    ph = 1.0 - epoch / 200.0
+    lam_semi = 10.0 * float(np.exp(-5.0 * ph * ph))
+
+    def onehot(idx):
+        o = torch.zeros(idx.size(0), nm)
+        o[np.arange(idx.size(0)), idx.long()] = 1
+        return o
+
+    rec = dict(seed=seed, bs=bs, H=H, nm=nm, epoch=epoch, it0=it0)
+    logs_all = []
+    for step in range(2):
+        it = it0 + step
+        x_real = recipe.synth_images((B, 1, H, H), seed + 10 + step)
+        y_real = recipe.synth_labels(bs, H, H, 5, seed + 20 + step, block=8)
+        modal_org = torch.tensor([1] * bs + [3] * bs)
+        mj = (step + 2) % nm
+        alpha = torch.from_numpy(np.random.RandomState(seed + 30 + step).standard_normal((B, 1, 1, 1))).float()
+        ids = torch.from_numpy(np.random.RandomState(seed + 40 + step).permutation(16)[:64].astype(np.int64))
+        modal_trg = torch.zeros_like(modal_org).fill_(mj)
+        vec_org, vec_trg = onehot(modal_org), onehot(modal_trg)
+        vec_ot, vec_to = vec_trg - vec_org, vec_org - vec_trg
+
+        out_src, out_cls = D(x_real)
+        d_real = -torch.mean(out_src)
+        d_cls = F.cross_entropy(out_cls, modal_org)
+        _, x_fake, _, _ = G(x_real, vec_ot, sample_ids=[ids])
+        out_src, out_cls = D(x_fake.detach())
+        d_fake = torch.mean(out_src)
+        x_hat = (alpha * x_real.data + (1 - alpha) * x_fake.data).requires_grad_(True)
+        out_src, _ = D(x_hat)
+        dydx = torch.autograd.grad(out_src, x_hat, torch.ones(out_src.size()), retain_graph=True,
+                                   create_graph=True, only_inputs=True)[0]
+        d_gp = torch.mean((torch.sqrt(torch.sum(dydx.view(B, -1) ** 2, dim=1)) - 1) ** 2)
+        d_loss = d_real + d_fake + lam["cls"] * d_cls + lam["gp"] * d_gp
+        d_opt.zero_grad(); g_opt.zero_grad()
+        d_loss.backward()
+        if step == 0:
+            for k, v in grad_summary(D, ("conv_cls.weight", "main.0.weight")).items():
+                rec["D0_" + k] = v
+        d_opt.step()
+
+        y_fake, x_fake, feat_x, _ = G(x_real, vec_ot, sample_ids=[ids])
+        out_src, out_cls = D(x_fake)
+        g_fake = -torch.mean(out_src)
+        g_cls = F.cross_entropy(out_cls, modal_trg)
+        g_seg = crit(y_fake[:bs], y_real)
+        y_rec, x_rec, feat_f, _ = G(x_fake, vec_to, sample_ids=[ids])
+        g_rec = torch.mean(torch.abs(x_real - x_rec))
+        g_semi = crit(y_rec, torch.argmax(y_fake, dim=1))
+        g_nce = sum((nce(ff, fx) * 1.0).mean() for ff, fx in zip(feat_f, feat_x)) / 1
+        g_loss = g_fake + lam["rec"] * g_rec + lam["cls"] * g_cls + lam["seg"] * g_seg + lam_semi * g_semi + g_nce
+        d_opt.zero_grad(); g_opt.zero_grad()
+        g_loss.backward()
+        if step == 0:
+            for k, v in grad_summary(G, ("seg_decoder.fc.weight", "tsl_decoder.fc.bias", "netF.mlp_0.2.bias",
+                                         "tsl_encoder.pre.0.weight")).items():
+                rec["G0_" + k] = v
+            rec["seg0_s4"] = npy(y_fake[:, :, ::4, ::4])
+            rec["tsl0"] = npy(x_fake)
+        g_opt.step()
+        lr_ = 1e-2 * (1.0 - it / 30000) ** 0.9
+        for grp in list(g_opt.param_groups) + list(d_opt.param_groups):
+            grp["lr"] = lr_
+        logs_all.append([d_real.item(), d_fake.item(), d_cls.item(), d_gp.item(), g_fake.item(), g_rec.item(),
+                         g_cls.item(), g_seg.item(), g_semi.item(), g_nce.item()])
+        rec[f"mj{step}"] = mj
+    rec["scalar_names"] = np.array(["D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg",
+                                    "G_semi", "G_nce"])
+    rec["scalars"] = np.array(logs_all, dtype=np.float64)
+    gsd, dsd = G.state_dict(), D.state_dict()
+    rec["post_G_seg_fc"] = npy(gsd["seg_decoder.fc.weight"])
+    rec["post_G_tsl_pre"] = npy(gsd["tsl_encoder.pre.0.weight"])
+    rec["post_D_cls"] = npy(dsd["conv_cls.weight"])
+    rec["post_D_stem"] = npy(dsd["main.0.weight"])
+    save("iter_small", **rec)
+
+
+if __name__ == "__main__":
+    random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
+    which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small"]
+    for w in which:
+        globals()["gen_" + w]()

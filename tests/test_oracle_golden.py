@@ -1,0 +1,143 @@
+"""Pins oracle/smsut_oracle.py against the fixtures generated from the reference's own modules
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, l2_rel
+from oracle import recipe, smsut_oracle as O
+
+TOL = 2e-5        # same torch ops in a different composition: fp32 round-off only
+GTOL = 3e-3       # end-to-end gradients: see SURVEY.md section 9 (argmax / sign flips)
+
+
+def leaf(sd):
+    return {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+
+
+def test_unet_small_forward_loss_grads_and_steps(golden):
+    g = golden("unet_small")
+    sd = leaf(recipe.fill(recipe.unet_shapes(1, int(g["ncls"]), int(g["w"])), int(g["seed"])))
+    x, y = torch.from_numpy(g["x"]), torch.from_numpy(g["y"])
+    opt = torch.optim.SGD(list(sd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    out = O.unet_forward(sd, x)
+    assert rel_err(out.detach().numpy(), g["logits"]) < TOL
+    loss = O.dice_ce(out, y)
+    assert abs(loss.item() - g["losses"][0]) < 1e-5
+    loss.backward()
+    names = [str(n) for n in g["grad_names"]]
+    for n, ref in zip(names, g["grad_l2"]):
+        assert abs(float(sd[n].grad.double().norm()) - ref) <= GTOL * ref + 1e-7, n
+    for k in g.files:
+        if k.startswith("grad::"):
+            assert l2_rel(sd[k[6:]].grad.numpy(), g[k]) < GTOL, k
+    for p in sd.values():
+        p.grad = None
+    l0, _ = O.unet_train_step(sd, opt, x, y, 0)
+    l1, _ = O.unet_train_step(sd, opt, x, y, 1)
+    assert abs(l0 - g["losses"][0]) < 1e-5 and abs(l1 - g["losses"][1]) < 5e-5
+    assert rel_err(sd["encoder.pre_conv.weight"].detach().numpy(), g["post_pre_conv"]) < 1e-4
+    assert rel_err(sd["decoder.fc.weight"].detach().numpy(), g["post_fc"]) < 1e-4
+
+
+def test_unet_relu(golden):
+    g = golden("unet_relu")
+    sd = recipe.fill(recipe.unet_shapes(1, int(g["ncls"]), int(g["w"])), int(g["seed"]))
+    out = O.unet_forward(sd, torch.from_numpy(g["x"]), slope=0.0)
+    assert rel_err(out.numpy(), g["logits"]) < TOL
+
+
+def test_unet_256(golden):
+    g = golden("unet_256")
+    sd = leaf(recipe.fill(recipe.unet_shapes(1, 5, 16), int(g["seed"])))
+    x = recipe.synth_images((1, 1, 256, 256), int(g["seed"]) + 1)
+    y = recipe.synth_labels(1, 256, 256, 5, int(g["seed"]) + 2)
+    out = O.unet_forward(sd, x)
+    assert rel_err(out[:, :, ::8, ::8].detach().numpy(), g["logits_s8"]) < TOL
+    assert rel_err(out.double().sum((0, 2, 3)).detach().numpy(), g["logits_sum"]) < 1e-4
+    loss = O.dice_ce(out, y)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+
+
+def test_discriminator_with_gradient_penalty(golden):
+    g = golden("disc_small")
+    B = int(g["B"])
+    sd = leaf(recipe.fill(recipe.disc_shapes(int(g["S"]), int(g["nm"]), int(g["w"]), int(g["mw"])), int(g["seed"])))
+    x, xf, alpha = (torch.from_numpy(g[k]) for k in ("x", "xf", "alpha"))
+    src, cls = O.discriminator_forward(sd, x)
+    assert rel_err(src.detach().numpy(), g["out_src"]) < TOL
+    assert rel_err(cls.detach().numpy(), g["out_cls"]) < TOL
+    d_real = -src.mean()
+    d_cls = torch.nn.functional.cross_entropy(cls, torch.from_numpy(g["modal"]))
+    d_fake = O.discriminator_forward(sd, xf)[0].mean()
+    x_hat = (alpha * x + (1 - alpha) * xf).requires_grad_(True)
+    src_h, _ = O.discriminator_forward(sd, x_hat)
+    gp = O.gradient_penalty(src_h, x_hat)
+    got = np.array([d_real.item(), d_fake.item(), d_cls.item(), gp.item()])
+    assert np.allclose(got, g["scalars"], rtol=1e-4, atol=1e-6)
+    (d_real + d_fake + d_cls + 10.0 * gp).backward()
+    for n, ref in zip([str(n) for n in g["grad_names"]], g["grad_l2"]):
+        assert abs(float(sd[n].grad.double().norm()) - ref) <= GTOL * ref + 1e-7, n
+
+
+def test_ugan_small(golden):
+    g = golden("ugan_small")
+    sd = recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), int(g["seed"]))
+    x, m, ids = torch.from_numpy(g["x"]), torch.from_numpy(g["m"]), torch.from_numpy(g["ids"])
+    with torch.no_grad():
+        seg, tsl, feats, rid = O.ugan_forward(sd, x, m, [ids])
+        seg_v, tsl_v = O.ugan_forward(sd, x, None, val_phase=True)
+    assert rel_err(seg.numpy(), g["seg"]) < TOL
+    assert rel_err(tsl.numpy(), g["tsl"]) < TOL
+    assert rel_err(feats[0].numpy(), g["feat"]) < 1e-4
+    assert rel_err(seg_v.numpy(), g["seg_val"]) < TOL and rel_err(tsl_v.numpy(), g["tsl_val"]) < TOL
+
+
+def test_losses(golden):
+    g = golden("losses")
+    lg, lb = torch.from_numpy(g["logits"]), torch.from_numpy(g["labels"])
+    assert abs(O.dice_ce(lg, lb, 0.5, 0.5, True).item() - float(g["dicece_batch"])) < 1e-6
+    assert abs(O.dice_ce(lg, lb, 1.0, 1.0, False).item() - float(g["dicece_sample"])) < 1e-6
+    q, k = torch.from_numpy(g["q"]), torch.from_numpy(g["k"])
+    qn, kn = O.l2_normalize(q), O.l2_normalize(k)
+    assert rel_err(qn.numpy(), g["qn"]) < 1e-6
+    assert rel_err(O.patch_nce(qn, kn, 2).numpy(), g["nce"]) < 1e-5
+
+
+def test_full_iteration_scalars_and_post_step_weights(golden):
+    g = golden("iter_small")
+    bs, H, nm, seed = int(g["bs"]), int(g["H"]), int(g["nm"]), int(g["seed"])
+    B = 2 * bs
+    gsd = leaf(recipe.fill(recipe.ugan_shapes(1, 5, nm, 16), seed))
+    dsd = leaf(recipe.fill(recipe.disc_shapes(H, nm, 16, 256), seed + 1))
+    g_opt = torch.optim.SGD(list(gsd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    d_opt = torch.optim.Adam(list(dsd.values()), 1e-2, (0.9, 0.999), weight_decay=1e-3)
+    for step in range(2):
+        x_real = recipe.synth_images((B, 1, H, H), seed + 10 + step)
+        y_real = recipe.synth_labels(bs, H, H, 5, seed + 20 + step, block=8)
+        modal_org = torch.tensor([1] * bs + [3] * bs)
+        alpha = torch.from_numpy(np.random.RandomState(seed + 30 + step).standard_normal((B, 1, 1, 1))).float()
+        ids = torch.from_numpy(np.random.RandomState(seed + 40 + step).permutation(16)[:64].astype(np.int64))
+        logs, outs = O.ugan_consis_iteration(gsd, dsd, g_opt, d_opt, x_real, y_real, modal_org, int(g[f"mj{step}"]),
+                                             alpha, [ids], it=int(g["it0"]) + step, epoch=int(g["epoch"]),
+                                             nce_batch=bs, n_modal=nm)
+        got = np.array([logs[str(n)] for n in g["scalar_names"]])
+        # step 1 runs on post-step weights (Adam lr 1e-2 amplifies fp32 noise): looser
+        tol = 1e-4 if step == 0 else 2e-2
+        assert np.allclose(got, g["scalars"][step], rtol=tol, atol=1e-5), (step, got, g["scalars"][step])
+        if step == 0:
+            assert rel_err(outs["tsl"].numpy(), g["tsl0"]) < TOL
+            assert rel_err(outs["seg"][:, :, ::4, ::4].numpy(), g["seg0_s4"]) < TOL
+    assert rel_err(gsd["seg_decoder.fc.weight"].detach().numpy(), g["post_G_seg_fc"]) < 2e-3
+    assert rel_err(dsd["conv_cls.weight"].detach().numpy(), g["post_D_cls"]) < 5e-2
+
+
+def test_medpy_dc_formula_selfcheck():
+    a = np.zeros((4, 4), int); b = np.zeros((4, 4), int)
+    assert O.medpy_dc(a, b) == 0.0
+    a[:2] = 1; b[:2] = 1
+    assert O.medpy_dc(a, b) == 1.0
+    b[:] = 0; b[2:] = 1
+    assert O.medpy_dc(a, b) == 0.0
+    b[:] = 0; b[1:3] = 1
+    assert abs(O.medpy_dc(a, b) - 0.5) < 1e-12
