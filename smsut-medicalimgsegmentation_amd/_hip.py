@@ -1,0 +1,121 @@
+"""ctypes binding of the C-ABI library ``lib/libsmsut_hip.so`` (declared in ``include/smsut_hip.h``).
+
+PyTorch is used here only for device memory and the current HIP stream.  There is NO fallback:
+if the library is missing or a tensor is not on a HIP device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Dict, Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsmsut_hip.so")
+
+# signature codes: p = device pointer, i = int32, l = int64, f = float, d = double, s = stream (void*)
+# return type is int (0 = ok) unless the name is listed in _RET_I64.
+SIGNATURES: Dict[str, str] = {
+    # norm.hip
+    "smsut_in_chunks": "iii",
+    "smsut_instnorm_fwd": "ppppppp iii ff i s",
+    "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
+    "smsut_instnorm_bwd2": "ppppppppppp ppp pp iii f s",
+    # conv_naive.hip
+    "smsut_conv2d_fwd_generic": "pppp iiiiiiiiiii s",
+    "smsut_conv2d_dgrad_generic": "ppp iiiiiiiiiii s",
+    "smsut_conv2d_wgrad_generic_ws": "iiiiiii",
+    "smsut_conv2d_wgrad_generic": "pppp iiiiiiiiiii s",
+    "smsut_colsum_ws": "li",
+    "smsut_colsum": "ppp li s",
+    # pointwise.hip
+    "smsut_add_act": "ppp l f s",
+    "smsut_act_bwd": "ppp l f s",
+    "smsut_tanh_fwd": "pp l s",
+    "smsut_tanh_bwd": "ppp l s",
+    "smsut_bias_add": "ppp l i s",
+    "smsut_row_lerp": "pppp ll s",
+    "smsut_fill": "p f l s",
+    "smsut_scale": "pp f p l s",
+    "smsut_maxpool2_fwd": "pp iiii s",
+    "smsut_maxpool2_bwd": "ppp iiii s",
+    "smsut_avgpool2_fwd": "pp iiii s",
+    "smsut_avgpool2_bwd": "pp iiii s",
+    "smsut_bilinear2_fwd": "pp iiii s",
+    "smsut_bilinear2_bwd": "pp iiii s",
+    "smsut_copy_channels": "p ii p ii i l s",
+    "smsut_modal_planes": "ppp i l ii s",
+    # loss.hip
+    "smsut_dicece_ws": "i l ii",
+    "smsut_dicece_stats": "ppppp i l ii s",
+    "smsut_dicece_final": "ppp ii d ff s",
+    "smsut_dicece_bwd": "ppppp i l ii d ff s",
+    "smsut_sum_ws": "l i",
+    "smsut_sum": "ppp l d s",
+    "smsut_l1_fwd": "pppp l s",
+    "smsut_l1_bwd": "ppppp l s",
+    "smsut_gp_fwd": "pppp i l s",
+    "smsut_gp_bwd": "pppp i l s",
+    "smsut_ce_rows_fwd": "ppp ii s",
+    "smsut_ce_rows_bwd": "pppp ii s",
+    "smsut_gather_rows": "ppp i l ii s",
+    "smsut_scatter_rows": "ppp i l ii s",
+    "smsut_l2norm_fwd": "ppp ii s",
+    "smsut_l2norm_bwd": "pppp ii s",
+    "smsut_patchnce_fwd": "pppp iii f s",
+    "smsut_patchnce_bwd": "pppp iii f s",
+}
+_RET_I64 = {"smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws"}
+_NO_STATUS = _RET_I64 | {"smsut_in_chunks"}
+
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
+       "s": ctypes.c_void_p}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class SmsutHipError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the C-ABI library and bind every entry point; raises loudly when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SmsutHipError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = [_CT[c] for c in sig.replace(" ", "")]
+        fn.restype = ctypes.c_int64 if name in _RET_I64 else ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SmsutHipError("SMSUT HIP ops need tensors on a HIP device (no CPU fallback in the product path)")
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    """Invoke an entry point; tensors are passed as device pointers, the stream is appended by the caller."""
+    lib = load()
+    conv = [ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args]
+    rc = getattr(lib, name)(*conv)
+    if name in _NO_STATUS:
+        return rc
+    if rc != 0:
+        raise SmsutHipError(f"{name} failed with status {rc}" + (" (invalid argument)" if rc == -1 else " (hipError_t)"))
+    return rc

@@ -1,0 +1,228 @@
+// Generic direct convolution on NHWC fp32 (any kernel size / stride / zero padding): forward,
+// data-gradient and weight-gradient.  These are the shape-complete kernels: they serve the layers
+// whose FLOPs are negligible (stems with Cin 1/5, 1x1 heads with Cout 1/5, D's 4x4 s2 stem and
+// k4 `conv_cls`, network/ugan.py:202,213-215) and are the on-device cross-check for the MFMA
+// implicit-GEMM kernels in conv_mfma.hip, which take over every stride-1 "same" conv with
+// Cin%4==0 && Cout%16==0 (network/blocks.py:10-16).
+//
+// Layouts:  x [N][H][W][Cin],  w [KH][KW][Cin][Cout] ("HWIO"),  y [N][Ho][Wo][Cout].
+// ConvTranspose2d(k2,s2) (blocks.py:41) is the data-gradient form of a k2/s2/p0 conv, so the
+// up-path reuses dgrad (forward), fwd (its data-gradient) and wgrad with swapped operands.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+struct ConvGeom {
+  int N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+};
+
+__global__ void __launch_bounds__(TPB)
+conv_fwd_naive(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+               float* __restrict__ y, ConvGeom g, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int co = (int)(i % g.Cout);
+    int64_t p = i / g.Cout;
+    const int wo = (int)(p % g.Wo); p /= g.Wo;
+    const int ho = (int)(p % g.Ho);
+    const int n = (int)(p / g.Ho);
+    float acc = bias ? bias[co] : 0.f;
+    for (int kh = 0; kh < g.KH; ++kh) {
+      const int hi = ho * g.stride - g.pad + kh;
+      if (hi < 0 || hi >= g.H) continue;
+      for (int kw = 0; kw < g.KW; ++kw) {
+        const int wi = wo * g.stride - g.pad + kw;
+        if (wi < 0 || wi >= g.W) continue;
+        const float* xp = x + (((size_t)n * g.H + hi) * g.W + wi) * g.Cin;
+        const float* wp = w + ((size_t)(kh * g.KW + kw) * g.Cin) * g.Cout + co;
+        for (int ci = 0; ci < g.Cin; ++ci) acc = fmaf(xp[ci], wp[(size_t)ci * g.Cout], acc);
+      }
+    }
+    y[i] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(TPB)
+conv_dgrad_naive(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, ConvGeom g,
+                 int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int ci = (int)(i % g.Cin);
+    int64_t p = i / g.Cin;
+    const int wi = (int)(p % g.W); p /= g.W;
+    const int hi = (int)(p % g.H);
+    const int n = (int)(p / g.H);
+    float acc = 0.f;
+    for (int kh = 0; kh < g.KH; ++kh) {
+      const int hn = hi + g.pad - kh;
+      if (hn < 0 || hn % g.stride) continue;
+      const int ho = hn / g.stride;
+      if (ho >= g.Ho) continue;
+      for (int kw = 0; kw < g.KW; ++kw) {
+        const int wn = wi + g.pad - kw;
+        if (wn < 0 || wn % g.stride) continue;
+        const int wo = wn / g.stride;
+        if (wo >= g.Wo) continue;
+        const float* gp = gy + (((size_t)n * g.Ho + ho) * g.Wo + wo) * g.Cout;
+        const float* wp = w + ((size_t)(kh * g.KW + kw) * g.Cin + ci) * g.Cout;
+        int co = 0;
+        if ((g.Cout & 3) == 0) {
+          for (; co < g.Cout; co += 4) {
+            const float4 a = *(const float4*)(gp + co);
+            const float4 b = *(const float4*)(wp + co);
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc);
+            acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+          }
+        } else {
+          for (; co < g.Cout; ++co) acc = fmaf(gp[co], wp[co], acc);
+        }
+      }
+    }
+    gx[i] = acc;
+  }
+}
+
+// partial[chunk][KH*KW*Cin*Cout]: each thread owns one weight element and walks the chunk's output pixels.
+__global__ void __launch_bounds__(TPB)
+conv_wgrad_partial(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, ConvGeom g,
+                   int wsize, int64_t npix, int pix_per_chunk) {
+  const int e = blockIdx.x * TPB + threadIdx.x;
+  const int chunk = blockIdx.y;
+  if (e >= wsize) return;
+  const int co = e % g.Cout;
+  int t = e / g.Cout;
+  const int ci = t % g.Cin; t /= g.Cin;
+  const int kw = t % g.KW;
+  const int kh = t / g.KW;
+  const int64_t p0 = (int64_t)chunk * pix_per_chunk;
+  const int64_t p1 = min(p0 + (int64_t)pix_per_chunk, npix);
+  float acc = 0.f;
+  for (int64_t p = p0; p < p1; ++p) {
+    const int wo = (int)(p % g.Wo);
+    const int64_t q = p / g.Wo;
+    const int ho = (int)(q % g.Ho);
+    const int n = (int)(q / g.Ho);
+    const int hi = ho * g.stride - g.pad + kh;
+    const int wi = wo * g.stride - g.pad + kw;
+    if (hi < 0 || hi >= g.H || wi < 0 || wi >= g.W) continue;
+    acc = fmaf(x[(((size_t)n * g.H + hi) * g.W + wi) * g.Cin + ci], gy[(size_t)p * g.Cout + co], acc);
+  }
+  part[(size_t)chunk * wsize + e] = acc;
+}
+
+__global__ void __launch_bounds__(TPB)
+reduce_chunks(const float* __restrict__ part, float* __restrict__ out, int wsize, int chunks) {
+  const int e = blockIdx.x * TPB + threadIdx.x;
+  if (e >= wsize) return;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += (double)part[(size_t)c * wsize + e];
+  out[e] = (float)s;
+}
+
+// column sums of a [rows][C] matrix -> partial[chunk][C]
+__global__ void __launch_bounds__(TPB)
+colsum_partial(const float* __restrict__ x, float* __restrict__ part, int64_t rows, int C, int rows_per_chunk) {
+  const int chunk = blockIdx.x;
+  const int64_t r0 = (int64_t)chunk * rows_per_chunk;
+  const int64_t r1 = min(r0 + (int64_t)rows_per_chunk, rows);
+  const int TC = C < TPB ? C : TPB;
+  const int nrow = TPB / TC;
+  const int tc = threadIdx.x % TC, tr = threadIdx.x / TC;
+  __shared__ float sm[TPB];
+  for (int c0 = 0; c0 < C; c0 += TC) {
+    const int c = c0 + tc;
+    float acc = 0.f;
+    if (tr < nrow && c < C)
+      for (int64_t r = r0 + tr; r < r1; r += nrow) acc += x[(size_t)r * C + c];
+    __syncthreads();
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+      float tot = 0.f;
+      for (int r = 0; r < nrow; ++r) tot += sm[r * TC + tc];
+      part[(size_t)chunk * C + c] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+inline int wgrad_ppc(int64_t npix) {
+  int64_t ppc = cdiv64(npix, 1024);
+  if (ppc < 64) ppc = 64;
+  return (int)ppc;
+}
+
+inline bool geom_ok(const ConvGeom& g) {
+  if (g.N <= 0 || g.H <= 0 || g.W <= 0 || g.Cin <= 0 || g.Cout <= 0 || g.KH <= 0 || g.KW <= 0 || g.stride <= 0 ||
+      g.pad < 0)
+    return false;
+  return g.Ho == (g.H + 2 * g.pad - g.KH) / g.stride + 1 && g.Wo == (g.W + 2 * g.pad - g.KW) / g.stride + 1 &&
+         g.Ho > 0 && g.Wo > 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smsut_conv2d_fwd_generic(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+                             int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  ConvGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad};
+  SMSUT_REQUIRE(x && w && y && geom_ok(g));
+  const int64_t total = (int64_t)N * Ho * Wo * Cout;
+  conv_fwd_naive<<<ew_grid(total) * 4, TPB, 0, (hipStream_t)stream>>>(x, w, bias, y, g, total);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int smsut_conv2d_dgrad_generic(const float* gy, const float* w, float* gx, int N, int H, int W, int Cin, int Ho, int Wo,
+                               int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  ConvGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad};
+  SMSUT_REQUIRE(gy && w && gx && geom_ok(g));
+  const int64_t total = (int64_t)N * H * W * Cin;
+  conv_dgrad_naive<<<ew_grid(total) * 4, TPB, 0, (hipStream_t)stream>>>(gy, w, gx, g, total);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// workspace floats needed by smsut_conv2d_wgrad_generic
+int64_t smsut_conv2d_wgrad_generic_ws(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
+  const int64_t npix = (int64_t)N * Ho * Wo;
+  const int ppc = wgrad_ppc(npix);
+  return cdiv64(npix, ppc) * (int64_t)KH * KW * Cin * Cout;
+}
+
+int smsut_conv2d_wgrad_generic(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W,
+                               int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, void* stream) {
+  ConvGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad};
+  SMSUT_REQUIRE(x && gy && gw && workspace && geom_ok(g));
+  const int64_t npix = (int64_t)N * Ho * Wo;
+  const int ppc = wgrad_ppc(npix);
+  const int chunks = (int)cdiv64(npix, ppc);
+  const int wsize = KH * KW * Cin * Cout;
+  hipStream_t st = (hipStream_t)stream;
+  conv_wgrad_partial<<<dim3((wsize + TPB - 1) / TPB, chunks), TPB, 0, st>>>(x, gy, workspace, g, wsize, npix, ppc);
+  reduce_chunks<<<(wsize + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, wsize, chunks);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// out[c] = sum over rows of x[rows][C].  workspace: float[smsut_colsum_ws(rows, C)]
+int64_t smsut_colsum_ws(int64_t rows, int C) {
+  int64_t rpc = cdiv64(rows, 512);
+  if (rpc < 64) rpc = 64;
+  return cdiv64(rows, rpc) * C;
+}
+
+int smsut_colsum(const float* x, float* out, float* workspace, int64_t rows, int C, void* stream) {
+  SMSUT_REQUIRE(x && out && workspace && rows > 0 && C > 0);
+  int64_t rpc = cdiv64(rows, 512);
+  if (rpc < 64) rpc = 64;
+  const int chunks = (int)cdiv64(rows, rpc);
+  hipStream_t st = (hipStream_t)stream;
+  colsum_partial<<<chunks, TPB, 0, st>>>(x, workspace, rows, C, (int)rpc);
+  reduce_chunks<<<(C + TPB - 1) / TPB, TPB, 0, st>>>(workspace, out, C, chunks);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+}  // extern "C"

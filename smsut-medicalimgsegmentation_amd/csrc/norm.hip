@@ -1,0 +1,363 @@
+// InstanceNorm2d(affine) on NHWC fp32: forward, backward and backward-of-backward (for WGAN-GP).
+//
+// Reference semantics: nn.InstanceNorm2d(C, affine=True), eps 1e-5, biased variance, no running
+// stats (network/blocks.py:23), followed on the hot path by LeakyReLU(0.01) (blocks.py:28-32).
+//
+// Reductions are deterministic two-stage (per-chunk fp32 partials -> fp64 combine), no atomics.
+// Per-(n,c) quantities with M = H*W, xh = (x-mean)*rstd, gz = gy * lrelu'(y):
+//   fwd :  y  = act(xh*gamma + beta)
+//   bwd :  a = mean(gz), b = mean(gz*xh);  gx = gamma*rstd*(gz - a - xh*b);
+//          ggamma = sum_n M*b, gbeta = sum_n M*a
+//   bwd2:  given v = d/dgx, ug = d/dggamma, ub = d/dgbeta:
+//          cv = mean(v), dv = mean(v*xh), e = mean(v*gz), S = e - cv*a - dv*b
+//          d/dgy    = lrelu'(y) * (gamma*rstd*(v - cv - xh*dv) + ug*xh + ub)
+//          d/dx     = -gamma*rstd^2*(S*xh + b*(v-cv) + dv*(gz-a) - 2*b*dv*xh) + ug*rstd*(gz - a - xh*b)
+//          d/dgamma = sum_n rstd*M*S
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// MODE 0: sums of (x, x^2)           -- forward statistics
+// MODE 1: sums of (gz, gz*xh)        -- backward
+// MODE 2: sums of (v, v*xh, v*gz)    -- backward of backward
+template <int MODE> struct NSums { static constexpr int n = (MODE == 2) ? 3 : 2; };
+
+template <int MODE, int VEC>
+__global__ void __launch_bounds__(TPB)
+in_moments_partial(const float* __restrict__ t0,   // x | gy | v
+                   const float* __restrict__ t1,   // - | x  | x
+                   const float* __restrict__ t2,   // - | y (mask src, may be null) | gy
+                   const float* __restrict__ t3,   // - | -  | y (mask src, may be null)
+                   const float* __restrict__ mean, const float* __restrict__ rstd,
+                   float* __restrict__ part,        // [N][chunks][C][NS]
+                   int HW, int C, int pix_per_chunk, float slope) {
+  constexpr int NS = NSums<MODE>::n;
+  const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+  const int CV = C / VEC;
+  const int TC = CV < TPB ? CV : TPB;
+  const int rows = TPB / TC;
+  const int tc = threadIdx.x % TC, trow = threadIdx.x / TC;
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = min(p0 + pix_per_chunk, HW);
+  __shared__ float sm[TPB * 4 * 3];
+  const size_t base = (size_t)n * HW * C;
+
+  for (int cv0 = 0; cv0 < CV; cv0 += TC) {   // uniform trip count: barriers inside
+    const int cv = cv0 + tc;
+    const bool cv_ok = cv < CV;
+    float acc[NS][VEC];
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[s][j] = 0.f;
+    float mu[VEC], rs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      mu[j] = (MODE == 0 || !cv_ok) ? 0.f : mean[n * C + cv * VEC + j];
+      rs[j] = (MODE == 0 || !cv_ok) ? 1.f : rstd[n * C + cv * VEC + j];
+    }
+    if (trow < rows && cv_ok) {
+      for (int p = p0 + trow; p < p1; p += rows) {
+        const size_t off = base + (size_t)p * C + cv * VEC;
+        float a0[VEC], a1[VEC], a2[VEC], a3[VEC];
+        if constexpr (VEC == 4) {
+          *(float4*)a0 = *(const float4*)(t0 + off);
+          if (MODE >= 1) *(float4*)a1 = *(const float4*)(t1 + off);
+          if (MODE == 1 && t2) *(float4*)a2 = *(const float4*)(t2 + off);
+          if (MODE == 2) *(float4*)a2 = *(const float4*)(t2 + off);
+          if (MODE == 2 && t3) *(float4*)a3 = *(const float4*)(t3 + off);
+        } else {
+          a0[0] = t0[off];
+          if (MODE >= 1) a1[0] = t1[off];
+          if (MODE == 1 && t2) a2[0] = t2[off];
+          if (MODE == 2) a2[0] = t2[off];
+          if (MODE == 2 && t3) a3[0] = t3[off];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          if (MODE == 0) {
+            acc[0][j] += a0[j];
+            acc[1][j] += a0[j] * a0[j];
+          } else if (MODE == 1) {
+            const float gz = t2 ? a0[j] * lrelu_mask(a2[j], slope) : a0[j];
+            const float xh = (a1[j] - mu[j]) * rs[j];
+            acc[0][j] += gz;
+            acc[1][j] += gz * xh;
+          } else {
+            const float gz = t3 ? a2[j] * lrelu_mask(a3[j], slope) : a2[j];
+            const float xh = (a1[j] - mu[j]) * rs[j];
+            acc[0][j] += a0[j];
+            acc[1][j] += a0[j] * xh;
+            acc[NS - 1][j] += a0[j] * gz;
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sm[(threadIdx.x * NS + s) * VEC + j] = acc[s][j];
+    __syncthreads();
+    if (trow == 0 && cv_ok) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float tot = 0.f;
+          for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * NS + s) * VEC + j];
+          part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * NS + s] = tot;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// combine chunk partials in fp64 -> per-(n,c) means.  MODE 0 writes (mean, rstd).
+template <int MODE>
+__global__ void in_moments_final(const float* __restrict__ part, int chunks, int C, int HW, float eps,
+                                 float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+  constexpr int NS = NSums<MODE>::n;
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) s[k] = 0.0;
+  for (int ch = 0; ch < chunks; ++ch) {
+    const float* p = part + (((size_t)n * chunks + ch) * C + c) * NS;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) s[k] += (double)p[k];
+  }
+  const double inv = 1.0 / (double)HW;
+  if (MODE == 0) {
+    const double m = s[0] * inv;
+    double var = s[1] * inv - m * m;
+    if (var < 0.0) var = 0.0;
+    o0[n * C + c] = (float)m;
+    o1[n * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  } else {
+    o0[n * C + c] = (float)(s[0] * inv);
+    o1[n * C + c] = (float)(s[1] * inv);
+    if (MODE == 2) o2[n * C + c] = (float)(s[NS - 1] * inv);
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(TPB)
+in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+             int64_t total_vec, int HW, int C, float slope, int has_act) {
+  const int CV = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((int64_t)CV * HW));
+    float v[VEC];
+    if constexpr (VEC == 4) *(float4*)v = *(const float4*)(x + i * 4); else v[0] = x[i];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = cv * VEC + j;
+      const float sc = rstd[n * C + c] * gamma[c];
+      const float r = (v[j] - mean[n * C + c]) * sc + beta[c];
+      v[j] = has_act ? lrelu_f(r, slope) : r;
+    }
+    if constexpr (VEC == 4) *(float4*)(y + i * 4) = *(float4*)v; else y[i] = v[0];
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(TPB)
+in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ ymask,
+             const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
+             const float* __restrict__ am, const float* __restrict__ bm, float* __restrict__ gx,
+             int64_t total_vec, int HW, int C, float slope) {
+  const int CV = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((int64_t)CV * HW));
+    float g[VEC], xv[VEC], ym[VEC];
+    if constexpr (VEC == 4) {
+      *(float4*)g = *(const float4*)(gy + i * 4);
+      *(float4*)xv = *(const float4*)(x + i * 4);
+      if (ymask) *(float4*)ym = *(const float4*)(ymask + i * 4);
+    } else {
+      g[0] = gy[i]; xv[0] = x[i];
+      if (ymask) ym[0] = ymask[i];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int k = n * C + cv * VEC + j;
+      const float r = rstd[k];
+      const float gz = ymask ? g[j] * lrelu_mask(ym[j], slope) : g[j];
+      const float xh = (xv[j] - mean[k]) * r;
+      g[j] = gamma[cv * VEC + j] * r * (gz - am[k] - xh * bm[k]);
+    }
+    if constexpr (VEC == 4) *(float4*)(gx + i * 4) = *(float4*)g; else gx[i] = g[0];
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(TPB)
+in_apply_bwd2(const float* __restrict__ v, const float* __restrict__ x, const float* __restrict__ gy,
+              const float* __restrict__ ymask, const float* __restrict__ mean, const float* __restrict__ rstd,
+              const float* __restrict__ gamma, const float* __restrict__ am, const float* __restrict__ bm,
+              const float* __restrict__ cvm, const float* __restrict__ dvm, const float* __restrict__ em,
+              const float* __restrict__ ug, const float* __restrict__ ub,
+              float* __restrict__ d_gy, float* __restrict__ d_x,
+              int64_t total_vec, int HW, int C, float slope) {
+  const int CV = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((int64_t)CV * HW));
+    float vv[VEC], xv[VEC], g[VEC], ym[VEC], o1[VEC], o2[VEC];
+    if constexpr (VEC == 4) {
+      *(float4*)vv = *(const float4*)(v + i * 4);
+      *(float4*)xv = *(const float4*)(x + i * 4);
+      *(float4*)g = *(const float4*)(gy + i * 4);
+      if (ymask) *(float4*)ym = *(const float4*)(ymask + i * 4);
+    } else {
+      vv[0] = v[i]; xv[0] = x[i]; g[0] = gy[i];
+      if (ymask) ym[0] = ymask[i];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = cv * VEC + j;
+      const int k = n * C + c;
+      const float r = rstd[k], gm = gamma[c];
+      const float mk = ymask ? lrelu_mask(ym[j], slope) : 1.f;
+      const float gz = g[j] * mk;
+      const float xh = (xv[j] - mean[k]) * r;
+      const float a = am[k], b = bm[k], cvv = cvm[k], dv = dvm[k];
+      const float S = em[k] - cvv * a - dv * b;
+      const float ugc = ug ? ug[c] : 0.f, ubc = ub ? ub[c] : 0.f;
+      o1[j] = mk * (gm * r * (vv[j] - cvv - xh * dv) + ugc * xh + ubc);
+      o2[j] = -gm * r * r * (S * xh + b * (vv[j] - cvv) + dv * (gz - a) - 2.f * b * dv * xh) +
+              ugc * r * (gz - a - xh * b);
+    }
+    if constexpr (VEC == 4) {
+      *(float4*)(d_gy + i * 4) = *(float4*)o1;
+      *(float4*)(d_x + i * 4) = *(float4*)o2;
+    } else {
+      d_gy[i] = o1[0]; d_x[i] = o2[0];
+    }
+  }
+}
+
+// ggamma[c] = sum_n M*b[n,c]; gbeta[c] = sum_n M*a[n,c]
+__global__ void in_affine_grads(const float* __restrict__ am, const float* __restrict__ bm, int N, int C, int HW,
+                                float* __restrict__ ggamma, float* __restrict__ gbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sa = 0.0, sb = 0.0;
+  for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; sb += (double)bm[n * C + c]; }
+  ggamma[c] = (float)(sb * (double)HW);
+  gbeta[c] = (float)(sa * (double)HW);
+}
+
+// d/dgamma[c] = sum_n rstd*M*(e - cv*a - dv*b)
+__global__ void in_bwd2_gamma(const float* __restrict__ rstd, const float* __restrict__ am, const float* __restrict__ bm,
+                              const float* __restrict__ cvm, const float* __restrict__ dvm, const float* __restrict__ em,
+                              int N, int C, int HW, float* __restrict__ d_gamma) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const int k = n * C + c;
+    s += (double)rstd[k] * ((double)em[k] - (double)cvm[k] * am[k] - (double)dvm[k] * bm[k]);
+  }
+  d_gamma[c] = (float)(s * (double)HW);
+}
+
+inline int pick_chunk(int HW, int C, int N) {
+  // aim for >= ~1024 blocks overall while keeping >= 256 pixels per chunk
+  int ppc = 2048;
+  while (ppc > 256 && (int64_t)N * cdiv64(HW, ppc) < 1024) ppc >>= 1;
+  (void)C;
+  return ppc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int smsut_in_chunks(int N, int HW, int C) { return (int)cdiv64(HW, pick_chunk(HW, C, N)); }
+
+// workspace: float[N * smsut_in_chunks * C * 3]
+int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       float* workspace, int N, int HW, int C, float eps, float slope, int has_act, void* stream) {
+  SMSUT_REQUIRE(x && gamma && beta && y && mean && rstd && workspace && N > 0 && HW > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int ppc = pick_chunk(HW, C, N);
+  const int chunks = (int)cdiv64(HW, ppc);
+  dim3 g(chunks, N);
+  if (C % 4 == 0)
+    in_moments_partial<0, 4><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
+  else
+    in_moments_partial<0, 1><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
+  in_moments_final<0><<<dim3((C + 63) / 64, N), 64, 0, st>>>(workspace, chunks, C, HW, eps, mean, rstd, nullptr);
+  const int64_t total = (int64_t)N * HW * C;
+  if (C % 4 == 0)
+    in_apply_fwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total / 4, HW, C, slope, has_act);
+  else
+    in_apply_fwd<1><<<ew_grid(total), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total, HW, C, slope, has_act);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// ymask may be null (no activation).  Outputs gx [N,HW,C], a/b [N,C] (saved for bwd2), ggamma/gbeta [C] (may be null).
+int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask, const float* mean, const float* rstd,
+                       const float* gamma, float* gx, float* a_mean, float* b_mean, float* ggamma, float* gbeta,
+                       float* workspace, int N, int HW, int C, float slope, void* stream) {
+  SMSUT_REQUIRE(gy && x && mean && rstd && gamma && gx && a_mean && b_mean && workspace && N > 0 && HW > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int ppc = pick_chunk(HW, C, N);
+  const int chunks = (int)cdiv64(HW, ppc);
+  dim3 g(chunks, N);
+  if (C % 4 == 0)
+    in_moments_partial<1, 4><<<g, TPB, 0, st>>>(gy, x, ymask, nullptr, mean, rstd, workspace, HW, C, ppc, slope);
+  else
+    in_moments_partial<1, 1><<<g, TPB, 0, st>>>(gy, x, ymask, nullptr, mean, rstd, workspace, HW, C, ppc, slope);
+  in_moments_final<1><<<dim3((C + 63) / 64, N), 64, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
+  if (ggamma && gbeta) in_affine_grads<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b_mean, N, C, HW, ggamma, gbeta);
+  const int64_t total = (int64_t)N * HW * C;
+  if (C % 4 == 0)
+    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gy, x, ymask, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, slope);
+  else
+    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gy, x, ymask, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, slope);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Backward of smsut_instnorm_bwd (WGAN-GP double backward).  v = d/dgx; ug/ub = d/dggamma, d/dgbeta (may be null).
+// scratch: float[3*N*C] for cv/dv/e.
+int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const float* gy, const float* x,
+                        const float* ymask, const float* mean, const float* rstd, const float* gamma,
+                        const float* a_mean, const float* b_mean, float* d_gy, float* d_x, float* d_gamma,
+                        float* workspace, float* scratch, int N, int HW, int C, float slope, void* stream) {
+  SMSUT_REQUIRE(v && gy && x && mean && rstd && gamma && a_mean && b_mean && d_gy && d_x && d_gamma && workspace &&
+                scratch && N > 0 && HW > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int ppc = pick_chunk(HW, C, N);
+  const int chunks = (int)cdiv64(HW, ppc);
+  dim3 g(chunks, N);
+  float* cvm = scratch; float* dvm = scratch + (size_t)N * C; float* em = scratch + 2 * (size_t)N * C;
+  if (C % 4 == 0)
+    in_moments_partial<2, 4><<<g, TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, workspace, HW, C, ppc, slope);
+  else
+    in_moments_partial<2, 1><<<g, TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, workspace, HW, C, ppc, slope);
+  in_moments_final<2><<<dim3((C + 63) / 64, N), 64, 0, st>>>(workspace, chunks, C, HW, 0.f, cvm, dvm, em);
+  in_bwd2_gamma<<<(C + 63) / 64, 64, 0, st>>>(rstd, a_mean, b_mean, cvm, dvm, em, N, C, HW, d_gamma);
+  const int64_t total = (int64_t)N * HW * C;
+  if (C % 4 == 0)
+    in_apply_bwd2<4><<<ew_grid(total / 4), TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
+                                                          ug, ub, d_gy, d_x, total / 4, HW, C, slope);
+  else
+    in_apply_bwd2<1><<<ew_grid(total), TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
+                                                      ug, ub, d_gy, d_x, total, HW, C, slope);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,348 @@
+// Memory-bound NHWC fp32 helpers of the SMSUT hot path: activations, residual add, pooling,
+// bilinear x2, channel concat / split, modality planes.  All are grid-stride, 16 B/lane where the
+// channel count allows (guide G13), and launch on the caller's stream.
+#include "common.h"
+
+namespace {
+constexpr int TPB = 256;
+
+#define GRID_STRIDE(i, total) \
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < (total); i += (int64_t)gridDim.x * TPB)
+
+// y = lrelu(a (+ b)), vectorised when n4 covers the tensor
+__global__ void __launch_bounds__(TPB)
+k_add_act(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n, float slope) {
+  const int64_t n4 = n >> 2;
+  GRID_STRIDE(i, n4) {
+    float4 v = ((const float4*)a)[i];
+    if (b) { const float4 u = ((const float4*)b)[i]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+    v.x = lrelu_f(v.x, slope); v.y = lrelu_f(v.y, slope); v.z = lrelu_f(v.z, slope); v.w = lrelu_f(v.w, slope);
+    ((float4*)y)[i] = v;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+    y[i] = lrelu_f(a[i] + (b ? b[i] : 0.f), slope);
+}
+
+// gx = gy * lrelu'(y)
+__global__ void __launch_bounds__(TPB)
+k_act_bwd(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx, int64_t n, float slope) {
+  const int64_t n4 = n >> 2;
+  GRID_STRIDE(i, n4) {
+    float4 g = ((const float4*)gy)[i];
+    const float4 v = ((const float4*)y)[i];
+    g.x *= lrelu_mask(v.x, slope); g.y *= lrelu_mask(v.y, slope);
+    g.z *= lrelu_mask(v.z, slope); g.w *= lrelu_mask(v.w, slope);
+    ((float4*)gx)[i] = g;
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+    gx[i] = gy[i] * lrelu_mask(y[i], slope);
+}
+
+__global__ void __launch_bounds__(TPB)
+k_tanh_fwd(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  GRID_STRIDE(i, n) y[i] = tanhf(x[i]);
+}
+__global__ void __launch_bounds__(TPB)
+k_tanh_bwd(const float* __restrict__ gy, const float* __restrict__ y, float* __restrict__ gx, int64_t n) {
+  GRID_STRIDE(i, n) { const float t = y[i]; gx[i] = gy[i] * (1.f - t * t); }
+}
+
+// y[r][c] = x[r][c] + bias[c]
+__global__ void __launch_bounds__(TPB)
+k_bias_add(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ y, int64_t n, int C) {
+  GRID_STRIDE(i, n) y[i] = x[i] + bias[(int)(i % C)];
+}
+
+// out = alpha*a + beta*b  (optionally per-row alpha: x_hat of WGAN-GP, uganConsisTrainer.py:139)
+__global__ void __launch_bounds__(TPB)
+k_row_lerp(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ alpha,
+           float* __restrict__ out, int64_t n, int64_t row) {
+  GRID_STRIDE(i, n) { const float t = alpha[i / row]; out[i] = t * a[i] + (1.f - t) * b[i]; }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_fill(float* __restrict__ out, float v, int64_t n) { GRID_STRIDE(i, n) out[i] = v; }
+
+__global__ void __launch_bounds__(TPB)
+k_scale(const float* __restrict__ x, const float* __restrict__ s, float mul, float* __restrict__ out, int64_t n) {
+  const float f = (s ? s[0] : 1.f) * mul;
+  GRID_STRIDE(i, n) out[i] = x[i] * f;
+}
+
+// ---- 2x2 stride-2 pooling (H, W even) ------------------------------------------------------------
+__global__ void __launch_bounds__(TPB)
+k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float* b = x + (((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
+    // scan order (0,0),(0,1),(1,0),(1,1); NaN propagates like at::max_pool2d
+    float m = b[0];
+    float v = b[C]; if (v > m || v != v) m = v;
+    v = b[(size_t)W * C]; if (v > m || v != v) m = v;
+    v = b[(size_t)W * C + C]; if (v > m || v != v) m = v;
+    y[i] = m;
+  }
+}
+
+// gradient goes to the first element (scan order) equal to the pooled max -- at::max_pool2d's argmax
+__global__ void __launch_bounds__(TPB)
+k_maxpool_bwd(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int N, int H, int W,
+              int C) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const size_t o = (((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
+    const size_t o1 = o + C, o2 = o + (size_t)W * C, o3 = o2 + C;
+    const float v0 = x[o], v1 = x[o1], v2 = x[o2], v3 = x[o3];
+    int k = 0; float m = v0;
+    if (v1 > m || v1 != v1) { m = v1; k = 1; }
+    if (v2 > m || v2 != v2) { m = v2; k = 2; }
+    if (v3 > m || v3 != v3) { m = v3; k = 3; }
+    const float g = gy[i];
+    gx[o] = k == 0 ? g : 0.f; gx[o1] = k == 1 ? g : 0.f; gx[o2] = k == 2 ? g : 0.f; gx[o3] = k == 3 ? g : 0.f;
+  }
+}
+
+__global__ void __launch_bounds__(TPB)
+k_avgpool_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float* b = x + (((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
+    y[i] = (b[0] + b[C] + b[(size_t)W * C] + b[(size_t)W * C + C]) * 0.25f;
+  }
+}
+
+// gx[n,h,w,c] = 0.25 * gy[n,h/2,w/2,c]   (adjoint of avgpool; its own adjoint is avgpool again)
+__global__ void __launch_bounds__(TPB)
+k_avgpool_bwd(const float* __restrict__ gy, float* __restrict__ gx, int N, int H, int W, int C) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const int64_t total = (int64_t)N * H * W * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    gx[i] = 0.25f * gy[(((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c];
+  }
+}
+
+// ---- bilinear x2, align_corners=False (nn.Upsample, network/blocks.py:44) ---------------------------
+// src = max(0.5*(dst+0.5)-0.5, 0); i0 = floor(src); i1 = min(i0+1, size-1); lambda = src - i0
+__device__ __forceinline__ void bil_src(int d, int size, int& i0, int& i1, float& l1) {
+  float s = 0.5f * ((float)d + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  i1 = i0 + (i0 < size - 1 ? 1 : 0);
+  l1 = s - (float)i0;
+}
+
+__global__ void __launch_bounds__(TPB)
+k_bilinear2_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int wo = (int)(p % Wo); p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    int h0, h1, w0, w1; float lh, lw;
+    bil_src(ho, H, h0, h1, lh);
+    bil_src(wo, W, w0, w1, lw);
+    const float* b = x + (size_t)n * H * W * C + c;
+    const float v00 = b[((size_t)h0 * W + w0) * C], v01 = b[((size_t)h0 * W + w1) * C];
+    const float v10 = b[((size_t)h1 * W + w0) * C], v11 = b[((size_t)h1 * W + w1) * C];
+    y[i] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+  }
+}
+
+// adjoint in gather form: each input pixel collects from the <=4x4 outputs that reference it
+__global__ void __launch_bounds__(TPB)
+k_bilinear2_bwd(const float* __restrict__ gy, float* __restrict__ gx, int N, int H, int W, int C) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const int64_t total = (int64_t)N * H * W * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    float wh[4], ww[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oh = 2 * h - 1 + k, ow = 2 * w - 1 + k;
+      wh[k] = 0.f; ww[k] = 0.f;
+      if (oh >= 0 && oh < Ho) {
+        int i0, i1; float l; bil_src(oh, H, i0, i1, l);
+        wh[k] = (i0 == h ? 1.f - l : 0.f) + (i1 == h ? l : 0.f);
+      }
+      if (ow >= 0 && ow < Wo) {
+        int i0, i1; float l; bil_src(ow, W, i0, i1, l);
+        ww[k] = (i0 == w ? 1.f - l : 0.f) + (i1 == w ? l : 0.f);
+      }
+    }
+    const float* b = gy + (size_t)n * Ho * Wo * C + c;
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      if (wh[a] == 0.f) continue;
+      const int oh = 2 * h - 1 + a;
+      float r = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ww[k] == 0.f) continue;
+        r += ww[k] * b[((size_t)oh * Wo + (2 * w - 1 + k)) * C];
+      }
+      acc += wh[a] * r;
+    }
+    gx[i] = acc;
+  }
+}
+
+// ---- channel slices: dst[p][dst_off + c] = src[p][src_off + c], c < Cc --------------------------------
+__global__ void __launch_bounds__(TPB)
+k_copy_channels(const float* __restrict__ src, int Cs, int src_off, float* __restrict__ dst, int Cd, int dst_off,
+                int Cc, int64_t P) {
+  if (((Cc | Cs | Cd | src_off | dst_off) & 3) == 0) {
+    const int q = Cc >> 2;
+    const int64_t total = P * q;
+    GRID_STRIDE(i, total) {
+      const int c = (int)(i % q) << 2;
+      const int64_t p = i / q;
+      *(float4*)(dst + p * Cd + dst_off + c) = *(const float4*)(src + p * Cs + src_off + c);
+    }
+  } else {
+    const int64_t total = P * Cc;
+    GRID_STRIDE(i, total) {
+      const int c = (int)(i % Cc);
+      const int64_t p = i / Cc;
+      dst[p * Cd + dst_off + c] = src[p * Cs + src_off + c];
+    }
+  }
+}
+
+// tsl input: out[n][p][0..Cx) = x, out[n][p][Cx + j] = m[n][j]   (network/ugan.py:156-159)
+__global__ void __launch_bounds__(TPB)
+k_modal_planes(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ out, int N, int64_t HW,
+               int Cx, int M) {
+  const int Ct = Cx + M;
+  const int64_t total = (int64_t)N * HW * Ct;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Ct);
+    const int64_t p = i / Ct;
+    const int n = (int)(p / HW);
+    out[i] = c < Cx ? x[p * Cx + c] : m[n * M + (c - Cx)];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+#define ST ((hipStream_t)stream)
+
+int smsut_add_act(const float* a, const float* b, float* y, int64_t n, float slope, void* stream) {
+  SMSUT_REQUIRE(a && y && n > 0);
+  k_add_act<<<ew_grid(n / 4 + 1), TPB, 0, ST>>>(a, b, y, n, slope);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_act_bwd(const float* gy, const float* y, float* gx, int64_t n, float slope, void* stream) {
+  SMSUT_REQUIRE(gy && y && gx && n > 0);
+  k_act_bwd<<<ew_grid(n / 4 + 1), TPB, 0, ST>>>(gy, y, gx, n, slope);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_tanh_fwd(const float* x, float* y, int64_t n, void* stream) {
+  SMSUT_REQUIRE(x && y && n > 0);
+  k_tanh_fwd<<<ew_grid(n), TPB, 0, ST>>>(x, y, n);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_tanh_bwd(const float* gy, const float* y, float* gx, int64_t n, void* stream) {
+  SMSUT_REQUIRE(gy && y && gx && n > 0);
+  k_tanh_bwd<<<ew_grid(n), TPB, 0, ST>>>(gy, y, gx, n);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_bias_add(const float* x, const float* bias, float* y, int64_t rows, int C, void* stream) {
+  SMSUT_REQUIRE(x && bias && y && rows > 0 && C > 0);
+  k_bias_add<<<ew_grid(rows * C), TPB, 0, ST>>>(x, bias, y, rows * C, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_row_lerp(const float* a, const float* b, const float* alpha, float* out, int64_t rows, int64_t row_len,
+                   void* stream) {
+  SMSUT_REQUIRE(a && b && alpha && out && rows > 0 && row_len > 0);
+  k_row_lerp<<<ew_grid(rows * row_len), TPB, 0, ST>>>(a, b, alpha, out, rows * row_len, row_len);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_fill(float* out, float v, int64_t n, void* stream) {
+  SMSUT_REQUIRE(out && n > 0);
+  k_fill<<<ew_grid(n), TPB, 0, ST>>>(out, v, n);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// out = x * (*scale_dev or 1) * mul
+int smsut_scale(const float* x, const float* scale_dev, float mul, float* out, int64_t n, void* stream) {
+  SMSUT_REQUIRE(x && out && n > 0);
+  k_scale<<<ew_grid(n), TPB, 0, ST>>>(x, scale_dev, mul, out, n);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
+  k_maxpool_fwd<<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_maxpool2_bwd(const float* gy, const float* x, float* gx, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(gy && x && gx && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
+  k_maxpool_bwd<<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
+  k_avgpool_fwd<<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// (H, W) are the UN-pooled sizes: gy is [N,H/2,W/2,C], gx is [N,H,W,C]
+int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
+  k_avgpool_bwd<<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0);
+  k_bilinear2_fwd<<<ew_grid((int64_t)N * H * W * C * 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_bilinear2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0);
+  k_bilinear2_bwd<<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_copy_channels(const float* src, int Cs, int src_off, float* dst, int Cd, int dst_off, int Cc, int64_t P,
+                        void* stream) {
+  SMSUT_REQUIRE(src && dst && P > 0 && Cc > 0 && src_off >= 0 && dst_off >= 0 && src_off + Cc <= Cs &&
+                dst_off + Cc <= Cd);
+  k_copy_channels<<<ew_grid(P * Cc / 4 + 1), TPB, 0, ST>>>(src, Cs, src_off, dst, Cd, dst_off, Cc, P);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_modal_planes(const float* x, const float* m, float* out, int N, int64_t HW, int Cx, int M, void* stream) {
+  SMSUT_REQUIRE(x && m && out && N > 0 && HW > 0 && Cx > 0 && M > 0);
+  k_modal_planes<<<ew_grid((int64_t)N * HW * (Cx + M)), TPB, 0, ST>>>(x, m, out, N, HW, Cx, M);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,227 @@
+"""HIP-backed counterparts of the reference's ``network/blocks.py`` building blocks.
+
+Same constructor signatures, attribute names and ``state_dict`` keys/shapes; ``forward`` runs the
+gfx950 kernels through ``ops`` (no torch.nn compute).  Only ``norm_type='instance'`` is on the hot
+path (every trainer passes it: unetTrainer.py:42, ugan.py:89-96); ``'batch'`` raises.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+LRELU_SLOPE = 1e-2
+
+
+class Conv2d(nn.Module):
+    """Parameter holder for nn.Conv2d: ``weight`` is logical OIHW over [KH][KW][I][O] memory."""
+
+    def __init__(self, in_ch, out_ch, kernel_size, stride=1, padding=0, bias=False):
+        super().__init__()
+        self.in_channels, self.out_channels = in_ch, out_ch
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(ops.new_weight(out_ch, in_ch, kernel_size, kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_ch))
+        else:
+            self.register_parameter("bias", None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # nn.Conv2d defaults: kaiming_uniform(a=sqrt(5)) weight, U(+-1/sqrt(fan_in)) bias
+        fan_in = self.in_channels * self.kernel_size * self.kernel_size
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1.0 / math.sqrt(fan_in)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+
+    def extra_repr(self):
+        return f"{self.in_channels}, {self.out_channels}, k={self.kernel_size}, s={self.stride}, p={self.padding}"
+
+
+class ConvTranspose2x2(nn.Module):
+    """nn.ConvTranspose2d(in, out, kernel_size=2, stride=2, bias=False); weight logical [in, out, 2, 2]."""
+
+    def __init__(self, in_ch, out_ch):
+        super().__init__()
+        self.in_channels, self.out_channels = in_ch, out_ch
+        self.weight = nn.Parameter(ops.new_convT_weight(in_ch, out_ch))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+    def forward(self, x):
+        return ops.conv_transpose2x2(x, self.weight)
+
+
+class InstanceNorm2d(nn.Module):
+    """nn.InstanceNorm2d(C, affine=True): keys ``weight`` / ``bias`` only (no running stats)."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.num_features = channels
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x, slope=None):
+        """``slope`` fuses the following LeakyReLU/ReLU into the same kernel."""
+        return ops.instnorm_act(x, self.weight, self.bias, slope)
+
+
+class Act(nn.Module):
+    """LeakyReLU(slope) / ReLU (slope 0) marker; blocks read ``.slope`` and fuse it into the norm kernel."""
+
+    def __init__(self, slope):
+        super().__init__()
+        self.slope = float(slope)
+
+    def forward(self, x):
+        return ops.leaky_relu(x, self.slope)
+
+
+class Upsample2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) (parameter-free)."""
+
+    def forward(self, x):
+        return ops.bilinear_up2(x)
+
+
+def conv3x3(in_planes, out_planes, stride=1, groups=1, dilation=1):
+    if groups != 1 or dilation != 1:
+        raise NotImplementedError("hot path uses groups=1, dilation=1 only (reference blocks.py:10-12)")
+    return Conv2d(in_planes, out_planes, 3, stride=stride, padding=1, bias=False)
+
+
+def conv1x1(in_planes, out_planes, stride=1):
+    return Conv2d(in_planes, out_planes, 1, stride=stride, padding=0, bias=False)
+
+
+def get_norm(channels, norm_type):
+    if norm_type == "instance":
+        return InstanceNorm2d(channels)
+    if norm_type == "batch":
+        raise NotImplementedError("BatchNorm is outside the MI355X hot path: every reference trainer builds its "
+                                  "networks with norm_type='instance'")
+    raise NotImplementedError
+
+
+def get_act(act_type, inplace=True, negative=1e-2):
+    if act_type == "relu":
+        return Act(0.0)
+    if act_type == "lrelu":
+        return Act(negative)
+    raise NotImplementedError
+
+
+class UpSampleAndConcat(nn.Module):
+    def __init__(self, in_ch, out_ch, transposed=True):
+        super().__init__()
+        if transposed:
+            self.up = ConvTranspose2x2(in_ch, out_ch)
+        else:
+            self.up = nn.Sequential(Upsample2x(), conv1x1(in_ch, out_ch))      # keys: up.1.weight
+
+    def forward(self, x, skip):
+        return ops.concat_channels(self.up(x), skip)
+
+
+class BasicBlock(nn.Module):
+    def __init__(self, in_ch, out_ch, norm, act, **kwargs):
+        super().__init__()
+        self.conv1 = conv3x3(in_ch, out_ch)
+        self.bn1 = get_norm(out_ch, norm)
+        self.relu = get_act(act)
+        self.conv2 = conv3x3(out_ch, out_ch)
+        self.bn2 = get_norm(out_ch, norm)
+        self.downsample = in_ch != out_ch
+        if self.downsample:
+            self.shortcut1 = conv1x1(in_ch, out_ch)
+            self.shortcut2 = get_norm(out_ch, norm)
+
+    def forward(self, x):
+        s = self.relu.slope
+        y = self.bn1(self.conv1(x), slope=s)
+        y = self.bn2(self.conv2(y))
+        idn = self.shortcut2(self.shortcut1(x)) if self.downsample else x
+        return ops.add_act(y, idn, s)
+
+
+class BottleBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, norm_type="batch", act_type="relu", stride=1):
+        super().__init__()
+        assert stride in (1, 2)
+        self.conv1 = conv3x3(in_channels, out_channels)
+        self.bn1 = get_norm(out_channels, norm_type)
+        self.relu = get_act(act_type)
+        self.conv2 = conv3x3(out_channels, out_channels)
+        self.bn2 = get_norm(out_channels, norm_type)
+        self.stride = stride
+        self.downsample = None
+        if in_channels != out_channels:
+            self.downsample = nn.Sequential(conv1x1(in_channels, out_channels), get_norm(out_channels, norm_type))
+
+    def forward(self, x):
+        s = self.relu.slope
+        idn = ops.avg_pool2(x) if self.stride == 2 else x
+        y = self.bn1(self.conv1(x), slope=s)
+        if self.stride == 2:
+            y = ops.avg_pool2(y)
+        y = self.bn2(self.conv2(y))
+        if self.downsample is not None:
+            idn = self.downsample(idn)
+        return ops.add_act(y, idn, s)
+
+
+class Encoder(nn.Module):
+    def __init__(self, in_ch, block, width=32, norm="batch", act="lrelu", **kwargs):
+        super().__init__()
+        self.pre_conv = Conv2d(in_ch, width // 2, 5, stride=1, padding=2, bias=False)
+        self.pre_bn = get_norm(width // 2, norm)
+        self.pre_relu = get_act(act)
+        chans = [width // 2, width, 2 * width, 4 * width, 8 * width, 16 * width]
+        for i in range(1, 6):
+            setattr(self, f"layer{i}", block(chans[i - 1], chans[i], norm, act, **kwargs))
+            if i < 5:
+                setattr(self, f"pool{i}", MaxPool2x2())
+
+    def forward(self, x):
+        skips = []
+        x = self.pre_bn(self.pre_conv(x), slope=self.pre_relu.slope)
+        for i in range(1, 5):
+            x = getattr(self, f"layer{i}")(x)
+            skips.append(x)
+            x = getattr(self, f"pool{i}")(x)
+        return self.layer5(x), skips
+
+
+class MaxPool2x2(nn.Module):
+    """nn.MaxPool2d(2, 2)."""
+
+    def forward(self, x):
+        return ops.max_pool2(x)
+
+
+class Decoder(nn.Module):
+    def __init__(self, out_ch, block, width=32, norm="batch", act="lrelu", **kwargs):
+        super().__init__()
+        for lvl, m in zip((4, 3, 2, 1), (8, 4, 2, 1)):
+            setattr(self, f"up{lvl}", UpSampleAndConcat(2 * m * width, m * width))
+            setattr(self, f"layer{lvl}", block(2 * m * width, m * width, norm, act, **kwargs))
+        self.fc = conv1x1(width, out_ch)
+
+    def forward(self, x, skips):
+        for lvl in (4, 3, 2, 1):
+            x = getattr(self, f"layer{lvl}")(getattr(self, f"up{lvl}")(x, skips[lvl - 1]))
+        return self.fc(x)
+
+
+def init_conv_kaiming(module, nonlinearity):
+    """The reference's post-construction init loop (unet.py:21-27, ugan.py:100-106,145-151,217-223)."""
+    for m in module.modules():
+        if isinstance(m, (Conv2d, ConvTranspose2x2)):
+            nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity=nonlinearity)
+        elif isinstance(m, InstanceNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)

@@ -1,0 +1,16 @@
+"""``UNet`` with the reference's constructor signature (network/unet.py:13-32) on gfx950 kernels."""
+import torch.nn as nn
+
+from .blocks import BasicBlock, Decoder, Encoder, init_conv_kaiming
+
+
+class UNet(nn.Module):
+    def __init__(self, in_ch, out_ch, base_width=64, norm_type="batch", act_type="relu"):
+        super().__init__()
+        self.encoder = Encoder(in_ch, BasicBlock, base_width, norm=norm_type, act=act_type)
+        self.decoder = Decoder(out_ch, BasicBlock, base_width, norm=norm_type, act=act_type)
+        init_conv_kaiming(self, "relu" if act_type == "relu" else "leaky_relu")
+
+    def forward(self, x):
+        x, skips = self.encoder(x)
+        return self.decoder(x, skips)

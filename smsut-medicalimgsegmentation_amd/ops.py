@@ -1,0 +1,856 @@
+"""autograd plumbing over the HIP C-ABI (``_hip.py``): one ``torch.autograd.Function`` per kernel family.
+
+Memory conventions (what the kernels see):
+  * activations: logical NCHW tensors whose memory is dense NHWC (``torch.channels_last``);
+  * conv / linear weights: logical OIHW (the reference's ``state_dict`` shapes) whose memory is
+    ``[KH][KW][Cin][Cout]`` -- a permuted *view*, so checkpoints keep the reference's keys and shapes
+    while the kernels read coalesced ``Cout``-contiguous rows;
+  * ConvTranspose2d weights: logical ``[Cin, Cout, 2, 2]``, memory ``[kh][kw][Cout][Cin]`` (the HWIO
+    layout of the k2/s2 conv whose data-gradient the transposed conv is).
+
+Every family on the discriminator path is closed under differentiation (its ``backward`` is written
+with other differentiable Functions), because WGAN-GP differentiates D's backward again
+(reference trainer/uganShp0Trainer.py:127-134, ``create_graph=True``).
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _hip as H
+
+IN_EPS = 1e-5
+
+_INPUT_GRADS_ONLY = False
+
+
+@contextlib.contextmanager
+def input_grads_only():
+    """Inside this context the backward of conv / norm skips parameter gradients.  Used around the
+    WGAN-GP ``autograd.grad(out_src, x_hat, create_graph=True)`` call, which needs d/dx only."""
+    global _INPUT_GRADS_ONLY
+    prev, _INPUT_GRADS_ONLY = _INPUT_GRADS_ONLY, True
+    try:
+        yield
+    finally:
+        _INPUT_GRADS_ONLY = prev
+
+
+# ------------------------------------------------------------------------------------------- layout helpers
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Return ``x`` (logical NCHW, fp32) with dense NHWC memory."""
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got {tuple(x.shape)}")
+    if x.dtype != torch.float32:
+        raise TypeError("SMSUT HIP ops compute in fp32")
+    n, c, h, w = x.shape
+    want = (h * w * c, 1, w * c, c)
+    st = x.stride()
+    if all(x.size(d) == 1 or st[d] == want[d] for d in range(4)):
+        return x
+    out = torch.empty_strided((n, c, h, w), want, dtype=x.dtype, device=x.device)
+    out.copy_(x)
+    return out
+
+
+def new_act(n, c, h, w, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty_strided((n, c, h, w), (h * w * c, 1, w * c, c), dtype=torch.float32, device=like.device)
+
+
+def hwio_strides(o, i, kh, kw):
+    return (1, o, kw * i * o, i * o)
+
+
+def hwio(w: torch.Tensor) -> torch.Tensor:
+    """Logical OIHW weight with [KH][KW][I][O] memory (a no-op for parameters created by ``new_weight``)."""
+    o, i, kh, kw = w.shape
+    want = hwio_strides(o, i, kh, kw)
+    st = w.stride()
+    if all(w.size(d) == 1 or st[d] == want[d] for d in range(4)):
+        return w
+    out = torch.empty_strided((o, i, kh, kw), want, dtype=w.dtype, device=w.device)
+    out.copy_(w)
+    return out
+
+
+def new_weight(o, i, kh, kw, device=None) -> torch.Tensor:
+    return torch.empty_strided((o, i, kh, kw), hwio_strides(o, i, kh, kw), dtype=torch.float32, device=device)
+
+
+def convT_strides(ci, co, kh, kw):
+    # memory [kh][kw][co][ci]
+    return (1, ci, kw * co * ci, co * ci)
+
+
+def new_convT_weight(ci, co, kh=2, kw=2, device=None) -> torch.Tensor:
+    return torch.empty_strided((ci, co, kh, kw), convT_strides(ci, co, kh, kw), dtype=torch.float32, device=device)
+
+
+def convT_w(w: torch.Tensor) -> torch.Tensor:
+    ci, co, kh, kw = w.shape
+    want = convT_strides(ci, co, kh, kw)
+    st = w.stride()
+    if all(w.size(d) == 1 or st[d] == want[d] for d in range(4)):
+        return w
+    out = torch.empty_strided(tuple(w.shape), want, dtype=w.dtype, device=w.device)
+    out.copy_(w)
+    return out
+
+
+def new_linear_weight(out_f, in_f, device=None) -> torch.Tensor:
+    """Logical [out, in] with [in][out] memory == HWIO of a 1x1 conv."""
+    return torch.empty_strided((out_f, in_f), (1, out_f), dtype=torch.float32, device=device)
+
+
+def _ws(numel: int, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(max(int(numel), 1), dtype=torch.float32, device=like.device)
+
+
+def _s():
+    return H.stream_ptr()
+
+
+# ------------------------------------------------------------------------------------------- convolution
+def _out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def _conv_fwd_launch(x, w, bias, stride, pad):
+    n, ci, h, wd = x.shape
+    co, ci2, kh, kw = w.shape
+    assert ci == ci2, f"conv: Cin mismatch {ci} vs {ci2}"
+    ho, wo = _out_size(h, kh, stride, pad), _out_size(wd, kw, stride, pad)
+    y = new_act(n, co, ho, wo, x)
+    H.call("smsut_conv2d_fwd_generic", x, w, bias, y, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
+    return y
+
+
+def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
+    n, co, ho, wo = gy.shape
+    co2, ci, kh, kw = w.shape
+    assert co == co2
+    gx = new_act(n, ci, h, wd, gy)
+    H.call("smsut_conv2d_dgrad_generic", gy, w, gx, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
+    return gx
+
+
+def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
+    n, ci, h, wd = x.shape
+    _, co, ho, wo = gy.shape
+    gw = new_weight(co, ci, kh, kw, device=x.device)
+    ws = _ws(H.call("smsut_conv2d_wgrad_generic_ws", n, ho, wo, ci, co, kh, kw), x)
+    H.call("smsut_conv2d_wgrad_generic", x, gy, gw, ws, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
+    return gw
+
+
+class Conv2dFn(Function):
+    """y = conv2d(x, w) (+ bias).  Reference: nn.Conv2d uses at network/blocks.py:10-16,123; ugan.py:70,202,214-215."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad):
+        x, w = nhwc(x), hwio(w)
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.geom = (stride, pad)
+        return _conv_fwd_launch(x, w, bias, stride, pad)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.geom
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = Conv2dDgradFn.apply(gy, w, x.shape[2], x.shape[3], stride, pad)
+        if not _INPUT_GRADS_ONLY:
+            if ctx.needs_input_grad[1]:
+                gw = Conv2dWgradFn.apply(x, gy, w.shape[2], w.shape[3], stride, pad)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = SumPerChannelFn.apply(gy)
+        return gx, gw, gb, None, None
+
+
+class Conv2dDgradFn(Function):
+    """gx = conv2d_backward_data(gy, w); bilinear in (gy, w) so its backward is a conv and a wgrad."""
+
+    @staticmethod
+    def forward(ctx, gy, w, h, wd, stride, pad):
+        gy, w = nhwc(gy), hwio(w)
+        ctx.save_for_backward(gy, w)
+        ctx.geom = (h, wd, stride, pad)
+        return _conv_dgrad_launch(gy, w, h, wd, stride, pad)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        h, wd, stride, pad = ctx.geom
+        d_gy = d_w = None
+        if ctx.needs_input_grad[0]:
+            d_gy = Conv2dFn.apply(ggx, w, None, stride, pad)
+        if ctx.needs_input_grad[1]:
+            d_w = Conv2dWgradFn.apply(ggx, gy, w.shape[2], w.shape[3], stride, pad)
+        return d_gy, d_w, None, None, None, None
+
+
+class Conv2dWgradFn(Function):
+    """gw = conv2d_backward_weight(x, gy); bilinear in (x, gy)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, kh, kw, stride, pad):
+        x, gy = nhwc(x), nhwc(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.geom = (kh, kw, stride, pad)
+        return _conv_wgrad_launch(x, gy, kh, kw, stride, pad)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        kh, kw, stride, pad = ctx.geom
+        d_x = d_gy = None
+        if ctx.needs_input_grad[0]:
+            d_x = Conv2dDgradFn.apply(gy, ggw, x.shape[2], x.shape[3], stride, pad)
+        if ctx.needs_input_grad[1]:
+            d_gy = Conv2dFn.apply(x, ggw, None, stride, pad)
+        return d_x, d_gy, None, None, None, None
+
+
+class SumPerChannelFn(Function):
+    """out[c] = sum_{n,h,w} x[n,c,h,w]  (bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        ctx.shape = (n, c, h, w)
+        out = torch.empty(c, dtype=torch.float32, device=x.device)
+        rows = n * h * w
+        H.call("smsut_colsum", x, out, _ws(H.call("smsut_colsum_ws", rows, c), x), rows, c, _s())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        return BroadcastChannelFn.apply(g, n, h, w)
+
+
+class BroadcastChannelFn(Function):
+    """out[n,c,h,w] = v[c]  (adjoint of SumPerChannelFn)."""
+
+    @staticmethod
+    def forward(ctx, v, n, h, w):
+        c = v.numel()
+        y = new_act(n, c, h, w, v)
+        H.call("smsut_fill", y, 0.0, y.numel(), _s())
+        H.call("smsut_bias_add", y, v.contiguous(), y, n * h * w, c, _s())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return SumPerChannelFn.apply(g), None, None, None
+
+
+def cl(x):
+    """Autograd-tracked conversion to NHWC memory (a no-op for tensors produced by these ops)."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def conv2d(x, w, bias=None, stride=1, pad=0):
+    return Conv2dFn.apply(cl(x), w, bias, stride, pad)
+
+
+class ConvT2x2Fn(Function):
+    """ConvTranspose2d(k=2, s=2, bias=False) (network/blocks.py:41) == data-gradient of a k2/s2/p0 conv."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = nhwc(x), convT_w(w)
+        n, ci, h, wd = x.shape
+        ci2, co, kh, kw = w.shape
+        assert ci == ci2 and kh == 2 and kw == 2
+        ctx.save_for_backward(x, w)
+        y = new_act(n, co, 2 * h, 2 * wd, x)
+        # as the conv: Cin_conv = co, Cout_conv = ci, "gy" = x, "gx" = y
+        H.call("smsut_conv2d_dgrad_generic", x, w, y, n, 2 * h, 2 * wd, co, h, wd, ci, 2, 2, 2, 0, _s())
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = nhwc(gy)
+        n, ci, h, wd = x.shape
+        co = w.shape[1]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = new_act(n, ci, h, wd, x)
+            H.call("smsut_conv2d_fwd_generic", gy, w, None, gx, n, 2 * h, 2 * wd, co, h, wd, ci, 2, 2, 2, 0, _s())
+        if ctx.needs_input_grad[1]:
+            gw = new_convT_weight(ci, co, 2, 2, device=x.device)
+            ws = _ws(H.call("smsut_conv2d_wgrad_generic_ws", n, h, wd, co, ci, 2, 2), x)
+            H.call("smsut_conv2d_wgrad_generic", gy, x, gw, ws, n, 2 * h, 2 * wd, co, h, wd, ci, 2, 2, 2, 0, _s())
+        return gx, gw
+
+
+def conv_transpose2x2(x, w):
+    return ConvT2x2Fn.apply(x, w)
+
+
+def linear(x2d, w, bias):
+    """nn.Linear on [P, in] rows as a 1x1 conv over P 'images' of 1x1 pixels (network/ugan.py:295)."""
+    p, cin = x2d.shape
+    y = conv2d(x2d.reshape(p, cin, 1, 1), w.view(w.shape[0], w.shape[1], 1, 1), bias)
+    return y.reshape(p, -1)
+
+
+# ------------------------------------------------------------------------------------------- instance norm (+act)
+class InstNormActFn(Function):
+    """y = act(InstanceNorm(x) * gamma + beta); act = LeakyReLU(slope) or identity (network/blocks.py:19-32)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope, has_act):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, h, w, x)
+        mean = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        chunks = H.call("smsut_in_chunks", n, h * w, c)
+        H.call("smsut_instnorm_fwd", x, gamma, beta, y, mean, rstd, _ws(n * chunks * c * 3, x), n, h * w, c,
+               IN_EPS, float(slope), int(has_act), _s())
+        ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.cfg = (float(slope), bool(has_act))
+        ctx.mark_non_differentiable(mean, rstd)
+        return y, mean, rstd
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gr):
+        x, y, mean, rstd, gamma = ctx.saved_tensors
+        slope, has_act = ctx.cfg
+        want_affine = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRADS_ONLY
+        gx, gg, gb = InstNormActBwdFn.apply(gy, x, y, mean, rstd, gamma, slope, has_act, want_affine)
+        if not want_affine:
+            gg = gb = None
+        return gx, gg, gb, None, None
+
+
+class InstNormActBwdFn(Function):
+    """(gx, ggamma, gbeta) of InstNormActFn; its own backward is the closed-form second derivative
+    (csrc/norm.hip header) needed by the gradient penalty."""
+
+    @staticmethod
+    def forward(ctx, gy, x, y, mean, rstd, gamma, slope, has_act, want_affine):
+        gy = nhwc(gy)
+        n, c, h, w = x.shape
+        gx = new_act(n, c, h, w, x)
+        a = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        b = torch.empty_like(a)
+        gg = torch.empty(c, dtype=torch.float32, device=x.device)
+        gb = torch.empty_like(gg)
+        chunks = H.call("smsut_in_chunks", n, h * w, c)
+        H.call("smsut_instnorm_bwd", gy, x, y if has_act else None, mean, rstd, gamma, gx, a, b,
+               gg if want_affine else None, gb if want_affine else None, _ws(n * chunks * c * 3, x),
+               n, h * w, c, slope, _s())
+        ctx.save_for_backward(gy, x, y, mean, rstd, gamma, a, b)
+        ctx.cfg = (slope, has_act, want_affine)
+        return gx, gg, gb
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, v, ug, ub):
+        gy, x, y, mean, rstd, gamma, a, b = ctx.saved_tensors
+        slope, has_act, want_affine = ctx.cfg
+        v = nhwc(v)
+        n, c, h, w = x.shape
+        d_gy = new_act(n, c, h, w, x)
+        d_x = new_act(n, c, h, w, x)
+        d_gamma = torch.empty(c, dtype=torch.float32, device=x.device)
+        chunks = H.call("smsut_in_chunks", n, h * w, c)
+        if not want_affine:
+            ug = ub = None
+        H.call("smsut_instnorm_bwd2", v, ug, ub, gy, x, y if has_act else None, mean, rstd, gamma, a, b,
+               d_gy, d_x, d_gamma, _ws(n * chunks * c * 3, x), _ws(3 * n * c, x), n, h * w, c, slope, _s())
+        return d_gy, d_x, None, None, None, d_gamma, None, None, None
+
+
+def instnorm_act(x, gamma, beta, slope: Optional[float]):
+    """slope=None -> no activation."""
+    y, _, _ = InstNormActFn.apply(cl(x), gamma, beta, 0.0 if slope is None else slope, slope is not None)
+    return y
+
+
+# ------------------------------------------------------------------------------------------- activations / add
+class AddActFn(Function):
+    """y = LeakyReLU(a + b) (residual tail, network/blocks.py:78-79); b may be None."""
+
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        a = nhwc(a)
+        if b is not None:
+            b = nhwc(b)
+            assert a.shape == b.shape
+        y = new_act(*a.shape, a)
+        H.call("smsut_add_act", a, b, y, a.numel(), float(slope), _s())
+        ctx.save_for_backward(y)
+        ctx.slope = float(slope)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        g = ActBwdFn.apply(gy, y, ctx.slope)
+        return g, (g if ctx.has_b else None), None
+
+
+class ActBwdFn(Function):
+    """gx = gy * LeakyReLU'(y); linear in gy, so it is its own derivative."""
+
+    @staticmethod
+    def forward(ctx, gy, y, slope):
+        gy = nhwc(gy)
+        gx = new_act(*y.shape, y)
+        H.call("smsut_act_bwd", gy, y, gx, y.numel(), slope, _s())
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return gx
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return ActBwdFn.apply(gg, y, ctx.slope), None, None
+
+
+def add_act(a, b, slope):
+    return AddActFn.apply(cl(a), cl(b), slope)
+
+
+def leaky_relu(x, slope):
+    return AddActFn.apply(cl(x), None, slope)
+
+
+class TanhFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        y = new_act(*x.shape, x)
+        H.call("smsut_tanh_fwd", x, y, x.numel(), _s())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        gy = nhwc(gy)
+        gx = new_act(*y.shape, y)
+        H.call("smsut_tanh_bwd", gy, y, gx, y.numel(), _s())
+        return gx
+
+
+def tanh(x):
+    return TanhFn.apply(x)
+
+
+# ------------------------------------------------------------------------------------------- pooling / resampling
+class MaxPool2Fn(Function):
+    """nn.MaxPool2d(2, 2) (network/blocks.py:128-134)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, h // 2, w // 2, x)
+        H.call("smsut_maxpool2_fwd", x, y, n, h, w, c, _s())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = nhwc(gy)
+        n, c, h, w = x.shape
+        gx = new_act(n, c, h, w, x)
+        H.call("smsut_maxpool2_bwd", gy, x, gx, n, h, w, c, _s())
+        return gx
+
+
+class AvgPool2Fn(Function):
+    """F.avg_pool2d(x, 2) (network/blocks.py:101,107,112); linear, closed with AvgPool2BwdFn."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, h // 2, w // 2, x)
+        H.call("smsut_avgpool2_fwd", x, y, n, h, w, c, _s())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return AvgPool2BwdFn.apply(gy)
+
+
+class AvgPool2BwdFn(Function):
+    @staticmethod
+    def forward(ctx, gy):
+        gy = nhwc(gy)
+        n, c, ho, wo = gy.shape
+        gx = new_act(n, c, 2 * ho, 2 * wo, gy)
+        H.call("smsut_avgpool2_bwd", gy, gx, n, 2 * ho, 2 * wo, c, _s())
+        return gx
+
+    @staticmethod
+    def backward(ctx, gg):
+        return AvgPool2Fn.apply(gg)
+
+
+class Bilinear2Fn(Function):
+    """nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False) (network/blocks.py:44)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, 2 * h, 2 * w, x)
+        H.call("smsut_bilinear2_fwd", x, y, n, h, w, c, _s())
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = nhwc(gy)
+        n, c, ho, wo = gy.shape
+        gx = new_act(n, c, ho // 2, wo // 2, gy)
+        H.call("smsut_bilinear2_bwd", gy, gx, n, ho // 2, wo // 2, c, _s())
+        return gx
+
+
+def max_pool2(x):
+    return MaxPool2Fn.apply(x)
+
+
+def avg_pool2(x):
+    return AvgPool2Fn.apply(cl(x))
+
+
+def bilinear_up2(x):
+    return Bilinear2Fn.apply(x)
+
+
+class ConcatFn(Function):
+    """torch.cat([a, b], dim=1) (network/blocks.py:50) on NHWC memory."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = nhwc(a), nhwc(b)
+        n, ca, h, w = a.shape
+        cb = b.shape[1]
+        assert b.shape[0] == n and b.shape[2:] == a.shape[2:]
+        y = new_act(n, ca + cb, h, w, a)
+        p = n * h * w
+        H.call("smsut_copy_channels", a, ca, 0, y, ca + cb, 0, ca, p, _s())
+        H.call("smsut_copy_channels", b, cb, 0, y, ca + cb, ca, cb, p, _s())
+        ctx.split = (ca, cb)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = nhwc(gy)
+        ca, cb = ctx.split
+        n, _, h, w = gy.shape
+        p = n * h * w
+        ga = gb = None
+        if ctx.needs_input_grad[0]:
+            ga = new_act(n, ca, h, w, gy)
+            H.call("smsut_copy_channels", gy, ca + cb, 0, ga, ca, 0, ca, p, _s())
+        if ctx.needs_input_grad[1]:
+            gb = new_act(n, cb, h, w, gy)
+            H.call("smsut_copy_channels", gy, ca + cb, ca, gb, cb, 0, cb, p, _s())
+        return ga, gb
+
+
+def concat_channels(a, b):
+    return ConcatFn.apply(a, b)
+
+
+class ModalPlanesFn(Function):
+    """cat([x, m.view(B,n,1,1).repeat(1,1,H,W)], 1) (network/ugan.py:156-159)."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        x = nhwc(x)
+        n, cx, h, w = x.shape
+        m = m.to(torch.float32).contiguous()
+        nm = m.shape[1]
+        y = new_act(n, cx + nm, h, w, x)
+        H.call("smsut_modal_planes", x, m, y, n, h * w, cx, nm, _s())
+        ctx.dims = (cx, nm)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = nhwc(gy)
+        cx, nm = ctx.dims
+        n, _, h, w = gy.shape
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = new_act(n, cx, h, w, gy)
+            H.call("smsut_copy_channels", gy, cx + nm, 0, gx, cx, 0, cx, n * h * w, _s())
+        return gx, None
+
+
+def modal_planes(x, m):
+    return ModalPlanesFn.apply(x, m)
+
+
+# ------------------------------------------------------------------------------------------- losses
+class DiceCEFn(Function):
+    """weight_dc * SoftDice + weight_ce * CE on logits [N,C,H,W] / int64 labels [N,H,W] (misc/loss.py:8-63).
+
+    ``group``: optional torch.distributed process group; when given, the Dice statistics and the CE sum
+    are all-reduced so the loss equals the single-process global-batch value."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, w_ce, w_dc, batch_dice, group):
+        logits = nhwc(logits)
+        n, c, h, w = logits.shape
+        labels = labels.contiguous()
+        if labels.dtype != torch.int64:
+            raise TypeError("labels must be int64")
+        g = 1 if batch_dice else n
+        stats = torch.empty(g, c, 3, dtype=torch.float32, device=logits.device)
+        ce_sum = torch.empty(1, dtype=torch.float32, device=logits.device)
+        H.call("smsut_dicece_stats", logits, labels, stats, ce_sum, _ws(H.call("smsut_dicece_ws", n, h * w, c, g), logits),
+               n, h * w, c, g, _s())
+        npix = float(n * h * w)
+        if group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+            if batch_dice:
+                dist.all_reduce(stats, group=group)
+            dist.all_reduce(ce_sum, group=group)
+            npix *= world
+        out = torch.empty(3, dtype=torch.float32, device=logits.device)
+        H.call("smsut_dicece_final", stats, ce_sum, out, g, c, npix, float(w_dc), float(w_ce), _s())
+        ctx.save_for_backward(logits, labels, stats)
+        ctx.cfg = (g, npix, float(w_dc), float(w_ce))
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        logits, labels, stats = ctx.saved_tensors
+        g, npix, w_dc, w_ce = ctx.cfg
+        n, c, h, w = logits.shape
+        gl = new_act(n, c, h, w, logits)
+        H.call("smsut_dicece_bwd", logits, labels, stats, gout.contiguous(), gl, n, h * w, c, g, npix, w_dc, w_ce, _s())
+        return gl, None, None, None, None, None
+
+
+def dice_ce(logits, labels, weight_ce=1.0, weight_dc=1.0, batch_dice=False, group=None):
+    return DiceCEFn.apply(logits, labels, weight_ce, weight_dc, batch_dice, group)
+
+
+class ScaledSumFn(Function):
+    """out = scale * sum(x): the WGAN terms -/+mean(out_src) (uganConsisTrainer.py:130,136,154)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous() if x.dim() != 4 else nhwc(x)
+        out = torch.empty(1, dtype=torch.float32, device=x.device)
+        n = x.numel()
+        H.call("smsut_sum", x, out, _ws(H.call("smsut_sum_ws", n, 1), x), n, float(scale), _s())
+        ctx.meta = (x.shape, x.stride(), float(scale))
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        shape, stride, scale = ctx.meta
+        gx = torch.empty_strided(shape, stride, dtype=torch.float32, device=gout.device)
+        H.call("smsut_fill", gx, 1.0, gx.numel(), _s())
+        out = torch.empty_strided(shape, stride, dtype=torch.float32, device=gout.device)
+        H.call("smsut_scale", gx, gout.contiguous(), scale, out, gx.numel(), _s())
+        return out, None
+
+
+def mean_all(x, sign=1.0):
+    return ScaledSumFn.apply(x, sign / x.numel())
+
+
+class L1MeanFn(Function):
+    """mean(|a - b|) (uganConsisTrainer.py:162)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = nhwc(a), nhwc(b)
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        n = a.numel()
+        H.call("smsut_l1_fwd", a, b, out, _ws(H.call("smsut_sum_ws", n, 1), a), n, _s())
+        ctx.save_for_backward(a, b)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        ga = new_act(*a.shape, a) if ctx.needs_input_grad[0] else None
+        gb = new_act(*b.shape, b) if ctx.needs_input_grad[1] else None
+        if ga is not None or gb is not None:
+            H.call("smsut_l1_bwd", a, b, gout.contiguous(), ga, gb, a.numel(), _s())
+        return ga, gb
+
+
+def l1_mean(a, b):
+    return L1MeanFn.apply(a, b)
+
+
+class CERowsFn(Function):
+    """F.cross_entropy(logits[B,C], target[B]) (modality classification, uganConsisTrainer.py:131,155)."""
+
+    @staticmethod
+    def forward(ctx, z, tgt):
+        z = z.contiguous()
+        tgt = tgt.contiguous().to(torch.int64)
+        out = torch.empty(1, dtype=torch.float32, device=z.device)
+        H.call("smsut_ce_rows_fwd", z, tgt, out, z.shape[0], z.shape[1], _s())
+        ctx.save_for_backward(z, tgt)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        z, tgt = ctx.saved_tensors
+        gz = torch.empty_like(z)
+        H.call("smsut_ce_rows_bwd", z, tgt, gout.contiguous(), gz, z.shape[0], z.shape[1], _s())
+        return gz, None
+
+
+def cross_entropy_rows(z, tgt):
+    return CERowsFn.apply(z, tgt)
+
+
+class GradPenaltyFn(Function):
+    """mean((||dydx_b||_2 - 1)^2) over samples (uganShp0Trainer.py:131-134)."""
+
+    @staticmethod
+    def forward(ctx, dydx):
+        d = nhwc(dydx) if dydx.dim() == 4 else dydx.contiguous()
+        rows = d.shape[0]
+        n = d.numel() // rows
+        out = torch.empty(1, dtype=torch.float32, device=d.device)
+        norms = torch.empty(rows, dtype=torch.float32, device=d.device)
+        H.call("smsut_gp_fwd", d, out, norms, _ws(H.call("smsut_sum_ws", n, rows), d), rows, n, _s())
+        ctx.save_for_backward(d, norms)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        d, norms = ctx.saved_tensors
+        rows = d.shape[0]
+        g = torch.empty_strided(d.shape, d.stride(), dtype=torch.float32, device=d.device)
+        H.call("smsut_gp_bwd", d, norms, gout.contiguous(), g, rows, d.numel() // rows, _s())
+        return g
+
+
+def grad_penalty(dydx):
+    return GradPenaltyFn.apply(dydx)
+
+
+class GatherPatchesFn(Function):
+    """feat.permute(0,2,3,1).flatten(1,2)[:, ids, :].flatten(0,1) (network/ugan.py:318-327)."""
+
+    @staticmethod
+    def forward(ctx, feat, ids):
+        feat = nhwc(feat)
+        n, c, h, w = feat.shape
+        ids = ids.contiguous().to(torch.int64)
+        p = ids.numel()
+        out = torch.empty(n * p, c, dtype=torch.float32, device=feat.device)
+        H.call("smsut_gather_rows", feat, ids, out, n, h * w, c, p, _s())
+        ctx.save_for_backward(ids)
+        ctx.shape = (n, c, h, w)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        (ids,) = ctx.saved_tensors
+        n, c, h, w = ctx.shape
+        gfeat = new_act(n, c, h, w, gout)
+        H.call("smsut_scatter_rows", gout.contiguous(), ids, gfeat, n, h * w, c, ids.numel(), _s())
+        return gfeat, None
+
+
+def gather_patches(feat, ids):
+    return GatherPatchesFn.apply(feat, ids)
+
+
+class L2NormFn(Function):
+    """x / (||x||_2 + 1e-7) per row (network/networks.py:234-243)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        norms = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        H.call("smsut_l2norm_fwd", x, y, norms, x.shape[0], x.shape[1], _s())
+        ctx.save_for_backward(x, norms)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, norms = ctx.saved_tensors
+        gx = torch.empty_like(x)
+        H.call("smsut_l2norm_bwd", gy.contiguous(), x, norms, gx, x.shape[0], x.shape[1], _s())
+        return gx
+
+
+def l2_normalize(x):
+    return L2NormFn.apply(x)
+
+
+class PatchNCEFn(Function):
+    """Per-row PatchNCE loss (network/patchnce.py:13-51); ``k`` is detached as in the reference (:16)."""
+
+    @staticmethod
+    def forward(ctx, q, k, npatches, T):
+        q, k = q.contiguous(), k.detach().contiguous()
+        rows, dim = q.shape
+        loss = torch.empty(rows, dtype=torch.float32, device=q.device)
+        probs = torch.empty(rows, npatches + 1, dtype=torch.float32, device=q.device)
+        H.call("smsut_patchnce_fwd", q, k, loss, probs, rows, npatches, dim, float(T), _s())
+        ctx.save_for_backward(probs, k)
+        ctx.cfg = (npatches, float(T))
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gloss):
+        probs, k = ctx.saved_tensors
+        npatches, T = ctx.cfg
+        rows, dim = k.shape
+        gq = torch.empty(rows, dim, dtype=torch.float32, device=k.device)
+        H.call("smsut_patchnce_bwd", gloss.contiguous(), probs, k, gq, rows, npatches, dim, T, _s())
+        return gq, None, None, None
+
+
+def patch_nce(q, k, npatches, T=0.07):
+    return PatchNCEFn.apply(q, k, npatches, T)
+
+
+def row_lerp(a, b, alpha):
+    """alpha*a + (1-alpha)*b with one alpha per sample (x_hat of WGAN-GP, uganConsisTrainer.py:138-139); no grad."""
+    a, b = nhwc(a.detach()), nhwc(b.detach())
+    out = new_act(*a.shape, a)
+    rows = a.shape[0]
+    H.call("smsut_row_lerp", a, b, alpha.detach().reshape(-1).contiguous().to(torch.float32), out, rows,
+           a.numel() // rows, _s())
+    return out

@@ -1,0 +1,130 @@
+"""Module-level parity on the GPU: HIP modules vs the CPU oracle on the same seeded inputs and vs the
+committed golden fixtures (generated from the reference).  north_star tolerance: 1e-3 relative fp32 for
+logits / translated images / loss values; gradients are checked in l2-relative terms."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, l2_rel
+from oracle import recipe, smsut_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import smsut_amd
+    assert torch.cuda.is_available()
+    return smsut_amd
+
+
+def test_unet_small_vs_golden_and_oracle(pkg, golden):
+    from smsut_amd.network.unet import UNet
+    from smsut_amd.misc.loss import DiceAndCrossEntropyLoss
+    g = golden("unet_small")
+    ncls, w, seed = int(g["ncls"]), int(g["w"]), int(g["seed"])
+    net = UNet(1, ncls, w, norm_type="instance", act_type="lrelu")
+    net.load_state_dict(recipe.fill(recipe.unet_shapes(1, ncls, w), seed))
+    net.cuda().train()
+    x, y = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["y"]).cuda()
+    crit = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    out = net(x)
+    assert out.shape == (int(g["B"]), ncls, int(g["H"]), int(g["H"]))
+    assert rel_err(out.detach().cpu().numpy(), g["logits"]) < TOL
+    loss = crit(out, y)
+    assert abs(loss.item() - g["losses"][0]) < TOL * abs(g["losses"][0])
+    opt.zero_grad(); loss.backward()
+    grads = dict(net.named_parameters())
+    for n, ref in zip([str(n) for n in g["grad_names"]], g["grad_l2"]):
+        got = float(grads[n].grad.double().norm())
+        assert abs(got - ref) <= 5e-3 * ref + 1e-7, (n, got, ref)
+    for k in g.files:
+        if k.startswith("grad::"):
+            assert l2_rel(grads[k[6:]].grad.cpu().numpy(), g[k]) < 5e-3, k
+    opt.step()
+    loss1 = crit(net(x), y)
+    assert abs(loss1.item() - g["losses"][1]) < TOL * abs(g["losses"][1])
+
+
+def test_unet_relu_variant(pkg, golden):
+    from smsut_amd.network.unet import UNet
+    g = golden("unet_relu")
+    net = UNet(1, int(g["ncls"]), int(g["w"]), norm_type="instance", act_type="relu")
+    net.load_state_dict(recipe.fill(recipe.unet_shapes(1, int(g["ncls"]), int(g["w"])), int(g["seed"])))
+    out = net.cuda()(torch.from_numpy(g["x"]).cuda())
+    assert rel_err(out.detach().cpu().numpy(), g["logits"]) < TOL
+
+
+def test_unet_256_full_size(pkg, golden):
+    from smsut_amd.network.unet import UNet
+    from smsut_amd.misc.loss import DiceAndCrossEntropyLoss
+    g = golden("unet_256")
+    seed = int(g["seed"])
+    net = UNet(1, 5, 16, norm_type="instance", act_type="lrelu")
+    net.load_state_dict(recipe.fill(recipe.unet_shapes(1, 5, 16), seed))
+    net.cuda()
+    x = recipe.synth_images((1, 1, 256, 256), seed + 1).cuda()
+    y = recipe.synth_labels(1, 256, 256, 5, seed + 2).cuda()
+    out = net(x)
+    assert rel_err(out[:, :, ::8, ::8].detach().cpu().numpy(), g["logits_s8"]) < TOL
+    loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y)
+    assert abs(loss.item() - float(g["loss"])) < TOL * float(g["loss"])
+    loss.backward()
+    grads = dict(net.named_parameters())
+    for n, ref in zip([str(n) for n in g["grad_names"]], g["grad_l2"]):
+        got = float(grads[n].grad.double().norm())
+        assert abs(got - ref) <= 1e-2 * ref + 1e-7, (n, got, ref)
+
+
+def test_discriminator_and_gradient_penalty(pkg, golden):
+    from smsut_amd.network.ugan import Discriminator
+    from smsut_amd import ops
+    g = golden("disc_small")
+    B, S, nm, w, mw = (int(g[k]) for k in ("B", "S", "nm", "w", "mw"))
+    D = Discriminator(S, nm, w, max_width=mw)
+    D.load_state_dict(recipe.fill(recipe.disc_shapes(S, nm, w, mw), int(g["seed"])))
+    D.cuda().train()
+    x, xf, alpha = (torch.from_numpy(g[k]).cuda() for k in ("x", "xf", "alpha"))
+    src, cls = D(x)
+    assert rel_err(src.detach().cpu().numpy(), g["out_src"]) < TOL
+    assert rel_err(cls.detach().cpu().numpy(), g["out_cls"]) < TOL
+    d_real = ops.mean_all(src, -1.0)
+    d_cls = ops.cross_entropy_rows(cls, torch.from_numpy(g["modal"]).cuda())
+    d_fake = ops.mean_all(D(xf)[0], 1.0)
+    x_hat = ops.row_lerp(x, xf, alpha).requires_grad_(True)
+    src_h, _ = D(x_hat)
+    with ops.input_grads_only():
+        (dydx,) = torch.autograd.grad(src_h, x_hat, torch.ones_like(src_h), retain_graph=True, create_graph=True)
+    assert rel_err(dydx.detach().cpu().numpy(), g["dydx"]) < TOL
+    gp = ops.grad_penalty(dydx)
+    got = np.array([d_real.item(), d_fake.item(), d_cls.item(), gp.item()])
+    assert np.allclose(got, g["scalars"], rtol=TOL, atol=1e-6), (got, g["scalars"])
+    (d_real + d_fake + d_cls + 10.0 * gp).backward()
+    grads = dict(D.named_parameters())
+    for n, ref in zip([str(n) for n in g["grad_names"]], g["grad_l2"]):
+        got = float(grads[n].grad.double().norm())
+        assert abs(got - ref) <= 5e-3 * ref + 1e-6, (n, got, ref)
+    for k in g.files:
+        if k.startswith("grad::"):
+            assert l2_rel(grads[k[6:]].grad.cpu().numpy(), g[k]) < 5e-3, k
+
+
+def test_ugannce_forward(pkg, golden):
+    from smsut_amd.network.ugan import UGANnce
+    g = golden("ugan_small")
+    G = UGANnce(1, 5, 4, 16)
+    G.load_state_dict(recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), int(g["seed"])))
+    G.cuda().train()
+    x, m, ids = torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["m"]).cuda(), torch.from_numpy(g["ids"]).cuda()
+    seg, tsl, feats, rid = G(x, m, sample_ids=[ids])
+    assert rel_err(seg.detach().cpu().numpy(), g["seg"]) < TOL
+    assert rel_err(tsl.detach().cpu().numpy(), g["tsl"]) < TOL
+    assert rel_err(feats[0].detach().cpu().numpy(), g["feat"]) < TOL
+    seg_v, tsl_v = G(x, val_phase=True)
+    assert rel_err(seg_v.detach().cpu().numpy(), g["seg_val"]) < TOL
+    assert rel_err(tsl_v.detach().cpu().numpy(), g["tsl_val"]) < TOL
+    # random patch ids path: 16 positions at 64x64 input -> all 16 sampled once
+    _, _, f2, ids2 = G(x, m)
+    assert f2[0].shape == (4 * 16, 256) and sorted(ids2[0].tolist()) == list(range(16))

@@ -1,0 +1,245 @@
+"""Op-level parity of every HIP kernel family (called through the C-ABI) against plain PyTorch fp32/fp64 on CPU."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import smsut_amd
+    from smsut_amd import ops as o
+    assert torch.cuda.is_available(), "gpu tests need an MI355X"
+    return o
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape) * scale).float()
+
+
+def to_hwio(ops, w):
+    out = ops.new_weight(*w.shape, device="cuda")
+    out.copy_(w)
+    return out
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, bias
+    (2, 16, 16, 1, 8, 5, 1, 2, False),
+    (2, 16, 12, 5, 8, 5, 1, 2, False),
+    (2, 16, 16, 8, 16, 3, 1, 1, False),
+    (1, 8, 8, 32, 16, 3, 1, 1, False),
+    (2, 16, 16, 16, 5, 1, 1, 0, True),
+    (3, 32, 32, 1, 4, 4, 2, 1, True),
+    (2, 4, 4, 32, 4, 4, 1, 0, False),
+    (2, 4, 4, 32, 1, 3, 1, 1, False),
+    (2, 8, 8, 6, 10, 3, 1, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(ops, case):
+    n, h, w, ci, co, k, s, p, has_b = case
+    x = rnd(n, ci, h, w, seed=1).requires_grad_(True)
+    wt = (rnd(co, ci, k, k, seed=2) / np.sqrt(ci * k * k)).requires_grad_(True)
+    b = rnd(co, seed=3).requires_grad_(True) if has_b else None
+    y = F.conv2d(x, wt, b, stride=s, padding=p)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xd = dev(x.detach()).requires_grad_(True)
+    wd = to_hwio(ops, wt.detach()).requires_grad_(True)
+    bd = dev(b.detach()).requires_grad_(True) if has_b else None
+    yd = ops.conv2d(xd, wd, bd, s, p)
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-5
+    yd.backward(dev(gy))
+    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-5
+    assert rel_err(wd.grad.cpu().numpy(), wt.grad.numpy()) < 2e-5
+    assert wd.grad.stride() == wd.stride()
+    if has_b:
+        assert rel_err(bd.grad.cpu().numpy(), b.grad.numpy()) < 1e-5
+
+
+def test_conv_double_backward_matches_torch(ops):
+    """WGAN-GP style: grad of (||d y/d x||^2) w.r.t. the weight goes through dgrad's backward."""
+    x = rnd(2, 3, 8, 8, seed=1).double().requires_grad_(True)
+    wt = (rnd(4, 3, 3, 3, seed=2) / 5).double().requires_grad_(True)
+    y = F.conv2d(x, wt, padding=1)
+    (gx,) = torch.autograd.grad(y, x, torch.ones_like(y) * 0.5 + y.detach(), create_graph=True)
+    (gx.pow(2).sum()).backward()
+    xd = dev(x.detach().float()).requires_grad_(True)
+    wd = to_hwio(ops, wt.detach().float()).requires_grad_(True)
+    yd = ops.conv2d(xd, wd, None, 1, 1)
+    (gxd,) = torch.autograd.grad(yd, xd, torch.ones_like(yd) * 0.5 + yd.detach(), create_graph=True)
+    assert rel_err(gxd.detach().cpu().numpy(), gx.detach().numpy()) < 1e-5
+    # gx^2 sum has no torch-free kernel of its own here: use grad_penalty's sibling path = plain torch on device
+    (gxd.pow(2).sum()).backward()
+    assert rel_err(wd.grad.cpu().numpy(), wt.grad.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("c,hw,slope", [(8, 16, 0.01), (2, 8, None), (16, 32, 0.0), (6, 8, 0.01)])
+def test_instnorm_act_fwd_bwd(ops, c, hw, slope):
+    x = rnd(3, c, hw, hw, seed=5).double().requires_grad_(True)
+    g = (1 + 0.1 * rnd(c, seed=6)).double().requires_grad_(True)
+    b = (0.1 * rnd(c, seed=7)).double().requires_grad_(True)
+    y = F.instance_norm(x, weight=g, bias=b, eps=1e-5)
+    if slope is not None:
+        y = F.leaky_relu(y, slope)
+    gy = rnd(*y.shape, seed=8).double()
+    y.backward(gy)
+    xd, gd, bd = (dev(t.detach().float()).requires_grad_(True) for t in (x, g, b))
+    yd = ops.instnorm_act(xd, gd, bd, slope)
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-5
+    yd.backward(dev(gy.float()))
+    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 2e-5
+    assert rel_err(gd.grad.cpu().numpy(), g.grad.numpy()) < 2e-5
+    assert rel_err(bd.grad.cpu().numpy(), b.grad.numpy()) < 2e-5
+
+
+def test_instnorm_double_backward(ops):
+    """The closed-form second derivative (csrc/norm.hip) vs torch's autograd-of-autograd in fp64."""
+    c, hw, slope = 8, 8, 0.01
+    x = rnd(2, c, hw, hw, seed=5).double().requires_grad_(True)
+    g = (1 + 0.1 * rnd(c, seed=6)).double().requires_grad_(True)
+    b = (0.1 * rnd(c, seed=7)).double().requires_grad_(True)
+    y = F.leaky_relu(F.instance_norm(x, weight=g, bias=b, eps=1e-5), slope)
+    gy = rnd(*y.shape, seed=8).double().requires_grad_(True)
+    (gx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    v = rnd(*gx.shape, seed=9).double()
+    r_gy, r_x, r_g = torch.autograd.grad((gx * v).sum(), (gy, x, g))
+    xd, gd, bd = (dev(t.detach().float()).requires_grad_(True) for t in (x, g, b))
+    gyd = dev(gy.detach().float()).requires_grad_(True)
+    yd = ops.instnorm_act(xd, gd, bd, slope)
+    with ops.input_grads_only():
+        (gxd,) = torch.autograd.grad(yd, xd, gyd, create_graph=True)
+    assert rel_err(gxd.detach().cpu().numpy(), gx.detach().numpy()) < 2e-5
+    d_gy, d_x, d_g = torch.autograd.grad((gxd * dev(v.float())).sum(), (gyd, xd, gd))
+    assert rel_err(d_gy.cpu().numpy(), r_gy.numpy()) < 5e-5
+    assert rel_err(d_x.cpu().numpy(), r_x.numpy()) < 5e-5
+    assert rel_err(d_g.cpu().numpy(), r_g.numpy()) < 5e-5
+
+
+def test_pointwise_family(ops):
+    a, b = rnd(2, 6, 8, 8, seed=1).requires_grad_(True), rnd(2, 6, 8, 8, seed=2).requires_grad_(True)
+    y = F.leaky_relu(a + b, 0.01)
+    gy = rnd(*y.shape, seed=3)
+    y.backward(gy)
+    ad, bd = dev(a.detach()).requires_grad_(True), dev(b.detach()).requires_grad_(True)
+    yd = ops.add_act(ad, bd, 0.01)
+    yd.backward(dev(gy))
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-6
+    assert rel_err(ad.grad.cpu().numpy(), a.grad.numpy()) < 1e-6 and rel_err(bd.grad.cpu().numpy(), b.grad.numpy()) < 1e-6
+    # tanh
+    t = rnd(2, 1, 8, 8, seed=4).requires_grad_(True)
+    torch.tanh(t).backward(gy[:, :1])
+    td = dev(t.detach()).requires_grad_(True)
+    yt = ops.tanh(td)
+    yt.backward(dev(gy[:, :1].contiguous()))
+    assert rel_err(yt.detach().cpu().numpy(), torch.tanh(t).detach().numpy()) < 1e-6
+    assert rel_err(td.grad.cpu().numpy(), t.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["max", "avg", "bilinear"])
+def test_pool_and_upsample(ops, name):
+    x = rnd(2, 6, 8, 12, seed=11).requires_grad_(True)
+    if name == "max":
+        x.data[0, 0, 0, 0] = x.data[0, 0, 0, 1] = 9.0          # tie: first in scan order wins
+        y = F.max_pool2d(x, 2, 2); f = ops.max_pool2
+    elif name == "avg":
+        y = F.avg_pool2d(x, 2); f = ops.avg_pool2
+    else:
+        y = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False); f = ops.bilinear_up2
+    gy = rnd(*y.shape, seed=12)
+    y.backward(gy)
+    xd = dev(x.detach()).requires_grad_(True)
+    yd = f(xd)
+    yd.backward(dev(gy))
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-6
+    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-6
+
+
+def test_convT_concat_planes(ops):
+    x = rnd(2, 8, 4, 4, seed=1).requires_grad_(True)
+    w = (rnd(8, 6, 2, 2, seed=2) / 3).requires_grad_(True)
+    sk = rnd(2, 5, 8, 8, seed=3).requires_grad_(True)
+    y = torch.cat([F.conv_transpose2d(x, w, stride=2), sk], 1)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xd, skd = dev(x.detach()).requires_grad_(True), dev(sk.detach()).requires_grad_(True)
+    wd = ops.new_convT_weight(8, 6, device="cuda"); wd.copy_(w.detach()); wd.requires_grad_(True)
+    yd = ops.concat_channels(ops.conv_transpose2x2(xd, wd), skd)
+    yd.backward(dev(gy))
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-5
+    for got, ref in ((xd.grad, x.grad), (wd.grad, w.grad), (skd.grad, sk.grad)):
+        assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
+    m = torch.tensor([[-1., 0, 1, 0], [0, 0, 0, 0]])
+    xi = rnd(2, 1, 8, 8, seed=5)
+    ref = torch.cat([xi, m.view(2, 4, 1, 1).repeat(1, 1, 8, 8)], 1)
+    assert rel_err(ops.modal_planes(dev(xi), dev(m)).cpu().numpy(), ref.numpy()) < 1e-7
+
+
+@pytest.mark.parametrize("batch_dice", [True, False])
+def test_dice_ce(ops, batch_dice):
+    from oracle import smsut_oracle as O
+    lg = (rnd(3, 5, 16, 16, seed=1) * 2).requires_grad_(True)
+    lb = torch.from_numpy(np.random.RandomState(2).randint(0, 5, size=(3, 16, 16)).astype(np.int64))
+    ref = O.dice_ce(lg, lb, 0.5, 0.5, batch_dice)
+    ref.backward()
+    ld = dev(lg.detach()).requires_grad_(True)
+    out = ops.dice_ce(ld, dev(lb), 0.5, 0.5, batch_dice)
+    out.backward()
+    assert abs(out.item() - ref.item()) < 1e-6
+    assert rel_err(ld.grad.cpu().numpy(), lg.grad.numpy()) < 1e-5
+
+
+def test_small_losses(ops):
+    from oracle import smsut_oracle as O
+    a, b = rnd(4, 1, 8, 8, seed=1).requires_grad_(True), rnd(4, 1, 8, 8, seed=2)
+    ref = (a - b).abs().mean(); ref.backward()
+    ad = dev(a.detach()).requires_grad_(True)
+    out = ops.l1_mean(ad, dev(b)); out.backward()
+    assert abs(out.item() - ref.item()) < 1e-6 and rel_err(ad.grad.cpu().numpy(), a.grad.numpy()) < 1e-6
+    s = rnd(4, 1, 4, 4, seed=3).requires_grad_(True)
+    (-s.mean()).backward()
+    sd = dev(s.detach()).requires_grad_(True)
+    o2 = ops.mean_all(sd, -1.0); (o2 * 3.0).backward()
+    assert abs(o2.item() + s.mean().item()) < 1e-6 and rel_err(sd.grad.cpu().numpy(), 3 * s.grad.numpy()) < 1e-6
+    z = rnd(6, 4, seed=4).requires_grad_(True); t = torch.tensor([0, 3, 1, 2, 2, 0])
+    rz = F.cross_entropy(z, t); rz.backward()
+    zd = dev(z.detach()).requires_grad_(True)
+    oz = ops.cross_entropy_rows(zd, dev(t)); oz.backward()
+    assert abs(oz.item() - rz.item()) < 1e-6 and rel_err(zd.grad.cpu().numpy(), z.grad.numpy()) < 1e-5
+    d = rnd(3, 1, 8, 8, seed=5).requires_grad_(True)
+    rg = torch.mean((torch.sqrt(torch.sum(d.view(3, -1) ** 2, 1)) - 1) ** 2); rg.backward()
+    dd = dev(d.detach()).requires_grad_(True)
+    og = ops.grad_penalty(dd); og.backward()
+    assert abs(og.item() - rg.item()) < 1e-5 * max(1, abs(rg.item())) and rel_err(dd.grad.cpu().numpy(), d.grad.numpy()) < 1e-5
+    q, k = rnd(64, 32, seed=6).requires_grad_(True), rnd(64, 32, seed=7)
+    qn = O.l2_normalize(q); kn = O.l2_normalize(k)
+    rn = O.patch_nce(qn, kn, 2); rn.mean().backward()
+    qd = dev(q.detach()).requires_grad_(True)
+    on = ops.patch_nce(ops.l2_normalize(qd), ops.l2_normalize(dev(k)), 32); on.mean().backward()
+    assert rel_err(on.detach().cpu().numpy(), rn.detach().numpy()) < 1e-5
+    assert rel_err(qd.grad.cpu().numpy(), q.grad.numpy()) < 1e-4
+    f = rnd(2, 8, 4, 4, seed=8).requires_grad_(True); ids = torch.tensor([5, 0, 11, 7])
+    rf = f.permute(0, 2, 3, 1).flatten(1, 2)[:, ids, :].flatten(0, 1); gg = rnd(*rf.shape, seed=9); rf.backward(gg)
+    fd = dev(f.detach()).requires_grad_(True)
+    of = ops.gather_patches(fd, dev(ids)); of.backward(dev(gg))
+    assert rel_err(of.detach().cpu().numpy(), rf.detach().numpy()) < 1e-7 and rel_err(fd.grad.cpu().numpy(), f.grad.numpy()) < 1e-7
+    x2 = rnd(10, 16, seed=10).requires_grad_(True); w2 = (rnd(12, 16, seed=11) / 4).requires_grad_(True)
+    b2 = rnd(12, seed=12).requires_grad_(True)
+    r2 = F.linear(x2, w2, b2); g2 = rnd(*r2.shape, seed=13); r2.backward(g2)
+    xd2 = dev(x2.detach()).requires_grad_(True)
+    wd2 = ops.new_linear_weight(12, 16, device="cuda"); wd2.copy_(w2.detach()); wd2.requires_grad_(True)
+    bd2 = dev(b2.detach()).requires_grad_(True)
+    o2 = ops.linear(xd2, wd2, bd2); o2.backward(dev(g2))
+    assert rel_err(o2.detach().cpu().numpy(), r2.detach().numpy()) < 1e-5
+    for got, ref in ((xd2.grad, x2.grad), (wd2.grad, w2.grad), (bd2.grad, b2.grad)):
+        assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
