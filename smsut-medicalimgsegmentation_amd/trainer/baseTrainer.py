@@ -1,0 +1,190 @@
+"""``BaseTrainer`` -- the caller side of the hot path (reference trainer/baseTrainer.py:33-375), kept to what
+drives the kernels: device/bookkeeping, the DiceCE criterion, ``fit`` epoch loop, ``validate_epoch`` with the
+last-batch padding, Dice matrix, checkpoint save/load with the reference's file names.
+
+MI355X-first differences (all opt-in or invisible to a caller of the reference API):
+  * one process per GPU: ``LOCAL_RANK`` selects the device and, when ``WORLD_SIZE > 1``, gradients are averaged
+    with one flat RCCL all-reduce per network (``parallel.GradAllReducer``) instead of ``nn.DataParallel``;
+  * loaders default to the synthetic slice source (the PNG pipeline is outside the hot-path scope);
+  * TensorBoard / code snapshot / medpy are optional extras that are skipped when not installed.
+"""
+import abc
+import logging
+import os
+import time
+from os.path import join as pjoin
+
+import numpy as np
+import torch
+
+from .. import config as cfg
+from .. import parallel
+from ..misc.loss import DiceAndCrossEntropyLoss
+from ..misc.synthetic import SyntheticSliceLoader
+from ..misc.utils import Meter, get_mo_matrix, maybe_mkdir
+
+
+class BaseTrainer(abc.ABC):
+    def __init__(self, phase, args=None):
+        self.args = args
+        self.rank, self.world, self.local_rank, self.group = parallel.init_from_env()
+        if not torch.cuda.is_available():
+            raise RuntimeError("SMSUT trainers run on an MI355X (torch.device('cuda')); no CPU fallback")
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.phase = phase
+        self.fold = 0 if args is None else getattr(args, "fold", 0)
+        expr_name = getattr(args, "expr_name", None) if args is not None else None
+        self.expr_root = pjoin(cfg.expr_root, expr_name or self.__class__.__name__)
+        self.model_idx, self.logger, self.modality = None, None, "all"
+        if self.phase == "train" and self.rank == 0 and getattr(args, "write_env", True):
+            self.init_train_env(self.expr_root)
+        self.net = None
+        self.build_network()
+        self.loss = DiceAndCrossEntropyLoss(weight_ce=cfg.weight_ce, weight_dc=cfg.weight_dc, batch_dice=True,
+                                            process_group=self.group)        # baseTrainer.py:57
+        self.epoch = 0
+        self.iter = 0
+
+    # ------------------------------------------------------------------ bookkeeping (baseTrainer.py:65-123)
+    @staticmethod
+    def sigmoid_rampup(current, rampup_length):
+        if rampup_length == 0:
+            return 1.0
+        current = np.clip(current, 0.0, rampup_length)
+        ph = 1.0 - current / rampup_length
+        return float(np.exp(-5.0 * ph * ph))
+
+    def init_train_env(self, expr_root):
+        maybe_mkdir(expr_root)
+        self.model_idx = str(len(os.listdir(expr_root))).rjust(3, "0")
+        root = pjoin(expr_root, self.model_idx)
+        maybe_mkdir(root, *(pjoin(root, d) for d in ("ckpt", "tb", "result", "sample")))
+        logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s: %(message)s")
+        self.logger = logging.getLogger("FileLogger")
+        self.logger.addHandler(logging.FileHandler(pjoin(root, "train.log"), mode="a", encoding="utf-8"))
+        self.info(f"Create train environment in {root}.")
+
+    def info(self, s):
+        if self.logger is not None:
+            self.logger.info(s)
+        elif self.rank == 0:
+            print(s)
+
+    @abc.abstractmethod
+    def build_network(self):
+        ...
+
+    def load_model(self, model_idx=None, which_ckpt="last"):
+        path = pjoin(self.expr_root, model_idx or self.model_idx, "ckpt", f"{which_ckpt}.ckpt")
+        self.net.load_state_dict(torch.load(path, map_location="cpu"))
+        self.info(f"Load model from {path}.")
+
+    def save_model(self, prefix):
+        if self.rank != 0:
+            return
+        path = pjoin(self.expr_root, self.model_idx, "ckpt", f"{prefix}.ckpt")
+        torch.save({k: v.contiguous() for k, v in self.net.state_dict().items()}, path)
+        self.info(f"Save model to {path}.")
+
+    # ------------------------------------------------------------------ loaders
+    def get_loaders(self, loader_type):
+        """The reference builds PNG loaders here (baseTrainer.py:128-135); that pipeline is out of scope, so the
+        default is the synthetic source with the same batch contract."""
+        if loader_type not in ("inTurn", "base", "synthetic"):
+            raise NotImplementedError
+        n = getattr(self.args, "iters_per_epoch", None) or cfg.num_iter_per_epoch
+        mk = lambda labeled, nb: SyntheticSliceLoader(cfg.batch_size, n_batches=nb, device=self.device,
+                                                      labeled=labeled, rank=self.rank)
+        return mk(True, n), mk(False, n), mk(True, max(n // 10, 1))
+
+    # ------------------------------------------------------------------ epoch loop (baseTrainer.py:125-201)
+    def fit(self, loader_type="synthetic", max_epoch=None):
+        lb, ul, test = self.get_loaders(loader_type)
+        keys_min = [f"loss_{i}" for i in range(cfg.n_modal)] + ["loss"]
+        keys_max = [f"dice_{i}" for i in range(cfg.n_modal)] + ["dice"]
+        train_meter = Meter(keys_min, [], alpha=cfg.exp_alpha)
+        test_meter = Meter(keys_min, keys_max, alpha=1.0)
+        tic = time.time()
+        for epoch in range(max_epoch or cfg.max_epoch):
+            train_meter.reset_cur()
+            self.train_epoch(lb, ul, train_meter)
+            self.epoch += 1
+            train_meter.update_cur()
+            self.info("[TRN] Epoch: %d/%d, elapsed: %.2fs,%s" % (epoch, cfg.max_epoch, time.time() - tic, train_meter))
+            tic = time.time()
+            test_meter.reset_cur()
+            gt = self._collect_labels(test)
+            n_prd, prd = self.validate_epoch(test, gt, test_meter)
+            dices = self.validate_dice(prd, gt)
+            test_meter.accumulate(dices, {k: 1.0 for k in dices})
+            test_meter.update_cur()
+            self.info("[TST] Epoch: %d/%d, elapsed: %.2fs,%s" % (epoch, cfg.max_epoch, time.time() - tic, test_meter))
+            if self.model_idx is not None and test_meter.cur_values["dice"] >= test_meter.best_values["dice"]:
+                self.save_model(prefix="best")
+        if self.model_idx is not None:
+            self.save_model(prefix="last")
+
+    @staticmethod
+    def _collect_labels(loader):
+        """Ground-truth volumes keyed 'm_pid' from a loader whose names are 'm_pid_z' (get_label_npys, utils.py:163)."""
+        vols = {}
+        state = (loader.gen.get_state(), loader._i) if hasattr(loader, "gen") else None
+        for _, msk, _, names in loader:
+            for i, nm in enumerate(names):
+                m, pid, z = nm.split("_")
+                vols.setdefault(f"{m}_{pid}", {})[int(z)] = msk[i].cpu().numpy()
+        if state is not None:
+            loader.gen.set_state(state[0]); loader._i = state[1]
+        return {k: np.stack([v[z] for z in sorted(v)]) for k, v in vols.items()}
+
+    @abc.abstractmethod
+    def train_epoch(self, lb_loader, ul_loader, meter):
+        ...
+
+    def _forward_eval(self, img):
+        return self.net(img)
+
+    def validate_epoch(self, loader, npys, meter=None, save_path=None):
+        """baseTrainer.py:207-244 / uganShp0Trainer.py:250-287: no-grad inference, last batch padded to
+        cfg.batch_size, on-GPU argmax, volume assembly by name 'm_pid_z'."""
+        self.net.eval()
+        prd, n_prd = {k: np.zeros(v.shape, dtype=v.dtype) for k, v in npys.items()}, 0
+        with torch.no_grad():
+            for img, msk, mdl, inm in loader:
+                b, c, h, w = img.shape
+                img = img.to(self.device)
+                if b != cfg.batch_size:
+                    img = torch.cat([img, torch.zeros(cfg.batch_size - b, c, h, w, device=self.device)], 0)
+                out = self._forward_eval(img)
+                if b != cfg.batch_size:
+                    out = out[:b]
+                loss = self.loss(out, msk.to(self.device))
+                if meter is not None:
+                    v, n = meter.collect_loss_by(loss.item(), mdl[0].item(), img.size(0))
+                    meter.accumulate(v, n)
+                pred = torch.argmax(out, dim=1).cpu().numpy()
+                for i in range(b):
+                    m, pid, z = inm[i].split("_")
+                    prd[f"{m}_{pid}"][int(z)] = pred[i]
+                    n_prd += 1
+        return n_prd, prd
+
+    def validate_dice(self, prd_npys, gt_npys):
+        mo = get_mo_matrix(prd_npys, gt_npys)
+        d = {f"dice_{i}": mo[i, -1] for i in range(cfg.n_modal)}
+        d["dice"] = mo[-1, -1]
+        return d
+
+    def test(self, loader_type, expr_root):
+        """baseTrainer.py:254-318 minus ASSD / connected components (third-party CPU post-processing, out of scope)."""
+        _, _, loader = self.get_loaders(loader_type)
+        gt = self._collect_labels(loader)
+        n, prd = self.validate_epoch(loader, gt)
+        mo = get_mo_matrix(prd, gt)
+        maybe_mkdir(expr_root)
+        np.savetxt(pjoin(expr_root, "dice_matrix.csv"), mo, delimiter=",", fmt="%.6f")
+        return mo
+
+    def poly_lr(self):
+        return cfg.lr * (1.0 - self.iter / (cfg.max_epoch * cfg.num_iter_per_epoch)) ** 0.9

@@ -1,0 +1,178 @@
+"""``UGANConsisTrainer`` -- the hot loop the north star names (reference trainer/uganConsisTrainer.py:35-214).
+
+``train_iteration`` is one pass of :110-203: D-step (D(real), G(real->fake) detached, D(fake), WGAN-GP on x_hat,
+Adam) then G-step (G, D(fake), DiceCE on the labeled half, cycle reconstruction G(fake->rec), L1, consistency
+DiceCE against argmax pseudo labels from iteration 1000 on, PatchNCE, SGD), then the poly LR write.
+
+MI355X-first choices that do not change the arithmetic:
+  * the D-step's generator forward runs under ``no_grad`` (the reference builds a graph and then ``.detach()``es);
+  * D's parameters are frozen during the G-step, so the unused D gradients the reference's ``g_loss.backward()``
+    fills (and never steps) are neither computed nor all-reduced;
+  * the 10 logged scalars stay on the device and are fetched with ONE host sync when a caller asks for them
+    (the reference does 11 ``.item()`` syncs per iteration);
+  * RNG-dependent inputs (target modality, alpha ~ randn, patch ids ~ randperm) may be passed in for replay.
+"""
+import argparse
+import random
+import time
+from os.path import join as pjoin
+
+import numpy as np
+import torch
+
+from .. import config as cfg
+from .. import ops
+from .uganShp0Trainer import UGANShp0Trainer
+
+SCALARS = ("D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg", "G_semi", "G_nce")
+
+
+class UGANConsisTrainer(UGANShp0Trainer):
+    def __init__(self, phase, args=None):
+        super().__init__(phase, args)
+        self.lambda_semi = 10
+        self.semi_start_iter = 1000                      # :165
+
+    def consistency_loss(self, source, target):
+        return self.loss(source, torch.argmax(target, dim=1))                      # :45-53
+
+    def nce_loss(self, feat_x_pool, feat_f_pool):
+        total = 0.0
+        for f_f, f_x, crit in zip(feat_f_pool, feat_x_pool, self.criterionNCE):     # :55-64
+            total = total + ops.mean_all(crit(f_f, f_x), 1.0)
+        return total / len(cfg.nce_layers)
+
+    def train_iteration(self, x_real, y_real, modal_org, mj=None, alpha=None, sample_ids=None):
+        """One iteration; returns a float32 device tensor with the 10 scalars in ``SCALARS`` order."""
+        lambda_semi = self.lambda_semi * self.sigmoid_rampup(self.epoch, cfg.max_epoch)       # :74
+        bs = y_real.size(0)
+        if mj is None:
+            mj = random.randint(0, cfg.n_modal - 1)                                           # :114
+        modal_trg = torch.zeros_like(modal_org).fill_(mj)
+        vec_org = self.label2onehot(modal_org, cfg.n_modal).to(self.device)
+        vec_trg = self.label2onehot(modal_trg, cfg.n_modal).to(self.device)
+        vec_ot, vec_to = vec_trg - vec_org, vec_org - vec_trg
+        modal_org, modal_trg = modal_org.to(self.device), modal_trg.to(self.device)
+
+        # ------------------------------------------------------------ D-step (:129-146)
+        out_src, out_cls = self.D(x_real)
+        d_real = ops.mean_all(out_src, -1.0)
+        d_cls = ops.cross_entropy_rows(out_cls, modal_org)
+        with torch.no_grad():
+            _, x_fake, _, ids_d = self.net(x_real, vec_ot, sample_ids=sample_ids)
+        out_src, _ = self.D(x_fake)
+        d_fake = ops.mean_all(out_src, 1.0)
+        if alpha is None:
+            alpha = torch.randn(x_real.size(0), 1, 1, 1, device=self.device)                  # randn, not rand (:138)
+        x_hat = ops.row_lerp(x_real, x_fake, alpha).requires_grad_(True)
+        out_src, _ = self.D(x_hat)
+        d_gp = self.gradient_penalty(out_src, x_hat)
+        d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
+        self.d_optimizer.zero_grad(set_to_none=True); self.optimizer.zero_grad(set_to_none=True)
+        d_loss.backward()
+        self.d_reducer.reduce()
+        self.d_optimizer.step()
+
+        # ------------------------------------------------------------ G-step (:150-180)
+        for p in self.D.parameters():
+            p.requires_grad_(False)
+        y_fake, x_fake, feat_x, ids = self.net(x_real, vec_ot, sample_ids=sample_ids)
+        out_src, out_cls = self.D(x_fake)
+        g_fake = ops.mean_all(out_src, -1.0)
+        g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
+        g_seg = self.loss(y_fake[:bs], y_real)
+        y_rec, x_rec, feat_f, _ = self.net(x_fake, vec_to, sample_ids=ids)
+        g_rec = ops.l1_mean(x_real, x_rec)
+        if self.iter < self.semi_start_iter:
+            g_semi = torch.zeros((), device=self.device)
+        else:
+            g_semi = self.consistency_loss(y_rec, y_fake)
+        g_nce = self.nce_loss(feat_x, feat_f)
+        g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg \
+            + lambda_semi * g_semi + 1.0 * g_nce
+        self.d_optimizer.zero_grad(set_to_none=True); self.optimizer.zero_grad(set_to_none=True)
+        g_loss.backward()
+        self.g_reducer.reduce()
+        self.optimizer.step()
+        for p in self.D.parameters():
+            p.requires_grad_(True)
+
+        lr_ = self.poly_lr()                                                                   # :198-202
+        for grp in list(self.optimizer.param_groups) + list(self.d_optimizer.param_groups):
+            grp["lr"] = lr_
+        self.iter += 1
+        return torch.stack([t.detach().float() for t in
+                            (d_real, d_fake, d_cls, d_gp, g_fake, g_rec, g_cls, g_seg, g_semi, g_nce)])
+
+    def train_epoch(self, lb_loader, ul_loader, meter):
+        self.net.train(); self.D.train()
+        lb_itr, ul_itr = iter(lb_loader), iter(ul_loader)
+        tic = time.time()
+        for i in range(self.n_critic * cfg.num_iter_per_epoch):
+            try:
+                x1, y_real, mo1, _ = next(lb_itr)
+            except StopIteration:
+                lb_itr = iter(lb_loader); x1, y_real, mo1, _ = next(lb_itr)
+            try:
+                x2, _, mo2, _ = next(ul_itr)
+            except StopIteration:
+                ul_itr = iter(ul_loader); x2, _, mo2, _ = next(ul_itr)
+            x_real = torch.cat([x1.to(self.device, non_blocking=True), x2.to(self.device, non_blocking=True)], 0)
+            modal_org = torch.cat([mo1, mo2], 0)
+            scal = self.train_iteration(x_real, y_real.to(self.device, non_blocking=True), modal_org)
+            if meter is not None or (i + 1) % (self.n_critic * self.log_step) == 0:
+                vals = scal.tolist()                                                          # the one host sync
+                if meter is not None:
+                    v, n = meter.collect_loss_by(vals[SCALARS.index("G_seg")], mo1[0].item(), cfg.batch_size)
+                    meter.accumulate(v, n)
+                if (i + 1) % (self.n_critic * self.log_step) == 0:
+                    self.info("Iter: %d/%d(%d), elapsed: %.2fs, " % (i, cfg.num_iter_per_epoch, self.iter, time.time() - tic)
+                              + " ".join("%s: %.4f," % kv for kv in zip(SCALARS, vals)))
+                    tic = time.time()
+
+    def translate_all(self, x_fixed, modal_org):
+        """The per-epoch sample grid of :205-214 / saving_pseudo :216-: x translated to every modality (no grad)."""
+        vec_org = self.label2onehot(modal_org, cfg.n_modal).to(self.device)
+        outs = [x_fixed]
+        with torch.no_grad():
+            for vec in self.create_vectors(vec_org, cfg.n_modal):
+                _, x_fake, _, _ = self.net(x_fixed, vec - vec_org)
+                outs.append(x_fake)
+        return self.denorm(torch.cat(outs, dim=3))
+
+    def saving_pseudo(self, loader_type, expr_root):
+        """:216-304 without the JPEG writing (PIL/torchvision side): returns predictions and translations per batch."""
+        self.net.eval()
+        _, _, loader = self.get_loaders(loader_type)
+        out = []
+        with torch.no_grad():
+            for img, msk, mdl, inm in loader:
+                img = img.to(self.device)
+                grid = self.translate_all(img, mdl)
+                seg, _ = self.net(img, val_phase=True)
+                out.append((inm, torch.argmax(seg, dim=1).cpu(), grid.cpu()))
+        return out
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("-p", "--phase", type=str, choices=("train", "test", "pseudo"))
+    p.add_argument("-f", "--fold", type=int, default=0)
+    p.add_argument("-nm", "--expr_name", type=str)
+    p.add_argument("-i", "--model_id", type=str, help="only for test")
+    p.add_argument("-wh", "--which_ckpt", type=str, default="last")
+    args = p.parse_args(argv)
+    random.seed(cfg.seed); np.random.seed(cfg.seed); torch.manual_seed(cfg.seed); torch.cuda.manual_seed(cfg.seed)
+    trainer = UGANConsisTrainer(args.phase, args)
+    if args.phase == "train":
+        trainer.fit("synthetic")
+    elif args.phase == "test":
+        trainer.load_model(args.model_id, args.which_ckpt)
+        trainer.test("synthetic", pjoin(trainer.expr_root, args.model_id))
+    elif args.phase == "pseudo":
+        trainer.load_model(args.model_id, args.which_ckpt)
+        trainer.saving_pseudo("synthetic", pjoin(trainer.expr_root, args.model_id))
+
+
+if __name__ == "__main__":
+    main()

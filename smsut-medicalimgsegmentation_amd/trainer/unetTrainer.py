@@ -1,0 +1,72 @@
+"""``UnetTrainer`` (reference trainer/unetTrainer.py:35-85): supervised U-Net, SGD(0.9, wd 1e-3), poly LR --
+BASELINE configs 1-2."""
+import argparse
+import random
+
+import numpy as np
+import torch
+from torch.optim import SGD
+
+from .. import config as cfg
+from .. import parallel
+from ..network.unet import UNet
+from .baseTrainer import BaseTrainer
+
+
+class UnetTrainer(BaseTrainer):
+    def build_network(self):
+        self.net = UNet(cfg.img_channels, cfg.n_label + 1, cfg.base_width, norm_type="instance", act_type="lrelu")
+        self.net.to(self.device)
+        parallel.broadcast_parameters(self.net, self.group)
+        if self.phase == "train":
+            self.optimizer = SGD(self.net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
+            self.reducer = parallel.GradAllReducer(self.net.parameters(), self.group)
+
+    def train_step(self, img, msk):
+        """One iteration of unetTrainer.py:66-83 (forward, DiceCE, zero_grad, backward, step, poly LR).
+        Returns the loss as a 0-dim device tensor (no host sync)."""
+        out = self.net(img)
+        loss = self.loss(out, msk)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.reducer.reduce()
+        self.optimizer.step()
+        lr_ = self.poly_lr()
+        for g in self.optimizer.param_groups:
+            g["lr"] = lr_
+        self.iter += 1
+        return loss.detach()
+
+    def train_epoch(self, lb_loader, ul_loader, meter):
+        self.net.train()
+        it = iter(lb_loader)
+        for _ in range(cfg.num_iter_per_epoch):
+            try:
+                img, msk, mdl, _ = next(it)
+            except StopIteration:
+                it = iter(lb_loader)
+                img, msk, mdl, _ = next(it)
+            loss = self.train_step(img.to(self.device, non_blocking=True), msk.to(self.device, non_blocking=True))
+            v, n = meter.collect_loss_by(loss.item(), mdl[0].item(), img.size(0))
+            meter.accumulate(v, n)
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("-p", "--phase", type=str, choices=("train", "test"))
+    p.add_argument("-f", "--fold", type=int, default=0)
+    p.add_argument("-nm", "--expr_name", type=str)
+    p.add_argument("-i", "--model_id", type=str)
+    p.add_argument("-wh", "--which_ckpt", type=str, default="last")
+    args = p.parse_args(argv)
+    random.seed(cfg.seed); np.random.seed(cfg.seed); torch.manual_seed(cfg.seed); torch.cuda.manual_seed(cfg.seed)
+    t = UnetTrainer(args.phase, args)
+    if args.phase == "train":
+        t.fit("synthetic")
+    else:
+        t.load_model(args.model_id, args.which_ckpt)
+        t.test("synthetic", t.expr_root + "/" + args.model_id)
+
+
+if __name__ == "__main__":
+    main()

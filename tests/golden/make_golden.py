@@ -53,7 +53,7 @@ def load(module, shapes, seed):
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()     # copy: state_dict()/grad tensors alias live memory on CPU
 
 
 def grad_summary(module, full_keys=()):
@@ -245,6 +245,10 @@ def gen_iter_small():
             for k, v in grad_summary(D, ("conv_cls.weight", "main.0.weight")).items():
                 rec["D0_" + k] = v
         d_opt.step()
+        if step == 0:      # Adam's first update is +-lr per element: keep the post-step-0 weights to check it element-wise
+            rec["post0_D_cls"] = npy(D.state_dict()["conv_cls.weight"])
+            rec["post0_D_stem"] = npy(D.state_dict()["main.0.weight"])
+            rec["post0_D_bn"] = npy(D.state_dict()["main.2.bn1.weight"])
 
         y_fake, x_fake, feat_x, _ = G(x_real, vec_ot, sample_ids=[ids])
         out_src, out_cls = D(x_fake)
@@ -265,6 +269,9 @@ def gen_iter_small():
             rec["seg0_s4"] = npy(y_fake[:, :, ::4, ::4])
             rec["tsl0"] = npy(x_fake)
         g_opt.step()
+        if step == 0:
+            rec["post0_G_seg_fc"] = npy(G.state_dict()["seg_decoder.fc.weight"])
+            rec["post0_G_tsl_pre"] = npy(G.state_dict()["tsl_encoder.pre.0.weight"])
         lr_ = 1e-2 * (1.0 - it / 30000) ** 0.9
         for grp in list(g_opt.param_groups) + list(d_opt.param_groups):
             grp["lr"] = lr_
