@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Benchmark of the SMSUT hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload ugan|unet] [--per-gpu-batch B]
+
+Metric (BASELINE.json): slices/sec of the uganConsisTrainer step @256x256.  A "step" is one full iteration of
+reference trainer/uganConsisTrainer.py:110-203 (D-step with WGAN-GP double backward + G-step with cycle pass,
+DiceCE, consistency (iter >= 1000 branch enabled), PatchNCE, both optimizer steps) on synthetic slices already
+resident in HBM.  Per GPU: B/2 labeled + B/2 unlabeled slices (default B=16 = reference config.py:56 x2 = BASELINE
+config 3); N>1 is pure data parallel, one process per GPU, flat RCCL all-reduce of D and G gradients (weak scaling).
+``--workload unet`` times BASELINE config 2 instead (U-Net fwd + DiceCE + bwd + SGD, 32x1x256x256, 5 classes).
+
+Rank 0 prints ONE JSON line.  ``roofline`` is measured live with HIP events on the launch stream around the
+dominant kernel (the 3x3 conv at the layer shape that carries most FLOPs); ``cpu_baseline`` times the CPU oracle
+(``oracle/``, kind "port") on a bounded sample of the same workload on this host's cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(n, h, w, cin, cout, k):
+    return 2.0 * n * h * w * cin * cout * k * k
+
+
+def measure_dominant_conv(dev, batch):
+    """HIP-event timing of the dominant kernel: conv3x3 s1 p1 on the decoder-level-1 shape
+    ([B,32,256,256] -> 16 ch, blocks.py dec layer1.conv1; 9.2 % of the U-Net MACs on its own and the layer
+    class -- 3x3 @256^2 -- that holds the largest share).  Returns the roofline dict."""
+    from smsut_amd import ops, _hip
+    cin, cout, h = 32, 16, 256
+    x = torch.randn(batch, cin, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    w = ops.new_weight(cout, cin, 3, 3, device=dev)
+    w.copy_(torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5)
+    name, kind = ops.conv_fwd_kernel_name(cin, cout, 3, 1, 1)
+    for _ in range(3):
+        ops.conv2d(x, w, None, 1, 1)
+    torch.cuda.synchronize()
+    reps = 20
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        ops.conv2d(x, w, None, 1, 1)
+    e1.record(st)
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = conv_flops(batch, h, h, cin, cout, 3)
+    achieved = fl / (ms * 1e-3) / 1e12
+    byts = 4.0 * batch * h * h * (cin + cout)
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": name, "kernel_kind": kind, "shape": f"N{batch} 256x256 {cin}->{cout} k3",
+            "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
+            "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
+            "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
+
+
+def cpu_baseline_ugan(sample_b=4):
+    """One uganConsis iteration of the CPU oracle on (sample_b/2 + sample_b/2) 256x256 slices."""
+    import numpy as np
+    from oracle import recipe, smsut_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gsd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 2020).items()}
+    dsd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.disc_shapes(256, 4, 16, 256), 2021).items()}
+    g_opt = torch.optim.SGD(list(gsd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    d_opt = torch.optim.Adam(list(dsd.values()), 1e-2, (0.9, 0.999), weight_decay=1e-3)
+    bs = sample_b // 2
+    x = recipe.synth_images((sample_b, 1, 256, 256), 2020)
+    y = recipe.synth_labels(bs, 256, 256, 5, 2021)
+    mo = torch.tensor([0] * bs + [1] * bs)
+    alpha = torch.from_numpy(np.random.RandomState(1).standard_normal((sample_b, 1, 1, 1))).float()
+    ids = torch.from_numpy(np.random.RandomState(2).permutation(256)[:64].astype(np.int64))
+    t0 = time.time()
+    O.ugan_consis_iteration(gsd, dsd, g_opt, d_opt, x, y, mo, 2, alpha, [ids], it=1000, epoch=100, nce_batch=bs)
+    dt = time.time() - t0
+    return {"value": round(sample_b / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"1 uganConsis iteration of oracle/smsut_oracle.py, {bs} labeled + {bs} unlabeled 256x256 slices, "
+                      f"fp32, torch CPU {cores} threads, {dt:.1f} s"}
+
+
+def cpu_baseline_unet(sample_b=8):
+    from oracle import recipe, smsut_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.unet_shapes(1, 5, 16), 2020).items()}
+    opt = torch.optim.SGD(list(sd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    x = recipe.synth_images((sample_b, 1, 256, 256), 2020)
+    y = recipe.synth_labels(sample_b, 256, 256, 5, 2021)
+    O.unet_train_step(sd, opt, x, y, 0)
+    t0 = time.time()
+    n = 2
+    for i in range(n):
+        O.unet_train_step(sd, opt, x, y, i + 1)
+    dt = (time.time() - t0) / n
+    return {"value": round(sample_b / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
+            "sample": f"{n} U-Net fwd+DiceCE+bwd+SGD steps of oracle/smsut_oracle.py on {sample_b}x1x256x256, fp32, "
+                      f"torch CPU {cores} threads, {dt:.1f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=("ugan", "unet"), default="ugan")
+    ap.add_argument("--per-gpu-batch", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import smsut_amd  # noqa: F401
+    from smsut_amd import config as cfg, parallel
+    from smsut_amd.misc.synthetic import SyntheticSliceLoader
+
+    rank, world, local, group = parallel.init_from_env()
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.manual_seed(cfg.seed + rank)
+    ns = types.SimpleNamespace(fold=0, expr_name=None, write_env=False)
+
+    if args.workload == "ugan":
+        from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer
+        B = args.per_gpu_batch or 16
+        cfg.batch_size = B // 2                      # labeled half; PatchNCELoss(batch_size) as uganShp0Trainer.py:59
+        tr = UGANConsisTrainer("train", ns)
+        tr.net.train(); tr.D.train()
+        tr.iter, tr.epoch = 1000, 100                # consistency branch on
+        lb = SyntheticSliceLoader(B // 2, device=dev, labeled=True, rank=rank)
+        ul = SyntheticSliceLoader(B // 2, device=dev, labeled=False, rank=rank)
+        (x1, y1, m1, _), (x2, _, m2, _) = next(iter(lb)), next(iter(ul))
+        x_real = torch.cat([x1, x2], 0)
+        modal = torch.cat([m1, m2], 0)
+
+        def step():
+            return tr.train_iteration(x_real, y1, modal)
+        workload = f"uganConsisTrainer iteration (D-step + G-step, WGAN-GP, cycle, DiceCE, consistency, PatchNCE), " \
+                   f"{B // 2} labeled + {B // 2} unlabeled 1x256x256 slices per GPU, 5 classes, 4 modalities"
+        metric = "slices/sec uganConsisTrainer step @256x256"
+    else:
+        from smsut_amd.trainer.unetTrainer import UnetTrainer
+        B = args.per_gpu_batch or 32
+        cfg.batch_size = B
+        tr = UnetTrainer("train", ns)
+        tr.net.train()
+        ld = SyntheticSliceLoader(B, device=dev, rank=rank)
+        img, msk, _, _ = next(iter(ld))
+
+        def step():
+            return tr.train_step(img, msk)
+        workload = f"U-Net(1,5,16) fwd + DiceCE + bwd + SGD, {B}x1x256x256 per GPU (BASELINE config 2)"
+        metric = "slices/sec U-Net train step @256x256"
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    out = {"metric": metric, "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
+                      "parallelism": f"dp{world}", "weights": "random init (reference initialisers)"},
+           "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])]}
+    if not args.no_roofline:
+        out["roofline"] = measure_dominant_conv(dev, B)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_ugan() if args.workload == "ugan" else cpu_baseline_unet()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,446 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, fp32 in / fp32 accumulate
+// (v_mfma_f32_16x16x4_f32: exact f32, bit-identical to an fmaf chain -- MI355X_MICROARCH.md "Matrix cores").
+//
+// Covers every stride-1 "same" convolution of the hot path with a K-dimension (input channels) that is a
+// multiple of 4: the 3x3 and 1x1 convs of BasicBlock / BottleBlock (network/blocks.py:10-16,53-117), i.e.
+// > 97 % of the U-Net / ugan / discriminator FLOPs.  NHWC activations, [KH][KW][Cin][Cout] weights.
+//
+//   forward      out[p, n] = sum_{tap, k} in[p + off(tap), k] * W[tap][k][n]
+//   data-grad    the same kernel on gy with W read transposed and tap-flipped (``transposed`` = 1)
+//   weight-grad  gW[tap][k][n] = sum_p in[p + off(tap), k] * gy[p, n]   (GEMM with the pixels as K)
+//
+// Forward tiling (one 256-thread workgroup = 4 waves, one per SIMD):
+//   * output tile TH rows x 16 pixels x CO_T = 16*NTN channels; each wave owns MR rows x NR channel tiles,
+//     i.e. MR*NR accumulators of 16x16 (pixels along one image row are the MFMA M dimension);
+//   * the input channels are walked in chunks of 16; per chunk the haloed input tile [(TH+KS-1)][16+KS-1][16]
+//     and the weights [taps][16][CO_T] are staged in LDS once and reused by all taps / waves;
+//   * A fragments are ONE ds_read_b128 per (tap,row): lane (m, kq) reads channels 4kq..4kq+3 of pixel m and
+//     feeds them to 4 consecutive MFMAs (the k order inside a 16-chunk is permuted, which a sum does not
+//     see); B fragments likewise from a [tap][kq][n][4] image.  Pixel stride 24 floats (= 8 mod 16) and the
+//     n-major weight image make both reads bank-conflict-free for the b128 lane groups (MICROARCH "LDS").
+// Weight-grad tiling: a workgroup owns a (16*CIT x 16*COT) slab of gW for all taps and walks a range of
+// 8x16-pixel tiles; the 4 waves split each tile's rows (the GEMM K dimension), keep taps*CIT*COT
+// accumulators in registers across all its tiles, and are combined once at the end through LDS in a fixed
+// order; per-split slabs are summed by a second tiny kernel (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TPB = 256;
+constexpr int TW = 16;       // pixels per MFMA M tile (one image row segment)
+constexpr int CK = 16;       // input-channel chunk staged per LDS pass
+constexpr int SPIX = 24;     // floats between consecutive pixels of the staged input tile (16 + 8 pad)
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+template <int KS, int TH, int WM, int WN, int NTN>
+__global__ void __launch_bounds__(TPB)
+conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Kdim,
+              int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz) {
+  // (H, W) is the compute grid.  Regular conv: isc = osc = G = 1.  ConvTranspose2x2 forward: osc = 2 and
+  // blockIdx.z also enumerates the 4 output taps.  ConvTranspose2x2 data-gradient: isc = 2, G = 4 input taps.
+  constexpr int KK = KS * KS;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  constexpr int CO_T = 16 * NTN;
+  constexpr int MR = TH / WM, NR = NTN / WN;
+  static_assert(WM * WN == 4 && TH % WM == 0 && NTN % WN == 0, "wave grid");
+  extern __shared__ float smem[];
+  float* in_s = smem;                        // [IH][IW][SPIX]
+  float* w_s = smem + IH * IW * SPIX;        // [KK][4][CO_T][4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int tile = blockIdx.x;
+  const int ty = tile / tiles_x, tx = tile % tiles_x;
+  const int n_img = blockIdx.y;
+  const int tapo = blockIdx.z / nz;            // output tap (transposed conv forward), else 0
+  const int co0 = (blockIdx.z % nz) * CO_T;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const int Wi = W * isc;
+  const float* xin = x + (size_t)n_img * H * isc * Wi * Kdim;
+  w += (size_t)tapo * KK * Kdim * Ndim;
+
+  f32x4 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int g = 0; g < G; ++g)
+  for (int c0 = 0; c0 < Kdim; c0 += CK) {
+    const float* wg = w + (size_t)g * KK * Kdim * Ndim;
+    __syncthreads();
+    // ---- stage the haloed input tile for channels [c0, c0+16): one float4 (4 channels) per unit
+    for (int u = tid; u < IH * IW * 4; u += TPB) {
+      const int q = u & 3, pix = u >> 2;
+      const int iy = pix / IW, ix = pix % IW;
+      const int gy_ = y0 + iy - PAD, gx_ = x0 + ix - PAD;
+      const int c = c0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W && c < Kdim)
+        v = *(const float4*)(xin + ((size_t)(gy_ * isc + (g >> 1)) * Wi + gx_ * isc + (g & 1)) * Kdim + c);
+      *(float4*)(in_s + pix * SPIX + 4 * q) = v;
+    }
+    // ---- stage the weights of this chunk as [tap][kq][n][j], k = c0 + 4*kq + j
+    for (int u = tid; u < KK * 4 * CO_T; u += TPB) {
+      const int n = u % CO_T;
+      const int k4 = (u / CO_T) & 3;
+      const int tap = u / (4 * CO_T);
+      const int ng = co0 + n, kg = c0 + 4 * k4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ng < Ndim && kg < Kdim) {
+        if (!transposed) {
+          const float* p = wg + ((size_t)tap * Kdim + kg) * Ndim + ng;
+          v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim];
+        } else {
+          v = *(const float4*)(wg + ((size_t)(KK - 1 - tap) * Ndim + ng) * Kdim + kg);
+        }
+      }
+      *(float4*)(w_s + (size_t)u * 4) = v;
+    }
+    __syncthreads();
+    // ---- MFMA over taps
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      const int kh = tap / KS, kw = tap % KS;
+      f32x4 a[MR], b[NR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+        a[i] = *(const f32x4*)(in_s + ((wm * MR + i + kh) * IW + lm + kw) * SPIX + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        b[j] = *(const f32x4*)(w_s + (((tap * 4 + kq) * CO_T) + (wn * NR + j) * 16 + lm) * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+    }
+  }
+  // ---- epilogue: acc[i][j][r] is pixel (row wm*MR+i, col 4*kq + r), channel (wn*NR+j)*16 + lm
+  const int Wo = W * osc;
+  float* yout = y + (size_t)n_img * H * osc * Wo * Ndim;
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    const int gy_ = y0 + wm * MR + i;
+    if (gy_ >= H) continue;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int co = co0 + (wn * NR + j) * 16 + lm;
+      if (co >= Ndim) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gx_ = x0 + 4 * kq + r;
+        if (gx_ < W)
+          yout[((size_t)(gy_ * osc + (tapo >> 1)) * Wo + gx_ * osc + (tapo & 1)) * Ndim + co] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows (the GEMM K dimension)
+
+template <int KS, int CIT, int COT>
+__global__ void __launch_bounds__(TPB)
+conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
+                int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci) {
+  // gsc = 2 / 4 tap groups in blockIdx.y: weight-gradient of ConvTranspose2x2 (gy is the 2x larger tensor).
+  constexpr int KK = KS * KS;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
+  constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
+  constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;     // pixel stride = 16 (mod 32): 4 pixels x 16 ch conflict-free
+  constexpr int SO = (CO_T % 32 == 16) ? CO_T : CO_T + 16;
+  constexpr int NACC = KK * CIT * COT;
+  extern __shared__ float smem[];
+  float* in_s = smem;                         // [IH][IW][SI]
+  float* gy_s = smem + IH * IW * SI;          // [WTH][TW][SO]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x;
+  const int tg = blockIdx.y / nci;
+  const int ci0 = (blockIdx.y % nci) * CI_T, co0 = blockIdx.z * CO_T;
+  const int Wg = W * gsc;
+  const int tiles_img = tiles_x * tiles_y;
+  const int total_tiles = N * tiles_img;
+  const int t_begin = split * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, total_tiles);
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int n_img = t / tiles_img;
+    const int rem = t % tiles_img;
+    const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * TW;
+    const float* xin = x + (size_t)n_img * H * W * Cin;
+    const float* gin = gy + (size_t)n_img * H * gsc * Wg * Cout;
+    __syncthreads();
+    for (int u = tid; u < IH * IW * (CI_T / 4); u += TPB) {
+      const int q = u % (CI_T / 4), pix = u / (CI_T / 4);
+      const int iy = pix / IW, ix = pix % IW;
+      const int gy_ = y0 + iy - PAD, gx_ = x0 + ix - PAD;
+      const int c = ci0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W && c < Cin)
+        v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * Cin + c);
+      *(float4*)(in_s + pix * SI + 4 * q) = v;
+    }
+    for (int u = tid; u < WTH * TW * (CO_T / 4); u += TPB) {
+      const int q = u % (CO_T / 4), pix = u / (CO_T / 4);
+      const int iy = pix / TW, ix = pix % TW;
+      const int gy_ = y0 + iy, gx_ = x0 + ix;
+      const int c = co0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gy_ < H && gx_ < W && c < Cout)
+        v = *(const float4*)(gin + ((size_t)(gy_ * gsc + (tg >> 1)) * Wg + gx_ * gsc + (tg & 1)) * Cout + c);
+      *(float4*)(gy_s + pix * SO + 4 * q) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < WTH / 4; ++rr) {
+      const int r = wave * (WTH / 4) + rr;
+#pragma unroll
+      for (int ks = 0; ks < TW / 4; ++ks) {
+        const int px = ks * 4 + kq;                 // this lane's pixel (the MFMA k index) within the row
+        float b[COT];
+#pragma unroll
+        for (int j = 0; j < COT; ++j) b[j] = gy_s[(r * TW + px) * SO + j * 16 + lm];
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+          const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+          for (int i = 0; i < CIT; ++i) {
+            const float a = in_s[((r + kh) * IW + px + kw) * SI + i * 16 + lm];
+#pragma unroll
+            for (int j = 0; j < COT; ++j)
+              acc[(tap * CIT + i) * COT + j] = mfma16(a, b[j], acc[(tap * CIT + i) * COT + j]);
+          }
+        }
+      }
+    }
+  }
+  // ---- combine the 4 waves in a fixed order (wave 0 += wave 1, 2, 3) through LDS, then wave 0 stores the slab
+  float* red = smem;      // NACC * 64 * 4 floats
+  for (int src = 1; src < 4; ++src) {
+    __syncthreads();
+    if (wave == src) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) *(f32x4*)(red + ((size_t)i * 64 + lane) * 4) = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] += *(const f32x4*)(red + ((size_t)i * 64 + lane) * 4);
+    }
+  }
+  if (wave == 0) {
+    float* out = part + ((size_t)split * (gridDim.y / nci) + tg) * KK * Cin * Cout;
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+      for (int i = 0; i < CIT; ++i)
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+          const int co = co0 + j * 16 + lm;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ci = ci0 + i * 16 + 4 * kq + r;
+            if (ci < Cin && co < Cout) out[((size_t)tap * Cin + ci) * Cout + co] = acc[(tap * CIT + i) * COT + j][r];
+          }
+        }
+  }
+}
+
+__global__ void __launch_bounds__(TPB)
+sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
+  const int e = blockIdx.x * TPB + threadIdx.x;
+  if (e >= wsize) return;
+  float s = 0.f;
+  for (int c = 0; c < splits; ++c) s += part[(size_t)c * wsize + e];
+  out[e] = s;
+}
+
+template <int KS, int TH, int WM, int WN, int NTN>
+int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
+               int isc, int osc, int G, int ntap_out, hipStream_t st) {
+  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  constexpr size_t sh = (size_t)(IH * IW * SPIX + KS * KS * CK * 16 * NTN) * sizeof(float);
+  static_assert(sh <= 64 * 1024, "LDS budget");
+  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int nz = (Ndim + 16 * NTN - 1) / (16 * NTN);
+  dim3 grid(tiles_x * tiles_y, N, nz * ntap_out);
+  conv_mfma_fwd<KS, TH, WM, WN, NTN><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc, G,
+                                                            nz);
+  return 0;
+}
+
+template <int KS>
+int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
+                 int isc, int osc, int G, int ntap_out, hipStream_t st) {
+#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st
+  const int nt = (Ndim + 15) / 16;
+  const bool small = (int64_t)H * W <= 32 * 32;          // few tiles per image: shrink the tile to fill 256 CUs
+  if (nt == 1) {
+    if (small) return launch_fwd<KS, 4, 4, 1, 1>(ARGS);
+    return launch_fwd<KS, 16, 4, 1, 1>(ARGS);
+  }
+  if (nt == 2) {
+    if (small) return launch_fwd<KS, 4, 4, 1, 2>(ARGS);
+    return launch_fwd<KS, 16, 4, 1, 2>(ARGS);
+  }
+  if (small) return launch_fwd<KS, 4, 1, 4, 4>(ARGS);
+  return launch_fwd<KS, 8, 2, 2, 4>(ARGS);
+#undef ARGS
+}
+
+struct WgradPlan { int cit, cot, splits, tiles_per_split, tiles_x, tiles_y; };
+
+WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
+  WgradPlan p;
+  p.cit = (Cin > 16) ? 2 : 1;
+  p.cot = (Cout > 16) ? 2 : 1;
+  p.tiles_x = (W + TW - 1) / TW;
+  p.tiles_y = (H + WTH - 1) / WTH;
+  const int total = N * p.tiles_x * p.tiles_y;
+  const int slabs = ((Cin + 16 * p.cit - 1) / (16 * p.cit)) * ((Cout + 16 * p.cot - 1) / (16 * p.cot));
+  int want = (1024 + slabs - 1) / slabs;         // aim for ~1024 workgroups in flight (4 per CU)
+  if (want > total) want = total;
+  if (want < 1) want = 1;
+  p.tiles_per_split = (total + want - 1) / want;
+  p.splits = (total + p.tiles_per_split - 1) / p.tiles_per_split;
+  return p;
+}
+
+template <int KS, int CIT, int COT>
+int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int W, int Cin, int Cout,
+                 const WgradPlan& p, int gsc, int ntaps, hipStream_t st) {
+  constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
+  constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
+  constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;
+  constexpr int SO = (CO_T % 32 == 16) ? CO_T : CO_T + 16;
+  constexpr size_t stage = (size_t)(IH * IW * SI + WTH * TW * SO) * sizeof(float);
+  constexpr size_t red = (size_t)KS * KS * CIT * COT * 64 * 4 * sizeof(float);
+  constexpr size_t sh = stage > red ? stage : red;
+  static_assert(sh <= 64 * 1024, "LDS budget");
+  const int nci = (Cin + CI_T - 1) / CI_T;
+  dim3 grid(p.splits, nci * ntaps, (Cout + CO_T - 1) / CO_T);
+  conv_mfma_wgrad<KS, CIT, COT><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                      p.tiles_per_split, gsc, nci);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+// 1 when the MFMA kernels cover conv(k=KS, stride 1, pad (KS-1)/2) with this K (reduction) / N (output) channel pair
+int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim) {
+  return (KS == 1 || KS == 3) && stride == 1 && pad == (KS - 1) / 2 && Kdim >= 4 && (Kdim % 4) == 0 && Ndim >= 1;
+}
+
+// Forward (transposed = 0): x [N,H,W,Kdim], w [KS*KS][Kdim][Ndim] -> y [N,H,W,Ndim].
+// Data-gradient (transposed = 1): x = gy [N,H,W,Kdim = Cout], w = the forward weights [KS*KS][Ndim = Cin][Kdim = Cout],
+// y = gx [N,H,W,Ndim = Cin].
+int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
+                          int transposed, void* stream) {
+  SMSUT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(smsut_conv2d_mfma_supported(KS, 1, (KS - 1) / 2, Kdim, Ndim));
+  SMSUT_REQUIRE(!transposed || (Kdim % 4) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
+  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// ConvTranspose2d(k=2, s=2, bias=False) (network/blocks.py:41), weights [kh][kw][Cin][Cout]:
+//   forward  x [N,H,W,Cin] -> y [N,2H,2W,Cout]   : four 1x1 MFMA convs scattered to the 4 output taps
+//   dgrad    gy [N,2H,2W,Cout] -> gx [N,H,W,Cin] : one 1x1 MFMA conv over the 4 gathered taps (K = 4*Cout)
+//   wgrad    gw[tap] = sum_p x[p] (x) gy[2p + tap]
+int smsut_convT2x2_mfma_supported(int Cin, int Cout) { return Cin >= 4 && (Cin % 4) == 0 && Cout >= 4 && (Cout % 4) == 0; }
+
+int smsut_convT2x2_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout,
+                            void* stream) {
+  SMSUT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && smsut_convT2x2_mfma_supported(Cin, Cout));
+  dispatch_fwd<1>(x, w, y, N, H, W, Cin, Cout, 0, 1, 2, 1, 4, (hipStream_t)stream);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N, int H, int W, int Cin, int Cout,
+                              void* stream) {
+  SMSUT_REQUIRE(gy && w && gx && N > 0 && H > 0 && W > 0 && smsut_convT2x2_mfma_supported(Cin, Cout));
+  dispatch_fwd<1>(gy, w, gx, N, H, W, Cout, Cin, 1, 2, 1, 4, 1, (hipStream_t)stream);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int smsut_conv2d_wgrad_mfma_supported(int KS, int stride, int pad, int Cin, int Cout) {
+  return (KS == 1 || KS == 3) && stride == 1 && pad == (KS - 1) / 2 && Cin >= 4 && (Cin % 4) == 0 && Cout >= 4 &&
+         (Cout % 4) == 0;
+}
+
+// workspace floats: splits * KS*KS*Cin*Cout
+int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int KS) {
+  const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
+  return (int64_t)p.splits * KS * KS * Cin * Cout;
+}
+
+// gw [KS*KS][Cin][Cout] = sum over pixels of x (x) gy
+int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                            int Cout, int KS, void* stream) {
+  SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(smsut_conv2d_wgrad_mfma_supported(KS, 1, (KS - 1) / 2, Cin, Cout));
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
+  if (KS == 1) {
+    if (p.cit == 1 && p.cot == 1) launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    else if (p.cit == 1) launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+  } else {
+    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+  }
+  const int wsize = KS * KS * Cin * Cout;
+  sum_splits<<<(wsize + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int64_t smsut_convT2x2_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout) {
+  const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
+  return (int64_t)p.splits * 4 * Cin * Cout;
+}
+
+int smsut_convT2x2_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                              int Cout, void* stream) {
+  SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0 && smsut_convT2x2_mfma_supported(Cin, Cout));
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
+  if (p.cit == 1 && p.cot == 1) launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  else if (p.cit == 1) launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  const int wsize = 4 * Cin * Cout;
+  sum_splits<<<(wsize + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+}  // extern "C"

@@ -5,8 +5,8 @@ Memory conventions (what the kernels see):
   * conv / linear weights: logical OIHW (the reference's ``state_dict`` shapes) whose memory is
     ``[KH][KW][Cin][Cout]`` -- a permuted *view*, so checkpoints keep the reference's keys and shapes
     while the kernels read coalesced ``Cout``-contiguous rows;
-  * ConvTranspose2d weights: logical ``[Cin, Cout, 2, 2]``, memory ``[kh][kw][Cout][Cin]`` (the HWIO
-    layout of the k2/s2 conv whose data-gradient the transposed conv is).
+  * ConvTranspose2d weights: logical ``[Cin, Cout, 2, 2]``, memory ``[kh][kw][Cin][Cout]`` (four 1x1-conv
+    matrices, one per output tap).
 
 Every family on the discriminator path is closed under differentiation (its ``backward`` is written
 with other differentiable Functions), because WGAN-GP differentiates D's backward again
@@ -24,6 +24,10 @@ from torch.autograd.function import once_differentiable
 from . import _hip as H
 
 IN_EPS = 1e-5
+
+import os as _os
+# debugging / cross-check switch: route every conv through the shape-complete direct kernels
+FORCE_GENERIC_CONV = bool(int(_os.environ.get("SMSUT_FORCE_GENERIC_CONV", "0")))
 
 _INPUT_GRADS_ONLY = False
 
@@ -82,8 +86,8 @@ def new_weight(o, i, kh, kw, device=None) -> torch.Tensor:
 
 
 def convT_strides(ci, co, kh, kw):
-    # memory [kh][kw][co][ci]
-    return (1, ci, kw * co * ci, co * ci)
+    # memory [kh][kw][ci][co]
+    return (co, 1, kw * ci * co, ci * co)
 
 
 def new_convT_weight(ci, co, kh=2, kw=2, device=None) -> torch.Tensor:
@@ -125,7 +129,12 @@ def _conv_fwd_launch(x, w, bias, stride, pad):
     assert ci == ci2, f"conv: Cin mismatch {ci} vs {ci2}"
     ho, wo = _out_size(h, kh, stride, pad), _out_size(wd, kw, stride, pad)
     y = new_act(n, co, ho, wo, x)
-    H.call("smsut_conv2d_fwd_generic", x, w, bias, y, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
+    if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, ci, co):
+        H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, wd, ci, co, kh, 0, _s())
+        if bias is not None:
+            H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
+    else:
+        H.call("smsut_conv2d_fwd_generic", x, w, bias, y, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
     return y
 
 
@@ -134,7 +143,10 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
     co2, ci, kh, kw = w.shape
     assert co == co2
     gx = new_act(n, ci, h, wd, gy)
-    H.call("smsut_conv2d_dgrad_generic", gy, w, gx, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
+    if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, co, ci):
+        H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
+    else:
+        H.call("smsut_conv2d_dgrad_generic", gy, w, gx, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
     return gx
 
 
@@ -142,9 +154,20 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
     n, ci, h, wd = x.shape
     _, co, ho, wo = gy.shape
     gw = new_weight(co, ci, kh, kw, device=x.device)
-    ws = _ws(H.call("smsut_conv2d_wgrad_generic_ws", n, ho, wo, ci, co, kh, kw), x)
-    H.call("smsut_conv2d_wgrad_generic", x, gy, gw, ws, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
+    if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_wgrad_mfma_supported", kh, stride, pad, ci, co):
+        ws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, wd, ci, co, kh), x)
+        H.call("smsut_conv2d_wgrad_mfma", x, gy, gw, ws, n, h, wd, ci, co, kh, _s())
+    else:
+        ws = _ws(H.call("smsut_conv2d_wgrad_generic_ws", n, ho, wo, ci, co, kh, kw), x)
+        H.call("smsut_conv2d_wgrad_generic", x, gy, gw, ws, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
     return gw
+
+
+def conv_fwd_kernel_name(cin, cout, k, stride, pad):
+    """Which device kernel ``conv2d`` dispatches to for this layer shape: (symbol, 'mfma' | 'generic')."""
+    if H.call("smsut_conv2d_mfma_supported", k, stride, pad, cin, cout):
+        return "conv_mfma_fwd", "mfma"
+    return "conv_fwd_naive", "generic"
 
 
 class Conv2dFn(Function):
@@ -262,7 +285,7 @@ def conv2d(x, w, bias=None, stride=1, pad=0):
 
 
 class ConvT2x2Fn(Function):
-    """ConvTranspose2d(k=2, s=2, bias=False) (network/blocks.py:41) == data-gradient of a k2/s2/p0 conv."""
+    """ConvTranspose2d(k=2, s=2, bias=False) (network/blocks.py:41): four 1x1 MFMA convs, one per output tap."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -270,10 +293,11 @@ class ConvT2x2Fn(Function):
         n, ci, h, wd = x.shape
         ci2, co, kh, kw = w.shape
         assert ci == ci2 and kh == 2 and kw == 2
+        if not H.call("smsut_convT2x2_mfma_supported", ci, co):
+            raise H.SmsutHipError(f"ConvTranspose2x2 needs channel counts that are multiples of 4, got {ci}->{co}")
         ctx.save_for_backward(x, w)
         y = new_act(n, co, 2 * h, 2 * wd, x)
-        # as the conv: Cin_conv = co, Cout_conv = ci, "gy" = x, "gx" = y
-        H.call("smsut_conv2d_dgrad_generic", x, w, y, n, 2 * h, 2 * wd, co, h, wd, ci, 2, 2, 2, 0, _s())
+        H.call("smsut_convT2x2_fwd_mfma", x, w, y, n, h, wd, ci, co, _s())
         return y
 
     @staticmethod
@@ -286,11 +310,11 @@ class ConvT2x2Fn(Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = new_act(n, ci, h, wd, x)
-            H.call("smsut_conv2d_fwd_generic", gy, w, None, gx, n, 2 * h, 2 * wd, co, h, wd, ci, 2, 2, 2, 0, _s())
+            H.call("smsut_convT2x2_dgrad_mfma", gy, w, gx, n, h, wd, ci, co, _s())
         if ctx.needs_input_grad[1]:
             gw = new_convT_weight(ci, co, 2, 2, device=x.device)
-            ws = _ws(H.call("smsut_conv2d_wgrad_generic_ws", n, h, wd, co, ci, 2, 2), x)
-            H.call("smsut_conv2d_wgrad_generic", gy, x, gw, ws, n, 2 * h, 2 * wd, co, h, wd, ci, 2, 2, 2, 0, _s())
+            ws = _ws(H.call("smsut_convT2x2_wgrad_mfma_ws", n, h, wd, ci, co), x)
+            H.call("smsut_convT2x2_wgrad_mfma", x, gy, gw, ws, n, h, wd, ci, co, _s())
         return gx, gw
 
 

@@ -42,6 +42,21 @@ CONV_CASES = [
     (2, 4, 4, 32, 4, 4, 1, 0, False),
     (2, 4, 4, 32, 1, 3, 1, 1, False),
     (2, 8, 8, 6, 10, 3, 1, 1, False),
+    # MFMA implicit-GEMM shapes: every tile config, ragged tiles, K chunk tails (Cin 8 / 24 / 40), N tails
+    (2, 32, 32, 8, 16, 3, 1, 1, False),
+    (1, 48, 40, 16, 16, 3, 1, 1, False),
+    (2, 64, 64, 16, 32, 3, 1, 1, False),
+    (1, 72, 80, 32, 64, 3, 1, 1, False),
+    (2, 32, 32, 64, 128, 3, 1, 1, False),
+    (2, 16, 16, 24, 40, 3, 1, 1, False),
+    (3, 8, 8, 40, 256, 3, 1, 1, False),
+    (2, 4, 4, 128, 256, 3, 1, 1, False),
+    (2, 20, 12, 12, 5, 3, 1, 1, False),
+    (2, 64, 64, 8, 16, 1, 1, 0, False),
+    (2, 32, 32, 64, 32, 1, 1, 0, False),
+    (2, 16, 16, 256, 128, 1, 1, 0, False),
+    (2, 40, 40, 16, 5, 1, 1, 0, True),
+    (2, 128, 128, 32, 16, 3, 1, 1, False),
 ]
 
 
@@ -61,7 +76,7 @@ def test_conv2d_fwd_dgrad_wgrad(ops, case):
     assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-5
     yd.backward(dev(gy))
     assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-5
-    assert rel_err(wd.grad.cpu().numpy(), wt.grad.numpy()) < 2e-5
+    assert rel_err(wd.grad.cpu().numpy(), wt.grad.numpy()) < 5e-5      # sums over up to 32k pixels in fp32
     assert wd.grad.stride() == wd.stride()
     if has_b:
         assert rel_err(bd.grad.cpu().numpy(), b.grad.numpy()) < 1e-5
@@ -165,15 +180,31 @@ def test_pool_and_upsample(ops, name):
     assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-6
 
 
+@pytest.mark.parametrize("ci,co,h,w_", [(8, 4, 4, 4), (32, 16, 24, 20), (256, 128, 16, 16), (64, 32, 40, 8)])
+def test_convT_shapes(ops, ci, co, h, w_):
+    x = rnd(2, ci, h, w_, seed=1).requires_grad_(True)
+    w = (rnd(ci, co, 2, 2, seed=2) / np.sqrt(ci)).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, stride=2)
+    gy = rnd(*y.shape, seed=4)
+    y.backward(gy)
+    xd = dev(x.detach()).requires_grad_(True)
+    wd = ops.new_convT_weight(ci, co, device="cuda"); wd.copy_(w.detach()); wd.requires_grad_(True)
+    yd = ops.conv_transpose2x2(xd, wd)
+    yd.backward(dev(gy))
+    assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-5
+    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-5
+    assert rel_err(wd.grad.cpu().numpy(), w.grad.numpy()) < 5e-5
+
+
 def test_convT_concat_planes(ops):
     x = rnd(2, 8, 4, 4, seed=1).requires_grad_(True)
-    w = (rnd(8, 6, 2, 2, seed=2) / 3).requires_grad_(True)
+    w = (rnd(8, 4, 2, 2, seed=2) / 3).requires_grad_(True)
     sk = rnd(2, 5, 8, 8, seed=3).requires_grad_(True)
     y = torch.cat([F.conv_transpose2d(x, w, stride=2), sk], 1)
     gy = rnd(*y.shape, seed=4)
     y.backward(gy)
     xd, skd = dev(x.detach()).requires_grad_(True), dev(sk.detach()).requires_grad_(True)
-    wd = ops.new_convT_weight(8, 6, device="cuda"); wd.copy_(w.detach()); wd.requires_grad_(True)
+    wd = ops.new_convT_weight(8, 4, device="cuda"); wd.copy_(w.detach()); wd.requires_grad_(True)
     yd = ops.concat_channels(ops.conv_transpose2x2(xd, wd), skd)
     yd.backward(dev(gy))
     assert rel_err(yd.detach().cpu().numpy(), y.detach().numpy()) < 1e-5
