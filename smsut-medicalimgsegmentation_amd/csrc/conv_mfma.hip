@@ -264,13 +264,25 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   }
 }
 
+// out[e] = sum_c part[c][e]; wsize is a multiple of 4 on every MFMA path (Cin%4 == 0 or Cout%4 == 0)
 __global__ void __launch_bounds__(TPB)
 sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
-  const int e = blockIdx.x * TPB + threadIdx.x;
+  const int e = (blockIdx.x * TPB + threadIdx.x) * 4;
   if (e >= wsize) return;
-  float s = 0.f;
-  for (int c = 0; c < splits; ++c) s += part[(size_t)c * wsize + e];
-  out[e] = s;
+  if (e + 3 < wsize) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < splits; ++c) {
+      const float4 v = *(const float4*)(part + (size_t)c * wsize + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *(float4*)(out + e) = s;
+  } else {
+    for (int k = e; k < wsize; ++k) {
+      float s = 0.f;
+      for (int c = 0; c < splits; ++c) s += part[(size_t)c * wsize + k];
+      out[k] = s;
+    }
+  }
 }
 
 template <int KS, int TH, int WM, int WN, int NTN>
@@ -316,7 +328,11 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
   p.tiles_y = (H + WTH - 1) / WTH;
   const int total = N * p.tiles_x * p.tiles_y;
   const int slabs = ((Cin + 16 * p.cit - 1) / (16 * p.cit)) * ((Cout + 16 * p.cot - 1) / (16 * p.cot));
-  int want = (1024 + slabs - 1) / slabs;         // aim for ~1024 workgroups in flight (4 per CU)
+  int want = (1024 + slabs - 1) / slabs;         // aim for ~1024 workgroups in flight (4 per CU) ...
+  // ... but keep the per-split slabs that sum_splits has to re-read below ~8 MB (2M floats)
+  const int64_t wsz = (int64_t)Cin * Cout * 9;
+  const int cap = (int)((int64_t)(2 << 20) / wsz);
+  if (want > cap) want = cap;
   if (want > total) want = total;
   if (want < 1) want = 1;
   p.tiles_per_split = (total + want - 1) / want;
@@ -418,7 +434,7 @@ int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* w
     else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
   }
   const int wsize = KS * KS * Cin * Cout;
-  sum_splits<<<(wsize + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  sum_splits<<<(wsize + 4 * TPB - 1) / (4 * TPB), TPB, 0, st>>>(workspace, gw, wsize, p.splits);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -438,7 +454,7 @@ int smsut_convT2x2_wgrad_mfma(const float* x, const float* gy, float* gw, float*
   else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
   else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
   const int wsize = 4 * Cin * Cout;
-  sum_splits<<<(wsize + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  sum_splits<<<(wsize + 4 * TPB - 1) / (4 * TPB), TPB, 0, st>>>(workspace, gw, wsize, p.splits);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

@@ -96,27 +96,36 @@ conv_wgrad_partial(const float* __restrict__ x, const float* __restrict__ gy, fl
   const int kh = t / g.KW;
   const int64_t p0 = (int64_t)chunk * pix_per_chunk;
   const int64_t p1 = min(p0 + (int64_t)pix_per_chunk, npix);
+  // walk (n, ho, wo) incrementally: no div/mod in the loop
+  int wo = (int)(p0 % g.Wo);
+  const int64_t q0 = p0 / g.Wo;
+  int ho = (int)(q0 % g.Ho);
+  int n = (int)(q0 / g.Ho);
   float acc = 0.f;
-  for (int64_t p = p0; p < p1; ++p) {
-    const int wo = (int)(p % g.Wo);
-    const int64_t q = p / g.Wo;
-    const int ho = (int)(q % g.Ho);
-    const int n = (int)(q / g.Ho);
+  const float* gp = gy + (size_t)p0 * g.Cout + co;
+  for (int64_t p = p0; p < p1; ++p, gp += g.Cout) {
     const int hi = ho * g.stride - g.pad + kh;
     const int wi = wo * g.stride - g.pad + kw;
-    if (hi < 0 || hi >= g.H || wi < 0 || wi >= g.W) continue;
-    acc = fmaf(x[(((size_t)n * g.H + hi) * g.W + wi) * g.Cin + ci], gy[(size_t)p * g.Cout + co], acc);
+    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
+      acc = fmaf(x[(((size_t)n * g.H + hi) * g.W + wi) * g.Cin + ci], *gp, acc);
+    if (++wo == g.Wo) { wo = 0; if (++ho == g.Ho) { ho = 0; ++n; } }
   }
   part[(size_t)chunk * wsize + e] = acc;
 }
 
+// out[e] = sum_c part[c][e]: 64 elements x 4 chunk-lanes per block, fp64 accumulation, fixed order
 __global__ void __launch_bounds__(TPB)
 reduce_chunks(const float* __restrict__ part, float* __restrict__ out, int wsize, int chunks) {
-  const int e = blockIdx.x * TPB + threadIdx.x;
-  if (e >= wsize) return;
+  __shared__ double sm[TPB];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lane_c = threadIdx.x >> 6;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += (double)part[(size_t)c * wsize + e];
-  out[e] = (float)s;
+  if (e < wsize)
+    for (int c = lane_c; c < chunks; c += 4) s += (double)part[(size_t)c * wsize + e];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (lane_c == 0 && e < wsize)
+    out[e] = (float)(sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
 }
 
 // column sums of a [rows][C] matrix -> partial[chunk][C]
@@ -146,8 +155,10 @@ colsum_partial(const float* __restrict__ x, float* __restrict__ part, int64_t ro
   }
 }
 
-inline int wgrad_ppc(int64_t npix) {
-  int64_t ppc = cdiv64(npix, 1024);
+inline int wgrad_ppc(int64_t npix, int wsize) {
+  // small weight tensors (stems, heads) get many short chunks so the grid still fills the chip
+  const int64_t chunks_target = wsize <= 4096 ? 8192 : 1024;
+  int64_t ppc = cdiv64(npix, chunks_target);
   if (ppc < 64) ppc = 64;
   return (int)ppc;
 }
@@ -187,7 +198,7 @@ int smsut_conv2d_dgrad_generic(const float* gy, const float* w, float* gx, int N
 // workspace floats needed by smsut_conv2d_wgrad_generic
 int64_t smsut_conv2d_wgrad_generic_ws(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW) {
   const int64_t npix = (int64_t)N * Ho * Wo;
-  const int ppc = wgrad_ppc(npix);
+  const int ppc = wgrad_ppc(npix, KH * KW * Cin * Cout);
   return cdiv64(npix, ppc) * (int64_t)KH * KW * Cin * Cout;
 }
 
@@ -196,12 +207,12 @@ int smsut_conv2d_wgrad_generic(const float* x, const float* gy, float* gw, float
   ConvGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad};
   SMSUT_REQUIRE(x && gy && gw && workspace && geom_ok(g));
   const int64_t npix = (int64_t)N * Ho * Wo;
-  const int ppc = wgrad_ppc(npix);
-  const int chunks = (int)cdiv64(npix, ppc);
   const int wsize = KH * KW * Cin * Cout;
+  const int ppc = wgrad_ppc(npix, wsize);
+  const int chunks = (int)cdiv64(npix, ppc);
   hipStream_t st = (hipStream_t)stream;
   conv_wgrad_partial<<<dim3((wsize + TPB - 1) / TPB, chunks), TPB, 0, st>>>(x, gy, workspace, g, wsize, npix, ppc);
-  reduce_chunks<<<(wsize + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, wsize, chunks);
+  reduce_chunks<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, chunks);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -220,7 +231,7 @@ int smsut_colsum(const float* x, float* out, float* workspace, int64_t rows, int
   const int chunks = (int)cdiv64(rows, rpc);
   hipStream_t st = (hipStream_t)stream;
   colsum_partial<<<chunks, TPB, 0, st>>>(x, workspace, rows, C, (int)rpc);
-  reduce_chunks<<<(C + TPB - 1) / TPB, TPB, 0, st>>>(workspace, out, C, chunks);
+  reduce_chunks<<<(C + 63) / 64, TPB, 0, st>>>(workspace, out, C, chunks);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

@@ -57,18 +57,21 @@ k_dicece_partial(const float* __restrict__ logits, const int64_t* __restrict__ l
 }
 
 // stats[G][C][3] (fp32) and ce_sum[1]
-__global__ void k_dicece_reduce(const float* __restrict__ part, const float* __restrict__ part_ce, int nblk, int GC3,
-                                float* __restrict__ stats, float* __restrict__ ce_sum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// one 256-thread block per output word (GC3 statistics + 1 CE sum): fp64 tree over the per-block partials
+__global__ void __launch_bounds__(TPB)
+k_dicece_reduce(const float* __restrict__ part, const float* __restrict__ part_ce, int nblk, int GC3,
+                float* __restrict__ stats, float* __restrict__ ce_sum) {
+  __shared__ double sm4[4];
+  const int i = blockIdx.x;
+  double s = 0.0;
   if (i < GC3) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * GC3 + i];
-    stats[i] = (float)s;
+    for (int b = threadIdx.x; b < nblk; b += TPB) s += (double)part[(size_t)b * GC3 + i];
+  } else {
+    for (int b = threadIdx.x; b < nblk; b += TPB) s += (double)part_ce[b];
   }
-  if (i == 0) {
-    double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part_ce[b];
-    ce_sum[0] = (float)s;
+  s = block_sum_256_d(s, sm4);
+  if (threadIdx.x == 0) {
+    if (i < GC3) stats[i] = (float)s; else ce_sum[0] = (float)s;
   }
 }
 
@@ -368,7 +371,7 @@ int smsut_dicece_stats(const float* logits, const int64_t* labels, float* stats,
   float* part = workspace;
   float* part_ce = workspace + (size_t)nblk * G * C * 3;
   k_dicece_partial<<<dim3(pb, N), TPB, 0, ST>>>(logits, labels, part, part_ce, N, HW, C, G);
-  k_dicece_reduce<<<(G * C * 3 + 63) / 64, 64, 0, ST>>>(part, part_ce, nblk, G * C * 3, stats, ce_sum);
+  k_dicece_reduce<<<G * C * 3 + 1, TPB, 0, ST>>>(part, part_ce, nblk, G * C * 3, stats, ce_sum);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 // Stage 2: out[0] = w_dc*dice + w_ce*ce, out[1] = dice loss, out[2] = ce.  npix_total = (global) N*HW.

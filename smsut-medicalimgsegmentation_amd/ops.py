@@ -346,10 +346,13 @@ class InstNormActFn(Function):
         ctx.save_for_backward(x, y, mean, rstd, gamma)
         ctx.cfg = (float(slope), bool(has_act))
         ctx.mark_non_differentiable(mean, rstd)
+        ctx.set_materialize_grads(False)
         return y, mean, rstd
 
     @staticmethod
     def backward(ctx, gy, _gm, _gr):
+        if gy is None:          # reached only through the (non-differentiable) mask input of the double backward
+            return None, None, None, None, None
         x, y, mean, rstd, gamma = ctx.saved_tensors
         slope, has_act = ctx.cfg
         want_affine = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRADS_ONLY
@@ -378,6 +381,7 @@ class InstNormActBwdFn(Function):
                n, h * w, c, slope, _s())
         ctx.save_for_backward(gy, x, y, mean, rstd, gamma, a, b)
         ctx.cfg = (slope, has_act, want_affine)
+        ctx.set_materialize_grads(False)
         return gx, gg, gb
 
     @staticmethod
@@ -385,6 +389,8 @@ class InstNormActBwdFn(Function):
     def backward(ctx, v, ug, ub):
         gy, x, y, mean, rstd, gamma, a, b = ctx.saved_tensors
         slope, has_act, want_affine = ctx.cfg
+        if v is None:                       # only the affine gradients were used downstream
+            v = torch.zeros_like(x)
         v = nhwc(v)
         n, c, h, w = x.shape
         d_gy = new_act(n, c, h, w, x)
