@@ -1,0 +1,139 @@
+/* smsut_hip.h -- C ABI of the MI355X (gfx950) kernels behind the SMSUT conv hot path.
+ *
+ * The reference (Sue1347/SMSUT-MedicalImgSegmentation) has no native code and no FFI: its boundary is the Python
+ * module API (network.unet / network.ugan / network.networks constructors, trainer.uganConsisTrainer), whose
+ * arithmetic it delegates to torch operators.  Each entry point below replaces the torch operator(s) named in
+ * its comment at the cited reference call site(s); `smsut-medicalimgsegmentation_amd/ops.py` binds them behind
+ * torch.autograd.Function objects and INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory (fp32 unless typed otherwise), allocated and owned by the caller; the
+ *     library never allocates, frees or synchronises; `workspace` sizes come from the matching `*_ws` query;
+ *   - activations are dense NHWC: [N][H][W][C]; conv weights are [KH][KW][Cin][Cout]; ConvTranspose2x2 weights
+ *     are [kh][kw][Cin][Cout]; Linear weights are [in][out];
+ *   - `stream` is a hipStream_t passed as void*; every kernel is enqueued on it (graph-capture safe);
+ *   - return value: 0 = enqueued, -1 = invalid argument, > 0 = hipError_t of the launch; nothing throws;
+ *   - no global mutable state; safe to call from several host threads on different streams.
+ */
+#ifndef SMSUT_HIP_H
+#define SMSUT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------- convolution
+ * nn.Conv2d as used at network/blocks.py:10-16 (conv3x3 / conv1x1), blocks.py:123 + ugan.py:26 (5x5 stems),
+ * ugan.py:70 (1x1 heads with bias), ugan.py:202 (D stem k4 s2 p1 + bias), ugan.py:214-215 (conv_src / conv_cls).
+ * *_generic: any kernel size / stride / zero padding (direct convolution).
+ * *_mfma   : stride-1 "same" 1x1 / 3x3 on the matrix cores (v_mfma_f32_16x16x4_f32), the > 97 %-of-FLOPs path. */
+int smsut_conv2d_fwd_generic(const float* x, const float* w, const float* bias /*nullable*/, float* y, int N, int H,
+                             int W, int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad,
+                             void* stream);
+int smsut_conv2d_dgrad_generic(const float* gy, const float* w, float* gx, int N, int H, int W, int Cin, int Ho, int Wo,
+                               int Cout, int KH, int KW, int stride, int pad, void* stream);
+int64_t smsut_conv2d_wgrad_generic_ws(int N, int Ho, int Wo, int Cin, int Cout, int KH, int KW);
+int smsut_conv2d_wgrad_generic(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W,
+                               int Cin, int Ho, int Wo, int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim);
+/* transposed = 0: y[N,H,W,Ndim] = conv(x[N,H,W,Kdim], w[KS*KS][Kdim][Ndim]);
+ * transposed = 1: data-gradient, x = gy[N,H,W,Kdim=Cout], w = forward weights [KS*KS][Ndim=Cin][Kdim=Cout]. */
+int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
+                          int transposed, void* stream);
+int smsut_conv2d_wgrad_mfma_supported(int KS, int stride, int pad, int Cin, int Cout);
+int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int KS);
+int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                            int Cout, int KS, void* stream);
+
+/* nn.ConvTranspose2d(in, out, kernel_size=2, stride=2, bias=False) -- network/blocks.py:41 (U-Net / seg decoder up path). */
+int smsut_convT2x2_mfma_supported(int Cin, int Cout);
+int smsut_convT2x2_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
+int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N, int H, int W, int Cin, int Cout,
+                              void* stream);
+int64_t smsut_convT2x2_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout);
+int smsut_convT2x2_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                              int Cout, void* stream);
+
+/* bias gradient: out[c] = sum over rows of x[rows][C] */
+int64_t smsut_colsum_ws(int64_t rows, int C);
+int smsut_colsum(const float* x, float* out, float* workspace, int64_t rows, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- instance norm
+ * nn.InstanceNorm2d(C, affine=True) (+ the following LeakyReLU/ReLU) -- network/blocks.py:19-32,57-60,64.
+ * _bwd2 is the backward of _bwd, needed because WGAN-GP differentiates D's backward
+ * (trainer/uganShp0Trainer.py:127-134, create_graph=True). */
+int smsut_in_chunks(int N, int HW, int C); /* workspace = N * chunks * C * 3 floats */
+int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                       float* workspace, int N, int HW, int C, float eps, float slope, int has_act, void* stream);
+int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask /*nullable*/, const float* mean,
+                       const float* rstd, const float* gamma, float* gx, float* a_mean, float* b_mean,
+                       float* ggamma /*nullable*/, float* gbeta /*nullable*/, float* workspace, int N, int HW, int C,
+                       float slope, void* stream);
+int smsut_instnorm_bwd2(const float* v, const float* ug /*nullable*/, const float* ub /*nullable*/, const float* gy,
+                        const float* x, const float* ymask /*nullable*/, const float* mean, const float* rstd,
+                        const float* gamma, const float* a_mean, const float* b_mean, float* d_gy, float* d_x,
+                        float* d_gamma, float* workspace, float* scratch /*3*N*C*/, int N, int HW, int C, float slope,
+                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------- pointwise / resampling
+ * LeakyReLU + residual add (blocks.py:78-79,115-116), nn.Tanh (ugan.py:72-73), conv bias, F.avg_pool2d(x,2)
+ * (blocks.py:101,107), nn.MaxPool2d(2,2) (blocks.py:128-134), nn.Upsample(x2, bilinear, align_corners=False)
+ * (blocks.py:44), torch.cat (blocks.py:50, ugan.py:159), modality planes (ugan.py:156-157), x_hat (uganConsisTrainer.py:139). */
+int smsut_add_act(const float* a, const float* b /*nullable*/, float* y, int64_t n, float slope, void* stream);
+int smsut_act_bwd(const float* gy, const float* y, float* gx, int64_t n, float slope, void* stream);
+int smsut_tanh_fwd(const float* x, float* y, int64_t n, void* stream);
+int smsut_tanh_bwd(const float* gy, const float* y, float* gx, int64_t n, void* stream);
+int smsut_bias_add(const float* x, const float* bias, float* y, int64_t rows, int C, void* stream);
+int smsut_row_lerp(const float* a, const float* b, const float* alpha, float* out, int64_t rows, int64_t row_len,
+                   void* stream);
+int smsut_fill(float* out, float v, int64_t n, void* stream);
+int smsut_scale(const float* x, const float* scale_dev /*nullable*/, float mul, float* out, int64_t n, void* stream);
+int smsut_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int smsut_maxpool2_bwd(const float* gy, const float* x, float* gx, int N, int H, int W, int C, void* stream);
+int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
+int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int smsut_bilinear2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
+int smsut_copy_channels(const float* src, int Cs, int src_off, float* dst, int Cd, int dst_off, int Cc, int64_t P,
+                        void* stream);
+int smsut_modal_planes(const float* x, const float* m, float* out, int N, int64_t HW, int Cx, int M, void* stream);
+
+/* ---------------------------------------------------------------------------------------------- losses
+ * DiceAndCrossEntropyLoss / SoftDiceLoss (misc/loss.py:8-63): stage 1 = per-class {tp, sum_p, count} + CE sum,
+ * (optional all-reduce by the caller under data parallelism), stage 2 = scalar; G = 1 batch dice, G = N per sample. */
+int64_t smsut_dicece_ws(int N, int64_t HW, int C, int G);
+int smsut_dicece_stats(const float* logits, const int64_t* labels, float* stats, float* ce_sum, float* workspace, int N,
+                       int64_t HW, int C, int G, void* stream);
+int smsut_dicece_final(const float* stats, const float* ce_sum, float* out /*3*/, int G, int C, double npix_total,
+                       float w_dc, float w_ce, void* stream);
+int smsut_dicece_bwd(const float* logits, const int64_t* labels, const float* stats, const float* gout, float* glogits,
+                     int N, int64_t HW, int C, int G, double npix_total, float w_dc, float w_ce, void* stream);
+/* -/+ mean(out_src) (uganConsisTrainer.py:130,136,154), mean|a-b| (:162), F.cross_entropy on [B,n_modal] (:131,155),
+ * gradient penalty norm term (uganShp0Trainer.py:131-134). */
+int64_t smsut_sum_ws(int64_t n, int rows);
+int smsut_sum(const float* a, float* out, float* workspace, int64_t n, double scale, void* stream);
+int smsut_l1_fwd(const float* a, const float* b, float* out, float* workspace, int64_t n, void* stream);
+int smsut_l1_bwd(const float* a, const float* b, const float* gout, float* ga /*nullable*/, float* gb /*nullable*/,
+                 int64_t n, void* stream);
+int smsut_gp_fwd(const float* dydx, float* out, float* norms, float* workspace, int rows, int64_t n, void* stream);
+int smsut_gp_bwd(const float* dydx, const float* norms, const float* gout, float* g, int rows, int64_t n, void* stream);
+int smsut_ce_rows_fwd(const float* z, const int64_t* tgt, float* out, int B, int C, void* stream);
+int smsut_ce_rows_bwd(const float* z, const int64_t* tgt, const float* gout, float* gz, int B, int C, void* stream);
+/* PatchSampleF gather (ugan.py:318-327), networks.Normalize (networks.py:234-243), PatchNCELoss (patchnce.py:13-51). */
+int smsut_gather_rows(const float* feat, const int64_t* ids, float* out, int B, int64_t HW, int C, int P, void* stream);
+int smsut_scatter_rows(const float* gout, const int64_t* ids, float* gfeat, int B, int64_t HW, int C, int P,
+                       void* stream);
+int smsut_l2norm_fwd(const float* x, float* y, float* norms, int rows, int C, void* stream);
+int smsut_l2norm_bwd(const float* gy, const float* x, const float* norms, float* gx, int rows, int C, void* stream);
+int smsut_patchnce_fwd(const float* q, const float* k, float* loss, float* probs, int rows, int np, int dim, float T,
+                       void* stream);
+int smsut_patchnce_bwd(const float* gloss, const float* probs, const float* k, float* gq, int rows, int np, int dim,
+                       float T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMSUT_HIP_H */

@@ -111,6 +111,8 @@ def load() -> ctypes.CDLL:
 
 
 def stream_ptr() -> int:
+    if not torch.cuda.is_available():
+        raise SmsutHipError("SMSUT HIP ops need an MI355X (no HIP device visible; there is no CPU fallback)")
     return torch.cuda.current_stream().cuda_stream
 
 

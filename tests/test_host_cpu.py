@@ -1,0 +1,113 @@
+"""Host-side logic on CPU: state_dict compatibility with the reference (keys / OIHW shapes / checkpoint round trip),
+weight-memory layouts, drop-in module aliases, synthetic loader contract, Meter, Dice matrix, poly LR / ramp-up."""
+import io
+
+import numpy as np
+import torch
+
+import smsut_amd
+from oracle import recipe, smsut_oracle as O
+from smsut_amd import config as cfg, ops
+from smsut_amd.misc.synthetic import SyntheticSliceLoader
+from smsut_amd.misc.utils import Meter, binary_dc, get_mo_matrix
+from smsut_amd.network.ugan import UGAN, Discriminator, UGANnce
+from smsut_amd.network.unet import UNet
+
+
+def test_state_dict_keys_and_shapes_match_reference_tables():
+    for net, shapes in ((UNet(1, 5, 16, "instance", "lrelu"), recipe.unet_shapes(1, 5, 16)),
+                        (UNet(1, 2, 16, "instance", "lrelu"), recipe.unet_shapes(1, 2, 16)),
+                        (UGANnce(1, 5, 4, 16), recipe.ugan_shapes(1, 5, 4, 16)),
+                        (UGAN(1, 5, 4, 8), recipe.ugan_shapes(1, 5, 4, 8, nce=False)),
+                        (Discriminator(256, 4, 16, 256), recipe.disc_shapes(256, 4, 16, 256)),
+                        (Discriminator(512, 4, 16, 256), recipe.disc_shapes(512, 4, 16, 256))):
+        sd = net.state_dict()
+        assert list(sd) == list(shapes)
+        assert all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+    assert sum(p.numel() for p in UNet(1, 5, 16, "instance", "lrelu").parameters()) == 2031976
+    assert sum(p.numel() for p in UNet(1, 2, 16, "instance", "lrelu").parameters()) == 2031928
+    assert sum(p.numel() for p in UGANnce(1, 5, 4, 16).parameters()) == 3146678
+    assert sum(p.numel() for p in Discriminator(256, 4, 16, 256).parameters()) == 2421072
+
+
+def test_checkpoint_round_trip_preserves_values_and_kernel_layout():
+    net = UNet(1, 3, 4, "instance", "lrelu")
+    want = recipe.fill(recipe.unet_shapes(1, 3, 4), 5)
+    net.load_state_dict(want)
+    w = net.encoder.layer2.conv1.weight
+    assert w.stride() == ops.hwio_strides(*w.shape)            # still [KH][KW][I][O] memory after load
+    up = net.decoder.up2.up.weight
+    assert up.stride() == ops.convT_strides(*up.shape)
+    buf = io.BytesIO()
+    torch.save({k: v.contiguous() for k, v in net.state_dict().items()}, buf)      # as trainer.save_model writes it
+    buf.seek(0)
+    back = torch.load(buf)
+    for k, v in want.items():
+        assert back[k].is_contiguous() and torch.equal(back[k], v), k          # plain OIHW: loadable by the reference
+
+
+def test_hwio_view_is_the_same_tensor_logically():
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    v = ops.new_weight(2, 3, 3, 3)
+    v.copy_(w)
+    assert torch.equal(v, w)
+    flat = v.as_strided((v.numel(),), (1,))
+    assert torch.equal(flat.reshape(3, 3, 3, 2), w.permute(2, 3, 1, 0))       # memory order is [KH][KW][I][O]
+    t = ops.new_convT_weight(4, 2)
+    t.copy_(torch.arange(4 * 2 * 4, dtype=torch.float32).reshape(4, 2, 2, 2))
+    assert torch.equal(t.as_strided((t.numel(),), (1,)).reshape(2, 2, 4, 2), t.permute(2, 3, 0, 1))
+    lw = ops.new_linear_weight(5, 3)
+    lw.copy_(torch.arange(15, dtype=torch.float32).reshape(5, 3))
+    assert torch.equal(lw.as_strided((15,), (1,)).reshape(3, 5), lw.t())
+
+
+def test_dropin_aliases():
+    smsut_amd.install_dropin()
+    from network.ugan import UGANnce as A          # noqa: the reference's own import statements
+    from network.unet import UNet as B
+    from misc.loss import DiceAndCrossEntropyLoss
+    import config as c
+    from trainer.uganConsisTrainer import UGANConsisTrainer
+    assert A is UGANnce and B is UNet and c.nce_layers == [5] and c.batch_size == 8
+    assert hasattr(UGANConsisTrainer, "train_epoch") and hasattr(UGANConsisTrainer, "saving_pseudo")
+    assert DiceAndCrossEntropyLoss(0.5, 0.5, True).batch_dice is True
+
+
+def test_unsupported_surface_raises():
+    import pytest
+    with pytest.raises(NotImplementedError):
+        UNet(1, 5, 16)                               # default norm_type='batch' is outside the hot path
+
+
+def test_synthetic_loader_contract():
+    ld = SyntheticSliceLoader(4, size=32, n_classes=5, n_batches=5, device="cpu", seed=1)
+    mods = []
+    for img, msk, mod, names in ld:
+        assert img.shape == (4, 1, 32, 32) and img.dtype == torch.float32 and img.abs().max() <= 1
+        assert msk.shape == (4, 32, 32) and msk.dtype == torch.int64 and 0 <= msk.min() and msk.max() < 5
+        assert len(set(mod.tolist())) == 1 and len(names) == 4 and names[0].count("_") == 2
+        mods.append(int(mod[0]))
+    assert mods == [0, 1, 2, 3, 0]                   # single-modality batches, round robin
+
+
+def test_meter_and_dice_matrix():
+    m = Meter([f"loss_{i}" for i in range(4)] + ["loss"], ["dice"])
+    v, n = m.collect_loss_by(2.0, 1, 8)
+    m.accumulate(v, n)
+    v, n = m.collect_loss_by(4.0, 1, 8)
+    m.accumulate(v, n)
+    m.update_cur()
+    assert m.cur_values["loss"] == 3.0 and m.cur_values["loss_1"] == 3.0 and m.cur_values["loss_0"] == 0
+    a = np.zeros((2, 4, 4), int); b = np.zeros((2, 4, 4), int)
+    a[:, :2] = 1; b[:, 1:3] = 1
+    assert abs(binary_dc(a == 1, b == 1) - 0.5) < 1e-12 and binary_dc(a == 2, b == 2) == 0.0
+    assert binary_dc(a == 1, b == 1) == O.medpy_dc(a == 1, b == 1)
+    mo = get_mo_matrix({"ct_001": a}, {"ct_001": b})
+    assert mo.shape == (5, 5) and abs(mo[0, 0] - 0.5) < 1e-12 and abs(mo[0, -1] - 0.125) < 1e-12
+
+
+def test_schedules():
+    from smsut_amd.trainer.baseTrainer import BaseTrainer
+    assert abs(BaseTrainer.sigmoid_rampup(100, 200) - O.sigmoid_rampup(100, 200)) < 1e-12
+    assert BaseTrainer.sigmoid_rampup(5, 0) == 1.0 and abs(BaseTrainer.sigmoid_rampup(300, 200) - 1.0) < 1e-12
+    assert abs(O.poly_lr(1e-2, 15000, 30000) - 1e-2 * 0.5 ** 0.9) < 1e-15
