@@ -43,10 +43,26 @@ int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim)
  * transposed = 1: data-gradient, x = gy[N,H,W,Kdim=Cout], w = forward weights [KS*KS][Ndim=Cin][Kdim=Cout]. */
 int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                           int transposed, void* stream);
+/* tuning hook: same as smsut_conv2d_fwd_mfma with a forced tile configuration (returns -1 for an unknown cfg) */
+int smsut_conv2d_fwd_mfma_cfg(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
+                              int transposed, int cfg, void* stream);
 int smsut_conv2d_wgrad_mfma_supported(int KS, int stride, int pad, int Cin, int Cout);
 int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int KS);
 int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
                             int Cout, int KS, void* stream);
+
+/* Tiny-channel convolutions (HBM-bound): 5x5 stems (blocks.py:123, ugan.py:26), D's k4 s2 stem (ugan.py:202), 1x1 heads
+ * (blocks.py:166, ugan.py:70).  fwd/dgrad: direct, Cin <= 8, Cout in {4,8,12,16}; wgrad: MFMA with the flattened
+ * (tap, ci) index as M, KS*KS*Cin <= 128, Cout <= 16. */
+int smsut_conv2d_small_supported(int KS, int Cin, int Cout);
+int smsut_conv2d_small_fwd(const float* x, const float* w, const float* bias /*nullable*/, float* y, int N, int H, int W,
+                           int Cin, int Ho, int Wo, int Cout, int KS, int stride, int pad, void* stream);
+int smsut_conv2d_small_dgrad(const float* gy, const float* w, float* gx, int N, int H, int W, int Cin, int Ho, int Wo,
+                             int Cout, int KS, int stride, int pad, void* stream);
+int smsut_conv2d_flat_wgrad_supported(int KS, int stride, int Cin, int Cout);
+int64_t smsut_conv2d_flat_wgrad_ws(int N, int Ho, int Wo, int Cin, int Cout, int KS);
+int smsut_conv2d_flat_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                            int Ho, int Wo, int Cout, int KS, int stride, int pad, void* stream);
 
 /* nn.ConvTranspose2d(in, out, kernel_size=2, stride=2, bias=False) -- network/blocks.py:41 (U-Net / seg decoder up path). */
 int smsut_convT2x2_mfma_supported(int Cin, int Cout);

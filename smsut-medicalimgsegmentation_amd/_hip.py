@@ -32,6 +32,7 @@ SIGNATURES: Dict[str, str] = {
     # conv_mfma.hip
     "smsut_conv2d_mfma_supported": "iiiii",
     "smsut_conv2d_fwd_mfma": "ppp iiiiii i s",
+    "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",
     "smsut_conv2d_wgrad_mfma_supported": "iiiii",
     "smsut_conv2d_wgrad_mfma_ws": "iiiiii",
     "smsut_conv2d_wgrad_mfma": "pppp iiiiii s",
@@ -40,6 +41,13 @@ SIGNATURES: Dict[str, str] = {
     "smsut_convT2x2_dgrad_mfma": "ppp iiiii s",
     "smsut_convT2x2_wgrad_mfma_ws": "iiiii",
     "smsut_convT2x2_wgrad_mfma": "pppp iiiii s",
+    # conv_small.hip
+    "smsut_conv2d_small_supported": "iii",
+    "smsut_conv2d_small_fwd": "pppp iiiiiiiiii s",
+    "smsut_conv2d_small_dgrad": "ppp iiiiiiiiii s",
+    "smsut_conv2d_flat_wgrad_supported": "iiii",
+    "smsut_conv2d_flat_wgrad_ws": "iiiiii",
+    "smsut_conv2d_flat_wgrad": "pppp iiiiiiiiii s",
     # pointwise.hip
     "smsut_add_act": "ppp l f s",
     "smsut_act_bwd": "ppp l f s",
@@ -78,9 +86,10 @@ SIGNATURES: Dict[str, str] = {
     "smsut_patchnce_bwd": "pppp iii f s",
 }
 _RET_I64 = {"smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
-            "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws"}
+            "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
-                         "smsut_convT2x2_mfma_supported"}
+                         "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
+                         "smsut_conv2d_flat_wgrad_supported"}
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

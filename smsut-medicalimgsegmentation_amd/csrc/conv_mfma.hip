@@ -73,39 +73,75 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int g = 0; g < G; ++g)
-  for (int c0 = 0; c0 < Kdim; c0 += CK) {
-    const float* wg = w + (size_t)g * KK * Kdim * Ndim;
-    __syncthreads();
-    // ---- stage the haloed input tile for channels [c0, c0+16): one float4 (4 channels) per unit
-    for (int u = tid; u < IH * IW * 4; u += TPB) {
-      const int q = u & 3, pix = u >> 2;
-      const int iy = pix / IW, ix = pix % IW;
-      const int gy_ = y0 + iy - PAD, gx_ = x0 + ix - PAD;
-      const int c = c0 + 4 * q;
+  // Software pipeline over (tap group g, 16-channel chunk c0): the NEXT chunk's global loads are issued into
+  // registers right after the current chunk has been published to LDS, so their latency hides under the MFMAs.
+  constexpr int NI = (IH * IW * 4 + TPB - 1) / TPB;       // float4 units of the input tile per thread
+  constexpr int NW = (KK * 4 * CO_T + TPB - 1) / TPB;     // float4 units of the weight chunk per thread
+  float4 rin[NI], rw[NW];
+  const int nchunk = (Kdim + CK - 1) / CK;
+  const int nsteps = G * nchunk;
+  // per-thread unit descriptors, computed once (integer div/mod is ~40 VALU instructions each on CDNA)
+  int in_off[NI], in_q[NI];        // element offset of the pixel inside one image (tap group 0), or -1; channel quad
+  int w_off[NW], w_k[NW];          // element offset inside one tap-group chunk (c0 = 0), or -1; k of the unit
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int u = tid + i * TPB;
+    const int q = u & 3, pix = u >> 2;
+    const int iy = pix / IW, ix = pix % IW;
+    const int gy_ = y0 + iy - PAD, gx_ = x0 + ix - PAD;
+    const bool ok = u < IH * IW * 4 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+    in_off[i] = ok ? ((gy_ * isc) * Wi + gx_ * isc) * Kdim + 4 * q : -1;
+    in_q[i] = 4 * q;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int u = tid + i * TPB;
+    const int n = u % CO_T;
+    const int k4 = (u / CO_T) & 3;
+    const int tap = u / (4 * CO_T);
+    const int ng = co0 + n;
+    const bool ok = u < KK * 4 * CO_T && ng < Ndim;
+    w_k[i] = 4 * k4;
+    w_off[i] = !ok ? -1 : (!transposed ? (tap * Kdim + 4 * k4) * Ndim + ng : ((KK - 1 - tap) * Ndim + ng) * Kdim + 4 * k4);
+  }
+
+  auto prefetch = [&](int step) {
+    const int g = step / nchunk, c0 = (step % nchunk) * CK;
+    const float* wg = w + (size_t)g * KK * Kdim * Ndim + (transposed ? c0 : c0 * Ndim);
+    const float* xg = xin + ((size_t)(g >> 1) * Wi + (g & 1)) * Kdim + c0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W && c < Kdim)
-        v = *(const float4*)(xin + ((size_t)(gy_ * isc + (g >> 1)) * Wi + gx_ * isc + (g & 1)) * Kdim + c);
-      *(float4*)(in_s + pix * SPIX + 4 * q) = v;
+      if (in_off[i] >= 0 && c0 + in_q[i] < Kdim) v = *(const float4*)(xg + in_off[i]);
+      rin[i] = v;
     }
-    // ---- stage the weights of this chunk as [tap][kq][n][j], k = c0 + 4*kq + j
-    for (int u = tid; u < KK * 4 * CO_T; u += TPB) {
-      const int n = u % CO_T;
-      const int k4 = (u / CO_T) & 3;
-      const int tap = u / (4 * CO_T);
-      const int ng = co0 + n, kg = c0 + 4 * k4;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ng < Ndim && kg < Kdim) {
-        if (!transposed) {
-          const float* p = wg + ((size_t)tap * Kdim + kg) * Ndim + ng;
-          v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim];
-        } else {
-          v = *(const float4*)(wg + ((size_t)(KK - 1 - tap) * Ndim + ng) * Kdim + kg);
-        }
+      if (w_off[i] >= 0 && c0 + w_k[i] < Kdim) {
+        const float* p = wg + w_off[i];
+        if (!transposed) { v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim]; }
+        else v = *(const float4*)p;
       }
-      *(float4*)(w_s + (size_t)u * 4) = v;
+      rw[i] = v;
+    }
+  };
+
+  prefetch(0);
+  for (int step = 0; step < nsteps; ++step) {
+    __syncthreads();                         // every wave is done reading the previous chunk
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int u = tid + i * TPB;
+      if (u < IH * IW * 4) *(float4*)(in_s + (u >> 2) * SPIX + 4 * (u & 3)) = rin[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int u = tid + i * TPB;
+      if (u < KK * 4 * CO_T) *(float4*)(w_s + (size_t)u * 4) = rw[i];
     }
     __syncthreads();
+    if (step + 1 < nsteps) prefetch(step + 1);
     // ---- MFMA over taps
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
@@ -181,34 +217,65 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int t = t_begin; t < t_end; ++t) {
+  constexpr int NIN = (IH * IW * (CI_T / 4) + TPB - 1) / TPB;
+  constexpr int NGY = (WTH * TW * (CO_T / 4) + TPB - 1) / TPB;
+  float4 rin[NIN], rgy[NGY];
+  // per-thread unit descriptors, computed once: (iy << 8 | ix) inside the tile, or -1; channel of the unit
+  int in_yx[NIN], in_c[NIN], in_lds[NIN], gy_yx[NGY], gy_c[NGY], gy_lds[NGY];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int u = tid + i * TPB;
+    const int q = u % (CI_T / 4), pix = u / (CI_T / 4);
+    const int c = ci0 + 4 * q;
+    in_yx[i] = (u < IH * IW * (CI_T / 4) && c < Cin) ? (((pix / IW) << 8) | (pix % IW)) : -1;
+    in_c[i] = c;
+    in_lds[i] = pix * SI + 4 * q;
+  }
+#pragma unroll
+  for (int i = 0; i < NGY; ++i) {
+    const int u = tid + i * TPB;
+    const int q = u % (CO_T / 4), pix = u / (CO_T / 4);
+    const int c = co0 + 4 * q;
+    gy_yx[i] = (u < WTH * TW * (CO_T / 4) && c < Cout) ? (((pix / TW) << 8) | (pix % TW)) : -1;
+    gy_c[i] = c;
+    gy_lds[i] = pix * SO + 4 * q;
+  }
+
+  auto prefetch = [&](int t) {
     const int n_img = t / tiles_img;
     const int rem = t % tiles_img;
     const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * TW;
     const float* xin = x + (size_t)n_img * H * W * Cin;
     const float* gin = gy + (size_t)n_img * H * gsc * Wg * Cout;
-    __syncthreads();
-    for (int u = tid; u < IH * IW * (CI_T / 4); u += TPB) {
-      const int q = u % (CI_T / 4), pix = u / (CI_T / 4);
-      const int iy = pix / IW, ix = pix % IW;
-      const int gy_ = y0 + iy - PAD, gx_ = x0 + ix - PAD;
-      const int c = ci0 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W && c < Cin)
-        v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * Cin + c);
-      *(float4*)(in_s + pix * SI + 4 * q) = v;
+      const int gy_ = y0 + (in_yx[i] >> 8) - PAD, gx_ = x0 + (in_yx[i] & 255) - PAD;
+      if (in_yx[i] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W)
+        v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * Cin + in_c[i]);
+      rin[i] = v;
     }
-    for (int u = tid; u < WTH * TW * (CO_T / 4); u += TPB) {
-      const int q = u % (CO_T / 4), pix = u / (CO_T / 4);
-      const int iy = pix / TW, ix = pix % TW;
-      const int gy_ = y0 + iy, gx_ = x0 + ix;
-      const int c = co0 + 4 * q;
+#pragma unroll
+    for (int i = 0; i < NGY; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gy_ < H && gx_ < W && c < Cout)
-        v = *(const float4*)(gin + ((size_t)(gy_ * gsc + (tg >> 1)) * Wg + gx_ * gsc + (tg & 1)) * Cout + c);
-      *(float4*)(gy_s + pix * SO + 4 * q) = v;
+      const int gy_ = y0 + (gy_yx[i] >> 8), gx_ = x0 + (gy_yx[i] & 255);
+      if (gy_yx[i] >= 0 && gy_ < H && gx_ < W)
+        v = *(const float4*)(gin + ((size_t)(gy_ * gsc + (tg >> 1)) * Wg + gx_ * gsc + (tg & 1)) * Cout + gy_c[i]);
+      rgy[i] = v;
     }
+  };
+
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+      if (tid + i * TPB < IH * IW * (CI_T / 4)) *(float4*)(in_s + in_lds[i]) = rin[i];
+#pragma unroll
+    for (int i = 0; i < NGY; ++i)
+      if (tid + i * TPB < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
+    __syncthreads();
+    if (t + 1 < t_end) prefetch(t + 1);
 #pragma unroll
     for (int rr = 0; rr < WTH / 4; ++rr) {
       const int r = wave * (WTH / 4) + rr;
@@ -264,24 +331,34 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   }
 }
 
-// out[e] = sum_c part[c][e]; wsize is a multiple of 4 on every MFMA path (Cin%4 == 0 or Cout%4 == 0)
+// out[e] = sum_c part[c][e].  16 float4 columns x 16 split-lanes per block: each thread strides over the splits
+// (independent loads in flight), then a fixed-order LDS tree over the 16 lanes (deterministic).
 __global__ void __launch_bounds__(TPB)
 sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
-  const int e = (blockIdx.x * TPB + threadIdx.x) * 4;
-  if (e >= wsize) return;
+  __shared__ float4 sm[TPB];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = (blockIdx.x * 16 + col) * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e + 3 < wsize) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < splits; ++c) {
+    for (int c = sl; c < splits; c += 16) {
       const float4 v = *(const float4*)(part + (size_t)c * wsize + e);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    *(float4*)(out + e) = s;
-  } else {
-    for (int k = e; k < wsize; ++k) {
-      float s = 0.f;
-      for (int c = 0; c < splits; ++c) s += part[(size_t)c * wsize + k];
-      out[k] = s;
+  } else if (e < wsize) {
+    float* sp = (float*)&s;
+    for (int c = sl; c < splits; c += 16)
+      for (int k = 0; k < wsize - e; ++k) sp[k] += part[(size_t)c * wsize + e + k];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && e < wsize) {
+    float4 t = sm[col];
+    for (int l = 1; l < 16; ++l) {
+      const float4 v = sm[l * 16 + col];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
+    if (e + 3 < wsize) *(float4*)(out + e) = t;
+    else for (int k = 0; k < wsize - e; ++k) out[e + k] = ((float*)&t)[k];
   }
 }
 
@@ -303,18 +380,36 @@ template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  int isc, int osc, int G, int ntap_out, hipStream_t st) {
 #define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st
+  // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
+  // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
   const int nt = (Ndim + 15) / 16;
-  const bool small = (int64_t)H * W <= 32 * 32;          // few tiles per image: shrink the tile to fill 256 CUs
-  if (nt == 1) {
-    if (small) return launch_fwd<KS, 4, 4, 1, 1>(ARGS);
-    return launch_fwd<KS, 16, 4, 1, 1>(ARGS);
+  const int64_t tiles = (int64_t)((W + TW - 1) / TW) * ((H + 7) / 8) * N;
+  (void)tiles;
+  if (nt == 1) return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
+  return launch_fwd<KS, 16, 4, 1, 2>(ARGS);
+#undef ARGS
+}
+
+// tuning hook: force a tile configuration (scratch/bench_conv.py sweeps these to fill dispatch_fwd's table)
+template <int KS>
+int dispatch_fwd_cfg(int cfg, const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim,
+                     int transposed, hipStream_t st) {
+#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st
+  switch (cfg) {
+    case 0: return launch_fwd<KS, 16, 4, 1, 1>(ARGS);
+    case 1: return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
+    case 2: return launch_fwd<KS, 4, 4, 1, 1>(ARGS);
+    case 3: return launch_fwd<KS, 16, 4, 1, 2>(ARGS);
+    case 4: return launch_fwd<KS, 8, 4, 1, 2>(ARGS);
+    case 5: return launch_fwd<KS, 4, 4, 1, 2>(ARGS);
+    case 6: return launch_fwd<KS, 8, 2, 2, 4>(ARGS);
+    case 7: return launch_fwd<KS, 4, 1, 4, 4>(ARGS);
+    case 8: return launch_fwd<KS, 8, 4, 1, 4>(ARGS);
+    case 9: return launch_fwd<KS, 4, 2, 2, 4>(ARGS);
+    case 10: return launch_fwd<KS, 8, 2, 2, 2>(ARGS);
+    case 11: return launch_fwd<KS, 16, 2, 2, 2>(ARGS);
+    default: return -1;
   }
-  if (nt == 2) {
-    if (small) return launch_fwd<KS, 4, 4, 1, 2>(ARGS);
-    return launch_fwd<KS, 16, 4, 1, 2>(ARGS);
-  }
-  if (small) return launch_fwd<KS, 4, 1, 4, 4>(ARGS);
-  return launch_fwd<KS, 8, 2, 2, 4>(ARGS);
 #undef ARGS
 }
 
@@ -404,6 +499,16 @@ int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N,
   return SMSUT_OK;
 }
 
+int smsut_conv2d_fwd_mfma_cfg(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
+                              int transposed, int cfg, void* stream) {
+  SMSUT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && smsut_conv2d_mfma_supported(KS, 1, (KS - 1) / 2, Kdim, Ndim));
+  const int rc = KS == 1 ? dispatch_fwd_cfg<1>(cfg, x, w, y, N, H, W, Kdim, Ndim, transposed, (hipStream_t)stream)
+                         : dispatch_fwd_cfg<3>(cfg, x, w, y, N, H, W, Kdim, Ndim, transposed, (hipStream_t)stream);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
 int smsut_conv2d_wgrad_mfma_supported(int KS, int stride, int pad, int Cin, int Cout) {
   return (KS == 1 || KS == 3) && stride == 1 && pad == (KS - 1) / 2 && Cin >= 4 && (Cin % 4) == 0 && Cout >= 4 &&
          (Cout % 4) == 0;
@@ -434,7 +539,7 @@ int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* w
     else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
   }
   const int wsize = KS * KS * Cin * Cout;
-  sum_splits<<<(wsize + 4 * TPB - 1) / (4 * TPB), TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  sum_splits<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -454,7 +559,7 @@ int smsut_convT2x2_wgrad_mfma(const float* x, const float* gy, float* gw, float*
   else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
   else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
   const int wsize = 4 * Cin * Cout;
-  sum_splits<<<(wsize + 4 * TPB - 1) / (4 * TPB), TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  sum_splits<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

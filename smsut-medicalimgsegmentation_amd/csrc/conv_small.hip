@@ -1,0 +1,314 @@
+// Convolutions with a tiny channel count on one side: the 5x5 stems (Cin 1 / 1+n_modal -> base_width/2,
+// network/blocks.py:123, ugan.py:26), D's 4x4 stride-2 stem (ugan.py:202) and the 1x1 heads (16 -> 5 / 1,
+// blocks.py:166, ugan.py:70).  They carry < 1 % of the FLOPs but touch the full-resolution tensors, so they are
+// HBM-bound: what matters is one pass over the activations, not the matrix cores.
+//
+//   forward / data-gradient: direct VALU kernels, one output pixel per thread, all output channels in registers,
+//                            weights broadcast from LDS (every lane reads the same address);
+//   weight-gradient        : MFMA GEMM with the pixels as K and the flattened (tap, ci) index as M
+//                            ("im2col in the address": lane m adds its own tap offset to the pixel's LDS address),
+//                            per-split slabs + fixed-order sum -> deterministic, no atomics.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TPB = 256;
+constexpr int MAXW = 2048;          // weights held in LDS: KS*KS*Cin*Cout <= 2048 floats
+
+struct SmallGeom { int N, H, W, Cin, Ho, Wo, Cout, KS, stride, pad; };
+
+// y[n,ho,wo,:] = bias + sum_{kh,kw,ci} x[n,ho*s-p+kh,wo*s-p+kw,ci] * w[kh][kw][ci][:]      (COUT = 4*CQ channels)
+template <int CQ>
+__global__ void __launch_bounds__(TPB)
+small_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+          float* __restrict__ y, SmallGeom g, int64_t npix) {
+  __shared__ float4 ws[MAXW / 4];
+  const int wq = g.KS * g.KS * g.Cin * CQ;                     // float4 units; Cout == 4*CQ
+  for (int i = threadIdx.x; i < wq; i += TPB) ws[i] = ((const float4*)w)[i];
+  __syncthreads();
+  for (int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x; p < npix; p += (int64_t)gridDim.x * TPB) {
+    const int wo = (int)(p % g.Wo);
+    const int64_t q = p / g.Wo;
+    const int ho = (int)(q % g.Ho);
+    const int n = (int)(q / g.Ho);
+    float4 acc[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) acc[c] = bias ? ((const float4*)bias)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xn = x + (size_t)n * g.H * g.W * g.Cin;
+    for (int kh = 0; kh < g.KS; ++kh) {
+      const int hi = ho * g.stride - g.pad + kh;
+      if (hi < 0 || hi >= g.H) continue;
+      for (int kw = 0; kw < g.KS; ++kw) {
+        const int wi = wo * g.stride - g.pad + kw;
+        if (wi < 0 || wi >= g.W) continue;
+        const float* xp = xn + ((size_t)hi * g.W + wi) * g.Cin;
+        const float4* wp = ws + (size_t)(kh * g.KS + kw) * g.Cin * CQ;
+        for (int ci = 0; ci < g.Cin; ++ci) {
+          const float v = xp[ci];
+#pragma unroll
+          for (int c = 0; c < CQ; ++c) {
+            const float4 wv = wp[ci * CQ + c];
+            acc[c].x = fmaf(v, wv.x, acc[c].x); acc[c].y = fmaf(v, wv.y, acc[c].y);
+            acc[c].z = fmaf(v, wv.z, acc[c].z); acc[c].w = fmaf(v, wv.w, acc[c].w);
+          }
+        }
+      }
+    }
+    float4* yp = (float4*)(y + (size_t)p * (4 * CQ));
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) yp[c] = acc[c];
+  }
+}
+
+// gx[n,hi,wi,ci] = sum_{kh,kw,co} gy[n,ho,wo,co] * w[kh][kw][ci][co],  ho*s - p + kh = hi      (Cin <= 8)
+template <int CQ>
+__global__ void __launch_bounds__(TPB)
+small_dgrad(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, SmallGeom g,
+            int64_t npix) {
+  __shared__ float4 ws[MAXW / 4];
+  const int wq = g.KS * g.KS * g.Cin * CQ;
+  for (int i = threadIdx.x; i < wq; i += TPB) ws[i] = ((const float4*)w)[i];
+  __syncthreads();
+  for (int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x; p < npix; p += (int64_t)gridDim.x * TPB) {
+    const int wi = (int)(p % g.W);
+    const int64_t q = p / g.W;
+    const int hi = (int)(q % g.H);
+    const int n = (int)(q / g.H);
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    const float* gn = gy + (size_t)n * g.Ho * g.Wo * (4 * CQ);
+    for (int kh = 0; kh < g.KS; ++kh) {
+      const int hn = hi + g.pad - kh;
+      if (hn < 0 || hn % g.stride) continue;
+      const int ho = hn / g.stride;
+      if (ho >= g.Ho) continue;
+      for (int kw = 0; kw < g.KS; ++kw) {
+        const int wn = wi + g.pad - kw;
+        if (wn < 0 || wn % g.stride) continue;
+        const int wo = wn / g.stride;
+        if (wo >= g.Wo) continue;
+        const float4* gp = (const float4*)(gn + ((size_t)ho * g.Wo + wo) * (4 * CQ));
+        float4 gv[CQ];
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) gv[c] = gp[c];
+        const float4* wp = ws + (size_t)(kh * g.KS + kw) * g.Cin * CQ;
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+          if (ci < g.Cin) {
+#pragma unroll
+            for (int c = 0; c < CQ; ++c) {
+              const float4 wv = wp[ci * CQ + c];
+              acc[ci] = fmaf(gv[c].x, wv.x, acc[ci]); acc[ci] = fmaf(gv[c].y, wv.y, acc[ci]);
+              acc[ci] = fmaf(gv[c].z, wv.z, acc[ci]); acc[ci] = fmaf(gv[c].w, wv.w, acc[ci]);
+            }
+          }
+        }
+      }
+    }
+    float* op = gx + (size_t)p * g.Cin;
+#pragma unroll
+    for (int ci = 0; ci < 8; ++ci)
+      if (ci < g.Cin) op[ci] = acc[ci];
+  }
+}
+
+// ---- flattened-M MFMA weight gradient ---------------------------------------------------------------------
+constexpr int FTH = 8, FTW = 16;           // output-pixel tile; each wave takes 2 rows
+constexpr int MAXT = 4096;                 // staged input tile floats (IH*IW*Cin)
+
+template <int MT>
+__global__ void __launch_bounds__(TPB)
+flat_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, SmallGeom g,
+           int tiles_x, int tiles_y, int tiles_per_split) {
+  __shared__ float in_s[MAXT];
+  __shared__ float gy_s[FTH * FTW * 16];
+  __shared__ float red[MT * 64 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int IH = (FTH - 1) * g.stride + g.KS, IW = (FTW - 1) * g.stride + g.KS;
+  const int Mtot = g.KS * g.KS * g.Cin;
+  // this lane's row m of the flattened (tap, ci) dimension per M tile: LDS offset of its tap / channel
+  int moff[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = i * 16 + lm;
+    const int tap = m / g.Cin, ci = m % g.Cin;
+    moff[i] = m < Mtot ? ((tap / g.KS) * IW + (tap % g.KS)) * g.Cin + ci : -1;
+  }
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_img = tiles_x * tiles_y;
+  const int total = g.N * tiles_img;
+  const int t0 = blockIdx.x * tiles_per_split;
+  const int t1 = min(t0 + tiles_per_split, total);
+  for (int t = t0; t < t1; ++t) {
+    const int n = t / tiles_img, rem = t % tiles_img;
+    const int oy0 = (rem / tiles_x) * FTH, ox0 = (rem % tiles_x) * FTW;
+    const int iy0 = oy0 * g.stride - g.pad, ix0 = ox0 * g.stride - g.pad;
+    const float* xn = x + (size_t)n * g.H * g.W * g.Cin;
+    const float* gn = gy + (size_t)n * g.Ho * g.Wo * g.Cout;
+    __syncthreads();
+    for (int u = tid; u < IH * IW * g.Cin; u += TPB) {
+      const int ci = u % g.Cin, pix = u / g.Cin;
+      const int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+      in_s[u] = (iy >= 0 && iy < g.H && ix >= 0 && ix < g.W) ? xn[((size_t)iy * g.W + ix) * g.Cin + ci] : 0.f;
+    }
+    for (int u = tid; u < FTH * FTW * 16; u += TPB) {
+      const int c = u & 15, pix = u >> 4;
+      const int oy = oy0 + pix / FTW, ox = ox0 + pix % FTW;
+      gy_s[u] = (c < g.Cout && oy < g.Ho && ox < g.Wo) ? gn[((size_t)oy * g.Wo + ox) * g.Cout + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int rr = 0; rr < FTH / 4; ++rr) {
+      const int r = wave * (FTH / 4) + rr;
+#pragma unroll
+      for (int ks = 0; ks < FTW / 4; ++ks) {
+        const int px = ks * 4 + kq;
+        const float b = gy_s[(r * FTW + px) * 16 + lm];
+        const int base = (r * g.stride * IW + px * g.stride) * g.Cin;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float a = moff[i] >= 0 ? in_s[base + moff[i]] : 0.f;
+          acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // fixed-order combine of the 4 waves, then wave 0 writes the [Mtot][Cout] slab
+  for (int src = 1; src < 4; ++src) {
+    __syncthreads();
+    if (wave == src) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) *(f32x4*)(red + ((size_t)i * 64 + lane) * 4) = acc[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] += *(const f32x4*)(red + ((size_t)i * 64 + lane) * 4);
+    }
+  }
+  if (wave == 0) {
+    float* out = part + (size_t)blockIdx.x * Mtot * g.Cout;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = i * 16 + 4 * kq + r;               // accumulator row = M index, column lm = output channel
+        if (m < Mtot && lm < g.Cout) out[(size_t)m * g.Cout + lm] = acc[i][r];
+      }
+  }
+}
+
+// out[e] = sum_s part[s][e], e < wsize (small): one block per 16 elements, 16 split lanes, fp64, fixed order
+__global__ void __launch_bounds__(TPB)
+flat_sum(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
+  __shared__ double sm[TPB];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + col;
+  double s = 0.0;
+  if (e < wsize)
+    for (int c = sl; c < splits; c += 16) s += (double)part[(size_t)c * wsize + e];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && e < wsize) {
+    double t = 0.0;
+    for (int l = 0; l < 16; ++l) t += sm[l * 16 + col];
+    out[e] = (float)t;
+  }
+}
+
+inline bool geom_ok(const SmallGeom& g) {
+  return g.N > 0 && g.H > 0 && g.W > 0 && g.Cin > 0 && g.Cout > 0 && g.KS > 0 && g.stride > 0 && g.pad >= 0 &&
+         g.Ho == (g.H + 2 * g.pad - g.KS) / g.stride + 1 && g.Wo == (g.W + 2 * g.pad - g.KS) / g.stride + 1 && g.Ho > 0 &&
+         g.Wo > 0;
+}
+
+struct FlatPlan { int tiles_x, tiles_y, splits, tiles_per_split; };
+inline FlatPlan flat_plan(const SmallGeom& g) {
+  FlatPlan p;
+  p.tiles_x = (g.Wo + FTW - 1) / FTW;
+  p.tiles_y = (g.Ho + FTH - 1) / FTH;
+  const int total = g.N * p.tiles_x * p.tiles_y;
+  int want = total < 2048 ? total : 2048;
+  p.tiles_per_split = (total + want - 1) / want;
+  p.splits = (total + p.tiles_per_split - 1) / p.tiles_per_split;
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// forward / data-gradient eligibility: Cout in {4, 8, 12, 16}, Cin <= 8, weights fit the LDS image
+int smsut_conv2d_small_supported(int KS, int Cin, int Cout) {
+  return KS >= 1 && Cin >= 1 && Cin <= 8 && Cout >= 4 && Cout <= 16 && (Cout % 4) == 0 && KS * KS * Cin * Cout <= MAXW;
+}
+
+int smsut_conv2d_small_fwd(const float* x, const float* w, const float* bias, float* y, int N, int H, int W, int Cin,
+                           int Ho, int Wo, int Cout, int KS, int stride, int pad, void* stream) {
+  SmallGeom g{N, H, W, Cin, Ho, Wo, Cout, KS, stride, pad};
+  SMSUT_REQUIRE(x && w && y && geom_ok(g) && smsut_conv2d_small_supported(KS, Cin, Cout));
+  const int64_t npix = (int64_t)N * Ho * Wo;
+  const int grid = ew_grid(npix) * 2;
+  hipStream_t st = (hipStream_t)stream;
+  switch (Cout / 4) {
+    case 1: small_fwd<1><<<grid, TPB, 0, st>>>(x, w, bias, y, g, npix); break;
+    case 2: small_fwd<2><<<grid, TPB, 0, st>>>(x, w, bias, y, g, npix); break;
+    case 3: small_fwd<3><<<grid, TPB, 0, st>>>(x, w, bias, y, g, npix); break;
+    default: small_fwd<4><<<grid, TPB, 0, st>>>(x, w, bias, y, g, npix); break;
+  }
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int smsut_conv2d_small_dgrad(const float* gy, const float* w, float* gx, int N, int H, int W, int Cin, int Ho, int Wo,
+                             int Cout, int KS, int stride, int pad, void* stream) {
+  SmallGeom g{N, H, W, Cin, Ho, Wo, Cout, KS, stride, pad};
+  SMSUT_REQUIRE(gy && w && gx && geom_ok(g) && smsut_conv2d_small_supported(KS, Cin, Cout));
+  const int64_t npix = (int64_t)N * H * W;
+  const int grid = ew_grid(npix) * 2;
+  hipStream_t st = (hipStream_t)stream;
+  switch (Cout / 4) {
+    case 1: small_dgrad<1><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
+    case 2: small_dgrad<2><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
+    case 3: small_dgrad<3><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
+    default: small_dgrad<4><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
+  }
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// weight-gradient eligibility: KS*KS*Cin <= 128 rows of the flattened M dimension, Cout <= 16, tile fits LDS
+int smsut_conv2d_flat_wgrad_supported(int KS, int stride, int Cin, int Cout) {
+  const int IH = (FTH - 1) * stride + KS, IW = (FTW - 1) * stride + KS;
+  return KS >= 1 && stride >= 1 && Cin >= 1 && Cout >= 1 && Cout <= 16 && KS * KS * Cin <= 128 && IH * IW * Cin <= MAXT;
+}
+
+int64_t smsut_conv2d_flat_wgrad_ws(int N, int Ho, int Wo, int Cin, int Cout, int KS) {
+  SmallGeom g{N, 0, 0, Cin, Ho, Wo, Cout, KS, 1, 0};
+  return (int64_t)flat_plan(g).splits * KS * KS * Cin * Cout;
+}
+
+int smsut_conv2d_flat_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                            int Ho, int Wo, int Cout, int KS, int stride, int pad, void* stream) {
+  SmallGeom g{N, H, W, Cin, Ho, Wo, Cout, KS, stride, pad};
+  SMSUT_REQUIRE(x && gy && gw && workspace && geom_ok(g) && smsut_conv2d_flat_wgrad_supported(KS, stride, Cin, Cout));
+  const FlatPlan p = flat_plan(g);
+  hipStream_t st = (hipStream_t)stream;
+  const int mt = (KS * KS * Cin + 15) / 16;
+  if (mt <= 1) flat_wgrad<1><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);
+  else if (mt <= 2) flat_wgrad<2><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);
+  else if (mt <= 4) flat_wgrad<4><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);
+  else flat_wgrad<8><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);
+  const int wsize = KS * KS * Cin * Cout;
+  flat_sum<<<(wsize + 15) / 16, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+}  // extern "C"

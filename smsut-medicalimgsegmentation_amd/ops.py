@@ -133,6 +133,8 @@ def _conv_fwd_launch(x, w, bias, stride, pad):
         H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, wd, ci, co, kh, 0, _s())
         if bias is not None:
             H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
+    elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_small_supported", kh, ci, co):
+        H.call("smsut_conv2d_small_fwd", x, w, bias, y, n, h, wd, ci, ho, wo, co, kh, stride, pad, _s())
     else:
         H.call("smsut_conv2d_fwd_generic", x, w, bias, y, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
     return y
@@ -145,6 +147,8 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
     gx = new_act(n, ci, h, wd, gy)
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, co, ci):
         H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
+    elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_small_supported", kh, ci, co):
+        H.call("smsut_conv2d_small_dgrad", gy, w, gx, n, h, wd, ci, ho, wo, co, kh, stride, pad, _s())
     else:
         H.call("smsut_conv2d_dgrad_generic", gy, w, gx, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())
     return gx
@@ -157,6 +161,9 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_wgrad_mfma_supported", kh, stride, pad, ci, co):
         ws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, wd, ci, co, kh), x)
         H.call("smsut_conv2d_wgrad_mfma", x, gy, gw, ws, n, h, wd, ci, co, kh, _s())
+    elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_flat_wgrad_supported", kh, stride, ci, co):
+        ws = _ws(H.call("smsut_conv2d_flat_wgrad_ws", n, ho, wo, ci, co, kh), x)
+        H.call("smsut_conv2d_flat_wgrad", x, gy, gw, ws, n, h, wd, ci, ho, wo, co, kh, stride, pad, _s())
     else:
         ws = _ws(H.call("smsut_conv2d_wgrad_generic_ws", n, ho, wo, ci, co, kh, kw), x)
         H.call("smsut_conv2d_wgrad_generic", x, gy, gw, ws, n, h, wd, ci, ho, wo, co, kh, kw, stride, pad, _s())

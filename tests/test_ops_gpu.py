@@ -57,6 +57,13 @@ CONV_CASES = [
     (2, 16, 16, 256, 128, 1, 1, 0, False),
     (2, 40, 40, 16, 5, 1, 1, 0, True),
     (2, 128, 128, 32, 16, 3, 1, 1, False),
+    # tiny-channel kernels: stems (direct fwd/dgrad + flattened-M MFMA wgrad), D stem k4 s2 + bias, heads
+    (2, 64, 48, 1, 8, 5, 1, 2, False),
+    (2, 40, 40, 5, 8, 5, 1, 2, False),
+    (3, 64, 64, 1, 16, 4, 2, 1, True),
+    (2, 32, 32, 2, 4, 5, 1, 2, False),
+    (2, 24, 40, 16, 1, 1, 1, 0, True),
+    (2, 72, 40, 16, 5, 1, 1, 0, False),
 ]
 
 
