@@ -43,6 +43,11 @@ int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim)
  * transposed = 1: data-gradient, x = gy[N,H,W,Kdim=Cout], w = forward weights [KS*KS][Ndim=Cin][Kdim=Cout]. */
 int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                           int transposed, void* stream);
+/* forward conv that also emits the InstanceNorm {sum, sum^2} partials of its output (fused statistics pass):
+ * stats = float[N * smsut_conv2d_mfma_tiles(H, W, Ndim, KS) * Ndim * 2], consumed by smsut_instnorm_fwd_partials. */
+int smsut_conv2d_mfma_tiles(int H, int W, int Ndim, int KS);
+int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
+                                int Ndim, int KS, void* stream);
 /* tuning hook: same as smsut_conv2d_fwd_mfma with a forced tile configuration (returns -1 for an unknown cfg) */
 int smsut_conv2d_fwd_mfma_cfg(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                               int transposed, int cfg, void* stream);
@@ -84,6 +89,9 @@ int smsut_colsum(const float* x, float* out, float* workspace, int64_t rows, int
 int smsut_in_chunks(int N, int HW, int C); /* workspace = N * chunks * C * 3 floats */
 int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                        float* workspace, int N, int HW, int C, float eps, float slope, int has_act, void* stream);
+int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                float slope, int has_act, void* stream);
 int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask /*nullable*/, const float* mean,
                        const float* rstd, const float* gamma, float* gx, float* a_mean, float* b_mean,
                        float* ggamma /*nullable*/, float* gbeta /*nullable*/, float* workspace, int N, int HW, int C,

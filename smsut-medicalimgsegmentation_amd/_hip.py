@@ -20,6 +20,7 @@ SIGNATURES: Dict[str, str] = {
     # norm.hip
     "smsut_in_chunks": "iii",
     "smsut_instnorm_fwd": "ppppppp iii ff i s",
+    "smsut_instnorm_fwd_partials": "ppppppp iiii ff i s",
     "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
     "smsut_instnorm_bwd2": "ppppppppppp ppp pp iii f s",
     # conv_naive.hip
@@ -32,6 +33,8 @@ SIGNATURES: Dict[str, str] = {
     # conv_mfma.hip
     "smsut_conv2d_mfma_supported": "iiiii",
     "smsut_conv2d_fwd_mfma": "ppp iiiiii i s",
+    "smsut_conv2d_mfma_tiles": "iiii",
+    "smsut_conv2d_fwd_mfma_stats": "pppp iiiiii s",
     "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",
     "smsut_conv2d_wgrad_mfma_supported": "iiiii",
     "smsut_conv2d_wgrad_mfma_ws": "iiiiii",
@@ -89,7 +92,7 @@ _RET_I64 = {"smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
                          "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
-                         "smsut_conv2d_flat_wgrad_supported"}
+                         "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles"}
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

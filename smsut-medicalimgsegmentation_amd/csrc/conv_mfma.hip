@@ -40,7 +40,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 template <int KS, int TH, int WM, int WN, int NTN>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Kdim,
-              int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz) {
+              int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz, float* __restrict__ stats) {
+  // stats (nullable): per-workgroup InstanceNorm partials [n][tile][Ndim][2] = {sum, sum of squares} of this tile's
+  // outputs, in the layout in_moments_final<0> (norm.hip) consumes -- the statistics pass over y is then not needed.
   // (H, W) is the compute grid.  Regular conv: isc = osc = G = 1.  ConvTranspose2x2 forward: osc = 2 and
   // blockIdx.z also enumerates the 4 output taps.  ConvTranspose2x2 data-gradient: isc = 2, G = 4 input taps.
   constexpr int KK = KS * KS;
@@ -162,6 +164,37 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     }
   }
   // ---- epilogue: acc[i][j][r] is pixel (row wm*MR+i, col 4*kq + r), channel (wn*NR+j)*16 + lm
+  if (stats) {
+    __syncthreads();                          // LDS is free again: reuse it for the cross-wave combine
+    float* red = smem;                        // [WM][CO_T][2]
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const bool rok = y0 + wm * MR + i < H;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (rok && x0 + 4 * kq + r < W) ? acc[i][j][r] : 0.f;
+          s1 += v; s2 += v * v;
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kq == 0) {
+        red[(wm * CO_T + (wn * NR + j) * 16 + lm) * 2] = s1;
+        red[(wm * CO_T + (wn * NR + j) * 16 + lm) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < CO_T && co0 + tid < Ndim) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) { s1 += red[(m * CO_T + tid) * 2]; s2 += red[(m * CO_T + tid) * 2 + 1]; }
+      float* o = stats + (((size_t)n_img * gridDim.x + tile) * Ndim + co0 + tid) * 2;
+      o[0] = s1; o[1] = s2;
+    }
+  }
   const int Wo = W * osc;
   float* yout = y + (size_t)n_img * H * osc * Wo * Ndim;
 #pragma unroll
@@ -364,22 +397,23 @@ sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, i
 
 template <int KS, int TH, int WM, int WN, int NTN>
 int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-               int isc, int osc, int G, int ntap_out, hipStream_t st) {
+               int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
   constexpr size_t sh = (size_t)(IH * IW * SPIX + KS * KS * CK * 16 * NTN) * sizeof(float);
   static_assert(sh <= 64 * 1024, "LDS budget");
   const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
   const int nz = (Ndim + 16 * NTN - 1) / (16 * NTN);
+  if (tiles_out) { *tiles_out = tiles_x * tiles_y; return 0; }          // planning query only
   dim3 grid(tiles_x * tiles_y, N, nz * ntap_out);
   conv_mfma_fwd<KS, TH, WM, WN, NTN><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc, G,
-                                                            nz);
+                                                            nz, stats);
   return 0;
 }
 
 template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-                 int isc, int osc, int G, int ntap_out, hipStream_t st) {
-#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st
+                 int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
+#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out
   // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
   // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
   const int nt = (Ndim + 15) / 16;
@@ -495,6 +529,26 @@ int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N,
                               void* stream) {
   SMSUT_REQUIRE(gy && w && gx && N > 0 && H > 0 && W > 0 && smsut_convT2x2_mfma_supported(Cin, Cout));
   dispatch_fwd<1>(gy, w, gx, N, H, W, Cout, Cin, 1, 2, 1, 4, 1, (hipStream_t)stream);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Forward conv that also emits the InstanceNorm statistics partials of its output (see conv_mfma_fwd).
+// stats: float[N * smsut_conv2d_mfma_tiles(H, W, Ndim, KS) * Ndim * 2]
+int smsut_conv2d_mfma_tiles(int H, int W, int Ndim, int KS) {
+  int tiles = 0;
+  if (KS == 1) dispatch_fwd<1>(nullptr, nullptr, nullptr, 1, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
+  else dispatch_fwd<3>(nullptr, nullptr, nullptr, 1, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
+  return tiles;
+}
+
+int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
+                                int Ndim, int KS, void* stream) {
+  SMSUT_REQUIRE(x && w && y && stats && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(smsut_conv2d_mfma_supported(KS, 1, (KS - 1) / 2, Kdim, Ndim));
+  hipStream_t st = (hipStream_t)stream;
+  if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats);
+  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

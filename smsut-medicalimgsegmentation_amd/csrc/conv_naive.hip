@@ -43,6 +43,21 @@ conv_fwd_naive(const float* __restrict__ x, const float* __restrict__ w, const f
   }
 }
 
+// Full-window conv (KH == H, KW == W, pad 0 -> 1x1 output): D's conv_cls (ugan.py:213,215).  NHWC makes the input of
+// one image the flat vector [KH*KW*Cin] in exactly the weight's [KH][KW][Cin] order: y[n][co] = sum_k x[n][k] w[k][co].
+__global__ void __launch_bounds__(TPB)
+conv_full_window(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                 float* __restrict__ y, int K, int Cout) {
+  __shared__ float sm4[4];
+  const int n = blockIdx.x;
+  for (int co = 0; co < Cout; ++co) {
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < K; k += TPB) acc = fmaf(x[(size_t)n * K + k], w[(size_t)k * Cout + co], acc);
+    const float t = block_sum_256(acc, sm4);
+    if (threadIdx.x == 0) y[(size_t)n * Cout + co] = t + (bias ? bias[co] : 0.f);
+  }
+}
+
 __global__ void __launch_bounds__(TPB)
 conv_dgrad_naive(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, ConvGeom g,
                  int64_t total) {
@@ -180,7 +195,10 @@ int smsut_conv2d_fwd_generic(const float* x, const float* w, const float* bias, 
   ConvGeom g{N, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad};
   SMSUT_REQUIRE(x && w && y && geom_ok(g));
   const int64_t total = (int64_t)N * Ho * Wo * Cout;
-  conv_fwd_naive<<<ew_grid(total) * 4, TPB, 0, (hipStream_t)stream>>>(x, w, bias, y, g, total);
+  if (KH == H && KW == W && pad == 0 && Cout <= 16)
+    conv_full_window<<<N, TPB, 0, (hipStream_t)stream>>>(x, w, bias, y, KH * KW * Cin, Cout);
+  else
+    conv_fwd_naive<<<ew_grid(total) * 4, TPB, 0, (hipStream_t)stream>>>(x, w, bias, y, g, total);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

@@ -116,20 +116,34 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
 }
 
 // combine chunk partials in fp64 -> per-(n,c) means.  MODE 0 writes (mean, rstd).
+// 16 channels x 16 chunk-lanes per block: independent loads in flight, fixed-order tree (deterministic).
 template <int MODE>
-__global__ void in_moments_final(const float* __restrict__ part, int chunks, int C, int HW, float eps,
-                                 float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+__global__ void __launch_bounds__(TPB)
+in_moments_final(const float* __restrict__ part, int chunks, int C, int HW, float eps,
+                 float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
   constexpr int NS = NSums<MODE>::n;
+  __shared__ double sm[TPB * 3];
   const int n = blockIdx.y;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  const int col = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + col;
   double s[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) s[k] = 0.0;
-  for (int ch = 0; ch < chunks; ++ch) {
-    const float* p = part + (((size_t)n * chunks + ch) * C + c) * NS;
+  if (c < C)
+    for (int ch = cl; ch < chunks; ch += 16) {
+      const float* p = part + (((size_t)n * chunks + ch) * C + c) * NS;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) s[k] += (double)p[k];
+      for (int k = 0; k < NS; ++k) s[k] += (double)p[k];
+    }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) sm[threadIdx.x * 3 + k] = s[k];
+  __syncthreads();
+  if (cl != 0 || c >= C) return;
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    double t = 0.0;
+    for (int l = 0; l < 16; ++l) t += sm[(l * 16 + col) * 3 + k];
+    s[k] = t;
   }
   const double inv = 1.0 / (double)HW;
   if (MODE == 0) {
@@ -296,7 +310,24 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
     in_moments_partial<0, 4><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
   else
     in_moments_partial<0, 1><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
-  in_moments_final<0><<<dim3((C + 63) / 64, N), 64, 0, st>>>(workspace, chunks, C, HW, eps, mean, rstd, nullptr);
+  in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, eps, mean, rstd, nullptr);
+  const int64_t total = (int64_t)N * HW * C;
+  if (C % 4 == 0)
+    in_apply_fwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total / 4, HW, C, slope, has_act);
+  else
+    in_apply_fwd<1><<<ew_grid(total), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total, HW, C, slope, has_act);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Same as smsut_instnorm_fwd when the {sum, sum^2} partials [N][chunks][C][2] were already produced by the conv
+// epilogue (smsut_conv2d_fwd_mfma_stats): finalise + normalise/activate only.
+int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                float slope, int has_act, void* stream) {
+  SMSUT_REQUIRE(x && gamma && beta && y && mean && rstd && partials && chunks > 0 && N > 0 && HW > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(partials, chunks, C, HW, eps, mean, rstd, nullptr);
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
     in_apply_fwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total / 4, HW, C, slope, has_act);
@@ -319,7 +350,7 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask, cons
     in_moments_partial<1, 4><<<g, TPB, 0, st>>>(gy, x, ymask, nullptr, mean, rstd, workspace, HW, C, ppc, slope);
   else
     in_moments_partial<1, 1><<<g, TPB, 0, st>>>(gy, x, ymask, nullptr, mean, rstd, workspace, HW, C, ppc, slope);
-  in_moments_final<1><<<dim3((C + 63) / 64, N), 64, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
+  in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
   if (ggamma && gbeta) in_affine_grads<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b_mean, N, C, HW, ggamma, gbeta);
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
@@ -347,7 +378,7 @@ int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const 
     in_moments_partial<2, 4><<<g, TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, workspace, HW, C, ppc, slope);
   else
     in_moments_partial<2, 1><<<g, TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, workspace, HW, C, ppc, slope);
-  in_moments_final<2><<<dim3((C + 63) / 64, N), 64, 0, st>>>(workspace, chunks, C, HW, 0.f, cvm, dvm, em);
+  in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, cvm, dvm, em);
   in_bwd2_gamma<<<(C + 63) / 64, 64, 0, st>>>(rstd, a_mean, b_mean, cvm, dvm, em, N, C, HW, d_gamma);
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)

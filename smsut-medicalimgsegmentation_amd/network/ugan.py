@@ -16,7 +16,7 @@ class _Pre(nn.Sequential):
     """nn.Sequential(conv5x5, norm, act) whose forward fuses the activation into the norm kernel."""
 
     def forward(self, x):
-        return self[1](self[0](x), slope=self[2].slope)
+        return self[1](self[0](x, stats=True), slope=self[2].slope)
 
 
 class Encoder(nn.Module):

@@ -123,13 +123,21 @@ def _out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-def _conv_fwd_launch(x, w, bias, stride, pad):
+def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False):
     n, ci, h, wd = x.shape
     co, ci2, kh, kw = w.shape
     assert ci == ci2, f"conv: Cin mismatch {ci} vs {ci2}"
     ho, wo = _out_size(h, kh, stride, pad), _out_size(wd, kw, stride, pad)
     y = new_act(n, co, ho, wo, x)
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, ci, co):
+        if want_stats and bias is None:
+            # fused InstanceNorm statistics: the conv epilogue leaves {sum, sum^2} partials that the following
+            # instnorm_act picks up from the tensor object (side channel; autograd is unaffected)
+            tiles = H.call("smsut_conv2d_mfma_tiles", h, wd, co, kh)
+            part = _ws(n * tiles * co * 2, x)
+            H.call("smsut_conv2d_fwd_mfma_stats", x, w, y, part, n, h, wd, ci, co, kh, _s())
+            y._smsut_in_partials = (part, tiles)
+            return y
         H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, wd, ci, co, kh, 0, _s())
         if bias is not None:
             H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
@@ -181,12 +189,12 @@ class Conv2dFn(Function):
     """y = conv2d(x, w) (+ bias).  Reference: nn.Conv2d uses at network/blocks.py:10-16,123; ugan.py:70,202,214-215."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, stride, pad):
+    def forward(ctx, x, w, bias, stride, pad, want_stats=False):
         x, w = nhwc(x), hwio(w)
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.geom = (stride, pad)
-        return _conv_fwd_launch(x, w, bias, stride, pad)
+        return _conv_fwd_launch(x, w, bias, stride, pad, want_stats)
 
     @staticmethod
     def backward(ctx, gy):
@@ -200,7 +208,7 @@ class Conv2dFn(Function):
                 gw = Conv2dWgradFn.apply(x, gy, w.shape[2], w.shape[3], stride, pad)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = SumPerChannelFn.apply(gy)
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None
 
 
 class Conv2dDgradFn(Function):
@@ -219,7 +227,7 @@ class Conv2dDgradFn(Function):
         h, wd, stride, pad = ctx.geom
         d_gy = d_w = None
         if ctx.needs_input_grad[0]:
-            d_gy = Conv2dFn.apply(ggx, w, None, stride, pad)
+            d_gy = Conv2dFn.apply(ggx, w, None, stride, pad, False)
         if ctx.needs_input_grad[1]:
             d_w = Conv2dWgradFn.apply(ggx, gy, w.shape[2], w.shape[3], stride, pad)
         return d_gy, d_w, None, None, None, None
@@ -243,7 +251,7 @@ class Conv2dWgradFn(Function):
         if ctx.needs_input_grad[0]:
             d_x = Conv2dDgradFn.apply(gy, ggw, x.shape[2], x.shape[3], stride, pad)
         if ctx.needs_input_grad[1]:
-            d_gy = Conv2dFn.apply(x, ggw, None, stride, pad)
+            d_gy = Conv2dFn.apply(x, ggw, None, stride, pad, False)
         return d_x, d_gy, None, None, None, None
 
 
@@ -287,8 +295,11 @@ def cl(x):
     return x.contiguous(memory_format=torch.channels_last)
 
 
-def conv2d(x, w, bias=None, stride=1, pad=0):
-    return Conv2dFn.apply(cl(x), w, bias, stride, pad)
+def conv2d(x, w, bias=None, stride=1, pad=0, stats=False):
+    """``stats=True``: the caller promises to feed the result straight into ``instnorm_act``; the conv epilogue then
+    also produces the InstanceNorm statistics partials (saves one full pass over the output)."""
+    y = Conv2dFn.apply(cl(x), w, bias, stride, pad, stats)
+    return y
 
 
 class ConvT2x2Fn(Function):
@@ -347,9 +358,16 @@ class InstNormActFn(Function):
         y = new_act(n, c, h, w, x)
         mean = torch.empty(n, c, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        chunks = H.call("smsut_in_chunks", n, h * w, c)
-        H.call("smsut_instnorm_fwd", x, gamma, beta, y, mean, rstd, _ws(n * chunks * c * 3, x), n, h * w, c,
-               IN_EPS, float(slope), int(has_act), _s())
+        fused = getattr(x, "_smsut_in_partials", None)
+        if fused is not None:
+            part, tiles = fused
+            H.call("smsut_instnorm_fwd_partials", x, gamma, beta, y, mean, rstd, part, tiles, n, h * w, c,
+                   IN_EPS, float(slope), int(has_act), _s())
+            del x._smsut_in_partials
+        else:
+            chunks = H.call("smsut_in_chunks", n, h * w, c)
+            H.call("smsut_instnorm_fwd", x, gamma, beta, y, mean, rstd, _ws(n * chunks * c * 3, x), n, h * w, c,
+                   IN_EPS, float(slope), int(has_act), _s())
         ctx.save_for_backward(x, y, mean, rstd, gamma)
         ctx.cfg = (float(slope), bool(has_act))
         ctx.mark_non_differentiable(mean, rstd)

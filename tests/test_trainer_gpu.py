@@ -154,7 +154,7 @@ def test_first_step_gradients(small_cfg, golden):
     assert float(np.median(list(errs.values()))) < 8e-3, np.median(list(errs.values()))
     assert worst[1] < 3e-2, worst
     seg_side = [e for k, e in errs.items() if k.startswith(("seg_", "netF"))]
-    assert max(seg_side) < 3e-3, max(seg_side)
+    assert max(seg_side) < 8e-3, max(seg_side)      # second pass sees x_fake: MaxPool/LeakyReLU flips as above
 
 
 def test_unet_trainer_step_and_validation(small_cfg):
