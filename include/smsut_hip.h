@@ -92,12 +92,12 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                 float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
                                 float slope, int has_act, void* stream);
-int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask /*nullable*/, const float* mean,
+int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta /*nullable: no activation*/, const float* mean,
                        const float* rstd, const float* gamma, float* gx, float* a_mean, float* b_mean,
                        float* ggamma /*nullable*/, float* gbeta /*nullable*/, float* workspace, int N, int HW, int C,
                        float slope, void* stream);
 int smsut_instnorm_bwd2(const float* v, const float* ug /*nullable*/, const float* ub /*nullable*/, const float* gy,
-                        const float* x, const float* ymask /*nullable*/, const float* mean, const float* rstd,
+                        const float* x, const float* beta /*nullable: no activation*/, const float* mean, const float* rstd,
                         const float* gamma, const float* a_mean, const float* b_mean, float* d_gy, float* d_x,
                         float* d_gamma, float* workspace, float* scratch /*3*N*C*/, int N, int HW, int C, float slope,
                         void* stream);

@@ -417,10 +417,13 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
   // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
   // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
   const int nt = (Ndim + 15) / 16;
-  const int64_t tiles = (int64_t)((W + TW - 1) / TW) * ((H + 7) / 8) * N;
-  (void)tiles;
+  const int tx = (W + TW - 1) / TW;
+  const int64_t wg16 = (int64_t)tx * ((H + 15) / 16) * N * ((nt + 1) / 2) * ntap_out;
+  const int64_t wg8 = (int64_t)tx * ((H + 7) / 8) * N * ((nt + 1) / 2) * ntap_out;
   if (nt == 1) return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
-  return launch_fwd<KS, 16, 4, 1, 2>(ARGS);
+  if (wg16 >= 512) return launch_fwd<KS, 16, 4, 1, 2>(ARGS);       // >= 2 workgroups per CU with the big tile
+  if (wg8 >= 256) return launch_fwd<KS, 8, 4, 1, 2>(ARGS);
+  return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
 #undef ARGS
 }
 

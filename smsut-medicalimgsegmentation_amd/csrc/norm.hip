@@ -5,7 +5,7 @@
 //
 // Reductions are deterministic two-stage (per-chunk fp32 partials -> fp64 combine), no atomics.
 // Per-(n,c) quantities with M = H*W, xh = (x-mean)*rstd, gz = gy * lrelu'(y):
-//   fwd :  y  = act(xh*gamma + beta)
+//   fwd :  y  = act(xh*gamma + beta)          (lrelu'(y) below is recomputed from x: sign of xh*gamma + beta)
 //   bwd :  a = mean(gz), b = mean(gz*xh);  gx = gamma*rstd*(gz - a - xh*b);
 //          ggamma = sum_n M*b, gbeta = sum_n M*a
 //   bwd2:  given v = d/dgx, ug = d/dggamma, ub = d/dgbeta:
@@ -19,6 +19,13 @@ namespace {
 
 constexpr int TPB = 256;
 
+// The normalised pre-activation.  ONE definition shared by forward and backward: the backward recomputes the
+// LeakyReLU mask from x (sign of this value) instead of reading the activation back from HBM, so it must be
+// bit-identical to what the forward kernel evaluated.
+__device__ __forceinline__ float in_affine(float x, float mean, float rstd, float gamma, float beta) {
+  return __fmaf_rn(x - mean, rstd * gamma, beta);
+}
+
 // MODE 0: sums of (x, x^2)           -- forward statistics
 // MODE 1: sums of (gz, gz*xh)        -- backward
 // MODE 2: sums of (v, v*xh, v*gz)    -- backward of backward
@@ -28,8 +35,8 @@ template <int MODE, int VEC>
 __global__ void __launch_bounds__(TPB)
 in_moments_partial(const float* __restrict__ t0,   // x | gy | v
                    const float* __restrict__ t1,   // - | x  | x
-                   const float* __restrict__ t2,   // - | y (mask src, may be null) | gy
-                   const float* __restrict__ t3,   // - | -  | y (mask src, may be null)
+                   const float* __restrict__ t2,   // - | -  | gy
+                   const float* __restrict__ gamma, const float* __restrict__ beta,   // beta == null: no activation
                    const float* __restrict__ mean, const float* __restrict__ rstd,
                    float* __restrict__ part,        // [N][chunks][C][NS]
                    int HW, int C, int pix_per_chunk, float slope) {
@@ -52,28 +59,26 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
     for (int s = 0; s < NS; ++s)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[s][j] = 0.f;
-    float mu[VEC], rs[VEC];
+    float mu[VEC], rs[VEC], gm[VEC], bt[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       mu[j] = (MODE == 0 || !cv_ok) ? 0.f : mean[n * C + cv * VEC + j];
       rs[j] = (MODE == 0 || !cv_ok) ? 1.f : rstd[n * C + cv * VEC + j];
+      gm[j] = (MODE == 0 || !cv_ok || !beta) ? 1.f : gamma[cv * VEC + j];
+      bt[j] = (MODE == 0 || !cv_ok || !beta) ? 0.f : beta[cv * VEC + j];
     }
     if (trow < rows && cv_ok) {
       for (int p = p0 + trow; p < p1; p += rows) {
         const size_t off = base + (size_t)p * C + cv * VEC;
-        float a0[VEC], a1[VEC], a2[VEC], a3[VEC];
+        float a0[VEC], a1[VEC], a2[VEC];
         if constexpr (VEC == 4) {
           *(float4*)a0 = *(const float4*)(t0 + off);
           if (MODE >= 1) *(float4*)a1 = *(const float4*)(t1 + off);
-          if (MODE == 1 && t2) *(float4*)a2 = *(const float4*)(t2 + off);
           if (MODE == 2) *(float4*)a2 = *(const float4*)(t2 + off);
-          if (MODE == 2 && t3) *(float4*)a3 = *(const float4*)(t3 + off);
         } else {
           a0[0] = t0[off];
           if (MODE >= 1) a1[0] = t1[off];
-          if (MODE == 1 && t2) a2[0] = t2[off];
           if (MODE == 2) a2[0] = t2[off];
-          if (MODE == 2 && t3) a3[0] = t3[off];
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -81,12 +86,12 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
             acc[0][j] += a0[j];
             acc[1][j] += a0[j] * a0[j];
           } else if (MODE == 1) {
-            const float gz = t2 ? a0[j] * lrelu_mask(a2[j], slope) : a0[j];
+            const float gz = beta ? a0[j] * lrelu_mask(in_affine(a1[j], mu[j], rs[j], gm[j], bt[j]), slope) : a0[j];
             const float xh = (a1[j] - mu[j]) * rs[j];
             acc[0][j] += gz;
             acc[1][j] += gz * xh;
           } else {
-            const float gz = t3 ? a2[j] * lrelu_mask(a3[j], slope) : a2[j];
+            const float gz = beta ? a2[j] * lrelu_mask(in_affine(a1[j], mu[j], rs[j], gm[j], bt[j]), slope) : a2[j];
             const float xh = (a1[j] - mu[j]) * rs[j];
             acc[0][j] += a0[j];
             acc[1][j] += a0[j] * xh;
@@ -173,8 +178,7 @@ in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const 
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = cv * VEC + j;
-      const float sc = rstd[n * C + c] * gamma[c];
-      const float r = (v[j] - mean[n * C + c]) * sc + beta[c];
+      const float r = in_affine(v[j], mean[n * C + c], rstd[n * C + c], gamma[c], beta[c]);
       v[j] = has_act ? lrelu_f(r, slope) : r;
     }
     if constexpr (VEC == 4) *(float4*)(y + i * 4) = *(float4*)v; else y[i] = v[0];
@@ -183,7 +187,7 @@ in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const 
 
 template <int VEC>
 __global__ void __launch_bounds__(TPB)
-in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ ymask,
+in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
              const float* __restrict__ am, const float* __restrict__ bm, float* __restrict__ gx,
              int64_t total_vec, int HW, int C, float slope) {
@@ -191,22 +195,21 @@ in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const fl
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
     const int cv = (int)(i % CV);
     const int n = (int)(i / ((int64_t)CV * HW));
-    float g[VEC], xv[VEC], ym[VEC];
+    float g[VEC], xv[VEC];
     if constexpr (VEC == 4) {
       *(float4*)g = *(const float4*)(gy + i * 4);
       *(float4*)xv = *(const float4*)(x + i * 4);
-      if (ymask) *(float4*)ym = *(const float4*)(ymask + i * 4);
     } else {
       g[0] = gy[i]; xv[0] = x[i];
-      if (ymask) ym[0] = ymask[i];
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const int k = n * C + cv * VEC + j;
-      const float r = rstd[k];
-      const float gz = ymask ? g[j] * lrelu_mask(ym[j], slope) : g[j];
+      const int c = cv * VEC + j;
+      const int k = n * C + c;
+      const float r = rstd[k], gm = gamma[c];
+      const float gz = beta ? g[j] * lrelu_mask(in_affine(xv[j], mean[k], r, gm, beta[c]), slope) : g[j];
       const float xh = (xv[j] - mean[k]) * r;
-      g[j] = gamma[cv * VEC + j] * r * (gz - am[k] - xh * bm[k]);
+      g[j] = gm * r * (gz - am[k] - xh * bm[k]);
     }
     if constexpr (VEC == 4) *(float4*)(gx + i * 4) = *(float4*)g; else gx[i] = g[0];
   }
@@ -215,7 +218,7 @@ in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const fl
 template <int VEC>
 __global__ void __launch_bounds__(TPB)
 in_apply_bwd2(const float* __restrict__ v, const float* __restrict__ x, const float* __restrict__ gy,
-              const float* __restrict__ ymask, const float* __restrict__ mean, const float* __restrict__ rstd,
+              const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ rstd,
               const float* __restrict__ gamma, const float* __restrict__ am, const float* __restrict__ bm,
               const float* __restrict__ cvm, const float* __restrict__ dvm, const float* __restrict__ em,
               const float* __restrict__ ug, const float* __restrict__ ub,
@@ -225,22 +228,20 @@ in_apply_bwd2(const float* __restrict__ v, const float* __restrict__ x, const fl
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
     const int cv = (int)(i % CV);
     const int n = (int)(i / ((int64_t)CV * HW));
-    float vv[VEC], xv[VEC], g[VEC], ym[VEC], o1[VEC], o2[VEC];
+    float vv[VEC], xv[VEC], g[VEC], o1[VEC], o2[VEC];
     if constexpr (VEC == 4) {
       *(float4*)vv = *(const float4*)(v + i * 4);
       *(float4*)xv = *(const float4*)(x + i * 4);
       *(float4*)g = *(const float4*)(gy + i * 4);
-      if (ymask) *(float4*)ym = *(const float4*)(ymask + i * 4);
     } else {
       vv[0] = v[i]; xv[0] = x[i]; g[0] = gy[i];
-      if (ymask) ym[0] = ymask[i];
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int c = cv * VEC + j;
       const int k = n * C + c;
       const float r = rstd[k], gm = gamma[c];
-      const float mk = ymask ? lrelu_mask(ym[j], slope) : 1.f;
+      const float mk = beta ? lrelu_mask(in_affine(xv[j], mean[k], r, gm, beta[c]), slope) : 1.f;
       const float gz = g[j] * mk;
       const float xh = (xv[j] - mean[k]) * r;
       const float a = am[k], b = bm[k], cvv = cvm[k], dv = dvm[k];
@@ -307,9 +308,9 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
   const int chunks = (int)cdiv64(HW, ppc);
   dim3 g(chunks, N);
   if (C % 4 == 0)
-    in_moments_partial<0, 4><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
+    in_moments_partial<0, 4><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
   else
-    in_moments_partial<0, 1><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
+    in_moments_partial<0, 1><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
   in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, eps, mean, rstd, nullptr);
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
@@ -337,8 +338,9 @@ int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float*
   return SMSUT_OK;
 }
 
-// ymask may be null (no activation).  Outputs gx [N,HW,C], a/b [N,C] (saved for bwd2), ggamma/gbeta [C] (may be null).
-int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask, const float* mean, const float* rstd,
+// beta == null: no activation; otherwise the LeakyReLU mask is recomputed from x (sign of the normalised
+// pre-activation, bit-identical to the forward).  Outputs gx [N,HW,C], a/b [N,C] (saved for bwd2), ggamma/gbeta [C] (may be null).
+int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta, const float* mean, const float* rstd,
                        const float* gamma, float* gx, float* a_mean, float* b_mean, float* ggamma, float* gbeta,
                        float* workspace, int N, int HW, int C, float slope, void* stream) {
   SMSUT_REQUIRE(gy && x && mean && rstd && gamma && gx && a_mean && b_mean && workspace && N > 0 && HW > 0 && C > 0);
@@ -347,16 +349,16 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask, cons
   const int chunks = (int)cdiv64(HW, ppc);
   dim3 g(chunks, N);
   if (C % 4 == 0)
-    in_moments_partial<1, 4><<<g, TPB, 0, st>>>(gy, x, ymask, nullptr, mean, rstd, workspace, HW, C, ppc, slope);
+    in_moments_partial<1, 4><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
   else
-    in_moments_partial<1, 1><<<g, TPB, 0, st>>>(gy, x, ymask, nullptr, mean, rstd, workspace, HW, C, ppc, slope);
+    in_moments_partial<1, 1><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
   in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
   if (ggamma && gbeta) in_affine_grads<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b_mean, N, C, HW, ggamma, gbeta);
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
-    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gy, x, ymask, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, slope);
+    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, slope);
   else
-    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gy, x, ymask, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, slope);
+    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, slope);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -364,7 +366,7 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* ymask, cons
 // Backward of smsut_instnorm_bwd (WGAN-GP double backward).  v = d/dgx; ug/ub = d/dggamma, d/dgbeta (may be null).
 // scratch: float[3*N*C] for cv/dv/e.
 int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const float* gy, const float* x,
-                        const float* ymask, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, const float* mean, const float* rstd, const float* gamma,
                         const float* a_mean, const float* b_mean, float* d_gy, float* d_x, float* d_gamma,
                         float* workspace, float* scratch, int N, int HW, int C, float slope, void* stream) {
   SMSUT_REQUIRE(v && gy && x && mean && rstd && gamma && a_mean && b_mean && d_gy && d_x && d_gamma && workspace &&
@@ -375,17 +377,17 @@ int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const 
   dim3 g(chunks, N);
   float* cvm = scratch; float* dvm = scratch + (size_t)N * C; float* em = scratch + 2 * (size_t)N * C;
   if (C % 4 == 0)
-    in_moments_partial<2, 4><<<g, TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, workspace, HW, C, ppc, slope);
+    in_moments_partial<2, 4><<<g, TPB, 0, st>>>(v, x, gy, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
   else
-    in_moments_partial<2, 1><<<g, TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, workspace, HW, C, ppc, slope);
+    in_moments_partial<2, 1><<<g, TPB, 0, st>>>(v, x, gy, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
   in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, cvm, dvm, em);
   in_bwd2_gamma<<<(C + 63) / 64, 64, 0, st>>>(rstd, a_mean, b_mean, cvm, dvm, em, N, C, HW, d_gamma);
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
-    in_apply_bwd2<4><<<ew_grid(total / 4), TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
+    in_apply_bwd2<4><<<ew_grid(total / 4), TPB, 0, st>>>(v, x, gy, beta, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
                                                           ug, ub, d_gy, d_x, total / 4, HW, C, slope);
   else
-    in_apply_bwd2<1><<<ew_grid(total), TPB, 0, st>>>(v, x, gy, ymask, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
+    in_apply_bwd2<1><<<ew_grid(total), TPB, 0, st>>>(v, x, gy, beta, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
                                                       ug, ub, d_gy, d_x, total, HW, C, slope);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

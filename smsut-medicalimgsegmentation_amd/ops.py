@@ -368,7 +368,7 @@ class InstNormActFn(Function):
             chunks = H.call("smsut_in_chunks", n, h * w, c)
             H.call("smsut_instnorm_fwd", x, gamma, beta, y, mean, rstd, _ws(n * chunks * c * 3, x), n, h * w, c,
                    IN_EPS, float(slope), int(has_act), _s())
-        ctx.save_for_backward(x, y, mean, rstd, gamma)
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)       # y is NOT kept: the mask is recomputed from x
         ctx.cfg = (float(slope), bool(has_act))
         ctx.mark_non_differentiable(mean, rstd)
         ctx.set_materialize_grads(False)
@@ -378,10 +378,10 @@ class InstNormActFn(Function):
     def backward(ctx, gy, _gm, _gr):
         if gy is None:          # reached only through the (non-differentiable) mask input of the double backward
             return None, None, None, None, None
-        x, y, mean, rstd, gamma = ctx.saved_tensors
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
         slope, has_act = ctx.cfg
         want_affine = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRADS_ONLY
-        gx, gg, gb = InstNormActBwdFn.apply(gy, x, y, mean, rstd, gamma, slope, has_act, want_affine)
+        gx, gg, gb = InstNormActBwdFn.apply(gy, x, beta, mean, rstd, gamma, slope, has_act, want_affine)
         if not want_affine:
             gg = gb = None
         return gx, gg, gb, None, None
@@ -392,7 +392,7 @@ class InstNormActBwdFn(Function):
     (csrc/norm.hip header) needed by the gradient penalty."""
 
     @staticmethod
-    def forward(ctx, gy, x, y, mean, rstd, gamma, slope, has_act, want_affine):
+    def forward(ctx, gy, x, beta, mean, rstd, gamma, slope, has_act, want_affine):
         gy = nhwc(gy)
         n, c, h, w = x.shape
         gx = new_act(n, c, h, w, x)
@@ -401,10 +401,10 @@ class InstNormActBwdFn(Function):
         gg = torch.empty(c, dtype=torch.float32, device=x.device)
         gb = torch.empty_like(gg)
         chunks = H.call("smsut_in_chunks", n, h * w, c)
-        H.call("smsut_instnorm_bwd", gy, x, y if has_act else None, mean, rstd, gamma, gx, a, b,
+        H.call("smsut_instnorm_bwd", gy, x, beta if has_act else None, mean, rstd, gamma, gx, a, b,
                gg if want_affine else None, gb if want_affine else None, _ws(n * chunks * c * 3, x),
                n, h * w, c, slope, _s())
-        ctx.save_for_backward(gy, x, y, mean, rstd, gamma, a, b)
+        ctx.save_for_backward(gy, x, beta, mean, rstd, gamma, a, b)
         ctx.cfg = (slope, has_act, want_affine)
         ctx.set_materialize_grads(False)
         return gx, gg, gb
@@ -412,7 +412,7 @@ class InstNormActBwdFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, v, ug, ub):
-        gy, x, y, mean, rstd, gamma, a, b = ctx.saved_tensors
+        gy, x, beta, mean, rstd, gamma, a, b = ctx.saved_tensors
         slope, has_act, want_affine = ctx.cfg
         if v is None:                       # only the affine gradients were used downstream
             v = torch.zeros_like(x)
@@ -424,7 +424,7 @@ class InstNormActBwdFn(Function):
         chunks = H.call("smsut_in_chunks", n, h * w, c)
         if not want_affine:
             ug = ub = None
-        H.call("smsut_instnorm_bwd2", v, ug, ub, gy, x, y if has_act else None, mean, rstd, gamma, a, b,
+        H.call("smsut_instnorm_bwd2", v, ug, ub, gy, x, beta if has_act else None, mean, rstd, gamma, a, b,
                d_gy, d_x, d_gamma, _ws(n * chunks * c * 3, x), _ws(3 * n * c, x), n, h * w, c, slope, _s())
         return d_gy, d_x, None, None, None, d_gamma, None, None, None
 
