@@ -121,6 +121,16 @@ int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, voi
 int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
 int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_bilinear2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
+/* networks.py building blocks of ResnetGenerator / NLayerDiscriminator: reflection / replication /
+ * zero padding and cropping (mode 0 zero, 1 reflect, 2 replicate; (oy, ox) = (top, left) pad, negative = crop) and the
+ * anti-aliased Downsample(filt 3, stride 2, reflect) -- networks.py:37-60,95-105.  Upsample(filt 4, 'repl', stride 2)
+ * (networks.py:73-93) is arithmetically the x2 bilinear kernel above. */
+int smsut_window_fwd(const float* src, float* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int oy, int ox, int mode,
+                     void* stream);
+int smsut_window_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int Hd, int Wd, int C, int oy, int ox, int mode,
+                     void* stream);
+int smsut_blurdown_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int smsut_blurdown_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
 int smsut_copy_channels(const float* src, int Cs, int src_off, float* dst, int Cd, int dst_off, int Cc, int64_t P,
                         void* stream);
 int smsut_modal_planes(const float* x, const float* m, float* out, int N, int64_t HW, int Cx, int M, void* stream);

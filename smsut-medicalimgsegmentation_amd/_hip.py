@@ -66,6 +66,10 @@ SIGNATURES: Dict[str, str] = {
     "smsut_avgpool2_bwd": "pp iiii s",
     "smsut_bilinear2_fwd": "pp iiii s",
     "smsut_bilinear2_bwd": "pp iiii s",
+    "smsut_window_fwd": "pp iiiiiiiii s",
+    "smsut_window_bwd": "pp iiiiiiiii s",
+    "smsut_blurdown_fwd": "pp iiii s",
+    "smsut_blurdown_bwd": "pp iiii s",
     "smsut_copy_channels": "p ii p ii i l s",
     "smsut_modal_planes": "ppp i l ii s",
     # loss.hip

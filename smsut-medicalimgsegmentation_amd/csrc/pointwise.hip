@@ -253,6 +253,104 @@ k_modal_planes(const float* __restrict__ x, const float* __restrict__ m, float* 
   }
 }
 
+// ---- padding / cropping window copy and the anti-aliased (blur-pool) down-sampling of network/networks.py:37-60 ------
+// mode 0 zero, 1 reflect (nn.ReflectionPad2d), 2 replicate (nn.ReplicationPad2d); offsets may be negative (crop).
+__device__ __forceinline__ int map_index(int i, int size, int mode) {
+  if (i >= 0 && i < size) return i;
+  if (mode == 1) { if (i < 0) i = -i; if (i >= size) i = 2 * (size - 1) - i; return (i >= 0 && i < size) ? i : -1; }
+  if (mode == 2) return i < 0 ? 0 : size - 1;
+  return -1;
+}
+
+// dst[n,y,x,:] = src[n, map(y - oy), map(x - ox), :]
+__global__ void __launch_bounds__(TPB)
+k_window_fwd(const float* __restrict__ src, float* __restrict__ dst, int N, int Hs, int Ws, int Hd, int Wd, int C,
+             int oy, int ox, int mode) {
+  const int64_t total = (int64_t)N * Hd * Wd * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int x = (int)(p % Wd); p /= Wd;
+    const int y = (int)(p % Hd);
+    const int n = (int)(p / Hd);
+    const int sy = map_index(y - oy, Hs, mode), sx = map_index(x - ox, Ws, mode);
+    dst[i] = (sy >= 0 && sx >= 0) ? src[(((size_t)n * Hs + sy) * Ws + sx) * C + c] : 0.f;
+  }
+}
+
+// adjoint: gsrc[n,sy,sx,:] = sum over every dst position that maps to (sy, sx); R = search radius (max |pad|)
+__global__ void __launch_bounds__(TPB)
+k_window_bwd(const float* __restrict__ gdst, float* __restrict__ gsrc, int N, int Hs, int Ws, int Hd, int Wd, int C,
+             int oy, int ox, int mode, int R) {
+  const int64_t total = (int64_t)N * Hs * Ws * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int sx = (int)(p % Ws); p /= Ws;
+    const int sy = (int)(p % Hs);
+    const int n = (int)(p / Hs);
+    float acc = 0.f;
+    for (int y = max(0, sy + oy - 2 * R); y < min(Hd, sy + oy + 2 * R + 1); ++y) {
+      if (map_index(y - oy, Hs, mode) != sy) continue;
+      for (int x = max(0, sx + ox - 2 * R); x < min(Wd, sx + ox + 2 * R + 1); ++x) {
+        if (map_index(x - ox, Ws, mode) != sx) continue;
+        acc += gdst[(((size_t)n * Hd + y) * Wd + x) * C + c];
+      }
+    }
+    gsrc[i] = acc;
+  }
+}
+
+// Downsample(filt_size=3, stride=2, reflect pad 1): y[yo,xo] = sum_{i,j} f_i f_j x[refl(2yo-1+i), refl(2xo-1+j)], f = [1,2,1]/4
+__global__ void __launch_bounds__(TPB)
+k_blurdown_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const float f[3] = {0.25f, 0.5f, 0.25f};
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int xo = (int)(p % Wo); p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float acc = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int sy = map_index(2 * yo - 1 + a, H, 1);
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int sx = map_index(2 * xo - 1 + b, W, 1);
+        acc += f[a] * f[b] * x[(((size_t)n * H + sy) * W + sx) * C + c];
+      }
+    }
+    y[i] = acc;
+  }
+}
+__global__ void __launch_bounds__(TPB)
+k_blurdown_bwd(const float* __restrict__ gy, float* __restrict__ gx, int N, int H, int W, int C) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)N * H * W * C;
+  const float f[3] = {0.25f, 0.5f, 0.25f};
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    int64_t p = i / C;
+    const int sx = (int)(p % W); p /= W;
+    const int sy = (int)(p % H);
+    const int n = (int)(p / H);
+    float acc = 0.f;
+    for (int yo = max(0, sy / 2 - 2); yo < min(Ho, sy / 2 + 3); ++yo)
+      for (int a = 0; a < 3; ++a) {
+        if (map_index(2 * yo - 1 + a, H, 1) != sy) continue;
+        for (int xo = max(0, sx / 2 - 2); xo < min(Wo, sx / 2 + 3); ++xo)
+          for (int b = 0; b < 3; ++b) {
+            if (map_index(2 * xo - 1 + b, W, 1) != sx) continue;
+            acc += f[a] * f[b] * gy[(((size_t)n * Ho + yo) * Wo + xo) * C + c];
+          }
+      }
+    gx[i] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -330,6 +428,35 @@ int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, vo
 int smsut_bilinear2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0);
   k_bilinear2_bwd<<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// nn.ReflectionPad2d / nn.ReplicationPad2d / zero pad / crop (networks.py:95-105,618,835-851): dst is
+// [N][Hs+top+bottom][Ws+left+right][C]; (oy, ox) = (top, left), negative values crop.  mode 0 zero, 1 reflect, 2 replicate.
+int smsut_window_fwd(const float* src, float* dst, int N, int Hs, int Ws, int Hd, int Wd, int C, int oy, int ox, int mode,
+                     void* stream) {
+  SMSUT_REQUIRE(src && dst && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && mode >= 0 && mode <= 2);
+  k_window_fwd<<<ew_grid((int64_t)N * Hd * Wd * C), TPB, 0, ST>>>(src, dst, N, Hs, Ws, Hd, Wd, C, oy, ox, mode);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_window_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int Hd, int Wd, int C, int oy, int ox, int mode,
+                     void* stream) {
+  SMSUT_REQUIRE(gdst && gsrc && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0 && mode >= 0 && mode <= 2);
+  int R = abs(oy) > abs(ox) ? abs(oy) : abs(ox);
+  const int ry = abs(Hd - Hs - oy), rx = abs(Wd - Ws - ox);
+  if (ry > R) R = ry;
+  if (rx > R) R = rx;
+  k_window_bwd<<<ew_grid((int64_t)N * Hs * Ws * C), TPB, 0, ST>>>(gdst, gsrc, N, Hs, Ws, Hd, Wd, C, oy, ox, mode, R);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// networks.Downsample(channels, 'reflect', filt_size=3, stride=2) (networks.py:37-60): blur [1,2,1]x[1,2,1]/16, stride 2
+int smsut_blurdown_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(x && y && N > 0 && H > 1 && W > 1 && C > 0);
+  k_blurdown_fwd<<<ew_grid((int64_t)N * H * W * C / 4 + 1), TPB, 0, ST>>>(x, y, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_blurdown_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
+  SMSUT_REQUIRE(gy && gx && N > 0 && H > 1 && W > 1 && C > 0);
+  k_blurdown_bwd<<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_copy_channels(const float* src, int Cs, int src_off, float* dst, int Cd, int dst_off, int Cc, int64_t P,

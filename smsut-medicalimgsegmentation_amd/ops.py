@@ -595,6 +595,63 @@ def bilinear_up2(x):
     return Bilinear2Fn.apply(x)
 
 
+class WindowFn(Function):
+    """Padding (zero / reflect / replicate) or cropping as one window copy (networks.py:95-105,618,835-851)."""
+    MODES = {"zero": 0, "reflect": 1, "refl": 1, "replicate": 2, "repl": 2}
+
+    @staticmethod
+    def forward(ctx, x, top, bottom, left, right, mode):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        hd, wd = h + top + bottom, w + left + right
+        y = new_act(n, c, hd, wd, x)
+        H.call("smsut_window_fwd", x, y, n, h, w, hd, wd, c, top, left, mode, _s())
+        ctx.geom = (h, w, hd, wd, top, left, mode)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = nhwc(gy)
+        h, w, hd, wd, top, left, mode = ctx.geom
+        n, c = gy.shape[0], gy.shape[1]
+        gx = new_act(n, c, h, w, gy)
+        H.call("smsut_window_bwd", gy, gx, n, h, w, hd, wd, c, top, left, mode, _s())
+        return gx, None, None, None, None, None
+
+
+def pad2d(x, pads, mode="zero"):
+    """``pads`` = (left, right, top, bottom) like torch.nn.functional.pad; negative values crop."""
+    left, right, top, bottom = pads
+    return WindowFn.apply(cl(x), top, bottom, left, right, WindowFn.MODES[mode])
+
+
+class BlurDownFn(Function):
+    """networks.Downsample(C, 'reflect', filt_size=3, stride=2) (networks.py:37-60)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1, x)
+        H.call("smsut_blurdown_fwd", x, y, n, h, w, c, _s())
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        gy = nhwc(gy)
+        n, c, h, w = ctx.shape
+        gx = new_act(n, c, h, w, gy)
+        H.call("smsut_blurdown_bwd", gy, gx, n, h, w, c, _s())
+        return gx
+
+
+def blur_down2(x):
+    return BlurDownFn.apply(cl(x))
+
+
 class ConcatFn(Function):
     """torch.cat([a, b], dim=1) (network/blocks.py:50) on NHWC memory."""
 

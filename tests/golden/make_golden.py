@@ -190,6 +190,59 @@ def gen_losses():
          q=npy(q), k=npy(k), qn=npy(qn), nce=npy(nce))
 
 
+def _seeded_fill(module, seed):
+    """Deterministic values for modules whose key table is taken from the reference itself (networks.py zoo)."""
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k.endswith("filt"):
+            new[k] = v.clone()
+            continue
+        rs = np.random.RandomState((zlib_crc(k) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+        a = rs.standard_normal(tuple(v.shape))
+        a = a / np.sqrt(np.prod(v.shape[1:])) if v.dim() >= 2 else 0.1 * a
+        new[k] = torch.from_numpy(np.ascontiguousarray(a)).float()
+    module.load_state_dict(new)
+    return new
+
+
+def zlib_crc(k):
+    import zlib
+    return zlib.crc32(k.encode())
+
+
+def gen_networks_zoo():
+    """networks.ResnetGenerator / NLayerDiscriminator / PatchDiscriminator / Downsample / Upsample (SURVEY 8a rows
+    13-14): small instances with get_norm_layer('instance'); key/shape tables + outputs + a few grads."""
+    norm = ref_networks.get_norm_layer("instance")
+    seed = 71
+    G = ref_networks.ResnetGenerator(1, 1, ngf=8, norm_layer=norm, n_blocks=2)
+    w = _seeded_fill(G, seed)
+    x = recipe.synth_images((2, 1, 32, 32), seed + 1).requires_grad_(True)
+    y = G(x)
+    gy = torch.from_numpy(np.random.RandomState(seed + 2).standard_normal(tuple(y.shape))).float()
+    y.backward(gy)
+    feats = G(x.detach(), layers=[0, 4, 8], encode_only=True)
+    rec = dict(seed=seed, g_keys=np.array(list(w.keys())), g_shapes=np.array([str(tuple(v.shape)) for v in w.values()]),
+               g_x=npy(x), g_y=npy(y), g_gy=npy(gy), g_gx=npy(x.grad), g_feat8=npy(feats[2]),
+               **{"g_" + k: v for k, v in grad_summary(G, ("model.1.weight", "model.12.conv_block.1.bias", "model.19.bias")).items()})
+    D = ref_networks.NLayerDiscriminator(1, ndf=8, n_layers=3, norm_layer=norm)
+    wd = _seeded_fill(D, seed + 5)
+    xd = recipe.synth_images((2, 1, 64, 64), seed + 6).requires_grad_(True)
+    yd = D(xd)
+    gyd = torch.from_numpy(np.random.RandomState(seed + 7).standard_normal(tuple(yd.shape))).float()
+    yd.backward(gyd)
+    rec.update(d_keys=np.array(list(wd.keys())), d_shapes=np.array([str(tuple(v.shape)) for v in wd.values()]),
+               d_x=npy(xd), d_y=npy(yd), d_gy=npy(gyd), d_gx=npy(xd.grad),
+               **{"d_" + k: v for k, v in grad_summary(D, ("model.0.weight", "model.3.weight", "model.11.bias")).items()})
+    P = ref_networks.PatchDiscriminator(1, ndf=8, norm_layer=norm)
+    _seeded_fill(P, seed + 9)
+    rec["p_y"] = npy(P(recipe.synth_images((1, 1, 32, 32), seed + 10)))
+    t = recipe.synth_images((2, 3, 10, 12), seed + 11)
+    rec.update(t=npy(t), down=npy(ref_networks.Downsample(3)(t)), up=npy(ref_networks.Upsample(3)(t)))
+    save("networks_zoo", **rec)
+
+
 def gen_iter_small():
     """Two uganConsis iterations (uganConsisTrainer.py:110-203) at 64x64, B = 2 labeled + 2 unlabeled,
     PatchNCELoss(2) fed B=4 (the reference's batch_size/B mismatch), iter >= 1000 so the
@@ -291,6 +344,6 @@ def gen_iter_small():
 
 if __name__ == "__main__":
     random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
-    which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small"]
+    which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small", "networks_zoo"]
     for w in which:
         globals()["gen_" + w]()
