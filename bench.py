@@ -31,6 +31,19 @@ FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 HBM_PEAK_GBS = 8000.0
 
 
+def host_cores():
+    """Cores this process may actually use (the GPU box gives a 16-CPU share; os.cpu_count() reports the whole host)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def conv_flops(n, h, w, cin, cout, k):
     return 2.0 * n * h * w * cin * cout * k * k
 
@@ -68,12 +81,13 @@ def measure_dominant_conv(dev, batch):
             "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
 
 
-def cpu_baseline_ugan(sample_b=4):
+def cpu_baseline_ugan(sample_b=2):
     """One uganConsis iteration of the CPU oracle on (sample_b/2 + sample_b/2) 256x256 slices."""
     import numpy as np
     from oracle import recipe, smsut_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle uganConsis iteration on {sample_b} slices, {cores} threads ...")
     gsd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 2020).items()}
     dsd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.disc_shapes(256, 4, 16, 256), 2021).items()}
     g_opt = torch.optim.SGD(list(gsd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
@@ -92,10 +106,11 @@ def cpu_baseline_ugan(sample_b=4):
                       f"fp32, torch CPU {cores} threads, {dt:.1f} s"}
 
 
-def cpu_baseline_unet(sample_b=8):
+def cpu_baseline_unet(sample_b=4):
     from oracle import recipe, smsut_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle U-Net steps on {sample_b} slices, {cores} threads ...")
     sd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.unet_shapes(1, 5, 16), 2020).items()}
     opt = torch.optim.SGD(list(sd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
     x = recipe.synth_images((sample_b, 1, 256, 256), 2020)
@@ -143,11 +158,15 @@ def main():
         tr.iter, tr.epoch = 1000, 100                # consistency branch on
         lb = SyntheticSliceLoader(B // 2, device=dev, labeled=True, rank=rank)
         ul = SyntheticSliceLoader(B // 2, device=dev, labeled=False, rank=rank)
-        (x1, y1, m1, _), (x2, _, m2, _) = next(iter(lb)), next(iter(ul))
-        x_real = torch.cat([x1, x2], 0)
-        modal = torch.cat([m1, m2], 0)
+        li, ui = iter(lb), iter(ul)
+        batches = []                                   # a fresh batch per step, all resident in HBM before timing
+        for _ in range(args.warmup + args.steps):
+            (x1, y1, m1, _), (x2, _, m2, _) = next(li), next(ui)
+            batches.append((torch.cat([x1, x2], 0), y1, torch.cat([m1, m2], 0)))
+        it_batches = iter(batches)
 
         def step():
+            x_real, y1, modal = next(it_batches)
             return tr.train_iteration(x_real, y1, modal)
         workload = f"uganConsisTrainer iteration (D-step + G-step, WGAN-GP, cycle, DiceCE, consistency, PatchNCE), " \
                    f"{B // 2} labeled + {B // 2} unlabeled 1x256x256 slices per GPU, 5 classes, 4 modalities"
@@ -158,14 +177,17 @@ def main():
         cfg.batch_size = B
         tr = UnetTrainer("train", ns)
         tr.net.train()
-        ld = SyntheticSliceLoader(B, device=dev, rank=rank)
-        img, msk, _, _ = next(iter(ld))
+        ld = iter(SyntheticSliceLoader(B, device=dev, rank=rank, n_batches=args.warmup + args.steps))
+        batches = [next(ld)[:2] for _ in range(args.warmup + args.steps)]
+        it_batches = iter(batches)
 
         def step():
+            img, msk = next(it_batches)
             return tr.train_step(img, msk)
         workload = f"U-Net(1,5,16) fwd + DiceCE + bwd + SGD, {B}x1x256x256 per GPU (BASELINE config 2)"
         metric = "slices/sec U-Net train step @256x256"
 
+    log(f"{args.workload}: {args.warmup} warm-up + {args.steps} timed steps on {world} GPU(s) ...")
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -197,6 +219,7 @@ def main():
            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
                       "parallelism": f"dp{world}", "weights": "random init (reference initialisers)"},
            "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])]}
+    log(f"timed region done: {ms:.2f} ms/step")
     if not args.no_roofline:
         out["roofline"] = measure_dominant_conv(dev, B)
     if world == 1 and not args.no_cpu_baseline:

@@ -537,11 +537,12 @@ int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N,
 }
 
 // Forward conv that also emits the InstanceNorm statistics partials of its output (see conv_mfma_fwd).
-// stats: float[N * smsut_conv2d_mfma_tiles(H, W, Ndim, KS) * Ndim * 2]
-int smsut_conv2d_mfma_tiles(int H, int W, int Ndim, int KS) {
+// stats: float[N * smsut_conv2d_mfma_tiles(N, H, W, Ndim, KS) * Ndim * 2]
+// (the tile shape depends on N through the occupancy heuristic of dispatch_fwd, so N is part of the query)
+int smsut_conv2d_mfma_tiles(int N, int H, int W, int Ndim, int KS) {
   int tiles = 0;
-  if (KS == 1) dispatch_fwd<1>(nullptr, nullptr, nullptr, 1, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
-  else dispatch_fwd<3>(nullptr, nullptr, nullptr, 1, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
+  if (KS == 1) dispatch_fwd<1>(nullptr, nullptr, nullptr, N, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
+  else dispatch_fwd<3>(nullptr, nullptr, nullptr, N, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
   return tiles;
 }
 

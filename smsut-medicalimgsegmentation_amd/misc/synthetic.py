@@ -35,5 +35,5 @@ class SyntheticSliceLoader:
         return img.to(self.device, non_blocking=True), msk.to(self.device, non_blocking=True), mod, names
 
     def __iter__(self):
-        for _ in range(self.n_batches):
+        for _ in range(max(self.n_batches, 1)):
             yield self._batch()

@@ -133,7 +133,7 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False):
         if want_stats and bias is None:
             # fused InstanceNorm statistics: the conv epilogue leaves {sum, sum^2} partials that the following
             # instnorm_act picks up from the tensor object (side channel; autograd is unaffected)
-            tiles = H.call("smsut_conv2d_mfma_tiles", h, wd, co, kh)
+            tiles = H.call("smsut_conv2d_mfma_tiles", n, h, wd, co, kh)
             part = _ws(n * tiles * co * 2, x)
             H.call("smsut_conv2d_fwd_mfma_stats", x, w, y, part, n, h, wd, ci, co, kh, _s())
             y._smsut_in_partials = (part, tiles)

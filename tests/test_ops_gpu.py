@@ -281,3 +281,21 @@ def test_small_losses(ops):
     assert rel_err(o2.detach().cpu().numpy(), r2.detach().numpy()) < 1e-5
     for got, ref in ((xd2.grad, x2.grad), (wd2.grad, w2.grad), (bd2.grad, b2.grad)):
         assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("n,h,ci,co,k", [(16, 32, 32, 64, 3), (1, 32, 32, 64, 3), (16, 16, 64, 128, 3), (8, 64, 16, 32, 3),
+                                         (16, 64, 8, 16, 1), (3, 40, 24, 40, 3)])
+def test_fused_in_statistics_match_standalone_pass(ops, n, h, ci, co, k):
+    """conv epilogue statistics (side channel) == separate statistics pass, at batch sizes on both sides of the
+    occupancy heuristic that picks the tile shape (the partial layout depends on it)."""
+    x = dev(rnd(n, ci, h, h, seed=1))
+    w = to_hwio(ops, rnd(co, ci, k, k, seed=2) / np.sqrt(ci * k * k))
+    g, b = dev(1 + 0.1 * rnd(co, seed=3)), dev(0.1 * rnd(co, seed=4))
+    y_f = ops.conv2d(x, w, None, 1, (k - 1) // 2, stats=True)
+    assert hasattr(y_f, "_smsut_in_partials")
+    a_f = ops.instnorm_act(y_f, g, b, 0.01)
+    assert not hasattr(y_f, "_smsut_in_partials")
+    a_s = ops.instnorm_act(ops.conv2d(x, w, None, 1, (k - 1) // 2), g, b, 0.01)
+    assert rel_err(a_f.cpu().numpy(), a_s.cpu().numpy()) < 2e-5
+    ref = F.leaky_relu(F.instance_norm(F.conv2d(x.cpu(), w.cpu(), padding=(k - 1) // 2), weight=g.cpu(), bias=b.cpu()), 0.01)
+    assert rel_err(a_f.cpu().numpy(), ref.numpy()) < 2e-5

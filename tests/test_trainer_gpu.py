@@ -176,3 +176,41 @@ def test_unet_trainer_step_and_validation(small_cfg):
     assert n == 6 and all(prd[k].shape == gt[k].shape for k in gt)
     d = tr.validate_dice(prd, gt)
     assert 0.0 <= d["dice"] <= 1.0
+
+
+def test_full_size_iteration_scalars_vs_oracle(small_cfg):
+    """One full-size (256x256, 2 labeled + 2 unlabeled) uganConsis iteration, HIP vs the CPU oracle on the same
+    weights / inputs / RNG draws (optimizers at lr 0).  Guards everything that depends on the real tile / grid
+    heuristics (fused statistics layout, occupancy-driven tile choice), which small fixtures do not reach."""
+    from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer, SCALARS
+    from oracle import smsut_oracle as O
+    cfg = small_cfg
+    cfg.input_size, cfg.batch_size = 256, 2
+    tr = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+    g_w = recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 91)
+    d_w = recipe.fill(recipe.disc_shapes(256, 4, 16, 256), 92)
+    tr.net.load_state_dict(g_w); tr.D.load_state_dict(d_w)
+    tr.net.train(); tr.D.train()
+    tr.epoch, tr.iter = 100, 15000
+    for grp in list(tr.d_optimizer.param_groups) + list(tr.optimizer.param_groups):
+        grp["lr"] = 0.0
+    B = 4
+    x_real = recipe.synth_images((B, 1, 256, 256), 93)
+    y_real = recipe.synth_labels(2, 256, 256, 5, 94)
+    modal_org = torch.tensor([0, 0, 2, 2])
+    alpha = torch.from_numpy(np.random.RandomState(95).standard_normal((B, 1, 1, 1))).float()
+    ids = torch.from_numpy(np.random.RandomState(96).permutation(256)[:64].astype(np.int64))
+    got = np.array(tr.train_iteration(x_real.cuda(), y_real.cuda(), modal_org, mj=3, alpha=alpha.cuda(),
+                                      sample_ids=[ids.cuda()]).tolist())
+    torch.set_num_threads(8)
+    gsd = {k: v.clone().requires_grad_(True) for k, v in g_w.items()}
+    dsd = {k: v.clone().requires_grad_(True) for k, v in d_w.items()}
+    logs, _ = O.ugan_consis_iteration(gsd, dsd, torch.optim.SGD(list(gsd.values()), lr=0.0),
+                                      torch.optim.Adam(list(dsd.values()), 0.0), x_real, y_real, modal_org, 3, alpha, [ids],
+                                      it=15000, epoch=100, nce_batch=2)
+    ref = np.array([logs[k] for k in SCALARS])
+    rep = dict(zip(SCALARS, zip(got, ref)))
+    i_gp = SCALARS.index("D_gp")
+    rest = [i for i in range(len(SCALARS)) if i != i_gp]
+    assert np.allclose(got[rest], ref[rest], rtol=1e-3, atol=1e-5), rep
+    assert abs(got[i_gp] - ref[i_gp]) <= 1e-2 * abs(ref[i_gp]), rep
