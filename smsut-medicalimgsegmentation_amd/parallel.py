@@ -21,11 +21,16 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU boxes): SMSUT_DIST_BACKEND=gloo runs the N>1 path over gloo with device tensors,
+    # SMSUT_FORCE_DEVICE=0 puts every rank on the same card
+    forced = os.environ.get("SMSUT_FORCE_DEVICE")
+    if forced is not None:
+        local = int(forced)
     if world <= 1:
         return 0, 1, local, None
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        backend = os.environ.get("SMSUT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
