@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from .. import config as cfg
-from .. import ops
+from .. import graphs, ops
 from .uganShp0Trainer import UGANShp0Trainer
 
 SCALARS = ("D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg", "G_semi", "G_nce")
@@ -32,6 +32,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
         super().__init__(phase, args)
         self.lambda_semi = 10
         self.semi_start_iter = 1000                      # :165
+        self._semi_on = False
+        self._graphs = {}
+        self._lambda_semi_t = torch.zeros((), device=self.device)
 
     def consistency_loss(self, source, target):
         return self.loss(source, torch.argmax(target, dim=1))                      # :45-53
@@ -42,67 +45,118 @@ class UGANConsisTrainer(UGANShp0Trainer):
             total = total + ops.mean_all(crit(f_f, f_x), 1.0)
         return total / len(cfg.nce_layers)
 
-    def train_iteration(self, x_real, y_real, modal_org, mj=None, alpha=None, sample_ids=None):
-        """One iteration; returns a float32 device tensor with the 10 scalars in ``SCALARS`` order."""
-        lambda_semi = self.lambda_semi * self.sigmoid_rampup(self.epoch, cfg.max_epoch)       # :74
-        bs = y_real.size(0)
-        if mj is None:
-            mj = random.randint(0, cfg.n_modal - 1)                                           # :114
-        modal_trg = torch.zeros_like(modal_org).fill_(mj)
-        vec_org = self.label2onehot(modal_org, cfg.n_modal).to(self.device)
-        vec_trg = self.label2onehot(modal_trg, cfg.n_modal).to(self.device)
-        vec_ot, vec_to = vec_trg - vec_org, vec_org - vec_trg
-        modal_org, modal_trg = modal_org.to(self.device), modal_trg.to(self.device)
+    def _to_device_async(self, t):
+        if t.is_cuda:
+            return t.to(torch.int64)
+        n = t.numel()
+        if getattr(self, "_pin", None) is None or self._pin.numel() != n:
+            self._pin = torch.empty(n, dtype=torch.int64).pin_memory()
+        self._pin.copy_(t.reshape(-1))
+        return self._pin.to(self.device, non_blocking=True).clone()
 
-        # ------------------------------------------------------------ D-step (:129-146)
+    # ------------------------------------------------------------------ the two phases (each ends in .backward())
+    def _d_phase(self, x_real, vec_ot, modal_org, alpha, ids):
+        """D-step forward + backward (:129-144).  Returns [D_real, D_fake, D_cls, D_gp]."""
         out_src, out_cls = self.D(x_real)
         d_real = ops.mean_all(out_src, -1.0)
         d_cls = ops.cross_entropy_rows(out_cls, modal_org)
         with torch.no_grad():
-            _, x_fake, _, ids_d = self.net(x_real, vec_ot, sample_ids=sample_ids)
+            _, x_fake, _, _ = self.net(x_real, vec_ot, sample_ids=[ids])
         out_src, _ = self.D(x_fake)
         d_fake = ops.mean_all(out_src, 1.0)
-        if alpha is None:
-            alpha = torch.randn(x_real.size(0), 1, 1, 1, device=self.device)                  # randn, not rand (:138)
         x_hat = ops.row_lerp(x_real, x_fake, alpha).requires_grad_(True)
         out_src, _ = self.D(x_hat)
         d_gp = self.gradient_penalty(out_src, x_hat)
         d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
-        self.d_optimizer.zero_grad(set_to_none=True); self.optimizer.zero_grad(set_to_none=True)
         d_loss.backward()
-        self.d_reducer.reduce()
-        self.d_optimizer.step()
+        return torch.stack([t.detach().float() for t in (d_real, d_fake, d_cls, d_gp)])
 
-        # ------------------------------------------------------------ G-step (:150-180)
-        for p in self.D.parameters():
-            p.requires_grad_(False)
-        y_fake, x_fake, feat_x, ids = self.net(x_real, vec_ot, sample_ids=sample_ids)
+    def _g_phase(self, x_real, y_real, vec_ot, vec_to, modal_trg, ids, lambda_semi):
+        """G-step forward + backward (:150-179) with D frozen.  ``lambda_semi`` is a 0-dim device tensor (it changes
+        every epoch and must not be baked into a captured graph).  Returns [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]."""
+        bs = y_real.size(0)
+        y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
         out_src, out_cls = self.D(x_fake)
         g_fake = ops.mean_all(out_src, -1.0)
         g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
         g_seg = self.loss(y_fake[:bs], y_real)
-        y_rec, x_rec, feat_f, _ = self.net(x_fake, vec_to, sample_ids=ids)
+        y_rec, x_rec, feat_f, _ = self.net(x_fake, vec_to, sample_ids=[ids])
         g_rec = ops.l1_mean(x_real, x_rec)
-        if self.iter < self.semi_start_iter:
-            g_semi = torch.zeros((), device=self.device)
-        else:
+        if self._semi_on:
             g_semi = self.consistency_loss(y_rec, y_fake)
+        else:
+            g_semi = torch.zeros((), device=self.device)
         g_nce = self.nce_loss(feat_x, feat_f)
         g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg \
             + lambda_semi * g_semi + 1.0 * g_nce
-        self.d_optimizer.zero_grad(set_to_none=True); self.optimizer.zero_grad(set_to_none=True)
         g_loss.backward()
+        return torch.stack([t.detach().float() for t in (g_fake, g_rec, g_cls, g_seg, g_semi, g_nce)])
+
+    def _run_phase(self, name, fn, inputs, params):
+        """Eager call, or capture-once / replay as a hipGraph (graphs.GraphedPhase) when enabled."""
+        if not graphs.graphs_enabled(self.world) or self._graphs.get("disabled"):
+            for p in params:
+                p.grad = None
+            return fn(*inputs)
+        key = (name, self._semi_on) + tuple(tuple(t.shape) for t in inputs)
+        g = self._graphs.get(key)
+        if g is None:
+            try:
+                g = self._graphs[key] = graphs.GraphedPhase(fn, inputs, params)
+            except Exception as e:                                       # capture refused: stay eager, loudly
+                self.info(f"[graph] capture of {name} failed ({type(e).__name__}: {e}); running eagerly")
+                self._graphs["disabled"] = True
+                torch.cuda.synchronize()
+                return self._run_phase(name, fn, inputs, params)
+        return g(*inputs)
+
+    def train_iteration(self, x_real, y_real, modal_org, mj=None, alpha=None, sample_ids=None):
+        """One iteration; returns a float32 device tensor with the 10 scalars in ``SCALARS`` order."""
+        lambda_semi = self.lambda_semi * self.sigmoid_rampup(self.epoch, cfg.max_epoch)       # :74
+        if mj is None:
+            mj = random.randint(0, cfg.n_modal - 1)                                           # :114
+        # modality ids go to the device through a pinned staging buffer (a pageable .to(device) would make the host
+        # wait for the whole launch queue every iteration); the one-hots (:116-117) are built on the device
+        modal_org = self._to_device_async(modal_org)
+        modal_trg = torch.full_like(modal_org, mj)
+        vec_org = torch.zeros(modal_org.numel(), cfg.n_modal, device=self.device).scatter_(1, modal_org[:, None], 1.0)
+        vec_trg = torch.zeros_like(vec_org)
+        vec_trg[:, mj] = 1.0
+        vec_ot, vec_to = vec_trg - vec_org, vec_org - vec_trg
+        if alpha is None:
+            alpha = torch.randn(x_real.size(0), 1, 1, 1, device=self.device)                  # randn, not rand (:138)
+        if sample_ids is None:
+            # PatchSampleF draws torch.randperm(H*W)[:64] on the bottleneck map (ugan.py:321-323): H/16 x W/16.  The
+            # reference draws once in the D-step (unused there: x_fake is detached) and once in the G-step.
+            hw = (x_real.shape[2] // 16) * (x_real.shape[3] // 16)
+            torch.randperm(hw, device=self.device)                                             # the D-step's draw
+            ids = torch.randperm(hw, device=self.device)[: min(64, hw)]
+        else:
+            ids = sample_ids[0].to(self.device)
+        self._semi_on = self.iter >= self.semi_start_iter                                      # :165
+        lam_t = self._lambda_semi_t.fill_(lambda_semi)
+
+        # ------------------------------------------------------------ D-step (:129-146)
+        d_params = list(self.D.parameters())
+        d_scal = self._run_phase("D", self._d_phase, (x_real, vec_ot, modal_org, alpha, ids), d_params)
+        self.d_reducer.reduce()
+        self.d_optimizer.step()
+
+        # ------------------------------------------------------------ G-step (:150-180), D frozen
+        for p in d_params:
+            p.requires_grad_(False)
+        g_scal = self._run_phase("G", self._g_phase, (x_real, y_real, vec_ot, vec_to, modal_trg, ids, lam_t),
+                                 list(self.net.parameters()))
+        for p in d_params:
+            p.requires_grad_(True)
         self.g_reducer.reduce()
         self.optimizer.step()
-        for p in self.D.parameters():
-            p.requires_grad_(True)
 
         lr_ = self.poly_lr()                                                                   # :198-202
         for grp in list(self.optimizer.param_groups) + list(self.d_optimizer.param_groups):
             grp["lr"] = lr_
         self.iter += 1
-        return torch.stack([t.detach().float() for t in
-                            (d_real, d_fake, d_cls, d_gp, g_fake, g_rec, g_cls, g_seg, g_semi, g_nce)])
+        return torch.cat([d_scal, g_scal])
 
     def train_epoch(self, lb_loader, ul_loader, meter):
         self.net.train(); self.D.train()

@@ -8,7 +8,7 @@ import torch
 from torch.optim import SGD
 
 from .. import config as cfg
-from .. import parallel
+from .. import graphs, parallel
 from ..network.unet import UNet
 from .baseTrainer import BaseTrainer
 
@@ -21,21 +21,41 @@ class UnetTrainer(BaseTrainer):
         if self.phase == "train":
             self.optimizer = SGD(self.net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
             self.reducer = parallel.GradAllReducer(self.net.parameters(), self.group)
+        self._graph = None
+
+    def _phase(self, img, msk):
+        """forward + DiceCE + backward (the part that is captured into a hipGraph)."""
+        out = self.net(img)
+        loss = self.loss(out, msk)
+        loss.backward()
+        return loss.detach()
 
     def train_step(self, img, msk):
         """One iteration of unetTrainer.py:66-83 (forward, DiceCE, zero_grad, backward, step, poly LR).
         Returns the loss as a 0-dim device tensor (no host sync)."""
-        out = self.net(img)
-        loss = self.loss(out, msk)
-        self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if graphs.graphs_enabled(self.world) and self._graph is not False:
+            key = tuple(img.shape)
+            if self._graph is None or self._graph[0] != key:
+                try:
+                    self._graph = (key, graphs.GraphedPhase(self._phase, (img, msk), self.net.parameters()))
+                except Exception as e:                                   # capture refused: stay eager, loudly
+                    self.info(f"[graph] capture failed ({type(e).__name__}: {e}); running eagerly")
+                    self._graph = False
+                    torch.cuda.synchronize()
+            if self._graph:
+                loss = self._graph[1](img, msk)
+            else:
+                return self.train_step(img, msk)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
+            loss = self._phase(img, msk)
         self.reducer.reduce()
         self.optimizer.step()
         lr_ = self.poly_lr()
         for g in self.optimizer.param_groups:
             g["lr"] = lr_
         self.iter += 1
-        return loss.detach()
+        return loss
 
     def train_epoch(self, lb_loader, ul_loader, meter):
         self.net.train()
