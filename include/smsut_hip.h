@@ -92,6 +92,21 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                 float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
                                 float slope, int has_act, void* stream);
+int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float* rstd, int N, int HW, int C, float eps,
+                          void* stream);
+int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, float* b_mean, float* ggamma /*nullable*/,
+                          float* gbeta /*nullable*/, int N, int HW, int C, void* stream);
+int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* a_mean, const float* b_mean, float* gx, int N, int HW, int C, void* stream);
+/* residual tail of BasicBlock (blocks.py:60-79): out = act(IN(y2) + (IN(s) | s)), forward and backward in one pass each */
+int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
+                      const float* ms /*nullable: identity*/, const float* rs, const float* gs, const float* bs, float* out,
+                      int N, int HW, int C, float slope, void* stream);
+int smsut_restail_bwd(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                      const float* g2, const float* s, const float* ms /*nullable*/, const float* rs, const float* gs_,
+                      float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
+                      float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, int N, int HW, int C,
+                      float slope, void* stream);
 int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta /*nullable: no activation*/, const float* mean,
                        const float* rstd, const float* gamma, float* gx, float* a_mean, float* b_mean,
                        float* ggamma /*nullable*/, float* gbeta /*nullable*/, float* workspace, int N, int HW, int C,

@@ -21,6 +21,11 @@ SIGNATURES: Dict[str, str] = {
     "smsut_in_chunks": "iii",
     "smsut_instnorm_fwd": "ppppppp iii ff i s",
     "smsut_instnorm_fwd_partials": "ppppppp iiii ff i s",
+    "smsut_in_finalize_fwd": "p i pp iii f s",
+    "smsut_in_finalize_bwd": "p i pppp iii s",
+    "smsut_in_apply_bwd": "pppppppp iii s",
+    "smsut_restail_fwd": "pppppppppp p iii f s",
+    "smsut_restail_bwd": "pppppppppp pp ppp pppp p iii f s",
     "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
     "smsut_instnorm_bwd2": "ppppppppppp ppp pp iii f s",
     # conv_naive.hip

@@ -364,35 +364,56 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   }
 }
 
-// out[e] = sum_c part[c][e].  16 float4 columns x 16 split-lanes per block: each thread strides over the splits
-// (independent loads in flight), then a fixed-order LDS tree over the 16 lanes (deterministic).
+// out[e] = sum_c part[c][e].  COLS float4 columns x (256/COLS) split-lanes per block: each thread strides over the
+// splits with 4 independent accumulators (loads in flight), then a fixed-order LDS tree over the lanes (deterministic).
+template <int COLS>
 __global__ void __launch_bounds__(TPB)
 sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
+  constexpr int LANES = TPB / COLS;
   __shared__ float4 sm[TPB];
-  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int e = (blockIdx.x * 16 + col) * 4;
+  const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const int e = (blockIdx.x * COLS + col) * 4;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e + 3 < wsize) {
-    for (int c = sl; c < splits; c += 16) {
-      const float4 v = *(const float4*)(part + (size_t)c * wsize + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    float4 t0 = s, t1 = s, t2 = s, t3 = s;
+    int c = sl;
+    for (; c + 3 * LANES < splits; c += 4 * LANES) {
+      const float4 v0 = *(const float4*)(part + (size_t)c * wsize + e);
+      const float4 v1 = *(const float4*)(part + (size_t)(c + LANES) * wsize + e);
+      const float4 v2 = *(const float4*)(part + (size_t)(c + 2 * LANES) * wsize + e);
+      const float4 v3 = *(const float4*)(part + (size_t)(c + 3 * LANES) * wsize + e);
+      t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w;
+      t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
+      t2.x += v2.x; t2.y += v2.y; t2.z += v2.z; t2.w += v2.w;
+      t3.x += v3.x; t3.y += v3.y; t3.z += v3.z; t3.w += v3.w;
     }
+    for (; c < splits; c += LANES) {
+      const float4 v = *(const float4*)(part + (size_t)c * wsize + e);
+      t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
+    }
+    s.x = (t0.x + t1.x) + (t2.x + t3.x); s.y = (t0.y + t1.y) + (t2.y + t3.y);
+    s.z = (t0.z + t1.z) + (t2.z + t3.z); s.w = (t0.w + t1.w) + (t2.w + t3.w);
   } else if (e < wsize) {
     float* sp = (float*)&s;
-    for (int c = sl; c < splits; c += 16)
+    for (int c = sl; c < splits; c += LANES)
       for (int k = 0; k < wsize - e; ++k) sp[k] += part[(size_t)c * wsize + e + k];
   }
   sm[threadIdx.x] = s;
   __syncthreads();
   if (sl == 0 && e < wsize) {
     float4 t = sm[col];
-    for (int l = 1; l < 16; ++l) {
-      const float4 v = sm[l * 16 + col];
+    for (int l = 1; l < LANES; ++l) {
+      const float4 v = sm[l * COLS + col];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
     if (e + 3 < wsize) *(float4*)(out + e) = t;
     else for (int k = 0; k < wsize - e; ++k) out[e + k] = ((float*)&t)[k];
   }
+}
+
+inline void launch_sum_splits(const float* part, float* out, int wsize, int splits, hipStream_t st) {
+  if (splits >= 128) sum_splits<4><<<(wsize + 15) / 16, TPB, 0, st>>>(part, out, wsize, splits);      // 64 split-lanes
+  else sum_splits<16><<<(wsize + 63) / 64, TPB, 0, st>>>(part, out, wsize, splits);                    // 16 split-lanes
 }
 
 template <int KS, int TH, int WM, int WN, int NTN>
@@ -597,7 +618,7 @@ int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* w
     else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
   }
   const int wsize = KS * KS * Cin * Cout;
-  sum_splits<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  launch_sum_splits(workspace, gw, wsize, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -617,7 +638,7 @@ int smsut_convT2x2_wgrad_mfma(const float* x, const float* gy, float* gw, float*
   else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
   else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
   const int wsize = 4 * Cin * Cout;
-  sum_splits<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  launch_sum_splits(workspace, gw, wsize, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

@@ -285,6 +285,148 @@ __global__ void in_bwd2_gamma(const float* __restrict__ rstd, const float* __res
   d_gamma[c] = (float)(s * (double)HW);
 }
 
+// ---- fused residual tail of BasicBlock (network/blocks.py:60-79): out = act(IN(y2) + (IN(s) | idn)) -------------------
+// forward: one pass.  backward: gz = g_out * act'(out); per-(n,c) sums {gz, gz*y2hat, gz*shat} in one pass, then
+// gy2 = g2*r2*(gz - a - y2hat*b2) and gs = gs_*rs*(gz - a - shat*bs) (or g_idn = gz) in one pass.
+struct TailRef {
+  const float* y2; const float* m2; const float* r2; const float* g2; const float* b2;
+  const float* s;  const float* ms; const float* rs; const float* gs; const float* bs;   // ms == null: s is the identity
+};
+
+template <int VEC>
+__global__ void __launch_bounds__(TPB)
+restail_fwd(TailRef t, float* __restrict__ out, int64_t total_vec, int HW, int C, float slope) {
+  const int CV = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((int64_t)CV * HW));
+    float a[VEC], b[VEC];
+    if constexpr (VEC == 4) { *(float4*)a = *(const float4*)(t.y2 + i * 4); *(float4*)b = *(const float4*)(t.s + i * 4); }
+    else { a[0] = t.y2[i]; b[0] = t.s[i]; }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = cv * VEC + j, k = n * C + c;
+      const float u = in_affine(a[j], t.m2[k], t.r2[k], t.g2[c], t.b2[c]);
+      const float v = t.ms ? in_affine(b[j], t.ms[k], t.rs[k], t.gs[c], t.bs[c]) : b[j];
+      a[j] = lrelu_f(u + v, slope);
+    }
+    if constexpr (VEC == 4) *(float4*)(out + i * 4) = *(float4*)a; else out[i] = a[0];
+  }
+}
+
+// partial [N][chunks][C][3] = {sum gz, sum gz*y2hat, sum gz*shat}
+template <int VEC>
+__global__ void __launch_bounds__(TPB)
+restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
+                    int HW, int C, int pix_per_chunk, float slope) {
+  const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
+  const int CV = C / VEC;
+  const int TC = CV < TPB ? CV : TPB;
+  const int rows = TPB / TC;
+  const int tc = threadIdx.x % TC, trow = threadIdx.x / TC;
+  const int p0 = chunk * pix_per_chunk;
+  const int p1 = min(p0 + pix_per_chunk, HW);
+  __shared__ float sm[TPB * 4 * 3];
+  const size_t base = (size_t)n * HW * C;
+  for (int cv0 = 0; cv0 < CV; cv0 += TC) {
+    const int cv = cv0 + tc;
+    const bool cv_ok = cv < CV;
+    float acc[3][VEC];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[q][j] = 0.f;
+    float m2[VEC], r2[VEC], ms[VEC], rs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int k = n * C + cv * VEC + j;
+      m2[j] = cv_ok ? t.m2[k] : 0.f; r2[j] = cv_ok ? t.r2[k] : 1.f;
+      ms[j] = (cv_ok && t.ms) ? t.ms[k] : 0.f; rs[j] = (cv_ok && t.ms) ? t.rs[k] : 1.f;
+    }
+    if (trow < rows && cv_ok) {
+      for (int p = p0 + trow; p < p1; p += rows) {
+        const size_t off = base + (size_t)p * C + cv * VEC;
+        float g[VEC], o[VEC], y[VEC], sv[VEC];
+        if constexpr (VEC == 4) {
+          *(float4*)g = *(const float4*)(gout + off); *(float4*)o = *(const float4*)(out + off);
+          *(float4*)y = *(const float4*)(t.y2 + off);
+          if (t.ms) *(float4*)sv = *(const float4*)(t.s + off);
+        } else {
+          g[0] = gout[off]; o[0] = out[off]; y[0] = t.y2[off];
+          if (t.ms) sv[0] = t.s[off];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float gz = g[j] * lrelu_mask(o[j], slope);
+          acc[0][j] += gz;
+          acc[1][j] += gz * ((y[j] - m2[j]) * r2[j]);
+          if (t.ms) acc[2][j] += gz * ((sv[j] - ms[j]) * rs[j]);
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) sm[(threadIdx.x * 3 + q) * VEC + j] = acc[q][j];
+    __syncthreads();
+    if (trow == 0 && cv_ok) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float tot = 0.f;
+          for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * 3 + q) * VEC + j];
+          part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
+        }
+    }
+    __syncthreads();
+  }
+}
+
+template <int VEC>
+__global__ void __launch_bounds__(TPB)
+restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
+                  const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
+                  float* __restrict__ gs, int64_t total_vec, int HW, int C, float slope) {
+  const int CV = C / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
+    const int cv = (int)(i % CV);
+    const int n = (int)(i / ((int64_t)CV * HW));
+    float g[VEC], o[VEC], y[VEC], sv[VEC], o1[VEC], o2[VEC];
+    if constexpr (VEC == 4) {
+      *(float4*)g = *(const float4*)(gout + i * 4); *(float4*)o = *(const float4*)(out + i * 4);
+      *(float4*)y = *(const float4*)(t.y2 + i * 4);
+      if (t.ms) *(float4*)sv = *(const float4*)(t.s + i * 4);
+    } else {
+      g[0] = gout[i]; o[0] = out[i]; y[0] = t.y2[i];
+      if (t.ms) sv[0] = t.s[i];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int c = cv * VEC + j, k = n * C + c;
+      const float gz = g[j] * lrelu_mask(o[j], slope);
+      const float a = am[k];
+      o1[j] = t.g2[c] * t.r2[k] * (gz - a - ((y[j] - t.m2[k]) * t.r2[k]) * b2m[k]);
+      o2[j] = t.ms ? t.gs[c] * t.rs[k] * (gz - a - ((sv[j] - t.ms[k]) * t.rs[k]) * bsm[k]) : gz;
+    }
+    if constexpr (VEC == 4) { *(float4*)(gy2 + i * 4) = *(float4*)o1; *(float4*)(gs + i * 4) = *(float4*)o2; }
+    else { gy2[i] = o1[0]; gs[i] = o2[0]; }
+  }
+}
+
+// affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (shared by both norms), ggs = sum_n M*bs
+__global__ void restail_affine(const float* __restrict__ am, const float* __restrict__ b2m, const float* __restrict__ bsm,
+                               int N, int C, int HW, float* __restrict__ gg2, float* __restrict__ gb,
+                               float* __restrict__ ggs) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sa = 0.0, s2 = 0.0, ss = 0.0;
+  for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; s2 += (double)b2m[n * C + c]; if (bsm) ss += (double)bsm[n * C + c]; }
+  gg2[c] = (float)(s2 * HW); gb[c] = (float)(sa * HW);
+  if (ggs) ggs[c] = (float)(ss * HW);
+}
+
 inline int pick_chunk(int HW, int C, int N) {
   // aim for >= ~1024 blocks overall while keeping >= 256 pixels per chunk
   int ppc = 2048;
@@ -389,6 +531,86 @@ int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const 
   else
     in_apply_bwd2<1><<<ew_grid(total), TPB, 0, st>>>(v, x, gy, beta, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
                                                       ug, ub, d_gy, d_x, total, HW, C, slope);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Finalise forward partials [N][chunks][C][2] = {sum, sum^2} (from smsut_conv2d_fwd_mfma_fused) into mean / rstd.
+int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float* rstd, int N, int HW, int C, float eps,
+                          void* stream) {
+  SMSUT_REQUIRE(partials && mean && rstd && chunks > 0 && N > 0 && HW > 0 && C > 0);
+  in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, (hipStream_t)stream>>>(partials, chunks, C, HW, eps, mean, rstd, nullptr);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Finalise backward partials [N][chunks][C][2] = {sum gz, sum gz*xhat} (from smsut_conv2d_dgrad_mfma_fused) into the
+// per-(n,c) means a, b and the affine gradients ggamma / gbeta (nullable).
+int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, float* b_mean, float* ggamma, float* gbeta,
+                          int N, int HW, int C, void* stream) {
+  SMSUT_REQUIRE(partials && a_mean && b_mean && chunks > 0 && N > 0 && HW > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(partials, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
+  if (ggamma && gbeta) in_affine_grads<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b_mean, N, C, HW, ggamma, gbeta);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// gx = gamma*rstd*(gz - a - xhat*b) with gz ALREADY masked (output of smsut_conv2d_dgrad_mfma_fused).
+int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* a_mean, const float* b_mean, float* gx, int N, int HW, int C, void* stream) {
+  SMSUT_REQUIRE(gz && x && mean && rstd && gamma && a_mean && b_mean && gx && N > 0 && HW > 0 && C > 0);
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t total = (int64_t)N * HW * C;
+  if (C % 4 == 0)
+    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, 0.f);
+  else
+    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, 0.f);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// out = act(IN(y2) + (IN(s) | s)); ms == null: s is added as it is (identity shortcut).
+int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
+                      const float* ms, const float* rs, const float* gs, const float* bs, float* out, int N, int HW, int C,
+                      float slope, void* stream) {
+  SMSUT_REQUIRE(y2 && m2 && r2 && g2 && b2 && s && out && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs && bs)));
+  TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs, bs};
+  const int64_t total = (int64_t)N * HW * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0) restail_fwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(t, out, total / 4, HW, C, slope);
+  else restail_fwd<1><<<ew_grid(total), TPB, 0, st>>>(t, out, total, HW, C, slope);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Backward of the tail.  workspace: float[N * smsut_in_chunks(N,HW,C) * C * 3]; a/b2/bs: [N,C] scratch outputs;
+// gy2, gs: gradients w.r.t. the two raw conv outputs (gs = gradient of the identity when ms == null);
+// gg2/gb2/ggs/gbs: affine gradients (ggs/gbs nullable when ms == null).
+int smsut_restail_bwd(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                      const float* g2, const float* s, const float* ms, const float* rs, const float* gs_, float* gy2,
+                      float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
+                      float* gbs, float* workspace, int N, int HW, int C, float slope, void* stream) {
+  SMSUT_REQUIRE(gout && out && y2 && m2 && r2 && g2 && s && gy2 && gs && a_mean && b2_mean && bs_mean && gg2 && gb2 &&
+                workspace && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs_ && ggs && gbs)));
+  TailRef t{y2, m2, r2, g2, nullptr, s, ms, rs, gs_, nullptr};
+  hipStream_t st = (hipStream_t)stream;
+  const int ppc = pick_chunk(HW, C, N);
+  const int chunks = (int)cdiv64(HW, ppc);
+  dim3 g(chunks, N);
+  if (C % 4 == 0) restail_bwd_partial<4><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope);
+  else restail_bwd_partial<1><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope);
+  in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
+  restail_affine<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b2_mean, ms ? bs_mean : nullptr, N, C, HW, gg2, gb2, ms ? ggs : nullptr);
+  if (ms) {
+    hipError_t e = hipMemcpyAsync(gbs, gb2, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int64_t total = (int64_t)N * HW * C;
+  if (C % 4 == 0)
+    restail_bwd_apply<4><<<ew_grid(total / 4), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total / 4, HW, C, slope);
+  else
+    restail_bwd_apply<1><<<ew_grid(total), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total, HW, C, slope);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

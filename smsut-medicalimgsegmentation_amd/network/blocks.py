@@ -148,6 +148,12 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         s = self.relu.slope
+        ws = self.shortcut1.weight if self.downsample else None
+        if ops.basic_block_fusable(x, self.conv1.weight, ws):
+            sc = (ws, self.shortcut2.weight, self.shortcut2.bias) if self.downsample else (None, None, None)
+            return ops.basic_block(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                   self.bn2.weight, self.bn2.bias, *sc, s)
+        # op-by-op path (channel counts the MFMA kernels do not cover; also the cross-check for the fused one)
         y = self.bn1(self.conv1(x, stats=True), slope=s)
         y = self.bn2(self.conv2(y, stats=True))
         idn = self.shortcut2(self.shortcut1(x, stats=True)) if self.downsample else x

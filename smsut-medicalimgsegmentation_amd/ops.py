@@ -435,6 +435,139 @@ def instnorm_act(x, gamma, beta, slope: Optional[float]):
     return y
 
 
+# ------------------------------------------------------------------------------------------- fused BasicBlock
+FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
+
+
+def basic_block_fusable(x, w1, ws):
+    """The fused path needs the MFMA kernels on every conv of the block: channel counts that are multiples of 4."""
+    co, ci = w1.shape[0], w1.shape[1]
+    return (FUSED_BLOCK and not FORCE_GENERIC_CONV and x.is_cuda and ci % 4 == 0 and co % 4 == 0 and ci >= 4 and co >= 4
+            and (ws is not None or ci == co))
+
+
+class BasicBlockFn(Function):
+    """out = act(IN(conv3x3(act(IN(conv3x3(x))))) + IN(conv1x1(x)) | x)   (network/blocks.py:53-80).
+
+    Forward: every conv emits the InstanceNorm statistics of its output from its epilogue; IN2, the shortcut's IN, the
+    residual add and the activation are ONE pass (``smsut_restail_fwd``) -- z2 / zs never exist in HBM.
+    Backward: the tail is one reduce + one apply pass producing the gradients of both raw conv outputs.
+    (Also tried and measured slower on MI355X, r01: applying act(IN(.)) in conv2's / wgrad2's input staging and the
+    LeakyReLU-mask + IN-backward sums in dgrad2's epilogue -- the extra VALU work and the registers it needs, 102 -> 157
+    VGPRs, cost the MFMA kernels more than the memory passes they remove.)  First-order only (generator / U-Net)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):
+        x, w1, w2 = nhwc(x), hwio(w1), hwio(w2)
+        has_sc = ws is not None
+        if has_sc:
+            ws = hwio(ws)
+        n, ci, h, w = x.shape
+        co = w1.shape[0]
+        hw = h * w
+        st = _s()
+        dev = x.device
+        slope = float(slope)
+
+        def stat(c):
+            return torch.empty(n, c, dtype=torch.float32, device=dev), torch.empty(n, c, dtype=torch.float32, device=dev)
+
+        t3 = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, 3)
+        y1 = new_act(n, co, h, w, x)
+        p1 = _ws(n * t3 * co * 2, x)
+        H.call("smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
+        m1, r1 = stat(co)
+        a1 = new_act(n, co, h, w, x)
+        H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
+        y2 = new_act(n, co, h, w, x)
+        p2 = _ws(n * t3 * co * 2, x)
+        H.call("smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
+        m2, r2 = stat(co)
+        H.call("smsut_in_finalize_fwd", p2, t3, m2, r2, n, hw, co, IN_EPS, st)
+        if has_sc:
+            t1 = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, 1)
+            s = new_act(n, co, h, w, x)
+            ps = _ws(n * t1 * co * 2, x)
+            H.call("smsut_conv2d_fwd_mfma_stats", x, ws, s, ps, n, h, w, ci, co, 1, st)
+            ms, rs = stat(co)
+            H.call("smsut_in_finalize_fwd", ps, t1, ms, rs, n, hw, co, IN_EPS, st)
+        else:
+            s, ms, rs = x, None, None
+        out = new_act(n, co, h, w, x)
+        H.call("smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, co, slope, st)
+        ctx.has_sc = has_sc
+        ctx.slope = slope
+        if has_sc:
+            ctx.save_for_backward(x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs)
+        else:
+            ctx.save_for_backward(x, w1, w2, y1, a1, y2, out, m1, r1, m2, r2, g1, b1, g2)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        if ctx.has_sc:
+            x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs = ctx.saved_tensors
+        else:
+            x, w1, w2, y1, a1, y2, out, m1, r1, m2, r2, g1, b1, g2 = ctx.saved_tensors
+            ws = ms = rs = gs = None
+            s = x
+        slope = ctx.slope
+        g_out = nhwc(g_out)
+        n, ci, h, w = x.shape
+        co = w1.shape[0]
+        hw = h * w
+        st = _s()
+        dev = x.device
+
+        def vec(*shape):
+            return torch.empty(*shape, dtype=torch.float32, device=dev)
+
+        chunks = H.call("smsut_in_chunks", n, hw, co)
+        # ---- residual tail: gradients of both raw conv outputs (or of the identity) in one reduce + one apply pass
+        gy2, gs_t = new_act(n, co, h, w, x), new_act(n, co, h, w, x)
+        a_t, b2_t, bs_t = vec(n, co), vec(n, co), vec(n, co)
+        gg2, gb2 = vec(co), vec(co)
+        ggs, gbs = (vec(co), vec(co)) if ctx.has_sc else (None, None)
+        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, s, ms, rs, gs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2, ggs, gbs,
+               _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
+        # ---- conv2
+        ga1 = new_act(n, co, h, w, x)
+        H.call("smsut_conv2d_fwd_mfma", gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
+        gw2 = new_weight(co, co, 3, 3, device=dev)
+        H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x),
+               n, h, w, co, co, 3, st)
+        # ---- IN1 + LeakyReLU backward (mask recomputed from y1)
+        gy1 = new_act(n, co, h, w, x)
+        a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
+        H.call("smsut_instnorm_bwd", ga1, y1, b1, m1, r1, g1, gy1, a1m, b1m, gg1, gb1, _ws(n * chunks * co * 3, x),
+               n, hw, co, slope, st)
+        # ---- conv1 and the shortcut
+        gw1 = new_weight(co, ci, 3, 3, device=dev)
+        H.call("smsut_conv2d_wgrad_mfma", x, gy1, gw1, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), x),
+               n, h, w, ci, co, 3, st)
+        gws = None
+        if ctx.has_sc:
+            gws = new_weight(co, ci, 1, 1, device=dev)
+            H.call("smsut_conv2d_wgrad_mfma", x, gs_t, gws, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 1), x),
+                   n, h, w, ci, co, 1, st)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = new_act(n, ci, h, w, x)
+            H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 1, st)
+            if ctx.has_sc:
+                gxs = new_act(n, ci, h, w, x)
+                H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gxs, n, h, w, co, ci, 1, 1, st)
+                H.call("smsut_add_act", gx, gxs, gx, gx.numel(), 1.0, st)          # slope 1: plain add
+            else:
+                H.call("smsut_add_act", gx, gs_t, gx, gx.numel(), 1.0, st)
+        return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None
+
+
+def basic_block(x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):
+    return BasicBlockFn.apply(cl(x), w1, g1, b1, w2, g2, b2, ws, gs, bs, slope)
+
+
 # ------------------------------------------------------------------------------------------- activations / add
 class AddActFn(Function):
     """y = LeakyReLU(a + b) (residual tail, network/blocks.py:78-79); b may be None."""
