@@ -475,13 +475,19 @@ struct WgradPlan { int cit, cot, splits, tiles_per_split, tiles_x, tiles_y; };
 
 WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
   WgradPlan p;
+  // (2x2 slabs need 178 VGPRs + 144 AGPRs = one wave per SIMD, yet measured faster than 2x1 / 1x2 slabs at two waves
+  //  per SIMD, and forcing __launch_bounds__(256, 2) spills -- r01 sweeps, profiles/r01_notes.md)
   p.cit = (Cin > 16) ? 2 : 1;
   p.cot = (Cout > 16) ? 2 : 1;
   p.tiles_x = (W + TW - 1) / TW;
   p.tiles_y = (H + WTH - 1) / WTH;
   const int total = N * p.tiles_x * p.tiles_y;
   const int slabs = ((Cin + 16 * p.cit - 1) / (16 * p.cit)) * ((Cout + 16 * p.cot - 1) / (16 * p.cot));
-  int want = (1024 + slabs - 1) / slabs;         // aim for ~1024 workgroups in flight (4 per CU) ...
+  // PMC (r01, 64->64 @64^2): with 1024 two-tile workgroups the kernel averaged < 1 resident wave per SIMD -- the
+  // per-workgroup fixed cost (descriptor setup, first-tile latency, cross-wave combine, slab store) dominated.  The
+  // 144..186-VGPR variants fit 2 workgroups per CU, so ONE resident round of 512 workgroups with more tiles each.
+  const int target = (p.cit == 1 && p.cot == 1) ? 768 : 512;
+  int want = (target + slabs - 1) / slabs;
   // ... but keep the per-split slabs that sum_splits has to re-read below ~8 MB (2M floats)
   const int64_t wsz = (int64_t)Cin * Cout * 9;
   const int cap = (int)((int64_t)(2 << 20) / wsz);
