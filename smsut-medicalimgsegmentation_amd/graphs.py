@@ -33,18 +33,20 @@ class GraphedPhase:
         self.fn = fn
         self.params = list(grad_params)
         self.static_in = [t.detach().clone() for t in example_inputs]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._clear()
-                fn(*self.static_in)
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._clear()
+                    fn(*self.static_in)
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._clear()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.static_out = fn(*self.static_in)
+        self.graph.replay()          # capture records without executing: run it once so static_out holds real values
 
     def _clear(self):
         for p in self.params:

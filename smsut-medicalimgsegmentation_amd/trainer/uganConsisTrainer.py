@@ -34,6 +34,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self.semi_start_iter = 1000                      # :165
         self._semi_on = False
         self._graphs = {}
+        self._alias = None
+        self._g1 = None
+        self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
 
     def consistency_loss(self, source, target):
@@ -54,16 +57,25 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._pin.copy_(t.reshape(-1))
         return self._pin.to(self.device, non_blocking=True).clone()
 
-    # ------------------------------------------------------------------ the two phases (each ends in .backward())
-    def _d_phase(self, x_real, vec_ot, modal_org, alpha, ids):
+    # ------------------------------------------------------------------ the three phases of one iteration
+    # The reference runs G(x_real) twice per iteration with the SAME generator weights: once in the D-step (detached,
+    # :133-135) and again in the G-step (:151) -- D is updated in between, G is not, so both calls produce identical
+    # values.  Here it is computed ONCE (phase G1, with its autograd graph kept), the D-step consumes the detached
+    # result, and the G-step continues from the stored graph.  D(x_real) and D(x_fake) of the D-step share one batched
+    # pass (InstanceNorm is per sample, so the values are unchanged).
+    def _g1_phase(self, x_real, vec_ot, ids):
+        """G(x_real -> x_fake) with the autograd graph retained for the G-step; returns x_fake detached."""
+        y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
+        self._g1 = (y_fake, x_fake, feat_x)
+        return x_fake.detach()
+
+    def _d_phase(self, x_real, x_fake, modal_org, alpha):
         """D-step forward + backward (:129-144).  Returns [D_real, D_fake, D_cls, D_gp]."""
-        out_src, out_cls = self.D(x_real)
-        d_real = ops.mean_all(out_src, -1.0)
-        d_cls = ops.cross_entropy_rows(out_cls, modal_org)
-        with torch.no_grad():
-            _, x_fake, _, _ = self.net(x_real, vec_ot, sample_ids=[ids])
-        out_src, _ = self.D(x_fake)
-        d_fake = ops.mean_all(out_src, 1.0)
+        b = x_real.size(0)
+        out_src, out_cls = self.D(torch.cat([x_real, x_fake], 0))
+        d_real = ops.mean_all(out_src[:b], -1.0)
+        d_cls = ops.cross_entropy_rows(out_cls[:b], modal_org)
+        d_fake = ops.mean_all(out_src[b:], 1.0)
         x_hat = ops.row_lerp(x_real, x_fake, alpha).requires_grad_(True)
         out_src, _ = self.D(x_hat)
         d_gp = self.gradient_penalty(out_src, x_hat)
@@ -71,16 +83,20 @@ class UGANConsisTrainer(UGANShp0Trainer):
         d_loss.backward()
         return torch.stack([t.detach().float() for t in (d_real, d_fake, d_cls, d_gp)])
 
-    def _g_phase(self, x_real, y_real, vec_ot, vec_to, modal_trg, ids, lambda_semi):
-        """G-step forward + backward (:150-179) with D frozen.  ``lambda_semi`` is a 0-dim device tensor (it changes
-        every epoch and must not be baked into a captured graph).  Returns [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]."""
+    def _g2_phase(self, x_real, y_real, vec_to, modal_trg, ids, lambda_semi):
+        """Rest of the G-step (:152-179) with D frozen: D(x_fake), the cycle pass, the losses, backward through both
+        generator passes.  ``lambda_semi`` is a 0-dim device tensor (it changes every epoch and must not be baked into a
+        captured graph).  The second generator pass runs on parameter ALIASES (same storage, separate ``.grad``) so the
+        two passes' weight gradients are summed by one multi-tensor add instead of one add kernel per parameter.
+        Returns [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]."""
         bs = y_real.size(0)
-        y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
+        y_fake, x_fake, feat_x = self._g1
         out_src, out_cls = self.D(x_fake)
         g_fake = ops.mean_all(out_src, -1.0)
         g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
         g_seg = self.loss(y_fake[:bs], y_real)
-        y_rec, x_rec, feat_f, _ = self.net(x_fake, vec_to, sample_ids=[ids])
+        y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
+                                                             {"sample_ids": [ids]})
         g_rec = ops.l1_mean(x_real, x_rec)
         if self._semi_on:
             g_semi = self.consistency_loss(y_rec, y_fake)
@@ -90,11 +106,24 @@ class UGANConsisTrainer(UGANShp0Trainer):
         g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg \
             + lambda_semi * g_semi + 1.0 * g_nce
         g_loss.backward()
+        self._g1 = None
+        main, extra = [], []
+        for name, p in self.net.named_parameters():
+            a = self._alias[name]
+            if a.grad is not None:
+                if p.grad is None:
+                    p.grad = a.grad
+                else:
+                    main.append(p.grad); extra.append(a.grad)
+        if main:
+            torch._foreach_add_(main, extra)
         return torch.stack([t.detach().float() for t in (g_fake, g_rec, g_cls, g_seg, g_semi, g_nce)])
 
     def _run_phase(self, name, fn, inputs, params):
-        """Eager call, or capture-once / replay as a hipGraph (graphs.GraphedPhase) when enabled."""
-        if not graphs.graphs_enabled(self.world) or self._graphs.get("disabled"):
+        """Eager call, or capture-once / replay as a hipGraph (graphs.GraphedPhase) when enabled.  The very first
+        iteration always runs eagerly (it is the warm-up the capture needs)."""
+        use_graph = graphs.graphs_enabled(self.world) and not self._graphs.get("disabled") and self._eager_done
+        if not use_graph:
             for p in params:
                 p.grad = None
             return fn(*inputs)
@@ -102,12 +131,13 @@ class UGANConsisTrainer(UGANShp0Trainer):
         g = self._graphs.get(key)
         if g is None:
             try:
-                g = self._graphs[key] = graphs.GraphedPhase(fn, inputs, params)
+                g = self._graphs[key] = graphs.GraphedPhase(fn, inputs, params, warmup=0)
             except Exception as e:                                       # capture refused: stay eager, loudly
                 self.info(f"[graph] capture of {name} failed ({type(e).__name__}: {e}); running eagerly")
                 self._graphs["disabled"] = True
                 torch.cuda.synchronize()
                 return self._run_phase(name, fn, inputs, params)
+            return g.static_out                                          # the capture pass does not execute: replay it
         return g(*inputs)
 
     def train_iteration(self, x_real, y_real, modal_org, mj=None, alpha=None, sample_ids=None):
@@ -135,18 +165,24 @@ class UGANConsisTrainer(UGANShp0Trainer):
             ids = sample_ids[0].to(self.device)
         self._semi_on = self.iter >= self.semi_start_iter                                      # :165
         lam_t = self._lambda_semi_t.fill_(lambda_semi)
+        if self._alias is None:
+            self._alias = {k: p.detach().requires_grad_(True) for k, p in self.net.named_parameters()}
+        g_params = list(self.net.parameters())
+        d_params = list(self.D.parameters())
+
+        # ------------------------------------------------------------ G(x_real): once, shared by both steps
+        x_fake = self._run_phase("G1", self._g1_phase, (x_real, vec_ot, ids), [])
 
         # ------------------------------------------------------------ D-step (:129-146)
-        d_params = list(self.D.parameters())
-        d_scal = self._run_phase("D", self._d_phase, (x_real, vec_ot, modal_org, alpha, ids), d_params)
+        d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params)
         self.d_reducer.reduce()
         self.d_optimizer.step()
 
         # ------------------------------------------------------------ G-step (:150-180), D frozen
         for p in d_params:
             p.requires_grad_(False)
-        g_scal = self._run_phase("G", self._g_phase, (x_real, y_real, vec_ot, vec_to, modal_trg, ids, lam_t),
-                                 list(self.net.parameters()))
+        g_scal = self._run_phase("G2", self._g2_phase, (x_real, y_real, vec_to, modal_trg, ids, lam_t),
+                                 g_params + list(self._alias.values()))
         for p in d_params:
             p.requires_grad_(True)
         self.g_reducer.reduce()
@@ -156,6 +192,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         for grp in list(self.optimizer.param_groups) + list(self.d_optimizer.param_groups):
             grp["lr"] = lr_
         self.iter += 1
+        self._eager_done = True
         return torch.cat([d_scal, g_scal])
 
     def train_epoch(self, lb_loader, ul_loader, meter):

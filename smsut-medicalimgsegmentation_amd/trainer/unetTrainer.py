@@ -35,15 +35,17 @@ class UnetTrainer(BaseTrainer):
         Returns the loss as a 0-dim device tensor (no host sync)."""
         if graphs.graphs_enabled(self.world) and self._graph is not False:
             key = tuple(img.shape)
+            fresh = False
             if self._graph is None or self._graph[0] != key:
                 try:
                     self._graph = (key, graphs.GraphedPhase(self._phase, (img, msk), self.net.parameters()))
+                    fresh = True                                         # the constructor already replayed it once
                 except Exception as e:                                   # capture refused: stay eager, loudly
                     self.info(f"[graph] capture failed ({type(e).__name__}: {e}); running eagerly")
                     self._graph = False
                     torch.cuda.synchronize()
             if self._graph:
-                loss = self._graph[1](img, msk)
+                loss = self._graph[1].static_out if fresh else self._graph[1](img, msk)
             else:
                 return self.train_step(img, msk)
         else:
