@@ -56,6 +56,17 @@ int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int K
 int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
                             int Cout, int KS, void* stream);
 
+/* 1x1 convolutions as streaming GEMMs (shortcuts blocks.py:63,95-97; up-path blocks.py:45; nn.Linear ugan.py:295): the
+ * activation operand goes global -> registers (no LDS, no barrier in the loop), only the weights are staged.
+ * transposed = 1 is the data-gradient.  stats (nullable): InstanceNorm partials [N][smsut_conv1x1_tiles][Ndim][2]. */
+int smsut_conv1x1_supported(int Kdim, int Ndim);
+int smsut_conv1x1_tiles(int N, int HW, int Ndim);
+int smsut_conv1x1_fwd(const float* x, const float* w, float* y, float* stats /*nullable*/, int N, int HW, int Kdim,
+                      int Ndim, int transposed, void* stream);
+int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout);
+int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
+                        void* stream);
+
 /* Tiny-channel convolutions (HBM-bound): 5x5 stems (blocks.py:123, ugan.py:26), D's k4 s2 stem (ugan.py:202), 1x1 heads
  * (blocks.py:166, ugan.py:70).  fwd/dgrad: direct, Cin <= 8, Cout in {4,8,12,16}; wgrad: MFMA with the flattened
  * (tap, ci) index as M, KS*KS*Cin <= 128, Cout <= 16. */

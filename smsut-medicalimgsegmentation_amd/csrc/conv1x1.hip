@@ -1,0 +1,272 @@
+// 1x1 convolutions as streaming GEMMs on the matrix cores (fp32 in / fp32 accumulate).
+//
+// The 1x1 convs of the hot path -- BasicBlock / BottleBlock shortcuts (network/blocks.py:63,95-97), the translator's
+// up-path (blocks.py:45), nn.Linear of PatchSampleF (ugan.py:295) -- carry ~5 % of the FLOPs but touch full-resolution
+// tensors: they are HBM-bound (2.7 FLOP/B at 8->16 @256^2).  Unlike the 3x3 kernels there is no halo to share, so the
+// activation operand never goes through LDS: every lane loads its MFMA A fragment (4 consecutive channels of one pixel,
+// 16 B) straight from global memory, waves are independent (no barrier in the loop), and only the small weight matrix
+// is staged in LDS once per workgroup.  r01 profile: the LDS-tiled kernel spent 64 us per call on these shapes
+// (0.8 TB/s); this one is bounded by the memory pipe.
+//
+//   forward     y[p, n] = sum_k x[p, k] * W[k][n]                 (transposed = 0, W is [Cin][Cout])
+//   data-grad   gx[p, k] = sum_n gy[p, n] * W[k][n]               (transposed = 1: same kernel, W read transposed)
+//   weight-grad gW[k][n] = sum_p x[p, k] * gy[p, n]               (pixels are the GEMM K; per-split slabs + fixed-order sum)
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int TPB = 256;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// MR x 16 pixels per wave step, NR x 16 output channels per workgroup.
+template <int MR, int NR>
+__global__ void __launch_bounds__(TPB)
+conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ stats,
+            int64_t P, int HW, int Kdim, int Ndim, int transposed) {
+  constexpr int CO_T = 16 * NR;
+  extern __shared__ float w_s[];                 // [chunks][4 kq][CO_T][4]: k = 16*chunk + 4*kq + j
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int co0 = blockIdx.y * CO_T;
+  const int chunks = (Kdim + 15) / 16;
+  for (int u = tid; u < chunks * 4 * CO_T; u += TPB) {
+    const int n = u % CO_T;
+    const int kg = (u / CO_T) * 4;               // = 16*chunk + 4*kq
+    const int ng = co0 + n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ng < Ndim && kg < Kdim) {
+      if (!transposed) {
+        const float* p = w + (size_t)kg * Ndim + ng;
+        v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim];
+      } else {
+        v = *(const float4*)(w + (size_t)ng * Kdim + kg);
+      }
+    }
+    *(float4*)(w_s + (size_t)u * 4) = v;
+  }
+  __syncthreads();
+
+  const int64_t p0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * MR);
+  if (p0 >= P) return;
+  f32x4 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* xp[MR];
+  bool pok[MR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    const int64_t p = p0 + i * 16 + lm;
+    pok[i] = p < P;
+    xp[i] = x + (size_t)(pok[i] ? p : 0) * Kdim + 4 * kq;
+  }
+#pragma unroll 2
+  for (int c = 0; c < chunks; ++c) {
+    const bool kok = c * 16 + 4 * kq < Kdim;
+    f32x4 a[MR], b[NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+      a[i] = (pok[i] && kok) ? *(const f32x4*)(xp[i] + c * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NR; ++j) b[j] = *(const f32x4*)(w_s + ((size_t)(c * 4 + kq) * CO_T + j * 16 + lm) * 4);
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+  }
+  // acc[i][j][r]: pixel p0 + 16 i + 4 kq + r, channel co0 + 16 j + lm
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int co = co0 + j * 16 + lm;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t p = p0 + i * 16 + 4 * kq + r;
+        if (p < P && co < Ndim) {
+          const float v = acc[i][j][r];
+          y[(size_t)p * Ndim + co] = v;
+          s1 += v; s2 += v * v;
+        }
+      }
+    if (stats) {                                  // InstanceNorm partials: one tile per wave step (HW % (16*MR) == 0)
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (kq == 0 && co < Ndim) {
+        const int tiles = HW / (16 * MR);
+        const int64_t n_img = p0 / HW;
+        const int tile = (int)((p0 % HW) / (16 * MR));
+        float* o = stats + (((size_t)n_img * tiles + tile) * Ndim + co) * 2;
+        o[0] = s1; o[1] = s2;
+      }
+    }
+  }
+}
+
+// weight gradient: each wave walks groups of 4 pixels of its workgroup's pixel range with direct global loads
+template <int CIT, int COT>
+__global__ void __launch_bounds__(TPB)
+conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int64_t P, int Cin,
+              int Cout, int64_t pix_per_split) {
+  __shared__ float red[CIT * COT * 64 * 4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int ci0 = blockIdx.y * (16 * CIT), co0 = blockIdx.z * (16 * COT);
+  const int64_t pb = (int64_t)blockIdx.x * pix_per_split;
+  const int64_t pe = min(pb + pix_per_split, P);
+  f32x4 acc[CIT][COT];
+#pragma unroll
+  for (int i = 0; i < CIT; ++i)
+#pragma unroll
+    for (int j = 0; j < COT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bool iok[CIT], jok[COT];
+#pragma unroll
+  for (int i = 0; i < CIT; ++i) iok[i] = ci0 + i * 16 + lm < Cin;
+#pragma unroll
+  for (int j = 0; j < COT; ++j) jok[j] = co0 + j * 16 + lm < Cout;
+  const float* xb = x + ci0 + lm;
+  const float* gb = gy + co0 + lm;
+#pragma unroll 4
+  for (int64_t p = pb + 4 * wave + kq; p - kq < pe; p += 16) {      // this lane's pixel (the MFMA k index)
+    const bool ok = p < pe;
+    float a[CIT], b[COT];
+#pragma unroll
+    for (int i = 0; i < CIT; ++i) a[i] = (ok && iok[i]) ? xb[(size_t)p * Cin + i * 16] : 0.f;
+#pragma unroll
+    for (int j = 0; j < COT; ++j) b[j] = (ok && jok[j]) ? gb[(size_t)p * Cout + j * 16] : 0.f;
+#pragma unroll
+    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+      for (int j = 0; j < COT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+  }
+  for (int src = 1; src < 4; ++src) {             // fixed-order combine of the 4 waves
+    __syncthreads();
+    if (wave == src) {
+#pragma unroll
+      for (int i = 0; i < CIT; ++i)
+#pragma unroll
+        for (int j = 0; j < COT; ++j) *(f32x4*)(red + ((size_t)(i * COT + j) * 64 + lane) * 4) = acc[i][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < CIT; ++i)
+#pragma unroll
+        for (int j = 0; j < COT; ++j) acc[i][j] += *(const f32x4*)(red + ((size_t)(i * COT + j) * 64 + lane) * 4);
+    }
+  }
+  if (wave == 0) {
+    float* out = part + (size_t)blockIdx.x * Cin * Cout;
+#pragma unroll
+    for (int i = 0; i < CIT; ++i)
+#pragma unroll
+      for (int j = 0; j < COT; ++j) {
+        const int co = co0 + j * 16 + lm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = ci0 + i * 16 + 4 * kq + r;
+          if (ci < Cin && co < Cout) out[(size_t)ci * Cout + co] = acc[i][j][r];
+        }
+      }
+  }
+}
+
+__global__ void __launch_bounds__(TPB)
+sum_parts(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
+  __shared__ float sm[TPB];
+  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int e = blockIdx.x * 16 + col;
+  float s = 0.f;
+  if (e < wsize)
+    for (int c = sl; c < splits; c += 16) s += part[(size_t)c * wsize + e];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && e < wsize) {
+    float t = 0.f;
+    for (int l = 0; l < 16; ++l) t += sm[l * 16 + col];
+    out[e] = t;
+  }
+}
+
+struct Plan1 { int splits; int64_t pps; };
+inline Plan1 plan_wgrad1(int64_t P, int Cin, int Cout, int cit, int cot) {
+  const int slabs = ((Cin + 16 * cit - 1) / (16 * cit)) * ((Cout + 16 * cot - 1) / (16 * cot));
+  int64_t want = (1024 + slabs - 1) / slabs;
+  const int64_t maxs = P / 256 > 0 ? P / 256 : 1;           // >= 256 pixels per workgroup
+  if (want > maxs) want = maxs;
+  if (want < 1) want = 1;
+  Plan1 p;
+  p.pps = ((P + want - 1) / want + 15) / 16 * 16;           // multiple of 16: whole 4-pixel groups per wave
+  p.splits = (int)((P + p.pps - 1) / p.pps);
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+// eligibility of the streaming 1x1 kernels: K %4 == 0 (16-byte A fragments), K <= 512 (weights of one 32-channel
+// slab fit the 64 KiB LDS image)
+int smsut_conv1x1_supported(int Kdim, int Ndim) { return Kdim >= 4 && (Kdim % 4) == 0 && Kdim <= 512 && Ndim >= 1; }
+
+// number of statistics tiles per image the forward emits for this problem (0: statistics not available, e.g. HW % 64)
+int smsut_conv1x1_tiles(int N, int HW, int Ndim) {
+  const int64_t P = (int64_t)N * HW;
+  const int mr = (P / 256 >= 512) ? 4 : 1;
+  (void)Ndim;
+  return (HW % (16 * mr) == 0) ? HW / (16 * mr) : 0;
+}
+
+// y = x * W (+ optional InstanceNorm statistics partials [N][tiles][Ndim][2]); transposed = 1: data-gradient
+int smsut_conv1x1_fwd(const float* x, const float* w, float* y, float* stats, int N, int HW, int Kdim, int Ndim,
+                      int transposed, void* stream) {
+  SMSUT_REQUIRE(x && w && y && N > 0 && HW > 0 && smsut_conv1x1_supported(Kdim, Ndim));
+  const int64_t P = (int64_t)N * HW;
+  const int mr = (P / 256 >= 512) ? 4 : 1;
+  SMSUT_REQUIRE(!stats || HW % (16 * mr) == 0);
+  const int nr = Ndim <= 16 ? 1 : 2;
+  const int chunks = (Kdim + 15) / 16;
+  const size_t sh = (size_t)chunks * 4 * 16 * nr * 4 * sizeof(float);
+  dim3 grid((unsigned)cdiv64(P, 64 * mr), (Ndim + 16 * nr - 1) / (16 * nr));
+  hipStream_t st = (hipStream_t)stream;
+  if (mr == 4 && nr == 2) conv1x1_fwd<4, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
+  else if (mr == 4) conv1x1_fwd<4, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
+  else if (nr == 2) conv1x1_fwd<1, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
+  else conv1x1_fwd<1, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout) {
+  const int cit = Cin > 16 ? 2 : 1, cot = Cout > 16 ? 2 : 1;
+  return (int64_t)plan_wgrad1((int64_t)N * HW, Cin, Cout, cit, cot).splits * Cin * Cout;
+}
+
+// gw [Cin][Cout] = sum_p x[p][:]^T gy[p][:]
+int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
+                        void* stream) {
+  SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && HW > 0 && Cin > 0 && Cout > 0);
+  const int64_t P = (int64_t)N * HW;
+  const int cit = Cin > 16 ? 2 : 1, cot = Cout > 16 ? 2 : 1;
+  const Plan1 p = plan_wgrad1(P, Cin, Cout, cit, cot);
+  dim3 grid(p.splits, (Cin + 16 * cit - 1) / (16 * cit), (Cout + 16 * cot - 1) / (16 * cot));
+  hipStream_t st = (hipStream_t)stream;
+  if (cit == 2 && cot == 2) conv1x1_wgrad<2, 2><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
+  else if (cit == 2) conv1x1_wgrad<2, 1><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
+  else if (cot == 2) conv1x1_wgrad<1, 2><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
+  else conv1x1_wgrad<1, 1><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
+  const int wsize = Cin * Cout;
+  sum_parts<<<(wsize + 15) / 16, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+}  // extern "C"

@@ -129,6 +129,15 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False):
     assert ci == ci2, f"conv: Cin mismatch {ci} vs {ci2}"
     ho, wo = _out_size(h, kh, stride, pad), _out_size(wd, kw, stride, pad)
     y = new_act(n, co, ho, wo, x)
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV and H.call("smsut_conv1x1_supported", ci, co):
+        tiles = H.call("smsut_conv1x1_tiles", n, h * wd, co) if (want_stats and bias is None) else 0
+        part = _ws(n * tiles * co * 2, x) if tiles else None
+        H.call("smsut_conv1x1_fwd", x, w, y, part, n, h * wd, ci, co, 0, _s())
+        if bias is not None:
+            H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
+        if tiles:
+            y._smsut_in_partials = (part, tiles)
+        return y
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, ci, co):
         if want_stats and bias is None:
             # fused InstanceNorm statistics: the conv epilogue leaves {sum, sum^2} partials that the following
@@ -153,6 +162,9 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
     co2, ci, kh, kw = w.shape
     assert co == co2
     gx = new_act(n, ci, h, wd, gy)
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV and H.call("smsut_conv1x1_supported", co, ci):
+        H.call("smsut_conv1x1_fwd", gy, w, gx, None, n, h * wd, co, ci, 1, _s())
+        return gx
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, co, ci):
         H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
     elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_small_supported", kh, ci, co):
@@ -166,6 +178,9 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
     n, ci, h, wd = x.shape
     _, co, ho, wo = gy.shape
     gw = new_weight(co, ci, kh, kw, device=x.device)
+    if kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV and ci % 4 == 0 and co % 4 == 0:
+        H.call("smsut_conv1x1_wgrad", x, gy, gw, _ws(H.call("smsut_conv1x1_wgrad_ws", n, h * wd, ci, co), x), n, h * wd, ci, co, _s())
+        return gw
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_wgrad_mfma_supported", kh, stride, pad, ci, co):
         ws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, wd, ci, co, kh), x)
         H.call("smsut_conv2d_wgrad_mfma", x, gy, gw, ws, n, h, wd, ci, co, kh, _s())
@@ -485,10 +500,15 @@ class BasicBlockFn(Function):
         m2, r2 = stat(co)
         H.call("smsut_in_finalize_fwd", p2, t3, m2, r2, n, hw, co, IN_EPS, st)
         if has_sc:
-            t1 = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, 1)
             s = new_act(n, co, h, w, x)
-            ps = _ws(n * t1 * co * 2, x)
-            H.call("smsut_conv2d_fwd_mfma_stats", x, ws, s, ps, n, h, w, ci, co, 1, st)
+            t1 = H.call("smsut_conv1x1_tiles", n, hw, co) if H.call("smsut_conv1x1_supported", ci, co) else 0
+            if t1:
+                ps = _ws(n * t1 * co * 2, x)
+                H.call("smsut_conv1x1_fwd", x, ws, s, ps, n, hw, ci, co, 0, st)
+            else:
+                t1 = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, 1)
+                ps = _ws(n * t1 * co * 2, x)
+                H.call("smsut_conv2d_fwd_mfma_stats", x, ws, s, ps, n, h, w, ci, co, 1, st)
             ms, rs = stat(co)
             H.call("smsut_in_finalize_fwd", ps, t1, ms, rs, n, hw, co, IN_EPS, st)
         else:
@@ -549,15 +569,17 @@ class BasicBlockFn(Function):
         gws = None
         if ctx.has_sc:
             gws = new_weight(co, ci, 1, 1, device=dev)
-            H.call("smsut_conv2d_wgrad_mfma", x, gs_t, gws, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 1), x),
-                   n, h, w, ci, co, 1, st)
+            H.call("smsut_conv1x1_wgrad", x, gs_t, gws, _ws(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), x), n, hw, ci, co, st)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = new_act(n, ci, h, w, x)
             H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 1, st)
             if ctx.has_sc:
                 gxs = new_act(n, ci, h, w, x)
-                H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gxs, n, h, w, co, ci, 1, 1, st)
+                if H.call("smsut_conv1x1_supported", co, ci):
+                    H.call("smsut_conv1x1_fwd", gs_t, ws, gxs, None, n, hw, co, ci, 1, st)
+                else:
+                    H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gxs, n, h, w, co, ci, 1, 1, st)
                 H.call("smsut_add_act", gx, gxs, gx, gx.numel(), 1.0, st)          # slope 1: plain add
             else:
                 H.call("smsut_add_act", gx, gs_t, gx, gx.numel(), 1.0, st)
