@@ -23,6 +23,7 @@
 // accumulators in registers across all its tiles, and are combined once at the end through LDS in a fixed
 // order; per-split slabs are summed by a second tiny kernel (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -364,6 +365,126 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   }
 }
 
+// Tap-split weight gradient for the 32x32-channel slab (KS = 3): the 36 accumulator tiles (tap, ci-tile, co-tile) are
+// dealt round-robin to the 4 waves -- 9 each -- and every wave walks ALL pixels of the staged tile.  Compared with the
+// row-split kernel above (each wave 1/4 of the rows, all 36 tiles = 144 accumulator registers, one wave per SIMD,
+// three LDS combine rounds at the end) this needs 36 accumulator registers, keeps two workgroups per CU resident and
+// has no cross-wave combine: each wave stores its own tiles.  PMC r01 (64->64 @64^2): row-split 46 % MFMA busy.
+__global__ void __launch_bounds__(TPB)
+conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
+                   int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split) {
+  constexpr int KS = 3, KK = 9, PAD = 1, CIT = 2, COT = 2;
+  constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
+  constexpr int CI_T = 32, CO_T = 32, SI = 48, SO = 48;
+  constexpr int NSLOT = KK * CIT * COT / 4;                    // 9 accumulator tiles per wave
+  extern __shared__ float smem[];
+  float* in_s = smem;                         // [IH][IW][SI]
+  float* gy_s = smem + IH * IW * SI;          // [WTH][TW][SO]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x;
+  const int ci0 = blockIdx.y * CI_T, co0 = blockIdx.z * CO_T;
+  const int tiles_img = tiles_x * tiles_y;
+  const int total_tiles = N * tiles_img;
+  const int t_begin = split * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, total_tiles);
+
+  // unit u = wave + 4*slot = (tap*CIT + i)*COT + j  ->  j = wave & 1 for every slot of this wave
+  const int jt = wave & 1;
+  int a_off[NSLOT];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int ti = (wave + 4 * k) >> 1;                        // tap*CIT + i
+    const int tap = ti >> 1, i = ti & 1;
+    a_off[k] = ((tap / KS) * IW + (tap % KS)) * SI + i * 16;
+  }
+  f32x4 acc[NSLOT];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr int NIN = (IH * IW * (CI_T / 4) + TPB - 1) / TPB;
+  constexpr int NGY = (WTH * TW * (CO_T / 4) + TPB - 1) / TPB;
+  float4 rin[NIN], rgy[NGY];
+  int in_yx[NIN], in_c[NIN], in_lds[NIN], gy_yx[NGY], gy_c[NGY], gy_lds[NGY];
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int u = tid + i * TPB;
+    const int q = u % (CI_T / 4), pix = u / (CI_T / 4);
+    const int c = ci0 + 4 * q;
+    in_yx[i] = (u < IH * IW * (CI_T / 4) && c < Cin) ? (((pix / IW) << 8) | (pix % IW)) : -1;
+    in_c[i] = c;
+    in_lds[i] = pix * SI + 4 * q;
+  }
+#pragma unroll
+  for (int i = 0; i < NGY; ++i) {
+    const int u = tid + i * TPB;
+    const int q = u % (CO_T / 4), pix = u / (CO_T / 4);
+    const int c = co0 + 4 * q;
+    gy_yx[i] = (u < WTH * TW * (CO_T / 4) && c < Cout) ? (((pix / TW) << 8) | (pix % TW)) : -1;
+    gy_c[i] = c;
+    gy_lds[i] = pix * SO + 4 * q;
+  }
+  auto prefetch = [&](int t) {
+    const int n_img = t / tiles_img;
+    const int rem = t % tiles_img;
+    const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * TW;
+    const float* xin = x + (size_t)n_img * H * W * Cin;
+    const float* gin = gy + (size_t)n_img * H * W * Cout;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gy_ = y0 + (in_yx[i] >> 8) - PAD, gx_ = x0 + (in_yx[i] & 255) - PAD;
+      if (in_yx[i] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W)
+        v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * Cin + in_c[i]);
+      rin[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NGY; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int gy_ = y0 + (gy_yx[i] >> 8), gx_ = x0 + (gy_yx[i] & 255);
+      if (gy_yx[i] >= 0 && gy_ < H && gx_ < W) v = *(const float4*)(gin + ((size_t)gy_ * W + gx_) * Cout + gy_c[i]);
+      rgy[i] = v;
+    }
+  };
+
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NIN; ++i)
+      if (tid + i * TPB < IH * IW * (CI_T / 4)) *(float4*)(in_s + in_lds[i]) = rin[i];
+#pragma unroll
+    for (int i = 0; i < NGY; ++i)
+      if (tid + i * TPB < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
+    __syncthreads();
+    if (t + 1 < t_end) prefetch(t + 1);
+#pragma unroll 2
+    for (int r = 0; r < WTH; ++r) {
+#pragma unroll
+      for (int ks = 0; ks < TW / 4; ++ks) {
+        const int px = ks * 4 + kq;                 // this lane's pixel (the MFMA k index) within the row
+        const float b = gy_s[(r * TW + px) * SO + jt * 16 + lm];
+        const float* ap = in_s + (r * IW + px) * SI + lm;
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) acc[k] = mfma16(ap[a_off[k]], b, acc[k]);
+      }
+    }
+  }
+  float* out = part + (size_t)split * KK * Cin * Cout;
+  const int co = co0 + jt * 16 + lm;
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int ti = (wave + 4 * k) >> 1;
+    const int tap = ti >> 1, i = ti & 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = ci0 + i * 16 + 4 * kq + r;
+      if (ci < Cin && co < Cout) out[((size_t)tap * Cin + ci) * Cout + co] = acc[k][r];
+    }
+  }
+}
+
 // out[e] = sum_c part[c][e].  COLS float4 columns x (256/COLS) split-lanes per block: each thread strides over the
 // splits with 4 independent accumulators (loads in flight), then a fixed-order LDS tree over the lanes (deterministic).
 template <int COLS>
@@ -488,9 +609,12 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
   // 144..186-VGPR variants fit 2 workgroups per CU, so ONE resident round of 512 workgroups with more tiles each.
   const int target = (p.cit == 1 && p.cot == 1) ? 768 : 512;
   int want = (target + slabs - 1) / slabs;
-  // ... but keep the per-split slabs that sum_splits has to re-read below ~8 MB (2M floats)
+  // ... but keep the per-split slabs that sum_splits has to re-read bounded (default 32 MB = 8M floats; an 8 MB cap
+  // left the 64->64 layers with 208 workgroups for 256 CUs: PMC showed < 1 resident wave per SIMD).
   const int64_t wsz = (int64_t)Cin * Cout * 9;
-  const int cap = (int)((int64_t)(2 << 20) / wsz);
+  static const int cap_mfloats = [] { const char* e = getenv("SMSUT_WGRAD_CAP_MFLOATS"); return e ? atoi(e) : 8; }();
+  int cap = (int)(((int64_t)cap_mfloats << 20) / wsz);
+  if (cap < 1) cap = 1;
   if (want > cap) want = cap;
   if (want > total) want = total;
   if (want < 1) want = 1;
@@ -621,7 +745,12 @@ int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* w
     if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
     else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
     else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
-    else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    else {
+      constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * 48 + WTH * TW * 48) * sizeof(float);
+      dim3 grid(p.splits, (Cin + 31) / 32, (Cout + 31) / 32);
+      conv_mfma_wgrad_ts<<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                p.tiles_per_split);
+    }
   }
   const int wsize = KS * KS * Cin * Cout;
   launch_sum_splits(workspace, gw, wsize, p.splits, st);
