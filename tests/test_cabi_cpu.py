@@ -72,7 +72,7 @@ def test_support_queries_and_workspace_sizes(built):
     ws = built.smsut_conv2d_wgrad_mfma_ws(32, 256, 256, 16, 16, 3)
     assert ws % (9 * 16 * 16) == 0 and 0 < ws // (9 * 16 * 16) <= 1024
     ws_big = built.smsut_conv2d_wgrad_mfma_ws(32, 16, 16, 256, 256, 3)
-    assert ws_big * 4 <= 16 << 20            # split slabs stay small for the big-weight layers
+    assert ws_big * 4 <= 32 << 20            # split slabs stay bounded (SMSUT_WGRAD_CAP_MFLOATS, default 8M floats)
     assert built.smsut_in_chunks(32, 65536, 16) >= 32
 
 
