@@ -48,6 +48,19 @@ def conv_flops(n, h, w, cin, cout, k):
     return 2.0 * n * h * w * cin * cout * k * k
 
 
+def pmc_traffic_per_slice():
+    """HBM bytes per slice of the dominant kernel from the committed PMC passes (profiles/r01_pmc_dominant.json:
+    FETCH_SIZE and WRITE_SIZE collected in two separate ``rocprofv3 --pmc`` runs of ``bench.py --roofline-only``,
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  Counters cannot be read from
+    inside the process, so the live line carries the profiled per-slice figure scaled to this run's batch; the
+    launch is linear in slices (weights are 18 KB)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")) as f:
+            return float(json.load(f)["hbm_bytes_per_slice"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def measure_dominant_conv(dev, batch):
     """HIP-event timing of the dominant kernel: conv3x3 s1 p1 on the decoder-level-1 shape
     ([B,32,256,256] -> 16 ch, blocks.py dec layer1.conv1; 9.2 % of the U-Net MACs on its own and the layer
@@ -73,8 +86,11 @@ def measure_dominant_conv(dev, batch):
     fl = conv_flops(batch, h, h, cin, cout, 3)
     achieved = fl / (ms * 1e-3) / 1e12
     byts = 4.0 * batch * h * h * (cin + cout)
+    per_slice = pmc_traffic_per_slice()
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None if per_slice is None else round(per_slice * batch),
+            "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_dominant.json)",
             "kernel": name, "kernel_kind": kind, "shape": f"N{batch} 256x256 {cin}->{cout} k3",
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
@@ -135,6 +151,8 @@ def main():
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="run only the dominant-kernel leg (the command the rocprofv3 stats / PMC passes profile)")
     args = ap.parse_args()
 
     import smsut_amd  # noqa: F401
@@ -147,6 +165,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(cfg.seed + rank)
+    if args.roofline_only:
+        B = args.per_gpu_batch or (16 if args.workload == "ugan" else 32)
+        print(json.dumps({"roofline": measure_dominant_conv(dev, B)}))
+        return
     ns = types.SimpleNamespace(fold=0, expr_name=None, write_env=False)
 
     if args.workload == "ugan":

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Collects the round's profiles on the GPU box (run from the repo root through gpurun):
+#   bash profiles/collect.sh r01
+# 1. rocprofv3 --kernel-trace --stats of the two bench workloads and of the roofline leg alone
+# 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the roofline leg, as MI355X_MICROARCH.md prescribes
+# Raw output goes under gpurun_out/<tag>_*; profiles/summarize.py turns it into the files committed in profiles/.
+set -e
+tag=${1:-r01}
+out=gpurun_out
+common="--output-format csv"
+rocprofv3 --kernel-trace --stats $common -d $out/${tag}_ugan -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $out/${tag}_ugan.log 2>&1
+tail -1 $out/${tag}_ugan.log | cut -c1-160
+rocprofv3 --kernel-trace --stats $common -d $out/${tag}_unet -- python3 bench.py --workload unet --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $out/${tag}_unet.log 2>&1
+tail -1 $out/${tag}_unet.log | cut -c1-160
+rocprofv3 --kernel-trace --stats $common -d $out/${tag}_roof -- python3 bench.py --roofline-only > $out/${tag}_roof.log 2>&1
+tail -1 $out/${tag}_roof.log | cut -c1-400
+rocprofv3 --pmc FETCH_SIZE --kernel-trace $common -d $out/${tag}_pmc_fetch -- python3 bench.py --roofline-only > $out/${tag}_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace $common -d $out/${tag}_pmc_write -- python3 bench.py --roofline-only > $out/${tag}_pmc_write.log 2>&1
+python3 profiles/summarize.py $tag

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of profiles/collect.sh (under gpurun_out/<tag>_*) into the committed summaries:
+
+  profiles/<tag>_{ugan,unet,roofline}_kernel_stats.csv   rocprofv3 --kernel-trace --stats summaries (verbatim)
+  profiles/<tag>_pmc_{fetch,write}.csv                  counter rows of the dominant kernel (one row per dispatch)
+  profiles/<tag>_pmc_dominant.json                      HBM traffic per launch / per slice, with the gfx950 correction
+  profiles/<tag>_summary.md                             per-kernel table (ms/step, share) for both workloads
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
+DOMINANT = None   # instantiation of conv_mfma_fwd the roofline leg launches, read from its own stats below
+STEPS = 7     # 2 warm-up + 5 timed steps in collect.sh
+
+
+def one(pattern):
+    hits = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True))
+    if not hits:
+        raise SystemExit(f"missing {pattern}")
+    return hits[-1]
+
+
+def json_line(path):
+    """Last JSON line of a bench log (rocprofv3 appends its own stderr lines after it)."""
+    return [ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1]
+
+
+def short(name):
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    cut = name.find("(")
+    return name if cut < 0 else name[:cut]
+
+
+def stats_table(path, steps):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    lines = [f"all kernels of the process (7 steps + initialisation + synthetic batches) / 7: {tot / steps / 1e6:.2f} ms/step, "
+             f"{sum(int(r['Calls']) for r in rows) / steps:.0f} launches/step", "",
+             "| kernel | launches/step | avg us | ms/step | share |", "|---|---:|---:|---:|---:|"]
+    for r in rows[:28]:
+        lines.append(f"| `{short(r['Name'])}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | "
+                     f"{float(r['TotalDurationNs']) / steps / 1e6:.3f} | {float(r['Percentage']):.1f}% |")
+    return "\n".join(lines)
+
+
+def pmc_rows(path, counter):
+    vals = []
+    keep = []
+    with open(path) as f:
+        rd = csv.DictReader(f)
+        for r in rd:
+            if DOMINANT in r["Kernel_Name"].replace("(anonymous namespace)::", "") and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+                keep.append(r)
+    return vals, keep, rd.fieldnames
+
+
+md = [f"# {tag}: rocprofv3 summaries", "",
+      "Commands: `profiles/collect.sh` (rocprofv3 --kernel-trace --stats; PMC in separate passes).", ""]
+for wl in ("ugan", "unet"):
+    src = one(f"{tag}_{wl}/**/*_kernel_stats.csv")
+    shutil.copy(src, os.path.join(PROF, f"{tag}_{wl}_kernel_stats.csv"))
+    try:
+        j = json.loads(json_line(os.path.join(OUT, f"{tag}_{wl}.log")))
+        head = f"`bench.py` under the profiler: {j['ms_per_step']} ms/step, {j['value']} {j['unit']}"
+    except (ValueError, IndexError):
+        head = "(bench line unreadable)"
+    md += [f"## {wl} workload", "", head, "", stats_table(src, STEPS), ""]
+
+src = one(f"{tag}_roof/**/*_kernel_stats.csv")
+shutil.copy(src, os.path.join(PROF, f"{tag}_roofline_kernel_stats.csv"))
+roof = max((r for r in csv.DictReader(open(src)) if "conv_mfma_fwd" in r["Name"]), key=lambda r: int(r["Calls"]))
+DOMINANT = short(roof["Name"])
+live = json.loads(json_line(os.path.join(OUT, f"{tag}_roof.log")))["roofline"]
+
+fetch, frows, cols = pmc_rows(one(f"{tag}_pmc_fetch/**/*_counter_collection.csv"), "FETCH_SIZE")
+write, wrows, _ = pmc_rows(one(f"{tag}_pmc_write/**/*_counter_collection.csv"), "WRITE_SIZE")
+for nm, rows in (("fetch", frows), ("write", wrows)):
+    with open(os.path.join(PROF, f"{tag}_pmc_{nm}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=cols)
+        w.writeheader()
+        w.writerows(rows)
+batch = int(live["shape"].split()[0][1:])
+fetch_kb, write_kb = sum(fetch) / len(fetch), sum(write) / len(write)
+hbm = (2.0 * fetch_kb + write_kb) * 1024.0         # FETCH_SIZE/WRITE_SIZE are in KB; FETCH_SIZE x2 on gfx950
+dom = {"kernel": DOMINANT, "shape": live["shape"], "dispatches": len(fetch),
+       "FETCH_SIZE_kb_per_launch": round(fetch_kb, 1), "WRITE_SIZE_kb_per_launch": round(write_kb, 1),
+       "fetch_correction": 2.0,
+       "correction_note": "gfx950 FETCH_SIZE counts 128-B requests of wide coalesced reads at 64 B "
+                          "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B/lane stores",
+       "hbm_bytes_per_launch": round(hbm), "hbm_bytes_per_slice": round(hbm / batch),
+       "algorithmic_bytes_per_launch": round(live["algorithmic_gbytes_per_launch"] * 1e9),
+       "traffic_over_algorithmic": round(hbm / (live["algorithmic_gbytes_per_launch"] * 1e9), 3),
+       "rocprof_avg_launch_us": round(float(roof["AverageNs"]) / 1e3, 2),
+       "hip_event_avg_launch_us": round(live["avg_launch_ms"] * 1e3, 2)}
+json.dump(dom, open(os.path.join(PROF, f"{tag}_pmc_dominant.json"), "w"), indent=1)
+md += ["## dominant kernel (roofline leg, `bench.py --roofline-only`)", "",
+       f"`{DOMINANT}` at {live['shape']}: rocprofv3 average {dom['rocprof_avg_launch_us']} us over {roof['Calls']} launches; "
+       f"HIP events in bench.py {dom['hip_event_avg_launch_us']} us -> {live['achieved']} TFLOP/s = "
+       f"{live['frac'] * 100:.1f}% of the 157.3 TFLOP/s fp32 MFMA peak.", "",
+       f"PMC: FETCH_SIZE {fetch_kb:.1f} KB (x2 gfx950 correction), WRITE_SIZE {write_kb:.1f} KB per launch -> "
+       f"{hbm / 1e6:.1f} MB HBM traffic vs {dom['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic "
+       f"(x{dom['traffic_over_algorithmic']}).", ""]
+open(os.path.join(PROF, f"{tag}_summary.md"), "w").write("\n".join(md))
+print("\n".join(md[-4:]))
