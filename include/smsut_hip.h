@@ -44,8 +44,9 @@ int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim)
 int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                           int transposed, void* stream);
 /* forward conv that also emits the InstanceNorm {sum, sum^2} partials of its output (fused statistics pass):
- * stats = float[N * smsut_conv2d_mfma_tiles(N, H, W, Ndim, KS) * Ndim * 2], consumed by smsut_instnorm_fwd_partials. */
-int smsut_conv2d_mfma_tiles(int N, int H, int W, int Ndim, int KS);
+ * stats = float[N * smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, KS) * Ndim * 2], consumed by smsut_instnorm_fwd_partials
+ * (the tile shape is chosen per layer shape, so the whole shape is part of the query). */
+int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS);
 int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
                                 int Ndim, int KS, void* stream);
 /* tuning hook: same as smsut_conv2d_fwd_mfma with a forced tile configuration (returns -1 for an unknown cfg) */

@@ -22,14 +22,14 @@ for (h, ci, co, ks) in shapes:
     y = torch.empty_like(gy); gx = torch.empty_like(x)
     fl = 2.0 * B * h * h * ci * co * ks * ks
     res = []
-    for cfg in range(12):
+    for cfg in list(range(12)) + list(range(20, 30)):
         try:
             ms = timeit(lambda: H.call("smsut_conv2d_fwd_mfma_cfg", x, w, y, B, h, h, ci, co, ks, 0, cfg, H.stream_ptr()))
             res.append((fl / ms / 1e9, cfg))
         except Exception as e:
             pass
     resd = []
-    for cfg in range(12):
+    for cfg in list(range(12)) + list(range(20, 30)):
         try:
             ms = timeit(lambda: H.call("smsut_conv2d_fwd_mfma_cfg", gy, w, gx, B, h, h, co, ci, ks, 1, cfg, H.stream_ptr()))
             resd.append((fl / ms / 1e9, cfg))

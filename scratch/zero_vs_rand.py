@@ -1,0 +1,23 @@
+"""DVFS probe: same conv launch on random vs all-zero operands (MI355X_MICROARCH.md 'DVFS give-back')."""
+import sys; sys.path.insert(0, '.')
+import torch, smsut_amd
+from smsut_amd import ops, _hip as H
+def timeit(fn, reps=50):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+for (B, h, ci, co, cfgs) in [(16, 256, 32, 16, (1, 20, 22)), (32, 256, 32, 16, (1, 20)), (16, 64, 128, 64, (11, 3)), (64, 256, 32, 16, (1, 20))]:
+    fl = 2.0 * B * h * h * ci * co * 9
+    for kind in ('rand', 'zero', 'rand'):
+        x = (torch.randn if kind == 'rand' else torch.zeros)(B, ci, h, h, device='cuda').contiguous(memory_format=torch.channels_last)
+        w = ops.new_weight(co, ci, 3, 3, device='cuda')
+        if kind == 'rand': w.copy_(torch.randn(co, ci, 3, 3, device='cuda') * 0.05)
+        else: w.zero_()
+        y = torch.empty(B, co, h, h, device='cuda').contiguous(memory_format=torch.channels_last)
+        for cfg in cfgs:
+            ms = timeit(lambda: H.call("smsut_conv2d_fwd_mfma_cfg", x, w, y, B, h, h, ci, co, 3, 0, cfg, H.stream_ptr()))
+            print(f'N{B} H{h} {ci}->{co} {kind} cfg{cfg}: {ms*1e3:.1f} us {fl/ms/1e9:.1f} TF', flush=True)

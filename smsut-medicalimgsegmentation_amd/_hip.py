@@ -38,7 +38,7 @@ SIGNATURES: Dict[str, str] = {
     # conv_mfma.hip
     "smsut_conv2d_mfma_supported": "iiiii",
     "smsut_conv2d_fwd_mfma": "ppp iiiiii i s",
-    "smsut_conv2d_mfma_tiles": "iiiii",
+    "smsut_conv2d_mfma_tiles": "iiiiii",
     "smsut_conv2d_fwd_mfma_stats": "pppp iiiiii s",
     "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",
     "smsut_conv2d_wgrad_mfma_supported": "iiiii",

@@ -34,6 +34,16 @@ constexpr int TW = 16;       // pixels per MFMA M tile (one image row segment)
 constexpr int CK = 16;       // input-channel chunk staged per LDS pass
 constexpr int SPIX = 24;     // floats between consecutive pixels of the staged input tile (16 + 8 pad)
 
+#ifdef SMSUT_STAMPS   // diagnostic build only (scratch/ubench/stamps.py): wave timeline via s_memtime, MICROARCH "In-kernel stamps"
+__device__ unsigned long long* g_stamps = nullptr;      // [512 workgroups][4 waves][16]
+__device__ int g_stamp_base = 0;                        // first workgroup (blockIdx.x) recorded
+#define STAMP(i)                                                                                       \
+  if (g_stamps && lane == 0 && stamp_wg >= g_stamp_base && stamp_wg < g_stamp_base + 512)                \
+    g_stamps[(((stamp_wg - g_stamp_base) * 4 + wave) * 16) + (i)] = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(i)
+#endif
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -63,6 +73,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   const int tile = blockIdx.x;
   const int ty = tile / tiles_x, tx = tile % tiles_x;
   const int n_img = blockIdx.y;
+  [[maybe_unused]] const int stamp_wg = blockIdx.z == 0 ? (int)(blockIdx.y * gridDim.x + blockIdx.x) : -1;
   const int tapo = blockIdx.z / nz;            // output tap (transposed conv forward), else 0
   const int co0 = (blockIdx.z % nz) * CO_T;
   const int y0 = ty * TH, x0 = tx * TW;
@@ -130,9 +141,12 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     }
   };
 
+  STAMP(0);
   prefetch(0);
+  STAMP(1);
   for (int step = 0; step < nsteps; ++step) {
     __syncthreads();                         // every wave is done reading the previous chunk
+    if (step < 2) { STAMP(2 + 4 * step); }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int u = tid + i * TPB;
@@ -144,7 +158,9 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
       if (u < KK * 4 * CO_T) *(float4*)(w_s + (size_t)u * 4) = rw[i];
     }
     __syncthreads();
+    if (step < 2) { STAMP(3 + 4 * step); }
     if (step + 1 < nsteps) prefetch(step + 1);
+    if (step < 2) { STAMP(4 + 4 * step); }
     // ---- MFMA over taps
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
@@ -163,6 +179,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 #pragma unroll
           for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
     }
+    if (step < 2) { STAMP(5 + 4 * step); }
   }
   // ---- epilogue: acc[i][j][r] is pixel (row wm*MR+i, col 4*kq + r), channel (wn*NR+j)*16 + lm
   if (stats) {
@@ -196,6 +213,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
       o[0] = s1; o[1] = s2;
     }
   }
+  STAMP(10);
   const int Wo = W * osc;
   float* yout = y + (size_t)n_img * H * osc * Wo * Ndim;
 #pragma unroll
@@ -214,6 +232,216 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
       }
     }
   }
+  STAMP(11);
+}
+
+// ------------------------------------------------------------------------------------- persistent forward / dgrad
+// Same tile and fragment layout as conv_mfma_fwd, restructured for the small-Cin / large-image layers (the 256^2 and
+// 128^2 levels), where one tile is only 1-4 channel chunks of work.  s_memtime stamps of conv_mfma_fwd<3,8,4,1,1> at
+// N16 256^2 32->16 (profiles/r01_notes.md): a workgroup lives ~29.5k cycles of which only 8.2k are its two MFMA phases;
+// index set-up (3.4k), issuing the next chunk's loads (3.2k), the two barriers around the LDS publish (4.2k per chunk)
+// and the stats + store epilogue (5.4k) are serial phases of an in-order wave, and with 4 waves per SIMD the matrix
+// pipe idles 42 % of the time.  Here a workgroup
+//   * stages the WHOLE weight block [taps][Kdim][CO_T] in LDS once and computes its staging descriptors once,
+//   * walks a contiguous range of (image, tile) items,
+//   * and inside ONE straight-line region per chunk issues the next chunk's loads, the PREVIOUS item's statistics and
+//     stores (its accumulators are kept in a second register set) and the current chunk's MFMAs, so the scheduler can
+//     put the overhead instructions into the shadow of the MFMAs (24 of every 32 issue cycles are free).
+// Regular stride-1 "same" 3x3 conv; W % 16 == 0, H % TH == 0, Ndim % (16*NTN) == 0, Kdim == 16*NCH (checked by the host).
+template <int KS, int TH, int NTN, int NCH, bool STATS>
+__global__ void __launch_bounds__(TPB)
+conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
+                int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats) {
+  constexpr int KK = KS * KS;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  constexpr int CO_T = 16 * NTN;
+  constexpr int MR = TH / 4, NR = NTN;
+  constexpr int Kdim = 16 * NCH, K4 = Kdim / 4;
+  constexpr int UNITS = IH * IW * 4;          // float4 units of one 16-channel input chunk
+  constexpr int NI = (UNITS + TPB - 1) / TPB;
+  extern __shared__ float smem[];
+  float* in_s = smem;                         // [IH][IW][SPIX] + one dummy pixel (sink for the padding units)
+  float* red = smem + (IH * IW + 1) * SPIX;   // [2][4][CO_T][2] + dummy
+  float* w_s = red + 2 * 4 * CO_T * 2 + 8;    // [KK][K4][CO_T][4]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int co0 = blockIdx.y * CO_T;
+  const int total_items = N * tiles_img;
+  const int item0 = blockIdx.x * items_per_wg;
+  const int item1 = min(item0 + items_per_wg, total_items);
+  if (item0 >= item1) return;
+  const int tiles_y = tiles_img / tiles_x;
+  [[maybe_unused]] const int stamp_wg = blockIdx.y == 0 ? (int)blockIdx.x : -1;
+  STAMP(0);
+
+  // ---- resident weights
+  for (int u = tid; u < KK * K4 * CO_T; u += TPB) {
+    const int n = u % CO_T;
+    const int k4 = (u / CO_T) % K4;
+    const int tap = u / (CO_T * K4);
+    const int ng = co0 + n;
+    float4 v;
+    if (!transposed) {
+      const float* p = w + ((size_t)tap * Kdim + 4 * k4) * Ndim + ng;
+      v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim];
+    } else {
+      v = *(const float4*)(w + ((size_t)(KK - 1 - tap) * Ndim + ng) * Kdim + 4 * k4);
+    }
+    *(float4*)(w_s + (size_t)u * 4) = v;
+  }
+
+  // ---- per-thread staging descriptors (tile-independent): element offset relative to the tile's first halo pixel,
+  //      LDS destination, and which image borders the unit falls outside of (bit 0 top, 1 bottom, 2 left, 3 right)
+  int u_off[NI], u_lds[NI], u_flag[NI];
+  float4 rin[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int u = tid + i * TPB;
+    const bool real = u < UNITS;
+    const int uu = real ? u : 0;
+    const int q = uu & 3, pix = uu >> 2;
+    const int iy = pix / IW, ix = pix % IW;
+    u_off[i] = (iy * W + ix) * Kdim + 4 * q;
+    u_lds[i] = real ? pix * SPIX + 4 * q : IH * IW * SPIX;
+    u_flag[i] = (iy < PAD ? 1 : 0) | (iy >= TH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
+  }
+  // a unit outside the image reads the tile's first interior pixel instead (always valid) and is zeroed at publish
+  const int safe_off = (PAD * W + PAD) * Kdim;
+
+  // ---- cursors: item being prefetched (p*), item being computed (c*), item whose results are being written (e*)
+  int pn = item0 / tiles_img, pty, ptx;
+  { const int t = item0 - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
+  int cn = pn, cty = pty, ctx = ptx;
+  int en = pn, ety = pty, etx = ptx;
+  int pflags = 0;      // borders the prefetched tile touches
+  bool zero[NI];       // per unit: outside the image for the chunk currently in rin
+
+  auto prefetch = [&](int c) {                       // chunk c of item (pn, pty, ptx)
+    if (c == 0) pflags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
+    const int base = (((pn * H + pty * TH - PAD) * W) + ptx * TW - PAD) * Kdim + c * 16;   // may be "negative": only
+    const float* xb = x + base;                                                          // used with in-image offsets
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      zero[i] = (u_flag[i] & pflags) != 0;
+      rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : u_off[i]));
+    }
+  };
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    if (++tx_ == tiles_x) { tx_ = 0; if (++ty_ == tiles_y) { ty_ = 0; ++n_; } }
+  };
+  auto publish = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4 v = rin[i];
+      if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(in_s + u_lds[i]) = v;
+    }
+  };
+
+  f32x4 acc[MR][NR], pacc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; pacc[i][j] = acc[i][j]; }
+
+  // per-lane output offset of (row wave*MR, col 4*kq, channel lm) inside a tile; red[] slot of this lane
+  const int o_lane = ((wave * MR) * W + 4 * kq) * Ndim + lm;
+  const int red_slot = (wave * CO_T + lm) * 2;
+
+  // statistics + stores of the item in pacc / (en, ety, etx); straight-line, no branches
+  auto epilogue = [&](int par) {
+    if (STATS) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = pacc[i][j][r]; s1 += v; s2 += v * v; }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        float* rd = kq == 0 ? red + par * (4 * CO_T * 2) + j * 32 + red_slot : red + 2 * 4 * CO_T * 2;   // else: dummy slot
+        *(float2*)rd = make_float2(s1, s2);
+      }
+    }
+    float* yb = y + (((size_t)en * H + ety * TH) * W + etx * TW) * Ndim + co0;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yb[o_lane + (i * W + r) * Ndim + j * 16] = pacc[i][j][r];
+  };
+  auto stats_out = [&](int par) {                     // after the barrier that completes red[par]
+    if (STATS && tid < CO_T) {
+      const float* rd = red + par * (4 * CO_T * 2);
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { s1 += rd[(m * CO_T + tid) * 2]; s2 += rd[(m * CO_T + tid) * 2 + 1]; }
+      *(float2*)(stats + (((size_t)en * tiles_img + ety * tiles_x + etx) * Ndim + co0 + tid) * 2) = make_float2(s1, s2);
+    }
+  };
+  auto mma_chunk = [&](int c) {
+    const float* wc = w_s + (size_t)(c * 4) * CO_T * 4;
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      const int kh = tap / KS, kw = tap % KS;
+      f32x4 a[MR], b[NR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+        a[i] = *(const f32x4*)(in_s + ((wave * MR + i + kh) * IW + lm + kw) * SPIX + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        b[j] = *(const f32x4*)(wc + (((size_t)(tap * K4 + kq) * CO_T) + j * 16 + lm) * 4);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+    }
+  };
+
+  STAMP(1);
+  prefetch(0);
+  if (NCH == 1) advance(pn, pty, ptx);
+  __syncthreads();                                    // (also publishes w_s)
+  publish();
+  __syncthreads();
+  STAMP(2);
+  int par = 0;
+  for (int item = item0; item < item1; ++item) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      // ---- one straight-line region: next loads, previous item's results, this chunk's MFMAs
+      const bool more = c + 1 < NCH || item + 1 < item1;
+      if (more) {
+        prefetch((c + 1) % NCH);
+        if (c + 2 == NCH || (NCH == 1)) advance(pn, pty, ptx);     // the prefetch after the next one starts a new item
+      }
+      if (c == 0) epilogue(par);      // first item: pacc = 0 into the item's own outputs, overwritten below
+      mma_chunk(c);
+      if (item == item0 + 1 && c == 0) { STAMP(3); }
+      __syncthreads();                                // in_s is free; red[par] is complete
+      if (c == 0) { stats_out(par); par ^= 1; }
+      if (more) publish();
+      __syncthreads();
+      if (item == item0 + 1 && c == 0) { STAMP(4); }
+    }
+    // item done: keep its accumulators for the next region's epilogue
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) { pacc[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    en = cn; ety = cty; etx = ctx;
+    advance(cn, cty, ctx);
+  }
+  epilogue(par);
+  if (STATS) { __syncthreads(); stats_out(par); }
+  STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -552,12 +780,76 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
   return 0;
 }
 
+inline int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  return cus;
+}
+
+// Persistent variant: LDS bytes and eligibility (see conv_mfma_fwd_p).
+template <int KS, int TH, int NTN, int NCH>
+constexpr size_t fwd_p_lds() {
+  return (size_t)(((TH + KS - 1) * (TW + KS - 1) + 1) * SPIX + 2 * 4 * 16 * NTN * 2 + 8 + KS * KS * 16 * NCH * 16 * NTN) *
+         sizeof(float);
+}
+
+template <int KS, int TH, int NTN, int NCH>
+int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
+                 hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
+  constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
+  if constexpr (sh > 64 * 1024) return -1;
+  else {
+  if (Kdim != 16 * NCH || W % TW != 0 || H % TH != 0 || Ndim % (16 * NTN) != 0 ||
+      (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) >= (1ll << 31))
+    return -1;
+  const int tiles_x = W / TW, tiles_y = H / TH;
+  const int tiles_img = tiles_x * tiles_y;
+  if (tiles_out) { *tiles_out = tiles_img; return 0; }
+  const int nz = Ndim / (16 * NTN);
+  static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
+  if (occ == 0) {
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, conv_mfma_fwd_p<KS, TH, NTN, NCH, true>, TPB, sh) != hipSuccess || o < 1)
+      o = 1;
+    occ = o;
+  }
+  const int64_t slots = (int64_t)device_cus() * occ;
+  const int64_t items = (int64_t)N * tiles_img;
+  static const int rounds = [] { const char* e = getenv("SMSUT_P_ROUNDS"); return e ? atoi(e) : 1; }();
+  int ipw = (int)((items * nz + slots * rounds - 1) / (slots * rounds));   // each workgroup walks ipw consecutive items
+  if (ipw < 1) ipw = 1;
+  dim3 grid((unsigned)((items + ipw - 1) / ipw), nz);
+  if (stats)
+    conv_mfma_fwd_p<KS, TH, NTN, NCH, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
+                                                                 transposed, stats);
+  else
+    conv_mfma_fwd_p<KS, TH, NTN, NCH, false><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
+                                                                  transposed, nullptr);
+  return 0;
+  }
+}
+
 template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
 #define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out
   // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
   // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
+  if constexpr (KS == 3) {
+    // small-Cin / large-image layers: persistent kernel with resident weights (see conv_mfma_fwd_p); it declines
+    // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
+    static const bool use_p = [] { const char* e = getenv("SMSUT_CONV_PERSISTENT"); return !e || atoi(e) != 0; }();
+    if (use_p && isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && (int64_t)N * (H / 8) * (W / TW) * (Ndim / 16) >= 1024) {
+      int rc = -1;
+      if (Kdim == 16) rc = launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
+      else if (Kdim == 32) rc = launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
+      else if (Kdim == 64) rc = launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
+      if (rc == 0) return 0;
+    }
+  }
   const int nt = (Ndim + 15) / 16;
   const int tx = (W + TW - 1) / TW;
   const int64_t wg16 = (int64_t)tx * ((H + 15) / 16) * N * ((nt + 1) / 2) * ntap_out;
@@ -587,9 +879,27 @@ int dispatch_fwd_cfg(int cfg, const float* x, const float* w, float* y, int N, i
     case 9: return launch_fwd<KS, 4, 2, 2, 4>(ARGS);
     case 10: return launch_fwd<KS, 8, 2, 2, 2>(ARGS);
     case 11: return launch_fwd<KS, 16, 2, 2, 2>(ARGS);
-    default: return -1;
+    default: break;
   }
 #undef ARGS
+  if (KS == 3) {
+#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st
+    switch (cfg) {
+      case 20: return launch_fwd_p<3, 8, 1, 1>(PARGS);
+      case 21: return launch_fwd_p<3, 8, 1, 2>(PARGS);
+      case 22: return launch_fwd_p<3, 16, 1, 1>(PARGS);
+      case 23: return launch_fwd_p<3, 16, 1, 2>(PARGS);
+      case 24: return launch_fwd_p<3, 8, 2, 1>(PARGS);
+      case 25: return launch_fwd_p<3, 8, 2, 2>(PARGS);
+      case 26: return launch_fwd_p<3, 16, 2, 1>(PARGS);
+      case 27: return launch_fwd_p<3, 16, 2, 2>(PARGS);
+      case 28: return launch_fwd_p<3, 8, 1, 4>(PARGS);
+      case 29: return launch_fwd_p<3, 16, 1, 4>(PARGS);
+      default: break;
+    }
+#undef PARGS
+  }
+  return -1;
 }
 
 struct WgradPlan { int cit, cot, splits, tiles_per_split, tiles_x, tiles_y; };
@@ -645,6 +955,13 @@ int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int
 
 extern "C" {
 
+#ifdef SMSUT_STAMPS
+int smsut_dbg_set_stamps(void* buf, int base) {
+  hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_base), &base, sizeof(base));
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf));
+}
+#endif
+
 // 1 when the MFMA kernels cover conv(k=KS, stride 1, pad (KS-1)/2) with this K (reduction) / N (output) channel pair
 int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim) {
   return (KS == 1 || KS == 3) && stride == 1 && pad == (KS - 1) / 2 && Kdim >= 4 && (Kdim % 4) == 0 && Ndim >= 1;
@@ -688,12 +1005,12 @@ int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N,
 }
 
 // Forward conv that also emits the InstanceNorm statistics partials of its output (see conv_mfma_fwd).
-// stats: float[N * smsut_conv2d_mfma_tiles(N, H, W, Ndim, KS) * Ndim * 2]
-// (the tile shape depends on N through the occupancy heuristic of dispatch_fwd, so N is part of the query)
-int smsut_conv2d_mfma_tiles(int N, int H, int W, int Ndim, int KS) {
+// stats: float[N * smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, KS) * Ndim * 2]
+// (the kernel variant and its tile shape depend on the whole layer shape, so all of it is part of the query)
+int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS) {
   int tiles = 0;
-  if (KS == 1) dispatch_fwd<1>(nullptr, nullptr, nullptr, N, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
-  else dispatch_fwd<3>(nullptr, nullptr, nullptr, N, H, W, 4, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
+  if (KS == 1) dispatch_fwd<1>(nullptr, nullptr, nullptr, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
+  else dispatch_fwd<3>(nullptr, nullptr, nullptr, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
   return tiles;
 }
 

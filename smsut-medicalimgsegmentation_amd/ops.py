@@ -142,7 +142,7 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False):
         if want_stats and bias is None:
             # fused InstanceNorm statistics: the conv epilogue leaves {sum, sum^2} partials that the following
             # instnorm_act picks up from the tensor object (side channel; autograd is unaffected)
-            tiles = H.call("smsut_conv2d_mfma_tiles", n, h, wd, co, kh)
+            tiles = H.call("smsut_conv2d_mfma_tiles", n, h, wd, ci, co, kh)
             part = _ws(n * tiles * co * 2, x)
             H.call("smsut_conv2d_fwd_mfma_stats", x, w, y, part, n, h, wd, ci, co, kh, _s())
             y._smsut_in_partials = (part, tiles)
@@ -487,7 +487,8 @@ class BasicBlockFn(Function):
         def stat(c):
             return torch.empty(n, c, dtype=torch.float32, device=dev), torch.empty(n, c, dtype=torch.float32, device=dev)
 
-        t3 = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, 3)
+        t3 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 3)        # tile shape depends on (N, H, W, Cin, Cout)
+        t3b = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
         y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
         H.call("smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
@@ -495,10 +496,10 @@ class BasicBlockFn(Function):
         a1 = new_act(n, co, h, w, x)
         H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
         y2 = new_act(n, co, h, w, x)
-        p2 = _ws(n * t3 * co * 2, x)
+        p2 = _ws(n * t3b * co * 2, x)
         H.call("smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
-        H.call("smsut_in_finalize_fwd", p2, t3, m2, r2, n, hw, co, IN_EPS, st)
+        H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
         if has_sc:
             s = new_act(n, co, h, w, x)
             t1 = H.call("smsut_conv1x1_tiles", n, hw, co) if H.call("smsut_conv1x1_supported", ci, co) else 0
@@ -506,7 +507,7 @@ class BasicBlockFn(Function):
                 ps = _ws(n * t1 * co * 2, x)
                 H.call("smsut_conv1x1_fwd", x, ws, s, ps, n, hw, ci, co, 0, st)
             else:
-                t1 = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, 1)
+                t1 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 1)
                 ps = _ws(n * t1 * co * 2, x)
                 H.call("smsut_conv2d_fwd_mfma_stats", x, ws, s, ps, n, h, w, ci, co, 1, st)
             ms, rs = stat(co)

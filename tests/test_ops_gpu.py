@@ -57,6 +57,11 @@ CONV_CASES = [
     (2, 16, 16, 256, 128, 1, 1, 0, False),
     (2, 40, 40, 16, 5, 1, 1, 0, True),
     (2, 128, 128, 32, 16, 3, 1, 1, False),
+    # persistent resident-weight kernel (conv_mfma_fwd_p): Kdim 16 / 32 / 64 in fwd and dgrad, >= 1024 (tile, image) items
+    (8, 128, 128, 16, 16, 3, 1, 1, False),
+    (4, 128, 128, 32, 32, 3, 1, 1, False),
+    (4, 128, 256, 64, 16, 3, 1, 1, False),
+    (3, 256, 256, 16, 32, 3, 1, 1, False),
     # tiny-channel kernels: stems (direct fwd/dgrad + flattened-M MFMA wgrad), D stem k4 s2 + bias, heads
     (2, 64, 48, 1, 8, 5, 1, 2, False),
     (2, 40, 40, 5, 8, 5, 1, 2, False),
@@ -284,7 +289,8 @@ def test_small_losses(ops):
 
 
 @pytest.mark.parametrize("n,h,ci,co,k", [(16, 32, 32, 64, 3), (1, 32, 32, 64, 3), (16, 16, 64, 128, 3), (8, 64, 16, 32, 3),
-                                         (16, 64, 8, 16, 1), (3, 40, 24, 40, 3)])
+                                         (16, 64, 8, 16, 1), (3, 40, 24, 40, 3),
+                                         (16, 128, 16, 16, 3), (8, 128, 32, 32, 3), (9, 128, 64, 32, 3)])
 def test_fused_in_statistics_match_standalone_pass(ops, n, h, ci, co, k):
     """conv epilogue statistics (side channel) == separate statistics pass, at batch sizes on both sides of the
     occupancy heuristic that picks the tile shape (the partial layout depends on it)."""
