@@ -40,7 +40,9 @@ int smsut_conv2d_wgrad_generic(const float* x, const float* gy, float* gw, float
 
 int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim);
 /* transposed = 0: y[N,H,W,Ndim] = conv(x[N,H,W,Kdim], w[KS*KS][Kdim][Ndim]);
- * transposed = 1: data-gradient, x = gy[N,H,W,Kdim=Cout], w = forward weights [KS*KS][Ndim=Cin][Kdim=Cout]. */
+ * transposed = 1: data-gradient, x = gy[N,H,W,Kdim=Cout], w = forward weights [KS*KS][Ndim=Cin][Kdim=Cout];
+ * transposed | 2: the result is ADDED to what y already holds (second gradient path into a block input,
+ *                 reference autograd's accumulation for x used by conv1 and the shortcut, network/blocks.py:66-78). */
 int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                           int transposed, void* stream);
 /* forward conv that also emits the InstanceNorm {sum, sum^2} partials of its output (fused statistics pass):

@@ -66,6 +66,8 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   float* in_s = smem;                        // [IH][IW][SPIX]
   float* w_s = smem + IH * IW * SPIX;        // [KK][4][CO_T][4]
 
+  const bool accum = (transposed & 2) != 0;     // y += conv(x) instead of y = conv(x) (second gradient path of a block)
+  transposed &= 1;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -227,8 +229,10 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gx_ = x0 + 4 * kq + r;
-        if (gx_ < W)
-          yout[((size_t)(gy_ * osc + (tapo >> 1)) * Wo + gx_ * osc + (tapo & 1)) * Ndim + co] = acc[i][j][r];
+        if (gx_ < W) {
+          float* o = yout + ((size_t)(gy_ * osc + (tapo >> 1)) * Wo + gx_ * osc + (tapo & 1)) * Ndim + co;
+          *o = accum ? acc[i][j][r] + *o : acc[i][j][r];
+        }
       }
     }
   }
@@ -248,7 +252,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 //     stores (its accumulators are kept in a second register set) and the current chunk's MFMAs, so the scheduler can
 //     put the overhead instructions into the shadow of the MFMAs (24 of every 32 issue cycles are free).
 // Regular stride-1 "same" 3x3 conv; W % 16 == 0, H % TH == 0, Ndim % (16*NTN) == 0, Kdim == 16*NCH (checked by the host).
-template <int KS, int TH, int NTN, int NCH, bool STATS>
+template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats) {
@@ -342,6 +346,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   };
 
   f32x4 acc[MR][NR], pacc[MR][NR];
+  [[maybe_unused]] f32x4 pold[MR][NR];
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -373,7 +378,19 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
       for (int j = 0; j < NR; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yb[o_lane + (i * W + r) * Ndim + j * 16] = pacc[i][j][r];
+        for (int r = 0; r < 4; ++r) yb[o_lane + (i * W + r) * Ndim + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
+  };
+  // ACC: the values the outputs of item (n_, ty_, tx_) hold now (loaded one region before they are added and stored)
+  auto load_old = [&](int n_, int ty_, int tx_) {
+    if (ACC) {
+      const float* yb = y + (((size_t)n_ * H + ty_ * TH) * W + tx_ * TW) * Ndim + co0;
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pold[i][j][r] = yb[o_lane + (i * W + r) * Ndim + j * 16];
+    }
   };
   auto stats_out = [&](int par) {                     // after the barrier that completes red[par]
     if (STATS && tid < CO_T) {
@@ -406,6 +423,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   };
 
   STAMP(1);
+  load_old(cn, cty, ctx);
   prefetch(0);
   if (NCH == 1) advance(pn, pty, ptx);
   __syncthreads();                                    // (also publishes w_s)
@@ -422,7 +440,10 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         prefetch((c + 1) % NCH);
         if (c + 2 == NCH || (NCH == 1)) advance(pn, pty, ptx);     // the prefetch after the next one starts a new item
       }
-      if (c == 0) epilogue(par);      // first item: pacc = 0 into the item's own outputs, overwritten below
+      if (c == 0) {
+        epilogue(par);                // first item: pacc = 0 into the item's own outputs, overwritten below
+        load_old(cn, cty, ctx);
+      }
       mma_chunk(c);
       if (item == item0 + 1 && c == 0) { STAMP(3); }
       __syncthreads();                                // in_s is free; red[par] is complete
@@ -676,9 +697,13 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     }
   };
 
+  [[maybe_unused]] const int stamp_wg = (blockIdx.y == 0 && blockIdx.z == 0) ? (int)blockIdx.x : -1;
+  STAMP(0);
   if (t_begin < t_end) prefetch(t_begin);
+  STAMP(1);
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
+    if (t - t_begin < 2) { STAMP(2 + 4 * (t - t_begin)); }
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
       if (tid + i * TPB < IH * IW * (CI_T / 4)) *(float4*)(in_s + in_lds[i]) = rin[i];
@@ -686,7 +711,9 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     for (int i = 0; i < NGY; ++i)
       if (tid + i * TPB < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
     __syncthreads();
+    if (t - t_begin < 2) { STAMP(3 + 4 * (t - t_begin)); }
     if (t + 1 < t_end) prefetch(t + 1);
+    if (t - t_begin < 2) { STAMP(4 + 4 * (t - t_begin)); }
 #pragma unroll 2
     for (int r = 0; r < WTH; ++r) {
 #pragma unroll
@@ -698,7 +725,9 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
         for (int k = 0; k < NSLOT; ++k) acc[k] = mfma16(ap[a_off[k]], b, acc[k]);
       }
     }
+    if (t - t_begin < 2) { STAMP(5 + 4 * (t - t_begin)); }
   }
+  STAMP(10);
   float* out = part + (size_t)split * KK * Cin * Cout;
   const int co = co0 + jt * 16 + lm;
 #pragma unroll
@@ -711,6 +740,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
       if (ci < Cin && co < Cout) out[((size_t)tap * Cin + ci) * Cout + co] = acc[k][r];
     }
   }
+  STAMP(11);
 }
 
 // out[e] = sum_c part[c][e].  COLS float4 columns x (256/COLS) split-lanes per block: each thread strides over the
@@ -761,6 +791,7 @@ sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, i
 }
 
 inline void launch_sum_splits(const float* part, float* out, int wsize, int splits, hipStream_t st) {
+  // (column width 4 / 8 / 16 / 32 measured within noise of each other, r01 notes)
   if (splits >= 128) sum_splits<4><<<(wsize + 15) / 16, TPB, 0, st>>>(part, out, wsize, splits);      // 64 split-lanes
   else sum_splits<16><<<(wsize + 63) / 64, TPB, 0, st>>>(part, out, wsize, splits);                    // 16 split-lanes
 }
@@ -812,22 +843,25 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
   if (occ == 0) {
     int o = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, conv_mfma_fwd_p<KS, TH, NTN, NCH, true>, TPB, sh) != hipSuccess || o < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false>, TPB, sh) != hipSuccess ||
+        o < 1)
       o = 1;
     occ = o;
   }
   const int64_t slots = (int64_t)device_cus() * occ;
   const int64_t items = (int64_t)N * tiles_img;
-  static const int rounds = [] { const char* e = getenv("SMSUT_P_ROUNDS"); return e ? atoi(e) : 1; }();
-  int ipw = (int)((items * nz + slots * rounds - 1) / (slots * rounds));   // each workgroup walks ipw consecutive items
+  int ipw = (int)((items * nz + slots - 1) / slots);   // one resident round: each workgroup walks ipw consecutive items
   if (ipw < 1) ipw = 1;
   dim3 grid((unsigned)((items + ipw - 1) / ipw), nz);
-  if (stats)
-    conv_mfma_fwd_p<KS, TH, NTN, NCH, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
-                                                                 transposed, stats);
-  else
-    conv_mfma_fwd_p<KS, TH, NTN, NCH, false><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
-                                                                  transposed, nullptr);
+  const int tr = transposed & 1;
+#define P_LAUNCH(ST, AC) conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, \
+                                                                                        tiles_img, ipw, tr, stats)
+  if (transposed & 2) {
+    if (stats) return -1;
+    P_LAUNCH(false, true);
+  } else if (stats) P_LAUNCH(true, false);
+  else P_LAUNCH(false, false);
+#undef P_LAUNCH
   return 0;
   }
 }

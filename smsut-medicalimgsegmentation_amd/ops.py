@@ -573,17 +573,17 @@ class BasicBlockFn(Function):
             H.call("smsut_conv1x1_wgrad", x, gs_t, gws, _ws(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), x), n, hw, ci, co, st)
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = new_act(n, ci, h, w, x)
-            H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 1, st)
+            # the shortcut's gradient lands in gx first; the 3x3 data-gradient then accumulates into it in its store
+            # epilogue (transposed | 2), which replaces a separate 3-pass add
             if ctx.has_sc:
-                gxs = new_act(n, ci, h, w, x)
+                gx = new_act(n, ci, h, w, x)
                 if H.call("smsut_conv1x1_supported", co, ci):
-                    H.call("smsut_conv1x1_fwd", gs_t, ws, gxs, None, n, hw, co, ci, 1, st)
+                    H.call("smsut_conv1x1_fwd", gs_t, ws, gx, None, n, hw, co, ci, 1, st)
                 else:
-                    H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gxs, n, h, w, co, ci, 1, 1, st)
-                H.call("smsut_add_act", gx, gxs, gx, gx.numel(), 1.0, st)          # slope 1: plain add
+                    H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gx, n, h, w, co, ci, 1, 1, st)
             else:
-                H.call("smsut_add_act", gx, gs_t, gx, gx.numel(), 1.0, st)
+                gx = gs_t
+            H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
         return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None
 
 

@@ -288,6 +288,22 @@ def test_small_losses(ops):
         assert rel_err(got.cpu().numpy(), ref.numpy()) < 1e-5
 
 
+@pytest.mark.parametrize("n,h,w,kd,nd", [(2, 24, 40, 32, 16), (8, 128, 128, 32, 16), (4, 128, 128, 16, 32), (2, 16, 16, 128, 64)])
+def test_dgrad_accumulate_into_existing(ops, n, h, w, kd, nd):
+    """transposed | 2: gx += dgrad(gy) in the store epilogue (per-tile and persistent kernels), vs dgrad + add."""
+    from smsut_amd import _hip as H
+    cl = lambda t: dev(t).contiguous(memory_format=torch.channels_last)
+    gy = cl(rnd(n, kd, h, w, seed=1))
+    wt = to_hwio(ops, rnd(kd, nd, 3, 3, seed=2) / np.sqrt(kd * 9))        # forward weights [Cout=kd, Cin=nd]
+    base = cl(rnd(n, nd, h, w, seed=3))
+    ref = torch.empty_like(base)
+    H.call("smsut_conv2d_fwd_mfma", gy, wt, ref, n, h, w, kd, nd, 3, 1, H.stream_ptr())
+    want = (ref + base).cpu().numpy()
+    got = base.clone(memory_format=torch.channels_last)
+    H.call("smsut_conv2d_fwd_mfma", gy, wt, got, n, h, w, kd, nd, 3, 3, H.stream_ptr())
+    assert rel_err(got.cpu().numpy(), want) < 1e-6
+
+
 @pytest.mark.parametrize("n,h,ci,co,k", [(16, 32, 32, 64, 3), (1, 32, 32, 64, 3), (16, 16, 64, 128, 3), (8, 64, 16, 32, 3),
                                          (16, 64, 8, 16, 1), (3, 40, 24, 40, 3),
                                          (16, 128, 16, 16, 3), (8, 128, 32, 32, 3), (9, 128, 64, 32, 3)])
