@@ -17,6 +17,8 @@ from __future__ import annotations
 import contextlib
 from typing import Optional
 
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -552,6 +554,8 @@ class BasicBlockFn(Function):
         ggs, gbs = (vec(co), vec(co)) if ctx.has_sc else (None, None)
         H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, s, ms, rs, gs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2, ggs, gbs,
                _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
+        # (forking the three weight-gradient launches to a second stream inside this node was measured 1-3 % SLOWER
+        #  than the single-stream order below -- profiles/r01_notes.md)
         # ---- conv2
         ga1 = new_act(n, co, h, w, x)
         H.call("smsut_conv2d_fwd_mfma", gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
