@@ -181,6 +181,13 @@ int smsut_sum(const float* a, float* out, float* workspace, int64_t n, double sc
 int smsut_l1_fwd(const float* a, const float* b, float* out, float* workspace, int64_t n, void* stream);
 int smsut_l1_bwd(const float* a, const float* b, const float* gout, float* ga /*nullable*/, float* gb /*nullable*/,
                  int64_t n, void* stream);
+/* mean((softmax(a) - softmax(b))^2) over [P pixels][C] NHWC logits, gradient to a only: the mean-teacher consistency
+ * term (trainer/meanTeacherTrainer.py:113-131).  workspace: smsut_sum_ws(P, 1) floats. */
+int smsut_softmax_mse_fwd(const float* a, const float* b, float* out, float* workspace, int64_t P, int C, void* stream);
+int smsut_softmax_mse_bwd(const float* a, const float* b, const float* gout, float* ga, int64_t P, int C, void* stream);
+/* labels[p] = argmax_c logits[p][c] (first maximum): pseudo labels (uganConsisTrainer.py:45-53, crossPseTrainer.py:122-127)
+ * and the prediction map of validate_epoch (uganShp0Trainer.py:262-266). */
+int smsut_argmax_channels(const float* logits, int64_t* labels, int64_t P, int C, void* stream);
 int smsut_gp_fwd(const float* dydx, float* out, float* norms, float* workspace, int rows, int64_t n, void* stream);
 int smsut_gp_bwd(const float* dydx, const float* norms, const float* gout, float* g, int rows, int64_t n, void* stream);
 int smsut_ce_rows_fwd(const float* z, const int64_t* tgt, float* out, int B, int C, void* stream);

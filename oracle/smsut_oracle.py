@@ -319,3 +319,98 @@ def ugan_consis_iteration(g_sd: SD, d_sd: SD, g_opt, d_opt, x_real, y_real, moda
         for grp in opt.param_groups:
             grp["lr"] = lr_
     return logs, dict(seg=y_fake.detach(), tsl=x_fake.detach())
+
+
+# --------------------------------------------------------------------------- sibling trainers
+def mean_teacher_iteration(sd: SD, ema_sd: SD, opt, img, msk, noise, it: int, epoch: int,
+                           lambda_semi_base=1.0, epoch_rampup=30, ema_decay=0.99, base_lr=1e-2, max_it=30000,
+                           semi_start_iter=100):
+    """trainer/meanTeacherTrainer.py:86-149: student on [labeled | unlabeled], EMA teacher on the noised unlabeled
+    half, DiceCE + rampup * mean((softmax - softmax)^2) (from iteration 100), SGD, EMA update (:63-69), poly LR.
+    ``noise`` (:104, clamp(randn * 0.01)) is an input.  Returns (seg_loss, semi_loss)."""
+    bs = msk.size(0)
+    lambda_semi = lambda_semi_base * sigmoid_rampup(epoch, epoch_rampup)
+    out = unet_forward(sd, img)
+    with torch.no_grad():
+        ema_soft = torch.softmax(unet_forward(ema_sd, img[bs:] + noise), dim=1)
+    seg = dice_ce(out[:bs], msk)
+    semi = torch.zeros(()) if it < semi_start_iter else torch.mean((torch.softmax(out, dim=1)[bs:] - ema_soft) ** 2)
+    total = seg + lambda_semi * semi
+    opt.zero_grad()
+    total.backward()
+    opt.step()
+    alpha = 0.0 if it < 100 else min(1 - 1 / (it + 1), ema_decay)
+    with torch.no_grad():
+        for k in ema_sd:
+            ema_sd[k].mul_(alpha).add_(sd[k].detach(), alpha=1 - alpha)
+    lr_ = poly_lr(base_lr, it, max_it)
+    for g in opt.param_groups:
+        g["lr"] = lr_
+    return float(seg.item()), float(semi.item())
+
+
+def cross_pse_iteration(sd1: SD, sd2: SD, opt1, opt2, img, msk, it: int, epoch: int, lambda_semi_base=0.1,
+                        max_epoch=200, base_lr=1e-2, max_it=30000):
+    """trainer/crossPseTrainer.py:84-146: two U-Nets, DiceCE on the labeled half, each net's unlabeled half against
+    the OTHER net's argmax.  Returns (seg1, seg2, semi1, semi2)."""
+    bs = msk.size(0)
+    lambda_semi = lambda_semi_base * sigmoid_rampup(epoch, max_epoch)
+    out1 = unet_forward(sd1, img)
+    s1 = dice_ce(out1[:bs], msk)
+    out2 = unet_forward(sd2, img)
+    s2 = dice_ce(out2[:bs], msk)
+    pred1 = torch.argmax(out1[bs:], dim=1).detach()
+    pred2 = torch.argmax(out2[bs:], dim=1).detach()
+    semi1 = dice_ce(out1[bs:], pred2)
+    semi2 = dice_ce(out2[bs:], pred1)
+    total = s1 + s2 + lambda_semi * semi1 + lambda_semi * semi2
+    opt1.zero_grad(); opt2.zero_grad()
+    total.backward()
+    opt1.step(); opt2.step()
+    lr_ = poly_lr(base_lr, it, max_it)
+    for opt in (opt1, opt2):
+        for g in opt.param_groups:
+            g["lr"] = lr_
+    return tuple(float(t.item()) for t in (s1, s2, semi1, semi2))
+
+
+def ugan_iteration(g_sd: SD, d_sd: SD, g_opt, d_opt, x_real, y_real, modal_org, mj: int, alpha, it: int, epoch: int,
+                   n_modal=4, lambda_cls=1.0, lambda_rec=10.0, lambda_gp=10.0, lambda_seg=10.0, lambda_shp_base=10.0,
+                   lambda_shp_lazy=20.0, base_lr=1e-2, max_it=30000):
+    """trainer/uganTrainer.py:134-222 (UGAN without the NCE head, all slices labeled, shape term on the cycle's
+    segmentation with an epoch-ramped weight :122-123).  Returns the 9 scalars D_real..G_shp."""
+    lambda_shp = min(epoch * (lambda_shp_base / lambda_shp_lazy), lambda_seg)
+    modal_trg = torch.full_like(modal_org, mj)
+    vec_org, vec_trg = onehot(modal_org, n_modal), onehot(modal_trg, n_modal)
+    vec_ot, vec_to = vec_trg - vec_org, vec_org - vec_trg
+    out_src, out_cls = discriminator_forward(d_sd, x_real)
+    d_real = -out_src.mean()
+    d_cls = F.cross_entropy(out_cls, modal_org)
+    _, x_fake = ugan_forward(g_sd, x_real, vec_ot, n_modal=n_modal, with_nce=False)
+    out_src, _ = discriminator_forward(d_sd, x_fake.detach())
+    d_fake = out_src.mean()
+    x_hat = (alpha * x_real.detach() + (1 - alpha) * x_fake.detach()).requires_grad_(True)
+    out_src, _ = discriminator_forward(d_sd, x_hat)
+    d_gp = gradient_penalty(out_src, x_hat)
+    d_loss = d_real + d_fake + lambda_cls * d_cls + lambda_gp * d_gp
+    d_opt.zero_grad(); g_opt.zero_grad()
+    d_loss.backward()
+    d_opt.step()
+    y_fake, x_fake = ugan_forward(g_sd, x_real, vec_ot, n_modal=n_modal, with_nce=False)
+    out_src, out_cls = discriminator_forward(d_sd, x_fake)
+    g_fake = -out_src.mean()
+    g_cls = F.cross_entropy(out_cls, modal_trg)
+    g_seg = dice_ce(y_fake, y_real)
+    y_rec, x_rec = ugan_forward(g_sd, x_fake, vec_to, n_modal=n_modal, with_nce=False)
+    g_rec = (x_real - x_rec).abs().mean()
+    g_shp = dice_ce(y_rec, y_real)
+    g_loss = g_fake + lambda_rec * g_rec + lambda_cls * g_cls + lambda_seg * g_seg + lambda_shp * g_shp
+    d_opt.zero_grad(); g_opt.zero_grad()
+    g_loss.backward()
+    g_opt.step()
+    lr_ = poly_lr(base_lr, it, max_it)
+    for opt in (g_opt, d_opt):
+        for grp in opt.param_groups:
+            grp["lr"] = lr_
+    return tuple(float(t.item()) for t in (d_real, d_fake, d_cls, d_gp, g_fake, g_rec, g_cls, g_seg, g_shp))
+

@@ -21,7 +21,7 @@ STEPS = 7     # 2 warm-up + 5 timed steps in collect.sh
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True))
+    hits = sorted(glob.glob(os.path.join(OUT, pattern), recursive=True), key=os.path.getmtime)   # newest run last
     if not hits:
         raise SystemExit(f"missing {pattern}")
     return hits[-1]

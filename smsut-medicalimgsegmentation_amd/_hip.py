@@ -92,6 +92,9 @@ SIGNATURES: Dict[str, str] = {
     "smsut_sum": "ppp l d s",
     "smsut_l1_fwd": "pppp l s",
     "smsut_l1_bwd": "ppppp l s",
+    "smsut_softmax_mse_fwd": "pppp l i s",
+    "smsut_softmax_mse_bwd": "pppp l i s",
+    "smsut_argmax_channels": "pp l i s",
     "smsut_gp_fwd": "pppp i l s",
     "smsut_gp_bwd": "pppp i l s",
     "smsut_ce_rows_fwd": "ppp ii s",

@@ -274,7 +274,11 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   const int lm = lane & 15, kq = lane >> 4;
   const int co0 = blockIdx.y * CO_T;
   const int total_items = N * tiles_img;
-  const int item0 = blockIdx.x * items_per_wg;
+  // workgroups go to the 8 XCDs round-robin (MICROARCH "Workgroup dispatch"): give XCD k the k-th contiguous eighth of
+  // the items, so that the halo rows a strip shares with the strips above / below are hits in that XCD's own L2
+  // (PMC: 1.41x -> the algorithmic bytes with the plain mapping, every XCD fetching its neighbours' halos)
+  const int wg = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int item0 = wg * items_per_wg;
   const int item1 = min(item0 + items_per_wg, total_items);
   if (item0 >= item1) return;
   const int tiles_y = tiles_img / tiles_x;

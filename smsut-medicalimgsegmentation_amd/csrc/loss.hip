@@ -339,6 +339,58 @@ k_nce_bwd(const float* __restrict__ gloss, const float* __restrict__ probs, cons
   }
 }
 
+// ---- mean-teacher consistency: mean((softmax(a) - softmax(b))^2) over all elements (reference
+// trainer/meanTeacherTrainer.py:113-131), a and b NHWC logits [P pixels][C]; one thread per pixel, the C-vector in registers.
+__global__ void __launch_bounds__(TPB)
+k_softmax_mse_partial(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part, int64_t P, int C) {
+  __shared__ float sm4[4];
+  float acc = 0.f;
+  for (int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x; p < P; p += (int64_t)gridDim.x * TPB) {
+    float pa[MAXC], pb[MAXC];
+    float ma = -INFINITY, mb = -INFINITY;
+    for (int c = 0; c < C; ++c) { pa[c] = a[p * C + c]; pb[c] = b[p * C + c]; ma = fmaxf(ma, pa[c]); mb = fmaxf(mb, pb[c]); }
+    float sa = 0.f, sb = 0.f;
+    for (int c = 0; c < C; ++c) { pa[c] = __expf(pa[c] - ma); pb[c] = __expf(pb[c] - mb); sa += pa[c]; sb += pb[c]; }
+    const float ia = 1.f / sa, ib = 1.f / sb;
+    for (int c = 0; c < C; ++c) { const float d = pa[c] * ia - pb[c] * ib; acc += d * d; }
+  }
+  const float t = block_sum_256(acc, sm4);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+// ga[p][k] = gout * (2 / (P*C)) * pa_k * ((pa_k - pb_k) - sum_c pa_c (pa_c - pb_c))    (b carries no gradient: EMA teacher)
+__global__ void __launch_bounds__(TPB)
+k_softmax_mse_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gout,
+                  float* __restrict__ ga, int64_t P, int C) {
+  const float scale = gout[0] * 2.f / ((float)P * (float)C);
+  for (int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x; p < P; p += (int64_t)gridDim.x * TPB) {
+    float pa[MAXC], pb[MAXC];
+    float ma = -INFINITY, mb = -INFINITY;
+    for (int c = 0; c < C; ++c) { pa[c] = a[p * C + c]; pb[c] = b[p * C + c]; ma = fmaxf(ma, pa[c]); mb = fmaxf(mb, pb[c]); }
+    float sa = 0.f, sb = 0.f;
+    for (int c = 0; c < C; ++c) { pa[c] = __expf(pa[c] - ma); pb[c] = __expf(pb[c] - mb); sa += pa[c]; sb += pb[c]; }
+    const float ia = 1.f / sa, ib = 1.f / sb;
+    float dot = 0.f;
+    for (int c = 0; c < C; ++c) { pa[c] *= ia; pb[c] = pa[c] - pb[c] * ib; dot += pa[c] * pb[c]; }
+    for (int c = 0; c < C; ++c) ga[p * C + c] = scale * pa[c] * (pb[c] - dot);
+  }
+}
+
+// labels[p] = argmax_c logits[p][c] (first maximum, as torch.argmax): pseudo labels of the consistency / cross-pseudo
+// losses (uganConsisTrainer.py:45-53, crossPseTrainer.py:122-127) and the prediction map of validate_epoch
+__global__ void __launch_bounds__(TPB)
+k_argmax_channels(const float* __restrict__ z, int64_t* __restrict__ out, int64_t P, int C) {
+  for (int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x; p < P; p += (int64_t)gridDim.x * TPB) {
+    float best = z[p * C];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = z[p * C + c];
+      if (v > best || (v != v && best == best)) { best = v; bi = c; }     // NaN wins, like torch
+    }
+    out[p] = bi;
+  }
+}
+
 inline int pix_blocks(int64_t HW) {
   int64_t b = cdiv64(HW, TPB * 4);
   if (b > 64) b = 64;
@@ -413,6 +465,25 @@ int smsut_l1_bwd(const float* a, const float* b, const float* gout, float* ga, f
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 // WGAN-GP: out = mean_r (||dydx_r||_2 - 1)^2, norms[rows] saved for the backward
+// out = mean((softmax_c(a) - softmax_c(b))^2); a, b [P][C] NHWC logits; workspace: smsut_sum_ws(P, 1) floats
+int smsut_softmax_mse_fwd(const float* a, const float* b, float* out, float* workspace, int64_t P, int C, void* stream) {
+  SMSUT_REQUIRE(a && b && out && workspace && P > 0 && C > 0 && C <= MAXC);
+  const int nb = sum_blocks(P);
+  k_softmax_mse_partial<<<nb, TPB, 0, ST>>>(a, b, workspace, P, C);
+  k_sum_final<<<1, 64, 0, ST>>>(workspace, nb, 1.0 / ((double)P * C), out);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_softmax_mse_bwd(const float* a, const float* b, const float* gout, float* ga, int64_t P, int C, void* stream) {
+  SMSUT_REQUIRE(a && b && gout && ga && P > 0 && C > 0 && C <= MAXC);
+  k_softmax_mse_bwd<<<ew_grid(P), TPB, 0, ST>>>(a, b, gout, ga, P, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_argmax_channels(const float* z, int64_t* out, int64_t P, int C, void* stream) {
+  SMSUT_REQUIRE(z && out && P > 0 && C > 0);
+  k_argmax_channels<<<ew_grid(P), TPB, 0, ST>>>(z, out, P, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// WGAN-GP (kept below)
 int smsut_gp_fwd(const float* dydx, float* out, float* norms, float* workspace, int rows, int64_t n, void* stream) {
   SMSUT_REQUIRE(dydx && out && norms && workspace && rows > 0 && n > 0);
   const int nb = sum_blocks(n);

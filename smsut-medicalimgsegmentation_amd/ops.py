@@ -982,6 +982,43 @@ def l1_mean(a, b):
     return L1MeanFn.apply(a, b)
 
 
+class SoftmaxMSEFn(Function):
+    """mean((softmax(a, 1) - softmax(b, 1)) ** 2): the mean-teacher consistency term (reference
+    trainer/meanTeacherTrainer.py:113-131); ``b`` is the EMA teacher's output and gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = nhwc(a), nhwc(b)
+        assert a.shape == b.shape
+        n, c, h, w = a.shape
+        out = torch.empty(1, dtype=torch.float32, device=a.device)
+        H.call("smsut_softmax_mse_fwd", a, b, out, _ws(H.call("smsut_sum_ws", n * h * w, 1), a), n * h * w, c, _s())
+        ctx.save_for_backward(a, b)
+        return out[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        a, b = ctx.saved_tensors
+        n, c, h, w = a.shape
+        ga = new_act(n, c, h, w, a)
+        H.call("smsut_softmax_mse_bwd", a, b, gout.contiguous().reshape(1), ga, n * h * w, c, _s())
+        return ga, None
+
+
+def softmax_mse(a, b):
+    return SoftmaxMSEFn.apply(cl(a), cl(b).detach())
+
+
+def argmax_channels(logits):
+    """``torch.argmax(logits, dim=1)`` on NHWC memory -> int64 [N, H, W] (no gradient)."""
+    z = nhwc(logits.detach())
+    n, c, h, w = z.shape
+    out = torch.empty(n, h, w, dtype=torch.int64, device=z.device)
+    H.call("smsut_argmax_channels", z, out, n * h * w, c, _s())
+    return out
+
+
 class CERowsFn(Function):
     """F.cross_entropy(logits[B,C], target[B]) (modality classification, uganConsisTrainer.py:131,155)."""
 

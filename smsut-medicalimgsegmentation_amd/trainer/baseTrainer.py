@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from .. import config as cfg
-from .. import parallel
+from .. import ops, parallel
 from ..misc.loss import DiceAndCrossEntropyLoss
 from ..misc.synthetic import SyntheticSliceLoader
 from ..misc.utils import Meter, get_mo_matrix, maybe_mkdir
@@ -163,7 +163,7 @@ class BaseTrainer(abc.ABC):
                 if meter is not None:
                     v, n = meter.collect_loss_by(loss.item(), mdl[0].item(), img.size(0))
                     meter.accumulate(v, n)
-                pred = torch.argmax(out, dim=1).cpu().numpy()
+                pred = ops.argmax_channels(out).cpu().numpy()
                 for i in range(b):
                     m, pid, z = inm[i].split("_")
                     prd[f"{m}_{pid}"][int(z)] = pred[i]

@@ -40,7 +40,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._lambda_semi_t = torch.zeros((), device=self.device)
 
     def consistency_loss(self, source, target):
-        return self.loss(source, torch.argmax(target, dim=1))                      # :45-53
+        return self.loss(source, ops.argmax_channels(target))                    # :45-53
 
     def nce_loss(self, feat_x_pool, feat_f_pool):
         total = 0.0
@@ -241,7 +241,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
                 img = img.to(self.device)
                 grid = self.translate_all(img, mdl)
                 seg, _ = self.net(img, val_phase=True)
-                out.append((inm, torch.argmax(seg, dim=1).cpu(), grid.cpu()))
+                out.append((inm, ops.argmax_channels(seg).cpu(), grid.cpu()))
         return out
 
 

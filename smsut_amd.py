@@ -26,7 +26,8 @@ def _load():
 
 _DROPIN = ("config", "network", "network.blocks", "network.unet", "network.ugan", "network.networks",
            "network.patchnce", "misc", "misc.loss", "misc.utils", "trainer", "trainer.baseTrainer",
-           "trainer.unetTrainer", "trainer.uganShp0Trainer", "trainer.uganConsisTrainer")
+           "trainer.unetTrainer", "trainer.uganShp0Trainer", "trainer.uganConsisTrainer", "trainer.uganTrainer",
+           "trainer.meanTeacherTrainer", "trainer.crossPseTrainer")
 
 
 def install_dropin():

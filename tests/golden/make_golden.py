@@ -342,8 +342,127 @@ def gen_iter_small():
     save("iter_small", **rec)
 
 
+def gen_siblings():
+    """One/two iterations of the sibling trainers' arithmetic with the reference modules:
+    meanTeacherTrainer.py:86-149, crossPseTrainer.py:84-146, uganTrainer.py:134-222."""
+    from network.ugan import UGAN
+    H, bs = 64, 2
+    crit = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)
+    rec = dict(H=H, bs=bs)
+
+    def rampup(cur, length):
+        ph = 1.0 - np.clip(cur, 0.0, length) / length
+        return float(np.exp(-5.0 * ph * ph))
+
+    # ---- mean teacher: UNet(1,3,8) student + teacher, iterations 150 and 151 (consistency on, EMA alpha > 0)
+    stu = load(UNet(1, 3, 8, "instance", "lrelu"), recipe.unet_shapes(1, 3, 8), 71)
+    ema = load(UNet(1, 3, 8, "instance", "lrelu"), recipe.unet_shapes(1, 3, 8), 72)
+    for p in ema.parameters():
+        p.detach_()
+    stu.train(); ema.train()
+    opt = torch.optim.SGD(stu.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    mt = []
+    epoch = 20
+    for step in range(2):
+        it = 150 + step
+        img = recipe.synth_images((2 * bs, 1, H, H), 73 + step)
+        msk = recipe.synth_labels(bs, H, H, 3, 75 + step, block=8)
+        noise = torch.clamp(torch.from_numpy(np.random.RandomState(77 + step).standard_normal((bs, 1, H, H))).float() * 0.01,
+                            -0.02, 0.02)
+        out = stu(img)
+        out_soft = torch.softmax(out, dim=1)
+        with torch.no_grad():
+            ema_soft = torch.softmax(ema(img[bs:] + noise), dim=1)
+        seg = crit(out[:bs], msk)
+        semi = torch.mean((out_soft[bs:] - ema_soft) ** 2)
+        total = seg + 1 * rampup(epoch, 30) * semi
+        opt.zero_grad(); total.backward(); opt.step()
+        alpha = min(1 - 1 / (it + 1), 0.99)
+        for ep, p_ in zip(ema.parameters(), stu.parameters()):
+            ep.data.mul_(alpha).add_(p_.data, alpha=1 - alpha)
+        for g in opt.param_groups:
+            g["lr"] = 1e-2 * (1.0 - it / 30000) ** 0.9
+        mt.append([seg.item(), semi.item()])
+    rec["mt_scalars"] = np.array(mt, dtype=np.float64)
+    rec["mt_epoch"] = epoch
+    rec["mt_post_fc"] = npy(stu.state_dict()["decoder.fc.weight"])
+    rec["mt_post_ema_fc"] = npy(ema.state_dict()["decoder.fc.weight"])
+    rec["mt_post_ema_pre"] = npy(ema.state_dict()["encoder.pre_conv.weight"])
+
+    # ---- cross pseudo supervision: two UNet(1,3,8), one iteration
+    n1 = load(UNet(1, 3, 8, "instance", "lrelu"), recipe.unet_shapes(1, 3, 8), 81)
+    n2 = load(UNet(1, 3, 8, "instance", "lrelu"), recipe.unet_shapes(1, 3, 8), 82)
+    n1.train(); n2.train()
+    o1 = torch.optim.SGD(n1.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    o2 = torch.optim.SGD(n2.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    img = recipe.synth_images((2 * bs, 1, H, H), 83)
+    msk = recipe.synth_labels(bs, H, H, 3, 84, block=8)
+    epoch = 100
+    out1 = n1(img); s1 = crit(out1[:bs], msk)
+    out2 = n2(img); s2 = crit(out2[:bs], msk)
+    pred1 = torch.argmax(out1[bs:], dim=1).detach(); pred2 = torch.argmax(out2[bs:], dim=1).detach()
+    semi1 = crit(out1[bs:], pred2); semi2 = crit(out2[bs:], pred1)
+    lam = 0.1 * rampup(epoch, 200)
+    total = s1 + s2 + lam * semi1 + lam * semi2
+    o1.zero_grad(); o2.zero_grad(); total.backward(); o1.step(); o2.step()
+    rec["cp_scalars"] = np.array([s1.item(), s2.item(), semi1.item(), semi2.item()], dtype=np.float64)
+    rec["cp_epoch"] = epoch
+    rec["cp_post_fc1"] = npy(n1.state_dict()["decoder.fc.weight"])
+    rec["cp_post_fc2"] = npy(n2.state_dict()["decoder.fc.weight"])
+    rec["cp_pred1"] = npy(pred1).astype(np.uint8)
+
+    # ---- UGANTrainer: UGAN(1,3,4,8) + Discriminator(64,4,8), one iteration at epoch 10 (lambda_shp = 5)
+    nm = 4
+    G = load(UGAN(1, 3, nm, 8), recipe.ugan_shapes(1, 3, nm, 8, nce=False), 91)
+    D = load(Discriminator(H, nm, 8, max_width=512), recipe.disc_shapes(H, nm, 8, 512), 92)
+    G.train(); D.train()
+    g_opt = torch.optim.SGD(G.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    d_opt = torch.optim.Adam(D.parameters(), 1e-2, [0.9, 0.999], weight_decay=1e-3)
+    B, epoch, it, mj = 2, 10, 1500, 2
+    x_real = recipe.synth_images((B, 1, H, H), 93)
+    y_real = recipe.synth_labels(B, H, H, 3, 94, block=8)
+    modal_org = torch.tensor([1, 1])
+    alpha = torch.from_numpy(np.random.RandomState(95).standard_normal((B, 1, 1, 1))).float()
+
+    def onehot(idx):
+        o = torch.zeros(idx.size(0), nm)
+        o[np.arange(idx.size(0)), idx.long()] = 1
+        return o
+    modal_trg = torch.zeros_like(modal_org).fill_(mj)
+    vec_org, vec_trg = onehot(modal_org), onehot(modal_trg)
+    vec_ot, vec_to = vec_trg - vec_org, vec_org - vec_trg
+    out_src, out_cls = D(x_real)
+    d_real = -torch.mean(out_src); d_cls = F.cross_entropy(out_cls, modal_org)
+    _, x_fake = G(x_real, vec_ot)
+    out_src, out_cls = D(x_fake.detach()); d_fake = torch.mean(out_src)
+    x_hat = (alpha * x_real.data + (1 - alpha) * x_fake.data).requires_grad_(True)
+    out_src, _ = D(x_hat)
+    dydx = torch.autograd.grad(out_src, x_hat, torch.ones(out_src.size()), retain_graph=True, create_graph=True,
+                               only_inputs=True)[0]
+    d_gp = torch.mean((torch.sqrt(torch.sum(dydx.view(B, -1) ** 2, dim=1)) - 1) ** 2)
+    d_loss = d_real + d_fake + 1 * d_cls + 10 * d_gp
+    d_opt.zero_grad(); g_opt.zero_grad(); d_loss.backward(); d_opt.step()
+    y_fake, x_fake = G(x_real, vec_ot)
+    out_src, out_cls = D(x_fake)
+    g_fake = -torch.mean(out_src); g_cls = F.cross_entropy(out_cls, modal_trg)
+    g_seg = crit(y_fake, y_real)
+    y_rec, x_rec = G(x_fake, vec_to)
+    g_rec = torch.mean(torch.abs(x_real - x_rec)); g_shp = crit(y_rec, y_real)
+    lam_shp = min(epoch * (10 / 20), 10)
+    g_loss = g_fake + 10 * g_rec + 1 * g_cls + 10 * g_seg + lam_shp * g_shp
+    d_opt.zero_grad(); g_opt.zero_grad(); g_loss.backward()
+    rec["ug_grad_seg_fc"] = npy(G.seg_decoder.fc.weight.grad)
+    g_opt.step()
+    rec["ug_scalars"] = np.array([d_real.item(), d_fake.item(), d_cls.item(), d_gp.item(), g_fake.item(), g_rec.item(),
+                                  g_cls.item(), g_seg.item(), g_shp.item()], dtype=np.float64)
+    rec["ug_epoch"], rec["ug_it"], rec["ug_mj"] = epoch, it, mj
+    rec["ug_post_seg_fc"] = npy(G.state_dict()["seg_decoder.fc.weight"])
+    rec["ug_tsl"] = npy(x_fake)
+    save("siblings", **rec)
+
+
 if __name__ == "__main__":
     random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
-    which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small", "networks_zoo"]
+    which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small", "networks_zoo", "siblings"]
     for w in which:
         globals()["gen_" + w]()

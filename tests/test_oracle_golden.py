@@ -132,6 +132,47 @@ def test_full_iteration_scalars_and_post_step_weights(golden):
     assert rel_err(dsd["conv_cls.weight"].detach().numpy(), g["post_D_cls"]) < 5e-2
 
 
+def test_sibling_trainer_iterations(golden):
+    """meanTeacher / crossPse / uganTrainer arithmetic restated in oracle/ vs the replay with reference modules."""
+    g = golden("siblings")
+    H, bs = int(g["H"]), int(g["bs"])
+    # mean teacher
+    sd = leaf(recipe.fill(recipe.unet_shapes(1, 3, 8), 71))
+    ema = {k: v.clone() for k, v in recipe.fill(recipe.unet_shapes(1, 3, 8), 72).items()}
+    opt = torch.optim.SGD(list(sd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    for step in range(2):
+        img = recipe.synth_images((2 * bs, 1, H, H), 73 + step)
+        msk = recipe.synth_labels(bs, H, H, 3, 75 + step, block=8)
+        noise = torch.clamp(torch.from_numpy(np.random.RandomState(77 + step).standard_normal((bs, 1, H, H))).float() * 0.01,
+                            -0.02, 0.02)
+        seg, semi = O.mean_teacher_iteration(sd, ema, opt, img, msk, noise, 150 + step, int(g["mt_epoch"]))
+        assert abs(seg - g["mt_scalars"][step][0]) < 5e-5 and abs(semi - g["mt_scalars"][step][1]) < 1e-6 + 1e-3 * g["mt_scalars"][step][1]
+    assert rel_err(sd["decoder.fc.weight"].detach().numpy(), g["mt_post_fc"]) < 1e-4
+    assert rel_err(ema["decoder.fc.weight"].numpy(), g["mt_post_ema_fc"]) < 1e-5
+    assert rel_err(ema["encoder.pre_conv.weight"].numpy(), g["mt_post_ema_pre"]) < 1e-5
+    # cross pseudo supervision
+    s1 = leaf(recipe.fill(recipe.unet_shapes(1, 3, 8), 81)); s2 = leaf(recipe.fill(recipe.unet_shapes(1, 3, 8), 82))
+    o1 = torch.optim.SGD(list(s1.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    o2 = torch.optim.SGD(list(s2.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    img = recipe.synth_images((2 * bs, 1, H, H), 83); msk = recipe.synth_labels(bs, H, H, 3, 84, block=8)
+    got = O.cross_pse_iteration(s1, s2, o1, o2, img, msk, 0, int(g["cp_epoch"]))
+    assert np.allclose(got, g["cp_scalars"], rtol=2e-5, atol=2e-6)
+    assert rel_err(s1["decoder.fc.weight"].detach().numpy(), g["cp_post_fc1"]) < 1e-4
+    assert rel_err(s2["decoder.fc.weight"].detach().numpy(), g["cp_post_fc2"]) < 1e-4
+    # UGANTrainer
+    gs = leaf(recipe.fill(recipe.ugan_shapes(1, 3, 4, 8, nce=False), 91)); ds = leaf(recipe.fill(recipe.disc_shapes(H, 4, 8, 512), 92))
+    g_opt = torch.optim.SGD(list(gs.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    d_opt = torch.optim.Adam(list(ds.values()), 1e-2, (0.9, 0.999), weight_decay=1e-3)
+    x_real = recipe.synth_images((2, 1, H, H), 93); y_real = recipe.synth_labels(2, H, H, 3, 94, block=8)
+    alpha = torch.from_numpy(np.random.RandomState(95).standard_normal((2, 1, 1, 1))).float()
+    got = O.ugan_iteration(gs, ds, g_opt, d_opt, x_real, y_real, torch.tensor([1, 1]), int(g["ug_mj"]), alpha,
+                           int(g["ug_it"]), int(g["ug_epoch"]))
+    ref = g["ug_scalars"]
+    assert np.allclose(got[:4], ref[:4], rtol=1e-4, atol=1e-5), (got, ref)         # D-step: before any weight moved
+    assert np.allclose(got[5:], ref[5:], rtol=2e-3, atol=1e-5), (got, ref)         # G_rec, G_cls.. after D's Adam step
+    assert abs(got[4] - ref[4]) <= 0.05 * abs(ref[4]) + 1e-3, (got, ref)           # G_fake goes through the moved D
+
+
 def test_medpy_dc_formula_selfcheck():
     a = np.zeros((4, 4), int); b = np.zeros((4, 4), int)
     assert O.medpy_dc(a, b) == 0.0
