@@ -78,6 +78,52 @@ def test_unet_256_full_size(pkg, golden):
         assert abs(got - ref) <= 1e-2 * ref + 1e-7, (n, got, ref)
 
 
+def test_config5_shape_512_unet_ugan_disc_vs_oracle(pkg):
+    """BASELINE config 5's slice size (512x512) in the fp32 path: U-Net logits + loss + gradient norms, the translated
+    image of UGANnce and the 512-deep Discriminator (one more BottleBlock, ugan.py:205-215) against the CPU oracle on the
+    same seeded inputs.  (The fp16 MFMA variant of config 5 is not built yet -- DESIGN.md section 9.)"""
+    from smsut_amd.network.unet import UNet
+    from smsut_amd.network.ugan import UGANnce, Discriminator
+    from smsut_amd.misc.loss import DiceAndCrossEntropyLoss
+    torch.set_num_threads(16)
+    H = 512
+    x = recipe.synth_images((2, 1, H, H), 501)
+    y = recipe.synth_labels(2, H, H, 5, 502)
+    sd = recipe.fill(recipe.unet_shapes(1, 5, 16), 500)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.unet_forward(leaf, x)
+    ref_loss = O.dice_ce(ref, y)
+    ref_loss.backward()
+    net = UNet(1, 5, 16, norm_type="instance", act_type="lrelu")
+    net.load_state_dict(sd); net.cuda().train()
+    out = net(x.cuda())
+    assert rel_err(out.detach().cpu().numpy(), ref.detach().numpy()) < TOL
+    loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y.cuda())
+    assert abs(loss.item() - ref_loss.item()) < TOL * abs(ref_loss.item())
+    loss.backward()
+    for n, p in net.named_parameters():
+        if n in ("encoder.pre_conv.weight", "encoder.layer3.conv2.weight", "decoder.fc.weight", "decoder.layer1.conv1.weight"):
+            a, b = float(p.grad.double().norm()), float(leaf[n].grad.double().norm())
+            assert abs(a - b) <= 1e-2 * b + 1e-7, (n, a, b)
+    # generator + discriminator at 512^2 (forward)
+    gsd = recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 503)
+    dsd = recipe.fill(recipe.disc_shapes(H, 4, 16, 256), 504)
+    m = torch.tensor([[1.0, 0, -1.0, 0]])
+    ids = torch.from_numpy(np.random.RandomState(5).permutation(32 * 32)[:64].astype(np.int64))
+    with torch.no_grad():
+        seg_r, tsl_r, feat_r, _ = O.ugan_forward(gsd, x[:1], m, [ids])
+        src_r, cls_r = O.discriminator_forward(dsd, tsl_r)
+    G = UGANnce(1, 5, 4, 16); G.load_state_dict(gsd); G.cuda().train()
+    D = Discriminator(H, 4, 16, max_width=256); D.load_state_dict(dsd); D.cuda().train()
+    with torch.no_grad():
+        seg, tsl, feat, _ = G(x[:1].cuda(), m.cuda(), sample_ids=[ids.cuda()])
+        src, cls = D(tsl)
+    assert rel_err(seg.cpu().numpy(), seg_r.numpy()) < TOL and rel_err(tsl.cpu().numpy(), tsl_r.numpy()) < TOL
+    assert rel_err(feat[0].cpu().numpy(), feat_r[0].numpy()) < TOL
+    assert tuple(src.shape) == (1, 1, 4, 4) and rel_err(src.cpu().numpy(), src_r.numpy()) < 5e-3
+    assert rel_err(cls.cpu().numpy(), cls_r.numpy()) < 5e-3
+
+
 def test_discriminator_and_gradient_penalty(pkg, golden):
     from smsut_amd.network.ugan import Discriminator
     from smsut_amd import ops
