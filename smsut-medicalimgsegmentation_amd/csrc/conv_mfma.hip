@@ -449,12 +449,14 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         load_old(cn, cty, ctx);
       }
       mma_chunk(c);
-      if (item == item0 + 1 && c == 0) { STAMP(3); }
+      if (item == item0 + 1 && c < 2) { STAMP(3 + 4 * c); }
       __syncthreads();                                // in_s is free; red[par] is complete
+      if (item == item0 + 1 && c < 2) { STAMP(4 + 4 * c); }
       if (c == 0) { stats_out(par); par ^= 1; }
       if (more) publish();
+      if (item == item0 + 1 && c < 2) { STAMP(5 + 4 * c); }
       __syncthreads();
-      if (item == item0 + 1 && c == 0) { STAMP(4); }
+      if (item == item0 + 1 && c < 2) { STAMP(6 + 4 * c); }
     }
     // item done: keep its accumulators for the next region's epilogue
 #pragma unroll
@@ -466,7 +468,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   }
   epilogue(par);
   if (STATS) { __syncthreads(); stats_out(par); }
-  STAMP(5);
+  STAMP(11);
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
