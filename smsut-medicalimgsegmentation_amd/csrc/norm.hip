@@ -190,8 +190,16 @@ __global__ void __launch_bounds__(TPB)
 in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
              const float* __restrict__ am, const float* __restrict__ bm, float* __restrict__ gx,
-             int64_t total_vec, int HW, int C, float slope) {
+             int64_t total_vec, int HW, int C, float slope, int N, float* __restrict__ ggamma, float* __restrict__ gbeta) {
   const int CV = C / VEC;
+  if (ggamma && blockIdx.x == 0) {        // affine gradients ride along in block 0: ggamma = sum_n M*b, gbeta = sum_n M*a
+    for (int c = threadIdx.x; c < C; c += TPB) {
+      double sa = 0.0, sb = 0.0;
+      for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; sb += (double)bm[n * C + c]; }
+      ggamma[c] = (float)(sb * (double)HW);
+      gbeta[c] = (float)(sa * (double)HW);
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
     const int cv = (int)(i % CV);
     const int n = (int)(i / ((int64_t)CV * HW));
@@ -388,8 +396,17 @@ template <int VEC>
 __global__ void __launch_bounds__(TPB)
 restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
                   const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
-                  float* __restrict__ gs, int64_t total_vec, int HW, int C, float slope) {
+                  float* __restrict__ gs, int64_t total_vec, int HW, int C, float slope, int N, float* __restrict__ gg2,
+                  float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs) {
   const int CV = C / VEC;
+  if (blockIdx.x == 0) {   // affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (both norms), ggs = sum_n M*bs
+    for (int c = threadIdx.x; c < C; c += TPB) {
+      double sa = 0.0, s2 = 0.0, ss = 0.0;
+      for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; s2 += (double)b2m[n * C + c]; if (ggs) ss += (double)bsm[n * C + c]; }
+      gg2[c] = (float)(s2 * HW); gb2[c] = (float)(sa * HW);
+      if (ggs) { ggs[c] = (float)(ss * HW); gbs[c] = (float)(sa * HW); }
+    }
+  }
   for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
     const int cv = (int)(i % CV);
     const int n = (int)(i / ((int64_t)CV * HW));
@@ -413,18 +430,6 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
     if constexpr (VEC == 4) { *(float4*)(gy2 + i * 4) = *(float4*)o1; *(float4*)(gs + i * 4) = *(float4*)o2; }
     else { gy2[i] = o1[0]; gs[i] = o2[0]; }
   }
-}
-
-// affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (shared by both norms), ggs = sum_n M*bs
-__global__ void restail_affine(const float* __restrict__ am, const float* __restrict__ b2m, const float* __restrict__ bsm,
-                               int N, int C, int HW, float* __restrict__ gg2, float* __restrict__ gb,
-                               float* __restrict__ ggs) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sa = 0.0, s2 = 0.0, ss = 0.0;
-  for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; s2 += (double)b2m[n * C + c]; if (bsm) ss += (double)bsm[n * C + c]; }
-  gg2[c] = (float)(s2 * HW); gb[c] = (float)(sa * HW);
-  if (ggs) ggs[c] = (float)(ss * HW);
 }
 
 inline int pick_chunk(int HW, int C, int N) {
@@ -495,12 +500,14 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta, const
   else
     in_moments_partial<1, 1><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
   in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
-  if (ggamma && gbeta) in_affine_grads<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b_mean, N, C, HW, ggamma, gbeta);
+  float* gg = (ggamma && gbeta) ? ggamma : nullptr;       // affine gradients: computed by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
-    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, slope);
+    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, slope,
+                                                        N, gg, gbeta);
   else
-    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, slope);
+    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, slope,
+                                                    N, gg, gbeta);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -563,9 +570,11 @@ int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const
   hipStream_t st = (hipStream_t)stream;
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
-    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, 0.f);
+    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, 0.f,
+                                                        N, nullptr, nullptr);
   else
-    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, 0.f);
+    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, 0.f,
+                                                    N, nullptr, nullptr);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -601,16 +610,14 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
   if (C % 4 == 0) restail_bwd_partial<4><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope);
   else restail_bwd_partial<1><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope);
   in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
-  restail_affine<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b2_mean, ms ? bs_mean : nullptr, N, C, HW, gg2, gb2, ms ? ggs : nullptr);
-  if (ms) {
-    hipError_t e = hipMemcpyAsync(gbs, gb2, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-  }
+  // the affine gradients (and the copy gbs = gb2) are written by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
-    restail_bwd_apply<4><<<ew_grid(total / 4), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total / 4, HW, C, slope);
+    restail_bwd_apply<4><<<ew_grid(total / 4), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total / 4, HW, C, slope,
+                                                             N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr);
   else
-    restail_bwd_apply<1><<<ew_grid(total), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total, HW, C, slope);
+    restail_bwd_apply<1><<<ew_grid(total), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total, HW, C, slope,
+                                                         N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
