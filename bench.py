@@ -70,7 +70,7 @@ def measure_dominant_conv(dev, batch):
     x = torch.randn(batch, cin, h, h, device=dev).contiguous(memory_format=torch.channels_last)
     w = ops.new_weight(cout, cin, 3, 3, device=dev)
     w.copy_(torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5)
-    name, kind = ops.conv_fwd_kernel_name(cin, cout, 3, 1, 1)
+    name, kind = ops.conv_fwd_kernel_name(cin, cout, 3, 1, 1, batch, h, h)
     for _ in range(3):
         ops.conv2d(x, w, None, 1, 1)
     torch.cuda.synchronize()

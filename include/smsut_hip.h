@@ -49,6 +49,8 @@ int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H
  * stats = float[N * smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, KS) * Ndim * 2], consumed by smsut_instnorm_fwd_partials
  * (the tile shape is chosen per layer shape, so the whole shape is part of the query). */
 int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS);
+/* 1 when this shape runs the persistent resident-weight kernel (conv_mfma_fwd_p: small Cin, large image), else 0. */
+int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS);
 int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
                                 int Ndim, int KS, void* stream);
 /* tuning hook: same as smsut_conv2d_fwd_mfma with a forced tile configuration (returns -1 for an unknown cfg) */

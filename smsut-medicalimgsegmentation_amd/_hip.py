@@ -39,6 +39,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_mfma_supported": "iiiii",
     "smsut_conv2d_fwd_mfma": "ppp iiiiii i s",
     "smsut_conv2d_mfma_tiles": "iiiiii",
+    "smsut_conv2d_mfma_persistent": "iiiiii",
     "smsut_conv2d_fwd_mfma_stats": "pppp iiiiii s",
     "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",
     "smsut_conv2d_wgrad_mfma_supported": "iiiii",
@@ -110,7 +111,7 @@ _RET_I64 = {"smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
                          "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
-                         "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv1x1_supported",
+                         "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles"}
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,

@@ -24,6 +24,7 @@
 // order; per-split slabs are summed by a second tiny kernel (deterministic, no atomics).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -435,7 +436,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   __syncthreads();
   STAMP(2);
   int par = 0;
-  for (int item = item0; item < item1; ++item) {
+  // one item = NCH regions; FIRST (compile-time) drops the previous-item epilogue from the workgroup's first item
+  auto item_body = [&](int item, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       // ---- one straight-line region: next loads, previous item's results, this chunk's MFMAs
@@ -444,15 +447,15 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         prefetch((c + 1) % NCH);
         if (c + 2 == NCH || (NCH == 1)) advance(pn, pty, ptx);     // the prefetch after the next one starts a new item
       }
-      if (c == 0) {
-        epilogue(par);                // first item: pacc = 0 into the item's own outputs, overwritten below
+      if (c == 0 && !FIRST) {
+        epilogue(par);
         load_old(cn, cty, ctx);
       }
       mma_chunk(c);
       if (item == item0 + 1 && c < 2) { STAMP(3 + 4 * c); }
       __syncthreads();                                // in_s is free; red[par] is complete
       if (item == item0 + 1 && c < 2) { STAMP(4 + 4 * c); }
-      if (c == 0) { stats_out(par); par ^= 1; }
+      if (c == 0 && !FIRST) { stats_out(par); par ^= 1; }
       if (more) publish();
       if (item == item0 + 1 && c < 2) { STAMP(5 + 4 * c); }
       __syncthreads();
@@ -465,7 +468,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       for (int j = 0; j < NR; ++j) { pacc[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     en = cn; ety = cty; etx = ctx;
     advance(cn, cty, ctx);
-  }
+  };
+  item_body(item0, std::true_type{});
+  for (int item = item0 + 1; item < item1; ++item) item_body(item, std::false_type{});
   epilogue(par);
   if (STATS) { __syncthreads(); stats_out(par); }
   STAMP(11);
@@ -872,6 +877,14 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   }
 }
 
+// shapes the persistent kernel takes (3x3 regular conv): resident weight block fits, full tiles, enough items to fill
+// one resident round.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
+inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
+  static const bool use_p = [] { const char* e = getenv("SMSUT_CONV_PERSISTENT"); return !e || atoi(e) != 0; }();
+  return use_p && (Kdim == 16 || Kdim == 32 || Kdim == 64) && W % TW == 0 && H % 8 == 0 && Ndim % 16 == 0 &&
+         (int64_t)N * (H / 8) * (W / TW) * (Ndim / 16) >= 1024 && (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) < (1ll << 31);
+}
+
 template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
@@ -881,8 +894,7 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
   if constexpr (KS == 3) {
     // small-Cin / large-image layers: persistent kernel with resident weights (see conv_mfma_fwd_p); it declines
     // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
-    static const bool use_p = [] { const char* e = getenv("SMSUT_CONV_PERSISTENT"); return !e || atoi(e) != 0; }();
-    if (use_p && isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && (int64_t)N * (H / 8) * (W / TW) * (Ndim / 16) >= 1024) {
+    if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_p_eligible(N, H, W, Kdim, Ndim)) {
       int rc = -1;
       if (Kdim == 16) rc = launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
       else if (Kdim == 32) rc = launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
@@ -1052,6 +1064,11 @@ int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS) {
   if (KS == 1) dispatch_fwd<1>(nullptr, nullptr, nullptr, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
   else dispatch_fwd<3>(nullptr, nullptr, nullptr, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
   return tiles;
+}
+
+// 1 when conv(k=KS) on this shape runs the persistent resident-weight kernel (conv_mfma_fwd_p), 0 for the per-tile kernel
+int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS) {
+  return KS == 3 && fwd_p_eligible(N, H, W, Kdim, Ndim) ? 1 : 0;
 }
 
 int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,

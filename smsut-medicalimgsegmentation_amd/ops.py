@@ -17,8 +17,6 @@ from __future__ import annotations
 import contextlib
 from typing import Optional
 
-import os
-
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -195,9 +193,11 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
     return gw
 
 
-def conv_fwd_kernel_name(cin, cout, k, stride, pad):
+def conv_fwd_kernel_name(cin, cout, k, stride, pad, n=1, h=0, w=0):
     """Which device kernel ``conv2d`` dispatches to for this layer shape: (symbol, 'mfma' | 'generic')."""
     if H.call("smsut_conv2d_mfma_supported", k, stride, pad, cin, cout):
+        if h and w and H.call("smsut_conv2d_mfma_persistent", n, h, w, cin, cout, k):
+            return "conv_mfma_fwd_p", "mfma"
         return "conv_mfma_fwd", "mfma"
     return "conv_fwd_naive", "generic"
 
