@@ -230,8 +230,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.barrier()                      # leave together with rank 0 (which still measures the roofline leg)
+        dist.destroy_process_group()
         return
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
@@ -246,8 +246,9 @@ def main():
         out["roofline"] = measure_dominant_conv(dev, B)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_ugan() if args.workload == "ugan" else cpu_baseline_unet()
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
