@@ -150,6 +150,11 @@ int smsut_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, voi
 int smsut_maxpool2_bwd(const float* gy, const float* x, float* gx, int N, int H, int W, int C, void* stream);
 int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
+/* Device-side joint augmentation (rotate + elastic + random-resized-crop of data_loader/externalTransforms.py:45-90 as one
+ * resampling pass): source position = aff[n] * (xo, yo, 1) + bilinear(ctrl[n][2][P][P]); image bilinear, labels nearest,
+ * zeros outside.  img [N,H,W], msk [N,H,W] (nullable), aff [N][6], ctrl nullable when P == 0. */
+int smsut_warp_joint(const float* img, const int64_t* msk, const float* aff, const float* ctrl, float* oimg,
+                     int64_t* omsk, int N, int H, int W, int Ho, int Wo, int P, void* stream);
 int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_bilinear2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
 /* networks.py building blocks of ResnetGenerator / NLayerDiscriminator: reflection / replication /

@@ -33,3 +33,11 @@ weight_decay = 1e-3
 nce_layers = [5]               # config.py:77
 
 expr_root = "smsut_out"        # the reference's placeholder is '***/bimod-out' (config.py:46)
+base_root = None               # processed PNG dataset root ('***/bimod' upstream, config.py:44); None -> synthetic slices
+split_yaml = "semi-1910.yaml"  # config.py:54
+data_aug = dict(               # config.py:60-71
+    rotate=True, rotate_degrees=15,
+    resizeCrop=True, resizeCrop_size=input_size,
+    elasticDeform=True, elasticDeform_sigmas=(9., 13.), elasticDeform_points=3,
+    colorJitter=False, gammaCorrect=False, gammaCorrect_gammas=(0.7, 1.5),
+)

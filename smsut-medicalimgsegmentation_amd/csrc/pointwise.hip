@@ -351,6 +351,60 @@ k_blurdown_bwd(const float* __restrict__ gy, float* __restrict__ gx, int N, int 
   }
 }
 
+
+// ---- joint geometric augmentation on the device (replaces the reference's PIL workers: JointRotate, JointElasticDeform,
+// JointRandomResizedCrop of data_loader/externalTransforms.py:45-90 composed into ONE resampling pass).
+// For output pixel (yo, xo) of sample n the source position is
+//     (ys, xs) = A_n * (xo, yo, 1)  +  D_n(yo, xo)
+// A_n: 2x3 affine [a00 a01 a02; a10 a11 a12] mapping output pixel centres to source pixel coordinates (crop window +
+// rotation about the image centre, built on the host per sample); D_n: the elastic displacement, bilinear interpolation
+// of a PxP control grid of (dy, dx) offsets spanning the output image (P = 0: none).  Image: bilinear, zeros outside;
+// label map: nearest (round-half-away like lrintf's default would differ per platform, so floor(v + 0.5)), zeros outside.
+__global__ void __launch_bounds__(TPB)
+k_warp_joint(const float* __restrict__ img, const int64_t* __restrict__ msk, const float* __restrict__ aff,
+             const float* __restrict__ ctrl, float* __restrict__ oimg, int64_t* __restrict__ omsk, int N, int H, int W,
+             int Ho, int Wo, int P) {
+  const int64_t total = (int64_t)N * Ho * Wo;
+  GRID_STRIDE(i, total) {
+    const int xo = (int)(i % Wo);
+    const int yo = (int)((i / Wo) % Ho);
+    const int n = (int)(i / ((int64_t)Wo * Ho));
+    const float* a = aff + n * 6;
+    float xs = a[0] * xo + a[1] * yo + a[2];
+    float ys = a[3] * xo + a[4] * yo + a[5];
+    if (P > 0) {
+      const float gy = (Ho > 1) ? yo * (float)(P - 1) / (float)(Ho - 1) : 0.f;
+      const float gx = (Wo > 1) ? xo * (float)(P - 1) / (float)(Wo - 1) : 0.f;
+      int y0 = (int)floorf(gy), x0 = (int)floorf(gx);
+      if (y0 > P - 2) y0 = P - 2;
+      if (x0 > P - 2) x0 = P - 2;
+      if (y0 < 0) y0 = 0;
+      if (x0 < 0) x0 = 0;
+      const float fy = gy - y0, fx = gx - x0;
+      const float* c = ctrl + (size_t)n * 2 * P * P;
+      const int y1 = min(y0 + 1, P - 1), x1 = min(x0 + 1, P - 1);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float* ck = c + k * P * P;
+        const float d = (1.f - fy) * ((1.f - fx) * ck[y0 * P + x0] + fx * ck[y0 * P + x1]) +
+                        fy * ((1.f - fx) * ck[y1 * P + x0] + fx * ck[y1 * P + x1]);
+        if (k == 0) ys += d; else xs += d;
+      }
+    }
+    // image: bilinear with zero fill
+    const float fy0 = floorf(ys), fx0 = floorf(xs);
+    const int iy = (int)fy0, ix = (int)fx0;
+    const float wy = ys - fy0, wx = xs - fx0;
+    const float* src = img + (size_t)n * H * W;
+    auto at = [&](int y, int x) { return (y >= 0 && y < H && x >= 0 && x < W) ? src[(size_t)y * W + x] : 0.f; };
+    oimg[i] = (1.f - wy) * ((1.f - wx) * at(iy, ix) + wx * at(iy, ix + 1)) + wy * ((1.f - wx) * at(iy + 1, ix) + wx * at(iy + 1, ix + 1));
+    if (msk) {
+      const int ny = (int)floorf(ys + 0.5f), nx = (int)floorf(xs + 0.5f);
+      omsk[i] = (ny >= 0 && ny < H && nx >= 0 && nx < W) ? msk[(size_t)n * H * W + (size_t)ny * W + nx] : 0;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -418,6 +472,15 @@ int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, voi
 int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
   k_avgpool_bwd<<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// Joint geometric augmentation (see k_warp_joint): img [N,H,W] fp32 (one channel), msk [N,H,W] int64 (nullable),
+// aff [N][6], ctrl [N][2][P][P] (nullable when P == 0) -> oimg [N,Ho,Wo], omsk [N,Ho,Wo].
+int smsut_warp_joint(const float* img, const int64_t* msk, const float* aff, const float* ctrl, float* oimg,
+                     int64_t* omsk, int N, int H, int W, int Ho, int Wo, int P, void* stream) {
+  SMSUT_REQUIRE(img && aff && oimg && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (P == 0 || (P >= 2 && ctrl)) &&
+                (!msk || omsk));
+  k_warp_joint<<<ew_grid((int64_t)N * Ho * Wo), TPB, 0, ST>>>(img, msk, aff, ctrl, oimg, omsk, N, H, W, Ho, Wo, P);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {

@@ -89,10 +89,16 @@ class BaseTrainer(abc.ABC):
 
     # ------------------------------------------------------------------ loaders
     def get_loaders(self, loader_type):
-        """The reference builds PNG loaders here (baseTrainer.py:128-135); that pipeline is out of scope, so the
-        default is the synthetic source with the same batch contract."""
+        """baseTrainer.py:128-135.  With ``config.base_root`` pointing at a processed PNG dataset the 'inTurn' loaders
+        are the real ones (single-modality round-robin batches, joint augmentation on the device); otherwise the
+        synthetic source with the same batch contract."""
         if loader_type not in ("inTurn", "base", "synthetic"):
             raise NotImplementedError
+        if loader_type == "inTurn" and cfg.base_root and os.path.isdir(cfg.base_root):
+            from ..data_loader import inTurnLoader as inlod
+            mk = lambda phase, fold, aug: inlod.get_loader(cfg.base_root, phase, fold, cfg.batch_size, aug,
+                                                           device=self.device, split_yaml=cfg.split_yaml)
+            return mk("train", self.fold, cfg.data_aug), mk("val", self.fold, cfg.data_aug), mk("test", 0, None)
         n = getattr(self.args, "iters_per_epoch", None) or cfg.num_iter_per_epoch
         mk = lambda labeled, nb: SyntheticSliceLoader(cfg.batch_size, n_batches=nb, device=self.device,
                                                       labeled=labeled, rank=self.rank)

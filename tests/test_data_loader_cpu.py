@@ -1,0 +1,98 @@
+"""Input-pipeline row, host side: round-robin single-modality batch samplers, the PNG dataset reader and
+the augmentation parameter draws.  (The resampling kernel itself: tests/test_data_loader_gpu.py.)"""
+import math
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import smsut_amd  # noqa: F401
+from smsut_amd.data_loader import inTurnLoader as inlod
+from smsut_amd.data_loader import gpu_augment as ga
+
+
+def test_train_sampler_round_robin_single_modality_and_epoch_length():
+    random.seed(3)
+    samples = [list(range(0, 23)), list(range(100, 140)), list(range(200, 208))]
+    s = inlod.InTurnTrainBatchSampler([list(x) for x in samples], batch_size=4, shuffle=False)
+    # inTurnLoader.py:30-34: n = num_modality * max_m (len//bs - 1 if len % bs else len//bs)
+    assert len(s) == 3 * max(23 // 4 - 1, 40 // 4, 8 // 4)
+    batches = list(s)
+    assert len(batches) == len(s)
+    for k, b in enumerate(batches):
+        m = k % 3                                              # modalities take turns (shuffle=False)
+        assert len(b) == 4 and all(v in samples[m] for v in b), (k, b)
+    # a modality wraps (and reshuffles) when the next window would run past its end: every id of the short
+    # modality (8 slices, 2 batches per pass... the wrap test is s + bs >= len) is seen again and again
+    seen2 = [v for k, b in enumerate(batches) if k % 3 == 2 for v in b]
+    assert set(seen2) <= set(samples[2]) and len(seen2) == 4 * len(s) // 3
+    # same seed -> same stream (the sampler draws from ``random`` only)
+    random.seed(3)
+    s2 = inlod.InTurnTrainBatchSampler([list(x) for x in samples], batch_size=4, shuffle=False)
+    assert list(s2) == batches
+
+
+def test_train_sampler_shuffled_queue_visits_every_modality_each_round():
+    random.seed(5)
+    samples = [list(range(0, 16)), list(range(100, 116)), list(range(200, 216)), list(range(300, 316))]
+    s = inlod.InTurnTrainBatchSampler([list(x) for x in samples], batch_size=4, shuffle=True)
+    batches = list(s)
+    for r in range(len(batches) // 4):
+        mods = sorted(b[0] // 100 for b in batches[4 * r: 4 * r + 4])
+        assert mods == [0, 1, 2, 3]
+
+
+def test_test_sampler_covers_everything_in_order():
+    samples = [list(range(0, 10)), list(range(50, 57))]
+    s = inlod.InTurnTestBatchSampler(samples, 4)
+    b = list(s)
+    assert [v for x in b for v in x] == samples[0] + samples[1]
+    assert [len(x) for x in b] == [4, 4, 2, 4, 3] and len(s) == 10 // 4 + 7 // 4
+
+
+def test_resized_crop_params_distribution_and_bounds():
+    random.seed(11)
+    for _ in range(300):
+        i, j, h, w = ga.resized_crop_params(256, 256)
+        assert 0 <= i <= 256 - h and 0 <= j <= 256 - w and 0 < h <= 256 and 0 < w <= 256
+        assert 0.6 * 0.97 <= h * w / 65536.0 <= 1.0 and 0.72 <= w / h <= 1.39
+
+
+def test_affine_identity_and_rotation_centre():
+    a = ga.affine_for(0.0, (0, 0, 64, 64), (64, 64), (64, 64))
+    assert np.allclose(a, [1, 0, 0, 0, 1, 0], atol=1e-6)
+    a = ga.affine_for(90.0, (0, 0, 65, 65), (65, 65), (65, 65))          # centre pixel maps to itself
+    x, y = 32, 32
+    assert abs(a[0] * x + a[1] * y + a[2] - 32) < 1e-4 and abs(a[3] * x + a[4] * y + a[5] - 32) < 1e-4
+    a = ga.affine_for(0.0, (10, 20, 32, 32), (64, 64), (64, 64))         # 2x zoom of the window at (10, 20)
+    assert abs(a[0] - 0.5) < 1e-6 and abs(a[4] - 0.5) < 1e-6
+    assert abs(a[2] - (20 + 0.25 - 0.5)) < 1e-6 and abs(a[5] - (10 + 0.25 - 0.5)) < 1e-6
+
+
+def test_balance_dataset_reads_split_and_pngs(tmp_path):
+    yaml = pytest.importorskip("yaml")
+    Image = pytest.importorskip("PIL.Image")
+    split = {}
+    rs = np.random.RandomState(0)
+    for m in ("ct", "t1in", "t1out", "t2"):
+        split[m] = {"train": [["001"]], "val": [["002"]], "test": ["003"]}
+        for pid, nz in (("001", 4), ("002", 2), ("003", 2)):
+            for sub in ("images", "labels"):
+                os.makedirs(tmp_path / m / pid / sub, exist_ok=True)
+            for z in range(nz):
+                Image.fromarray(rs.randint(0, 255, (16, 16)).astype(np.uint8)).save(tmp_path / m / pid / "images" / f"{m}_{pid}_{z:03d}.png")
+                Image.fromarray(rs.randint(0, 5, (16, 16)).astype(np.uint8)).save(tmp_path / m / pid / "labels" / f"{m}_{pid}_{z:03d}.png")
+    with open(tmp_path / "split.yaml", "w") as f:
+        yaml.dump(split, f)
+    ds = inlod.BalanceDataset(str(tmp_path), "train", 0, "split.yaml")
+    assert len(ds) == 16 and [len(x) for x in ds.modal_sample_ids] == [4, 4, 4, 4]
+    assert ds.names[0] == "ct_001_000" and ds.modality[4] == 1 and tuple(ds.images.shape) == (16, 16, 16)
+    ds_t = inlod.BalanceDataset(str(tmp_path), "test", 0, "split.yaml")
+    assert len(ds_t) == 8
+    random.seed(1)
+    loader = inlod.InTurnLoader(ds, inlod.InTurnTrainBatchSampler(ds.modal_sample_ids, 2, False), "cpu", None)
+    img, msk, mdl, names = next(iter(loader))
+    assert tuple(img.shape) == (2, 1, 16, 16) and img.dtype == torch.float32 and float(img.min()) >= -1 and float(img.max()) <= 1
+    assert msk.dtype == torch.int64 and tuple(msk.shape) == (2, 16, 16) and mdl.tolist() == [0, 0] and names[0].startswith("ct_001_")
