@@ -124,6 +124,46 @@ def test_config5_shape_512_unet_ugan_disc_vs_oracle(pkg):
     assert rel_err(cls.cpu().numpy(), cls_r.numpy()) < 5e-3
 
 
+def test_batch_independence_at_full_size(pkg):
+    """Every op on the path is per-sample (convs, InstanceNorm), so a slice's logits / translation must not depend
+    on the batch it travels in -- checked at BASELINE config 2/3 sizes (B = 32 and B = 16 at 256x256), where the kernel
+    dispatch (persistent vs per-tile conv, split counts, chunk sizes) differs from the small-batch one, and on the
+    parameter gradients, which must be the SUM of per-slice gradients (linearity of the weight-gradient reduction)."""
+    from smsut_amd.network.unet import UNet
+    from smsut_amd.network.ugan import UGANnce
+    H = 256
+    net = UNet(1, 5, 16, norm_type="instance", act_type="lrelu")
+    net.load_state_dict(recipe.fill(recipe.unet_shapes(1, 5, 16), 600)); net.cuda().train()
+    x = recipe.synth_images((32, 1, H, H), 601).cuda()
+    big = net(x)
+    small = net(x[5:7])
+    assert rel_err(big[5:7].detach().cpu().numpy(), small.detach().cpu().numpy()) < 2e-5
+    # gradient linearity: d/dw sum_n f(x_n) over the batch == sum of two half-batch gradients
+    w = torch.randn_like(big)
+    (big * w).sum().backward()
+    g_full = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad(set_to_none=True)
+    (net(x[:16]) * w[:16]).sum().backward()
+    (net(x[16:]) * w[16:]).sum().backward()
+    for n, p in net.named_parameters():
+        if n in ("encoder.pre_conv.weight", "encoder.layer1.conv1.weight", "encoder.layer4.conv2.weight", "decoder.layer1.conv1.weight",
+                 "decoder.layer1.bn1.weight", "decoder.fc.weight", "decoder.up4.up.weight"):
+            # forward values differ by ~1e-6 between the two batch shapes, which flips a few LeakyReLU / MaxPool
+            # decisions: same noise floor as fp32-vs-fp64 of the reference itself (DESIGN.md "Parity"), l2-rel ~4e-3
+            assert l2_rel(p.grad.cpu().numpy(), g_full[n].cpu().numpy()) < 1.5e-2, n
+    G = UGANnce(1, 5, 4, 16)
+    G.load_state_dict(recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 602)); G.cuda().train()
+    xg = recipe.synth_images((16, 1, H, H), 603).cuda()
+    m = torch.zeros(16, 4, device="cuda"); m[:, 1] = 1.0; m[:, 3] = -1.0
+    ids = torch.arange(64, device="cuda")
+    with torch.no_grad():
+        seg_b, tsl_b, feat_b, _ = G(xg, m, sample_ids=[ids])
+        seg_s, tsl_s, feat_s, _ = G(xg[9:11], m[9:11], sample_ids=[ids])
+    assert rel_err(seg_b[9:11].cpu().numpy(), seg_s.cpu().numpy()) < 2e-5
+    assert rel_err(tsl_b[9:11].cpu().numpy(), tsl_s.cpu().numpy()) < 2e-5
+    assert rel_err(feat_b[0][9 * 64:11 * 64].cpu().numpy(), feat_s[0].cpu().numpy()) < 2e-5
+
+
 def test_discriminator_and_gradient_penalty(pkg, golden):
     from smsut_amd.network.ugan import Discriminator
     from smsut_amd import ops
