@@ -478,6 +478,10 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows (the GEMM K dimension)
+#ifndef WTS_STRIDE_VALUE
+#define WTS_STRIDE_VALUE 48
+#endif
+constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
 template <int KS, int CIT, int COT>
 __global__ void __launch_bounds__(TPB)
@@ -635,7 +639,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
                    int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split) {
   constexpr int KS = 3, KK = 9, PAD = 1, CIT = 2, COT = 2;
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
-  constexpr int CI_T = 32, CO_T = 32, SI = 48, SO = 48;
+  constexpr int CI_T = 32, CO_T = 32, SI = WTS_STRIDE, SO = WTS_STRIDE;
   constexpr int NSLOT = KK * CIT * COT / 4;                    // 9 accumulator tiles per wave
   extern __shared__ float smem[];
   float* in_s = smem;                         // [IH][IW][SI]
@@ -663,69 +667,74 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  constexpr int NIN = (IH * IW * (CI_T / 4) + TPB - 1) / TPB;
+  // Staging descriptors, computed once (full tiles and full 32-channel slabs only -- the host checks H % 8 == 0,
+  // W % 16 == 0, Cin % 32 == 0, Cout % 32 == 0 and 32-bit element offsets): element offset of the unit relative to the
+  // tile's first halo pixel, LDS slot (a dummy slot for the padding units), image borders the unit falls outside of.
+  constexpr int UIN = IH * IW * (CI_T / 4);
+  constexpr int NIN = (UIN + TPB - 1) / TPB;
   constexpr int NGY = (WTH * TW * (CO_T / 4) + TPB - 1) / TPB;
+  static_assert(WTH * TW * (CO_T / 4) % TPB == 0, "gy tile units divide evenly");
   float4 rin[NIN], rgy[NGY];
-  int in_yx[NIN], in_c[NIN], in_lds[NIN], gy_yx[NGY], gy_c[NGY], gy_lds[NGY];
+  int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
     const int u = tid + i * TPB;
-    const int q = u % (CI_T / 4), pix = u / (CI_T / 4);
-    const int c = ci0 + 4 * q;
-    in_yx[i] = (u < IH * IW * (CI_T / 4) && c < Cin) ? (((pix / IW) << 8) | (pix % IW)) : -1;
-    in_c[i] = c;
-    in_lds[i] = pix * SI + 4 * q;
+    const bool real = u < UIN;
+    const int uu = real ? u : 0;
+    const int q = uu % (CI_T / 4), pix = uu / (CI_T / 4);
+    const int iy = pix / IW, ix = pix % IW;
+    in_off[i] = (iy * W + ix) * Cin + 4 * q;
+    in_lds[i] = real ? pix * SI + 4 * q : (IH * IW * SI + WTH * TW * SO);          // dummy slot behind both tiles
+    in_flag[i] = (iy < PAD ? 1 : 0) | (iy >= WTH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
   }
 #pragma unroll
   for (int i = 0; i < NGY; ++i) {
     const int u = tid + i * TPB;
     const int q = u % (CO_T / 4), pix = u / (CO_T / 4);
-    const int c = co0 + 4 * q;
-    gy_yx[i] = (u < WTH * TW * (CO_T / 4) && c < Cout) ? (((pix / TW) << 8) | (pix % TW)) : -1;
-    gy_c[i] = c;
+    gy_off[i] = ((pix / TW) * W + (pix % TW)) * Cout + 4 * q;
     gy_lds[i] = pix * SO + 4 * q;
   }
-  auto prefetch = [&](int t) {
-    const int n_img = t / tiles_img;
-    const int rem = t % tiles_img;
-    const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * TW;
-    const float* xin = x + (size_t)n_img * H * W * Cin;
-    const float* gin = gy + (size_t)n_img * H * W * Cout;
+  const int safe_off = (PAD * W + PAD) * Cin;              // first interior pixel of the tile: always inside the image
+  int pn = t_begin / tiles_img, pty, ptx;                  // cursor of the tile being prefetched
+  { const int t = t_begin - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
+  bool zero[NIN];
+  auto prefetch = [&]() {
+    const int flags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
+    const float* xb = x + (((pn * H + pty * WTH - PAD) * W) + ptx * TW - PAD) * Cin + ci0;
+    const float* gb = gy + (((pn * H + pty * WTH) * W) + ptx * TW) * Cout + co0;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int gy_ = y0 + (in_yx[i] >> 8) - PAD, gx_ = x0 + (in_yx[i] & 255) - PAD;
-      if (in_yx[i] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W)
-        v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * Cin + in_c[i]);
-      rin[i] = v;
+      zero[i] = (in_flag[i] & flags) != 0;
+      rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : in_off[i]));
     }
 #pragma unroll
-    for (int i = 0; i < NGY; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int gy_ = y0 + (gy_yx[i] >> 8), gx_ = x0 + (gy_yx[i] & 255);
-      if (gy_yx[i] >= 0 && gy_ < H && gx_ < W) v = *(const float4*)(gin + ((size_t)gy_ * W + gx_) * Cout + gy_c[i]);
-      rgy[i] = v;
-    }
+    for (int i = 0; i < NGY; ++i) rgy[i] = *(const float4*)(gb + gy_off[i]);
+    if (++ptx == tiles_x) { ptx = 0; if (++pty == tiles_y) { pty = 0; ++pn; } }
   };
 
   [[maybe_unused]] const int stamp_wg = (blockIdx.y == 0 && blockIdx.z == 0) ? (int)blockIdx.x : -1;
   STAMP(0);
-  if (t_begin < t_end) prefetch(t_begin);
+  if (t_begin < t_end) prefetch();
   STAMP(1);
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
     if (t - t_begin < 2) { STAMP(2 + 4 * (t - t_begin)); }
 #pragma unroll
-    for (int i = 0; i < NIN; ++i)
-      if (tid + i * TPB < IH * IW * (CI_T / 4)) *(float4*)(in_s + in_lds[i]) = rin[i];
+    for (int i = 0; i < NIN; ++i) {
+      float4 v = rin[i];
+      if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(in_s + in_lds[i]) = v;
+    }
 #pragma unroll
-    for (int i = 0; i < NGY; ++i)
-      if (tid + i * TPB < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
+    for (int i = 0; i < NGY; ++i) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
     __syncthreads();
     if (t - t_begin < 2) { STAMP(3 + 4 * (t - t_begin)); }
-    if (t + 1 < t_end) prefetch(t + 1);
+    if (t + 1 < t_end) prefetch();
     if (t - t_begin < 2) { STAMP(4 + 4 * (t - t_begin)); }
-#pragma unroll 2
+#ifndef WTS_UNROLL
+#define WTS_UNROLL 8
+#endif
+#pragma unroll WTS_UNROLL
     for (int r = 0; r < WTH; ++r) {
 #pragma unroll
       for (int ks = 0; ks < TW / 4; ++ks) {
@@ -739,17 +748,14 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     if (t - t_begin < 2) { STAMP(5 + 4 * (t - t_begin)); }
   }
   STAMP(10);
-  float* out = part + (size_t)split * KK * Cin * Cout;
-  const int co = co0 + jt * 16 + lm;
+  float* out = part + (size_t)split * KK * Cin * Cout + (size_t)(ci0 + 4 * kq) * Cout + co0 + jt * 16 + lm;
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) {
     const int ti = (wave + 4 * k) >> 1;
     const int tap = ti >> 1, i = ti & 1;
+    float* o = out + (tap * Cin + i * 16) * Cout;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ci = ci0 + i * 16 + 4 * kq + r;
-      if (ci < Cin && co < Cout) out[((size_t)tap * Cin + ci) * Cout + co] = acc[k][r];
-    }
+    for (int r = 0; r < 4; ++r) o[r * Cout] = acc[k][r];
   }
   STAMP(11);
 }
@@ -1119,12 +1125,13 @@ int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* w
     if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
     else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
     else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
-    else {
-      constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * 48 + WTH * TW * 48) * sizeof(float);
-      dim3 grid(p.splits, (Cin + 31) / 32, (Cout + 31) / 32);
+    else if (H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
+             (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {
+      constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE + 4) * sizeof(float);
+      dim3 grid(p.splits, Cin / 32, Cout / 32);
       conv_mfma_wgrad_ts<<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
                                                 p.tiles_per_split);
-    }
+    } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
   }
   const int wsize = KS * KS * Cin * Cout;
   launch_sum_splits(workspace, gw, wsize, p.splits, st);
