@@ -808,9 +808,14 @@ sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, i
 }
 
 inline void launch_sum_splits(const float* part, float* out, int wsize, int splits, hipStream_t st) {
-  // (column width 4 / 8 / 16 / 32 measured within noise of each other, r01 notes)
-  if (splits >= 128) sum_splits<4><<<(wsize + 15) / 16, TPB, 0, st>>>(part, out, wsize, splits);      // 64 split-lanes
-  else sum_splits<16><<<(wsize + 63) / 64, TPB, 0, st>>>(part, out, wsize, splits);                    // 16 split-lanes
+  // COLS float4 columns (COLS*16 contiguous bytes per split row) x 256/COLS split-lanes per block, ~100-150 blocks:
+  // in-process A/B on the layer shapes (scratch/wgrad_ab2.py) -- 4 columns x 64 lanes (the earlier choice for >= 128
+  // splits) made the whole weight-gradient call 10-24 % slower at 256^2 / 128^2; 32 / 64 columns win from 32x32 / 64x64
+  // weights on (longer contiguous rows per request).
+  (void)splits;
+  if (wsize >= 32768) sum_splits<64><<<(wsize + 255) / 256, TPB, 0, st>>>(part, out, wsize, splits);
+  else if (wsize >= 8192) sum_splits<32><<<(wsize + 127) / 128, TPB, 0, st>>>(part, out, wsize, splits);
+  else sum_splits<16><<<(wsize + 63) / 64, TPB, 0, st>>>(part, out, wsize, splits);
 }
 
 template <int KS, int TH, int WM, int WN, int NTN>
