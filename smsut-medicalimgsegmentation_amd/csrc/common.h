@@ -20,9 +20,12 @@
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // grid-stride launch width for memory-bound elementwise kernels: 256 CUs x 8 blocks (guide G11)
+#ifndef SMSUT_EW_GRID_CAP
+#define SMSUT_EW_GRID_CAP 2048
+#endif
 static inline int ew_grid(int64_t work_items, int block = 256) {
   int64_t g = cdiv64(work_items, block);
-  if (g > 2048) g = 2048;
+  if (g > SMSUT_EW_GRID_CAP) g = SMSUT_EW_GRID_CAP;
   if (g < 1) g = 1;
   return (int)g;
 }

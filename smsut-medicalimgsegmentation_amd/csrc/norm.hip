@@ -434,8 +434,11 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
 
 inline int pick_chunk(int HW, int C, int N) {
   // aim for >= ~1024 blocks overall while keeping >= 256 pixels per chunk
+#ifndef SMSUT_IN_BLOCKS
+#define SMSUT_IN_BLOCKS 1024
+#endif
   int ppc = 2048;
-  while (ppc > 256 && (int64_t)N * cdiv64(HW, ppc) < 1024) ppc >>= 1;
+  while (ppc > 256 && (int64_t)N * cdiv64(HW, ppc) < SMSUT_IN_BLOCKS) ppc >>= 1;
   (void)C;
   return ppc;
 }
