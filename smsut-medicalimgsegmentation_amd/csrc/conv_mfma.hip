@@ -24,6 +24,7 @@
 // order; per-split slabs are summed by a second tiny kernel (deterministic, no atomics).
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 #include <type_traits>
 
 namespace {
@@ -902,6 +903,10 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
 #define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out
   // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
   // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
+  static const bool log_shapes = getenv("SMSUT_LOG_CONV") != nullptr;      // shape census for tuning (stderr)
+  if (log_shapes && !tiles_out)
+    fprintf(stderr, "[conv] KS %d N %d H %d W %d K %d N %d tr %d isc %d osc %d G %d p3 %d\n", KS, N, H, W, Kdim, Ndim,
+            transposed, isc, osc, G, (int)(KS == 3 && isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_p_eligible(N, H, W, Kdim, Ndim)));
   if constexpr (KS == 3) {
     // small-Cin / large-image layers: persistent kernel with resident weights (see conv_mfma_fwd_p); it declines
     // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
