@@ -51,6 +51,12 @@ int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H
 int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS);
 /* 1 when this shape runs the persistent resident-weight kernel (conv_mfma_fwd_p: small Cin, large image), else 0. */
 int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS);
+/* data-gradient of conv2 inside a BasicBlock (its input was LeakyReLU(IN(y1)), blocks.py:66-72) with the InstanceNorm backward
+ * folded into the epilogue: gz = g * mask(y1) is written instead of g, plus the per-tile partials {sum gz, sum gz*xhat}
+ * [N][smsut_conv2d_mfma_tiles(N,H,W,Kdim,Ndim,3)][Ndim][2].  Persistent-kernel shapes only (-1 otherwise). */
+int smsut_conv2d_dgrad_mfma_bwdstats(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     float slope, int N, int H, int W, int Kdim, int Ndim, void* stream);
 int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
                                 int Ndim, int KS, void* stream);
 /* tuning hook: same as smsut_conv2d_fwd_mfma with a forced tile configuration (returns -1 for an unknown cfg) */
@@ -110,10 +116,12 @@ int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float*
                                 float slope, int has_act, void* stream);
 int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float* rstd, int N, int HW, int C, float eps,
                           void* stream);
-int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, float* b_mean, float* ggamma /*nullable*/,
-                          float* gbeta /*nullable*/, int N, int HW, int C, void* stream);
+/* InstanceNorm backward fed by the dgrad epilogue (smsut_conv2d_dgrad_mfma_bwdstats): finalise the {sum gz, sum gz*xhat}
+ * partials into a / b, then gx = gamma*rstd*(gz - a - xhat*b) on the ALREADY masked gz (+ affine gradients, nullable). */
+int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, float* b_mean, int N, int HW, int C, void* stream);
 int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
-                       const float* a_mean, const float* b_mean, float* gx, int N, int HW, int C, void* stream);
+                       const float* a_mean, const float* b_mean, float* gx, float* ggamma /*nullable*/,
+                       float* gbeta /*nullable*/, int N, int HW, int C, void* stream);
 /* residual tail of BasicBlock (blocks.py:60-79): out = act(IN(y2) + (IN(s) | s)), forward and backward in one pass each */
 int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
                       const float* ms /*nullable: identity*/, const float* rs, const float* gs, const float* bs, float* out,

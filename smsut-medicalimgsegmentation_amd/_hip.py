@@ -22,8 +22,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_instnorm_fwd": "ppppppp iii ff i s",
     "smsut_instnorm_fwd_partials": "ppppppp iiii ff i s",
     "smsut_in_finalize_fwd": "p i pp iii f s",
-    "smsut_in_finalize_bwd": "p i pppp iii s",
-    "smsut_in_apply_bwd": "pppppppp iii s",
+    "smsut_in_finalize_bwd": "p i pp iii s",
+    "smsut_in_apply_bwd": "pppppppp pp iii s",
     "smsut_restail_fwd": "pppppppppp p iii f s",
     "smsut_restail_bwd": "pppppppppp pp ppp pppp p iii f s",
     "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
@@ -40,6 +40,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_fwd_mfma": "ppp iiiiii i s",
     "smsut_conv2d_mfma_tiles": "iiiiii",
     "smsut_conv2d_mfma_persistent": "iiiiii",
+    "smsut_conv2d_dgrad_mfma_bwdstats": "ppppppppp f iiiii s",
     "smsut_conv2d_fwd_mfma_stats": "pppp iiiiii s",
     "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",
     "smsut_conv2d_wgrad_mfma_supported": "iiiii",

@@ -71,3 +71,11 @@ __device__ __forceinline__ float block_max_256(float v, float* sm4) {
 
 __device__ __forceinline__ float lrelu_f(float v, float slope) { return v > 0.f ? v : v * slope; }
 __device__ __forceinline__ float lrelu_mask(float y, float slope) { return y > 0.f ? 1.f : slope; }
+
+// The normalised pre-activation of InstanceNorm.  ONE definition shared by the forward, the backward (which recomputes
+// the LeakyReLU mask from x -- the sign of this value -- instead of reading the activation back from HBM) and the conv
+// epilogue that folds the backward statistics in: it must be bit-identical everywhere.
+__device__ __forceinline__ float in_affine(float x, float mean, float rstd, float gamma, float beta) {
+  return __fmaf_rn(x - mean, rstd * gamma, beta);
+}
+

@@ -254,10 +254,18 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 //     stores (its accumulators are kept in a second register set) and the current chunk's MFMAs, so the scheduler can
 //     put the overhead instructions into the shadow of the MFMAs (24 of every 32 issue cycles are free).
 // Regular stride-1 "same" 3x3 conv; W % 16 == 0, H % TH == 0, Ndim % (16*NTN) == 0, Kdim == 16*NCH (checked by the host).
-template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC>
+// BST ("backward statistics", data-gradient of conv2 inside a BasicBlock): the result g is the gradient w.r.t.
+// a1 = LeakyReLU(IN(y1)); the epilogue multiplies it by the activation mask recomputed from y1 (in_affine), stores
+// gz = g * mask, and emits the per-tile partials {sum gz, sum gz * xhat} of the InstanceNorm backward -- the separate
+// reduction pass over (g, y1) disappears (in_moments_partial<1>: 4.5 % of the uganConsis iteration).
+struct BstRef { const float* y1; const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
+
+template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
-                int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats) {
+                int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
+                BstRef bst = BstRef{}) {
+  static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
@@ -352,26 +360,40 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   };
 
   f32x4 acc[MR][NR], pacc[MR][NR];
-  [[maybe_unused]] f32x4 pold[MR][NR];
+  [[maybe_unused]] f32x4 pold[MR][NR];                 // ACC: what the outputs hold now; BST: y1 at the output positions
+  [[maybe_unused]] float nm[NR], nr[NR], ng[NR], nb[NR];   // BST: mean / rstd of (image en, channel), gamma, beta
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j) { acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; pacc[i][j] = acc[i][j]; }
 
+  if (BST) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { ng[j] = bst.gamma[co0 + j * 16 + lm]; nb[j] = bst.beta[co0 + j * 16 + lm]; }
+  }
   // per-lane output offset of (row wave*MR, col 4*kq, channel lm) inside a tile; red[] slot of this lane
   const int o_lane = ((wave * MR) * W + 4 * kq) * Ndim + lm;
   const int red_slot = (wave * CO_T + lm) * 2;
 
   // statistics + stores of the item in pacc / (en, ety, etx); straight-line, no branches
   auto epilogue = [&](int par) {
-    if (STATS) {
+    if (STATS || BST) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < MR; ++i)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { const float v = pacc[i][j][r]; s1 += v; s2 += v * v; }
+          for (int r = 0; r < 4; ++r) {
+            if (BST) {
+              const float yv = pold[i][j][r];
+              const float gz = pacc[i][j][r] * lrelu_mask(in_affine(yv, nm[j], nr[j], ng[j], nb[j]), bst.slope);
+              pacc[i][j][r] = gz;                       // stored below
+              s1 += gz; s2 += gz * ((yv - nm[j]) * nr[j]);
+            } else {
+              const float v = pacc[i][j][r]; s1 += v; s2 += v * v;
+            }
+          }
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
         float* rd = kq == 0 ? red + par * (4 * CO_T * 2) + j * 32 + red_slot : red + 2 * 4 * CO_T * 2;   // else: dummy slot
@@ -388,8 +410,15 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   };
   // ACC: the values the outputs of item (n_, ty_, tx_) hold now (loaded one region before they are added and stored)
   auto load_old = [&](int n_, int ty_, int tx_) {
-    if (ACC) {
-      const float* yb = y + (((size_t)n_ * H + ty_ * TH) * W + tx_ * TW) * Ndim + co0;
+    if (BST) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        nm[j] = bst.mean[(size_t)n_ * Ndim + co0 + j * 16 + lm];
+        nr[j] = bst.rstd[(size_t)n_ * Ndim + co0 + j * 16 + lm];
+      }
+    }
+    if (ACC || BST) {
+      const float* yb = (BST ? bst.y1 : y) + (((size_t)n_ * H + ty_ * TH) * W + tx_ * TW) * Ndim + co0;
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -399,7 +428,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     }
   };
   auto stats_out = [&](int par) {                     // after the barrier that completes red[par]
-    if (STATS && tid < CO_T) {
+    if ((STATS || BST) && tid < CO_T) {
       const float* rd = red + par * (4 * CO_T * 2);
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -473,7 +502,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   item_body(item0, std::true_type{});
   for (int item = item0 + 1; item < item1; ++item) item_body(item, std::false_type{});
   epilogue(par);
-  if (STATS) { __syncthreads(); stats_out(par); }
+  if (STATS || BST) { __syncthreads(); stats_out(par); }
   STAMP(11);
 }
 
@@ -852,7 +881,7 @@ constexpr size_t fwd_p_lds() {
 
 template <int KS, int TH, int NTN, int NCH>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-                 hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
+                 hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr) {
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
   if constexpr (sh > 64 * 1024) return -1;
   else {
@@ -879,7 +908,11 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   const int tr = transposed & 1;
 #define P_LAUNCH(ST, AC) conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, \
                                                                                         tiles_img, ipw, tr, stats)
-  if (transposed & 2) {
+  if (bst) {
+    if (!stats || (transposed & 2)) return -1;
+    conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
+                                                                                 tr, stats, *bst);
+  } else if (transposed & 2) {
     if (stats) return -1;
     P_LAUNCH(false, true);
   } else if (stats) P_LAUNCH(true, false);
@@ -1094,6 +1127,25 @@ int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float*
   hipStream_t st = (hipStream_t)stream;
   if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats);
   else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Data-gradient of a 3x3 conv whose input was a = LeakyReLU(IN(y1)) (conv2 of a BasicBlock): writes gz = g * mask(y1) and the
+// per-tile partials {sum gz, sum gz * xhat} [N][tiles][Ndim][2] of the InstanceNorm backward (tiles =
+// smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3)).  Only where smsut_conv2d_mfma_persistent(...) == 1; -1 otherwise.
+int smsut_conv2d_dgrad_mfma_bwdstats(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     float slope, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(gy && w && gz && stats && y1 && mean && rstd && gamma && beta && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(fwd_p_eligible(N, H, W, Kdim, Ndim));
+  const BstRef b{y1, mean, rstd, gamma, beta, slope};
+  hipStream_t st = (hipStream_t)stream;
+  int rc = -1;
+  if (Kdim == 16) rc = launch_fwd_p<3, 8, 1, 1>(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
+  else if (Kdim == 32) rc = launch_fwd_p<3, 8, 1, 2>(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
+  else if (Kdim == 64) rc = launch_fwd_p<3, 8, 1, 4>(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
+  SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

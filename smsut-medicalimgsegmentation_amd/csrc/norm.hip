@@ -19,12 +19,7 @@ namespace {
 
 constexpr int TPB = 256;
 
-// The normalised pre-activation.  ONE definition shared by forward and backward: the backward recomputes the
-// LeakyReLU mask from x (sign of this value) instead of reading the activation back from HBM, so it must be
-// bit-identical to what the forward kernel evaluated.
-__device__ __forceinline__ float in_affine(float x, float mean, float rstd, float gamma, float beta) {
-  return __fmaf_rn(x - mean, rstd * gamma, beta);
-}
+// in_affine() -- the normalised pre-activation, ONE definition for forward, backward and the conv epilogues: common.h
 
 // MODE 0: sums of (x, x^2)           -- forward statistics
 // MODE 1: sums of (gz, gz*xh)        -- backward
@@ -266,17 +261,6 @@ in_apply_bwd2(const float* __restrict__ v, const float* __restrict__ x, const fl
       d_gy[i] = o1[0]; d_x[i] = o2[0];
     }
   }
-}
-
-// ggamma[c] = sum_n M*b[n,c]; gbeta[c] = sum_n M*a[n,c]
-__global__ void in_affine_grads(const float* __restrict__ am, const float* __restrict__ bm, int N, int C, int HW,
-                                float* __restrict__ ggamma, float* __restrict__ gbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double sa = 0.0, sb = 0.0;
-  for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; sb += (double)bm[n * C + c]; }
-  ggamma[c] = (float)(sb * (double)HW);
-  gbeta[c] = (float)(sa * (double)HW);
 }
 
 // d/dgamma[c] = sum_n rstd*M*(e - cv*a - dv*b)
@@ -554,30 +538,31 @@ int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float*
   return SMSUT_OK;
 }
 
-// Finalise backward partials [N][chunks][C][2] = {sum gz, sum gz*xhat} (from smsut_conv2d_dgrad_mfma_fused) into the
-// per-(n,c) means a, b and the affine gradients ggamma / gbeta (nullable).
-int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, float* b_mean, float* ggamma, float* gbeta,
-                          int N, int HW, int C, void* stream) {
+// Finalise backward partials [N][chunks][C][2] = {sum gz, sum gz*xhat} (from smsut_conv2d_dgrad_mfma_bwdstats) into the
+// per-(n,c) means a, b.
+int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, float* b_mean, int N, int HW, int C,
+                          void* stream) {
   SMSUT_REQUIRE(partials && a_mean && b_mean && chunks > 0 && N > 0 && HW > 0 && C > 0);
-  hipStream_t st = (hipStream_t)stream;
-  in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(partials, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
-  if (ggamma && gbeta) in_affine_grads<<<(C + 63) / 64, 64, 0, st>>>(a_mean, b_mean, N, C, HW, ggamma, gbeta);
+  in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, (hipStream_t)stream>>>(partials, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
 
-// gx = gamma*rstd*(gz - a - xhat*b) with gz ALREADY masked (output of smsut_conv2d_dgrad_mfma_fused).
+// gx = gamma*rstd*(gz - a - xhat*b) with gz ALREADY masked (output of smsut_conv2d_dgrad_mfma_bwdstats); ggamma / gbeta
+// (nullable) are the affine gradients sum_n HW*b, sum_n HW*a.
 int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
-                       const float* a_mean, const float* b_mean, float* gx, int N, int HW, int C, void* stream) {
+                       const float* a_mean, const float* b_mean, float* gx, float* ggamma, float* gbeta, int N, int HW, int C,
+                       void* stream) {
   SMSUT_REQUIRE(gz && x && mean && rstd && gamma && a_mean && b_mean && gx && N > 0 && HW > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
+  float* gg = (ggamma && gbeta) ? ggamma : nullptr;
   const int64_t total = (int64_t)N * HW * C;
   if (C % 4 == 0)
     in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, 0.f,
-                                                        N, nullptr, nullptr);
+                                                        N, gg, gbeta);
   else
     in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, 0.f,
-                                                    N, nullptr, nullptr);
+                                                    N, gg, gbeta);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

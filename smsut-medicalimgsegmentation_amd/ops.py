@@ -454,6 +454,7 @@ def instnorm_act(x, gamma, beta, slope: Optional[float]):
 
 # ------------------------------------------------------------------------------------------- fused BasicBlock
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
+FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
 
 
 def basic_block_fusable(x, w1, ws):
@@ -556,17 +557,24 @@ class BasicBlockFn(Function):
                _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
         # (forking the three weight-gradient launches to a second stream inside this node was measured 1-3 % SLOWER
         #  than the single-stream order below -- profiles/r01_notes.md)
-        # ---- conv2
+        # ---- conv2 data-gradient + IN1 / LeakyReLU backward (mask recomputed from y1)
         ga1 = new_act(n, co, h, w, x)
-        H.call("smsut_conv2d_fwd_mfma", gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
+        gy1 = new_act(n, co, h, w, x)
+        a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
+        if FUSED_BWD_STATS and H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3):
+            # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
+            tb = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
+            pb = _ws(n * tb * co * 2, x)
+            H.call("smsut_conv2d_dgrad_mfma_bwdstats", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+            H.call("smsut_in_finalize_bwd", pb, tb, a1m, b1m, n, hw, co, st)
+            H.call("smsut_in_apply_bwd", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, n, hw, co, st)
+        else:
+            H.call("smsut_conv2d_fwd_mfma", gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
+            H.call("smsut_instnorm_bwd", ga1, y1, b1, m1, r1, g1, gy1, a1m, b1m, gg1, gb1, _ws(n * chunks * co * 3, x),
+                   n, hw, co, slope, st)
         gw2 = new_weight(co, co, 3, 3, device=dev)
         H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x),
                n, h, w, co, co, 3, st)
-        # ---- IN1 + LeakyReLU backward (mask recomputed from y1)
-        gy1 = new_act(n, co, h, w, x)
-        a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
-        H.call("smsut_instnorm_bwd", ga1, y1, b1, m1, r1, g1, gy1, a1m, b1m, gg1, gb1, _ws(n * chunks * co * 3, x),
-               n, hw, co, slope, st)
         # ---- conv1 and the shortcut
         gw1 = new_weight(co, ci, 3, 3, device=dev)
         H.call("smsut_conv2d_wgrad_mfma", x, gy1, gw1, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), x),
