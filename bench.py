@@ -97,49 +97,56 @@ def measure_dominant_conv(dev, batch):
             "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
 
 
-def cpu_baseline_ugan(sample_b=2):
-    """One uganConsis iteration of the CPU oracle on (sample_b/2 + sample_b/2) 256x256 slices."""
+def cpu_baseline_ugan(sample_b=16, timed=3):
+    """uganConsis iterations of the CPU oracle on the SAME per-GPU workload (sample_b/2 + sample_b/2 256x256 slices):
+    one untimed warm-up iteration on 2 slices, then ``timed`` iterations (~15-25 s of CPU work on 16 cores)."""
     import numpy as np
     from oracle import recipe, smsut_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: oracle uganConsis iteration on {sample_b} slices, {cores} threads ...")
+    log(f"cpu_baseline: oracle uganConsis, {timed} iterations on {sample_b} slices, {cores} threads ...")
     gsd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 2020).items()}
     dsd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.disc_shapes(256, 4, 16, 256), 2021).items()}
     g_opt = torch.optim.SGD(list(gsd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
     d_opt = torch.optim.Adam(list(dsd.values()), 1e-2, (0.9, 0.999), weight_decay=1e-3)
-    bs = sample_b // 2
-    x = recipe.synth_images((sample_b, 1, 256, 256), 2020)
-    y = recipe.synth_labels(bs, 256, 256, 5, 2021)
-    mo = torch.tensor([0] * bs + [1] * bs)
-    alpha = torch.from_numpy(np.random.RandomState(1).standard_normal((sample_b, 1, 1, 1))).float()
-    ids = torch.from_numpy(np.random.RandomState(2).permutation(256)[:64].astype(np.int64))
+
+    def one(b, seed):
+        bs = b // 2
+        x = recipe.synth_images((b, 1, 256, 256), seed)
+        y = recipe.synth_labels(bs, 256, 256, 5, seed + 1)
+        mo = torch.tensor([0] * bs + [1] * bs)
+        alpha = torch.from_numpy(np.random.RandomState(seed).standard_normal((b, 1, 1, 1))).float()
+        ids = torch.from_numpy(np.random.RandomState(seed + 2).permutation(256)[:64].astype(np.int64))
+        O.ugan_consis_iteration(gsd, dsd, g_opt, d_opt, x, y, mo, 2, alpha, [ids], it=1000, epoch=100, nce_batch=bs)
+    one(2, 2020)                                           # warm-up (thread pool, allocator)
     t0 = time.time()
-    O.ugan_consis_iteration(gsd, dsd, g_opt, d_opt, x, y, mo, 2, alpha, [ids], it=1000, epoch=100, nce_batch=bs)
-    dt = time.time() - t0
+    for i in range(timed):
+        one(sample_b, 2030 + 10 * i)
+        log(f"cpu_baseline: iteration {i + 1}/{timed} done, {time.time() - t0:.1f} s")
+    dt = (time.time() - t0) / timed
     return {"value": round(sample_b / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
-            "sample": f"1 uganConsis iteration of oracle/smsut_oracle.py, {bs} labeled + {bs} unlabeled 256x256 slices, "
-                      f"fp32, torch CPU {cores} threads, {dt:.1f} s"}
+            "sample": f"{timed} uganConsis iterations of oracle/smsut_oracle.py on {sample_b // 2} labeled + {sample_b // 2} unlabeled "
+                      f"256x256 slices (the per-GPU workload), fp32, torch CPU {cores} threads, {dt:.1f} s/iteration"}
 
 
-def cpu_baseline_unet(sample_b=4):
+def cpu_baseline_unet(sample_b=32, timed=2):
     from oracle import recipe, smsut_oracle as O
     cores = host_cores()
     torch.set_num_threads(cores)
-    log(f"cpu_baseline: oracle U-Net steps on {sample_b} slices, {cores} threads ...")
+    log(f"cpu_baseline: oracle U-Net, {timed} steps on {sample_b} slices, {cores} threads ...")
     sd = {k: v.requires_grad_(True) for k, v in recipe.fill(recipe.unet_shapes(1, 5, 16), 2020).items()}
     opt = torch.optim.SGD(list(sd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
     x = recipe.synth_images((sample_b, 1, 256, 256), 2020)
     y = recipe.synth_labels(sample_b, 256, 256, 5, 2021)
-    O.unet_train_step(sd, opt, x, y, 0)
+    O.unet_train_step(sd, opt, x[:2], y[:2], 0)           # warm-up
     t0 = time.time()
-    n = 2
-    for i in range(n):
+    for i in range(timed):
         O.unet_train_step(sd, opt, x, y, i + 1)
-    dt = (time.time() - t0) / n
+        log(f"cpu_baseline: step {i + 1}/{timed} done, {time.time() - t0:.1f} s")
+    dt = (time.time() - t0) / timed
     return {"value": round(sample_b / dt, 3), "unit": "slices/s", "cores": cores, "kind": "port",
-            "sample": f"{n} U-Net fwd+DiceCE+bwd+SGD steps of oracle/smsut_oracle.py on {sample_b}x1x256x256, fp32, "
-                      f"torch CPU {cores} threads, {dt:.1f} s/step"}
+            "sample": f"{timed} U-Net fwd+DiceCE+bwd+SGD steps of oracle/smsut_oracle.py on {sample_b}x1x256x256 (the per-GPU "
+                      f"workload), fp32, torch CPU {cores} threads, {dt:.1f} s/step"}
 
 
 def main():
