@@ -65,7 +65,7 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
     pok[i] = p < P;
     xp[i] = x + (size_t)(pok[i] ? p : 0) * Kdim + 4 * kq;
   }
-#pragma unroll 2
+// (runtime trip count: the partial unroll request is not honoured for every instantiation)
   for (int c = 0; c < chunks; ++c) {
     const bool kok = c * 16 + 4 * kq < Kdim;
     f32x4 a[MR], b[NR];
@@ -134,7 +134,7 @@ conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
   for (int j = 0; j < COT; ++j) jok[j] = co0 + j * 16 + lm < Cout;
   const float* xb = x + ci0 + lm;
   const float* gb = gy + co0 + lm;
-#pragma unroll 4
+// (runtime trip count)
   for (int64_t p = pb + 4 * wave + kq; p - kq < pe; p += 16) {      // this lane's pixel (the MFMA k index)
     const bool ok = p < pe;
     float a[CIT], b[COT];

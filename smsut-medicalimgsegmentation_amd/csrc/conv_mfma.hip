@@ -866,7 +866,9 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
 inline int device_cus() {
   static const int cus = [] {
     int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      n = 256;
     return n > 0 ? n : 256;
   }();
   return cus;
