@@ -175,6 +175,8 @@ int smsut_window_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int 
                      void* stream);
 int smsut_blurdown_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_blurdown_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
+/* torch.cat([a, b], 1) (dir 0) and its backward split (dir 1; a / b nullable) in one pass over the wide tensor. */
+int smsut_concat2(float* a, int Ca, float* b, int Cb, float* y, int64_t P, int dir, void* stream);
 int smsut_copy_channels(const float* src, int Cs, int src_off, float* dst, int Cd, int dst_off, int Cc, int64_t P,
                         void* stream);
 int smsut_modal_planes(const float* x, const float* m, float* out, int N, int64_t HW, int Cx, int M, void* stream);

@@ -85,6 +85,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_blurdown_fwd": "pp iiii s",
     "smsut_blurdown_bwd": "pp iiii s",
     "smsut_copy_channels": "p ii p ii i l s",
+    "smsut_concat2": "p i p i p l i s",
     "smsut_modal_planes": "ppp i l ii s",
     # loss.hip
     "smsut_dicece_ws": "i l ii",

@@ -239,6 +239,24 @@ k_copy_channels(const float* __restrict__ src, int Cs, int src_off, float* __res
   }
 }
 
+// torch.cat([a, b], 1) / its split in ONE pass: every lane moves one float4 of a concatenated pixel row, so the wide
+// tensor is read / written in full contiguous rows (two half-row copies touch every 128-B line of it twice).
+// dir 0: y[p][0..Ca) = a[p], y[p][Ca..Ca+Cb) = b[p];  dir 1: the reverse (a / b nullable: that half is skipped).
+__global__ void __launch_bounds__(TPB)
+k_concat2(float* __restrict__ a, int Ca, float* __restrict__ b, int Cb, float* __restrict__ y, int64_t P, int dir) {
+  const int q = (Ca + Cb) >> 2, qa = Ca >> 2;
+  const int64_t total = P * q;
+  GRID_STRIDE(i, total) {
+    const int c4 = (int)(i % q);
+    const int64_t p = i / q;
+    float* part = c4 < qa ? (a ? a + p * Ca + 4 * c4 : nullptr) : (b ? b + p * Cb + 4 * (c4 - qa) : nullptr);
+    float* wide = y + p * (Ca + Cb) + 4 * c4;
+    if (!part) continue;
+    if (dir == 0) *(float4*)wide = *(const float4*)part;
+    else *(float4*)part = *(const float4*)wide;
+  }
+}
+
 // tsl input: out[n][p][0..Cx) = x, out[n][p][Cx + j] = m[n][j]   (network/ugan.py:156-159)
 __global__ void __launch_bounds__(TPB)
 k_modal_planes(const float* __restrict__ x, const float* __restrict__ m, float* __restrict__ out, int N, int64_t HW,
@@ -527,6 +545,12 @@ int smsut_copy_channels(const float* src, int Cs, int src_off, float* dst, int C
   SMSUT_REQUIRE(src && dst && P > 0 && Cc > 0 && src_off >= 0 && dst_off >= 0 && src_off + Cc <= Cs &&
                 dst_off + Cc <= Cd);
   k_copy_channels<<<ew_grid(P * Cc / 4 + 1), TPB, 0, ST>>>(src, Cs, src_off, dst, Cd, dst_off, Cc, P);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// One-pass concat (dir 0) / split (dir 1) of two channel blocks, both multiples of 4 channels; a / b nullable in dir 1.
+int smsut_concat2(float* a, int Ca, float* b, int Cb, float* y, int64_t P, int dir, void* stream) {
+  SMSUT_REQUIRE(y && P > 0 && Ca > 0 && Cb > 0 && (Ca & 3) == 0 && (Cb & 3) == 0 && (dir == 0 ? (a && b) : (a || b)));
+  k_concat2<<<ew_grid(P * (Ca + Cb) / 4), TPB, 0, ST>>>(a, Ca, b, Cb, y, P, dir);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_modal_planes(const float* x, const float* m, float* out, int N, int64_t HW, int Cx, int M, void* stream) {

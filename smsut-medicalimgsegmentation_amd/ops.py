@@ -454,6 +454,7 @@ def instnorm_act(x, gamma, beta, slope: Optional[float]):
 
 # ------------------------------------------------------------------------------------------- fused BasicBlock
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
+ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
 
 
@@ -831,8 +832,11 @@ class ConcatFn(Function):
         assert b.shape[0] == n and b.shape[2:] == a.shape[2:]
         y = new_act(n, ca + cb, h, w, a)
         p = n * h * w
-        H.call("smsut_copy_channels", a, ca, 0, y, ca + cb, 0, ca, p, _s())
-        H.call("smsut_copy_channels", b, cb, 0, y, ca + cb, ca, cb, p, _s())
+        if ONE_PASS_CONCAT and ca % 4 == 0 and cb % 4 == 0:
+            H.call("smsut_concat2", a, ca, b, cb, y, p, 0, _s())
+        else:
+            H.call("smsut_copy_channels", a, ca, 0, y, ca + cb, 0, ca, p, _s())
+            H.call("smsut_copy_channels", b, cb, 0, y, ca + cb, ca, cb, p, _s())
         ctx.split = (ca, cb)
         return y
 
@@ -843,13 +847,15 @@ class ConcatFn(Function):
         ca, cb = ctx.split
         n, _, h, w = gy.shape
         p = n * h * w
-        ga = gb = None
-        if ctx.needs_input_grad[0]:
-            ga = new_act(n, ca, h, w, gy)
-            H.call("smsut_copy_channels", gy, ca + cb, 0, ga, ca, 0, ca, p, _s())
-        if ctx.needs_input_grad[1]:
-            gb = new_act(n, cb, h, w, gy)
-            H.call("smsut_copy_channels", gy, ca + cb, ca, gb, cb, 0, cb, p, _s())
+        ga = new_act(n, ca, h, w, gy) if ctx.needs_input_grad[0] else None
+        gb = new_act(n, cb, h, w, gy) if ctx.needs_input_grad[1] else None
+        if ONE_PASS_CONCAT and ca % 4 == 0 and cb % 4 == 0 and (ga is not None or gb is not None):
+            H.call("smsut_concat2", ga, ca, gb, cb, gy, p, 1, _s())
+        else:
+            if ga is not None:
+                H.call("smsut_copy_channels", gy, ca + cb, 0, ga, ca, 0, ca, p, _s())
+            if gb is not None:
+                H.call("smsut_copy_channels", gy, ca + cb, ca, gb, cb, 0, cb, p, _s())
         return ga, gb
 
 
