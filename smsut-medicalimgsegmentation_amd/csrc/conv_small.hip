@@ -204,20 +204,31 @@ flat_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __r
   }
 }
 
-// out[e] = sum_s part[s][e], e < wsize (small): one block per 16 elements, 16 split lanes, fp64, fixed order
+// out[e] = sum_s part[s][e], e < wsize (small, up to ~2000 splits): one block per 4 elements x 64 split lanes, four
+// independent fp64 accumulators per lane (loads in flight), fixed-order LDS tree (deterministic)
+constexpr int FS_COLS = 4;
 __global__ void __launch_bounds__(TPB)
 flat_sum(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
+  constexpr int LANES = TPB / FS_COLS;
   __shared__ double sm[TPB];
-  const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + col;
-  double s = 0.0;
-  if (e < wsize)
-    for (int c = sl; c < splits; c += 16) s += (double)part[(size_t)c * wsize + e];
-  sm[threadIdx.x] = s;
+  const int col = threadIdx.x % FS_COLS, sl = threadIdx.x / FS_COLS;
+  const int e = blockIdx.x * FS_COLS + col;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (e < wsize) {
+    int c = sl;
+    for (; c + 3 * LANES < splits; c += 4 * LANES) {
+      s0 += (double)part[(size_t)c * wsize + e];
+      s1 += (double)part[(size_t)(c + LANES) * wsize + e];
+      s2 += (double)part[(size_t)(c + 2 * LANES) * wsize + e];
+      s3 += (double)part[(size_t)(c + 3 * LANES) * wsize + e];
+    }
+    for (; c < splits; c += LANES) s0 += (double)part[(size_t)c * wsize + e];
+  }
+  sm[threadIdx.x] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (sl == 0 && e < wsize) {
     double t = 0.0;
-    for (int l = 0; l < 16; ++l) t += sm[l * 16 + col];
+    for (int l = 0; l < LANES; ++l) t += sm[l * FS_COLS + col];
     out[e] = (float)t;
   }
 }
@@ -306,7 +317,7 @@ int smsut_conv2d_flat_wgrad(const float* x, const float* gy, float* gw, float* w
   else if (mt <= 4) flat_wgrad<4><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);
   else flat_wgrad<8><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);
   const int wsize = KS * KS * Cin * Cout;
-  flat_sum<<<(wsize + 15) / 16, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  flat_sum<<<(wsize + FS_COLS - 1) / FS_COLS, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
