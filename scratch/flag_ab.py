@@ -6,6 +6,11 @@ import torch, smsut_amd
 from smsut_amd import ops, config as cfg
 from smsut_amd.misc.synthetic import SyntheticSliceLoader
 flag = sys.argv[1]; wl = sys.argv[2] if len(sys.argv) > 2 else "ugan"
+import importlib
+mod = ops
+if '.' in flag:
+    mname, flag = flag.rsplit('.', 1)
+    mod = importlib.import_module('smsut_amd.' + mname)
 ns = types.SimpleNamespace(fold=0, expr_name=None, write_env=False); dev = torch.device("cuda")
 if wl == "ugan":
     from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer
@@ -33,7 +38,7 @@ for _ in range(3): step()
 res = {0: [], 1: []}
 for rnd in range(6):
     for v in (0, 1):
-        setattr(ops, flag, bool(v))
+        setattr(mod, flag, bool(v))
         step(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
