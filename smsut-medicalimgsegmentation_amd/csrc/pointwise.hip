@@ -69,78 +69,111 @@ k_scale(const float* __restrict__ x, const float* __restrict__ s, float mul, flo
   GRID_STRIDE(i, n) out[i] = x[i] * f;
 }
 
+// VEC channels of one pixel as one access (VEC = 4 when C % 4 == 0: the index arithmetic -- three div/mod -- and the
+// memory instructions are then per float4, not per float; these kernels were instruction-bound, profiles/r01_notes.md)
+template <int VEC> __device__ __forceinline__ void ldp(const float* __restrict__ p, float (&o)[VEC]) {
+  if constexpr (VEC == 4) *(float4*)o = *(const float4*)p; else o[0] = p[0];
+}
+template <int VEC> __device__ __forceinline__ void stp(float* __restrict__ p, const float (&v)[VEC]) {
+  if constexpr (VEC == 4) *(float4*)p = *(const float4*)v; else p[0] = v[0];
+}
+
 // ---- 2x2 stride-2 pooling (H, W even) ------------------------------------------------------------
+template <int VEC>
 __global__ void __launch_bounds__(TPB)
 k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
-  const int Ho = H >> 1, Wo = W >> 1;
-  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / VEC;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    int64_t p = i / C;
+    const int c = (int)(i % CV) * VEC;
+    int64_t p = i / CV;
     const int wo = (int)(p % Wo); p /= Wo;
     const int ho = (int)(p % Ho);
     const int n = (int)(p / Ho);
     const float* b = x + (((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
     // scan order (0,0),(0,1),(1,0),(1,1); NaN propagates like at::max_pool2d
-    float m = b[0];
-    float v = b[C]; if (v > m || v != v) m = v;
-    v = b[(size_t)W * C]; if (v > m || v != v) m = v;
-    v = b[(size_t)W * C + C]; if (v > m || v != v) m = v;
-    y[i] = m;
+    float m[VEC], v[VEC];
+    ldp<VEC>(b, m);
+    ldp<VEC>(b + C, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) if (v[j] > m[j] || v[j] != v[j]) m[j] = v[j];
+    ldp<VEC>(b + (size_t)W * C, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) if (v[j] > m[j] || v[j] != v[j]) m[j] = v[j];
+    ldp<VEC>(b + (size_t)W * C + C, v);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) if (v[j] > m[j] || v[j] != v[j]) m[j] = v[j];
+    stp<VEC>(y + i * VEC, m);
   }
 }
 
 // gradient goes to the first element (scan order) equal to the pooled max -- at::max_pool2d's argmax
+template <int VEC>
 __global__ void __launch_bounds__(TPB)
 k_maxpool_bwd(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int N, int H, int W,
               int C) {
-  const int Ho = H >> 1, Wo = W >> 1;
-  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / VEC;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    int64_t p = i / C;
+    const int c = (int)(i % CV) * VEC;
+    int64_t p = i / CV;
     const int wo = (int)(p % Wo); p /= Wo;
     const int ho = (int)(p % Ho);
     const int n = (int)(p / Ho);
     const size_t o = (((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
     const size_t o1 = o + C, o2 = o + (size_t)W * C, o3 = o2 + C;
-    const float v0 = x[o], v1 = x[o1], v2 = x[o2], v3 = x[o3];
-    int k = 0; float m = v0;
-    if (v1 > m || v1 != v1) { m = v1; k = 1; }
-    if (v2 > m || v2 != v2) { m = v2; k = 2; }
-    if (v3 > m || v3 != v3) { m = v3; k = 3; }
-    const float g = gy[i];
-    gx[o] = k == 0 ? g : 0.f; gx[o1] = k == 1 ? g : 0.f; gx[o2] = k == 2 ? g : 0.f; gx[o3] = k == 3 ? g : 0.f;
+    float v0[VEC], v1[VEC], v2[VEC], v3[VEC], g[VEC];
+    ldp<VEC>(x + o, v0); ldp<VEC>(x + o1, v1); ldp<VEC>(x + o2, v2); ldp<VEC>(x + o3, v3);
+    ldp<VEC>(gy + i * VEC, g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      int k = 0; float m = v0[j];
+      if (v1[j] > m || v1[j] != v1[j]) { m = v1[j]; k = 1; }
+      if (v2[j] > m || v2[j] != v2[j]) { m = v2[j]; k = 2; }
+      if (v3[j] > m || v3[j] != v3[j]) { m = v3[j]; k = 3; }
+      v0[j] = k == 0 ? g[j] : 0.f; v1[j] = k == 1 ? g[j] : 0.f; v2[j] = k == 2 ? g[j] : 0.f; v3[j] = k == 3 ? g[j] : 0.f;
+    }
+    stp<VEC>(gx + o, v0); stp<VEC>(gx + o1, v1); stp<VEC>(gx + o2, v2); stp<VEC>(gx + o3, v3);
   }
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(TPB)
 k_avgpool_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
-  const int Ho = H >> 1, Wo = W >> 1;
-  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / VEC;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    int64_t p = i / C;
+    const int c = (int)(i % CV) * VEC;
+    int64_t p = i / CV;
     const int wo = (int)(p % Wo); p /= Wo;
     const int ho = (int)(p % Ho);
     const int n = (int)(p / Ho);
     const float* b = x + (((size_t)n * H + 2 * ho) * W + 2 * wo) * C + c;
-    y[i] = (b[0] + b[C] + b[(size_t)W * C] + b[(size_t)W * C + C]) * 0.25f;
+    float a0[VEC], a1[VEC], a2[VEC], a3[VEC];
+    ldp<VEC>(b, a0); ldp<VEC>(b + C, a1); ldp<VEC>(b + (size_t)W * C, a2); ldp<VEC>(b + (size_t)W * C + C, a3);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) a0[j] = (a0[j] + a1[j] + a2[j] + a3[j]) * 0.25f;
+    stp<VEC>(y + i * VEC, a0);
   }
 }
 
 // gx[n,h,w,c] = 0.25 * gy[n,h/2,w/2,c]   (adjoint of avgpool; its own adjoint is avgpool again)
+template <int VEC>
 __global__ void __launch_bounds__(TPB)
 k_avgpool_bwd(const float* __restrict__ gy, float* __restrict__ gx, int N, int H, int W, int C) {
-  const int Ho = H >> 1, Wo = W >> 1;
-  const int64_t total = (int64_t)N * H * W * C;
+  const int Ho = H >> 1, Wo = W >> 1, CV = C / VEC;
+  const int64_t total = (int64_t)N * H * W * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    int64_t p = i / C;
+    const int c = (int)(i % CV) * VEC;
+    int64_t p = i / CV;
     const int w = (int)(p % W); p /= W;
     const int h = (int)(p % H);
     const int n = (int)(p / H);
-    gx[i] = 0.25f * gy[(((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c];
+    float g[VEC];
+    ldp<VEC>(gy + (((size_t)n * Ho + (h >> 1)) * Wo + (w >> 1)) * C + c, g);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) g[j] *= 0.25f;
+    stp<VEC>(gx + i * VEC, g);
   }
 }
 
@@ -154,13 +187,14 @@ __device__ __forceinline__ void bil_src(int d, int size, int& i0, int& i1, float
   l1 = s - (float)i0;
 }
 
+template <int VEC>
 __global__ void __launch_bounds__(TPB)
 k_bilinear2_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C) {
-  const int Ho = 2 * H, Wo = 2 * W;
-  const int64_t total = (int64_t)N * Ho * Wo * C;
+  const int Ho = 2 * H, Wo = 2 * W, CV = C / VEC;
+  const int64_t total = (int64_t)N * Ho * Wo * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    int64_t p = i / C;
+    const int c = (int)(i % CV) * VEC;
+    int64_t p = i / CV;
     const int wo = (int)(p % Wo); p /= Wo;
     const int ho = (int)(p % Ho);
     const int n = (int)(p / Ho);
@@ -168,20 +202,25 @@ k_bilinear2_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H
     bil_src(ho, H, h0, h1, lh);
     bil_src(wo, W, w0, w1, lw);
     const float* b = x + (size_t)n * H * W * C + c;
-    const float v00 = b[((size_t)h0 * W + w0) * C], v01 = b[((size_t)h0 * W + w1) * C];
-    const float v10 = b[((size_t)h1 * W + w0) * C], v11 = b[((size_t)h1 * W + w1) * C];
-    y[i] = (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11);
+    float v00[VEC], v01[VEC], v10[VEC], v11[VEC];
+    ldp<VEC>(b + ((size_t)h0 * W + w0) * C, v00); ldp<VEC>(b + ((size_t)h0 * W + w1) * C, v01);
+    ldp<VEC>(b + ((size_t)h1 * W + w0) * C, v10); ldp<VEC>(b + ((size_t)h1 * W + w1) * C, v11);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+      v00[j] = (1.f - lh) * ((1.f - lw) * v00[j] + lw * v01[j]) + lh * ((1.f - lw) * v10[j] + lw * v11[j]);
+    stp<VEC>(y + i * VEC, v00);
   }
 }
 
 // adjoint in gather form: each input pixel collects from the <=4x4 outputs that reference it
+template <int VEC>
 __global__ void __launch_bounds__(TPB)
 k_bilinear2_bwd(const float* __restrict__ gy, float* __restrict__ gx, int N, int H, int W, int C) {
-  const int Ho = 2 * H, Wo = 2 * W;
-  const int64_t total = (int64_t)N * H * W * C;
+  const int Ho = 2 * H, Wo = 2 * W, CV = C / VEC;
+  const int64_t total = (int64_t)N * H * W * CV;
   GRID_STRIDE(i, total) {
-    const int c = (int)(i % C);
-    int64_t p = i / C;
+    const int c = (int)(i % CV) * VEC;
+    int64_t p = i / CV;
     const int w = (int)(p % W); p /= W;
     const int h = (int)(p % H);
     const int n = (int)(p / H);
@@ -200,22 +239,31 @@ k_bilinear2_bwd(const float* __restrict__ gy, float* __restrict__ gx, int N, int
       }
     }
     const float* b = gy + (size_t)n * Ho * Wo * C + c;
-    float acc = 0.f;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       if (wh[a] == 0.f) continue;
       const int oh = 2 * h - 1 + a;
-      float r = 0.f;
+      float r[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) r[j] = 0.f;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (ww[k] == 0.f) continue;
-        r += ww[k] * b[((size_t)oh * Wo + (2 * w - 1 + k)) * C];
+        float v[VEC];
+        ldp<VEC>(b + ((size_t)oh * Wo + (2 * w - 1 + k)) * C, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) r[j] += ww[k] * v[j];
       }
-      acc += wh[a] * r;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += wh[a] * r[j];
     }
-    gx[i] = acc;
+    stp<VEC>(gx + i * VEC, acc);
   }
 }
+
 
 // ---- channel slices: dst[p][dst_off + c] = src[p][src_off + c], c < Cc --------------------------------
 __global__ void __launch_bounds__(TPB)
@@ -473,23 +521,27 @@ int smsut_scale(const float* x, const float* scale_dev, float mul, float* out, i
 }
 int smsut_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
-  k_maxpool_fwd<<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  if (C % 4 == 0) k_maxpool_fwd<4><<<ew_grid(((int64_t)N * H * W * C / 4) / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  else k_maxpool_fwd<1><<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_maxpool2_bwd(const float* gy, const float* x, float* gx, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(gy && x && gx && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
-  k_maxpool_bwd<<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C);
+  if (C % 4 == 0) k_maxpool_bwd<4><<<ew_grid(((int64_t)N * H * W * C / 4) / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C);
+  else k_maxpool_bwd<1><<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
-  k_avgpool_fwd<<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  if (C % 4 == 0) k_avgpool_fwd<4><<<ew_grid(((int64_t)N * H * W * C / 4) / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  else k_avgpool_fwd<1><<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 // (H, W) are the UN-pooled sizes: gy is [N,H/2,W/2,C], gx is [N,H,W,C]
 int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
-  k_avgpool_bwd<<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  if (C % 4 == 0) k_avgpool_bwd<4><<<ew_grid(((int64_t)N * H * W * C) / 4), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  else k_avgpool_bwd<1><<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 // Joint geometric augmentation (see k_warp_joint): img [N,H,W] fp32 (one channel), msk [N,H,W] int64 (nullable),
@@ -503,12 +555,14 @@ int smsut_warp_joint(const float* img, const int64_t* msk, const float* aff, con
 }
 int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0);
-  k_bilinear2_fwd<<<ew_grid((int64_t)N * H * W * C * 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  if (C % 4 == 0) k_bilinear2_fwd<4><<<ew_grid(((int64_t)N * H * W * C * 4) / 4), TPB, 0, ST>>>(x, y, N, H, W, C);
+  else k_bilinear2_fwd<1><<<ew_grid((int64_t)N * H * W * C * 4), TPB, 0, ST>>>(x, y, N, H, W, C);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_bilinear2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(gy && gx && N > 0 && H > 0 && W > 0 && C > 0);
-  k_bilinear2_bwd<<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  if (C % 4 == 0) k_bilinear2_bwd<4><<<ew_grid(((int64_t)N * H * W * C) / 4), TPB, 0, ST>>>(gy, gx, N, H, W, C);
+  else k_bilinear2_bwd<1><<<ew_grid((int64_t)N * H * W * C), TPB, 0, ST>>>(gy, gx, N, H, W, C);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 // nn.ReflectionPad2d / nn.ReplicationPad2d / zero pad / crop (networks.py:95-105,618,835-851): dst is
