@@ -96,20 +96,50 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
       }
     }
     __syncthreads();
+    if (TC <= 64 && (TC & (TC - 1)) == 0) {
+      // lanes of a wave that share a channel group sit TC apart: xor-tree inside the wave, then 4 wave totals through
+      // LDS (the old form below left 64 x 12 serial LDS reads to 4 threads of the block -- as long as the main loop)
+      for (int off = TC; off < 64; off <<= 1) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) sm[(threadIdx.x * NS + s) * VEC + j] = acc[s][j];
-    __syncthreads();
-    if (trow == 0 && cv_ok) {
+          for (int j = 0; j < VEC; ++j) acc[s][j] += __shfl_xor(acc[s][j], off, 64);
+      }
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      if (lane < TC) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) sm[((wv * TC + lane) * NS + s) * VEC + j] = acc[s][j];
+      }
+      __syncthreads();
+      if (threadIdx.x < TC && cv_ok) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) tot += sm[((w4 * TC + tc) * NS + s) * VEC + j];
+            part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * NS + s] = tot;
+          }
+      }
+    } else {
 #pragma unroll
       for (int s = 0; s < NS; ++s)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float tot = 0.f;
-          for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * NS + s) * VEC + j];
-          part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * NS + s] = tot;
-        }
+        for (int j = 0; j < VEC; ++j) sm[(threadIdx.x * NS + s) * VEC + j] = acc[s][j];
+      __syncthreads();
+      if (trow == 0 && cv_ok) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float tot = 0.f;
+            for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * NS + s) * VEC + j];
+            part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * NS + s] = tot;
+          }
+      }
     }
     __syncthreads();
   }
@@ -371,20 +401,48 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
       }
     }
     __syncthreads();
+    if (TC <= 64 && (TC & (TC - 1)) == 0) {          // in-wave xor-tree + 4 wave totals (see in_moments_partial)
+      for (int off = TC; off < 64; off <<= 1) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+        for (int q = 0; q < 3; ++q)
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) sm[(threadIdx.x * 3 + q) * VEC + j] = acc[q][j];
-    __syncthreads();
-    if (trow == 0 && cv_ok) {
+          for (int j = 0; j < VEC; ++j) acc[q][j] += __shfl_xor(acc[q][j], off, 64);
+      }
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      if (lane < TC) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) sm[((wv * TC + lane) * 3 + q) * VEC + j] = acc[q][j];
+      }
+      __syncthreads();
+      if (threadIdx.x < TC && cv_ok) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w4 = 0; w4 < 4; ++w4) tot += sm[((w4 * TC + tc) * 3 + q) * VEC + j];
+            part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
+          }
+      }
+    } else {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-          float tot = 0.f;
-          for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * 3 + q) * VEC + j];
-          part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
-        }
+        for (int j = 0; j < VEC; ++j) sm[(threadIdx.x * 3 + q) * VEC + j] = acc[q][j];
+      __syncthreads();
+      if (trow == 0 && cv_ok) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            float tot = 0.f;
+            for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * 3 + q) * VEC + j];
+            part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
+          }
+      }
     }
     __syncthreads();
   }
