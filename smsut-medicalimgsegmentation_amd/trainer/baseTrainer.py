@@ -24,6 +24,17 @@ from ..misc.synthetic import SyntheticSliceLoader
 from ..misc.utils import Meter, get_mo_matrix, maybe_mkdir
 
 
+def make_sgd(params, lr, momentum, weight_decay):
+    """torch.optim.SGD with the single-kernel ("fused") multi-tensor step: same update rule as the reference's optimizer
+    (baseline trainers: SGD(lr, momentum=0.9, weight_decay)), ~3 launches instead of ~12 per step.  The parameters, their
+    gradients and the momentum buffers share the HWIO strides, which is all the fused kernel needs (dense, same layout)."""
+    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=True)
+
+
+def make_adam(params, lr, betas, weight_decay):
+    return torch.optim.Adam(params, lr, betas, weight_decay=weight_decay, fused=True)
+
+
 class BaseTrainer(abc.ABC):
     def __init__(self, phase, args=None):
         self.args = args

@@ -6,12 +6,11 @@ import random
 
 import numpy as np
 import torch
-from torch.optim import SGD
 
 from .. import config as cfg
 from .. import ops, parallel
 from ..network.unet import UNet
-from .baseTrainer import BaseTrainer
+from .baseTrainer import BaseTrainer, make_sgd
 
 
 class crossPseTrainer(BaseTrainer):
@@ -26,8 +25,8 @@ class crossPseTrainer(BaseTrainer):
         parallel.broadcast_parameters(self.net, self.group)
         parallel.broadcast_parameters(self.net2, self.group)
         if self.phase == "train":
-            self.optimizer1 = SGD(self.net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
-            self.optimizer2 = SGD(self.net2.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
+            self.optimizer1 = make_sgd(self.net.parameters(), cfg.lr, 0.9, cfg.weight_decay)
+            self.optimizer2 = make_sgd(self.net2.parameters(), cfg.lr, 0.9, cfg.weight_decay)
             self.reducer1 = parallel.GradAllReducer(self.net.parameters(), self.group)
             self.reducer2 = parallel.GradAllReducer(self.net2.parameters(), self.group)
 

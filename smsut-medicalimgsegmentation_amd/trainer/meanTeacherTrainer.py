@@ -7,12 +7,11 @@ import random
 
 import numpy as np
 import torch
-from torch.optim import SGD
 
 from .. import config as cfg
 from .. import ops, parallel
 from ..network.unet import UNet
-from .baseTrainer import BaseTrainer
+from .baseTrainer import BaseTrainer, make_sgd
 
 
 class meanTeacherTrainer(BaseTrainer):
@@ -34,7 +33,7 @@ class meanTeacherTrainer(BaseTrainer):
             for p in self.ema.parameters():
                 p.requires_grad_(False)
             parallel.broadcast_parameters(self.ema, self.group)
-            self.optimizer = SGD(self.net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
+            self.optimizer = make_sgd(self.net.parameters(), cfg.lr, 0.9, cfg.weight_decay)
             self.reducer = parallel.GradAllReducer(self.net.parameters(), self.group)
 
     def update_ema_variable(self):

@@ -6,13 +6,12 @@ from os.path import join as pjoin
 
 import numpy as np
 import torch
-from torch.optim import SGD, Adam
 
 from .. import config as cfg
 from .. import ops, parallel
 from ..network.patchnce import PatchNCELoss
 from ..network.ugan import Discriminator, UGANnce
-from .baseTrainer import BaseTrainer
+from .baseTrainer import BaseTrainer, make_adam, make_sgd
 
 
 class UGANShp0Trainer(BaseTrainer):
@@ -30,8 +29,8 @@ class UGANShp0Trainer(BaseTrainer):
         parallel.broadcast_parameters(self.net, self.group)
         parallel.broadcast_parameters(self.D, self.group)
         if self.phase == "train":
-            self.optimizer = SGD(self.net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
-            self.d_optimizer = Adam(self.D.parameters(), cfg.lr, [self.beta1, self.beta2], weight_decay=cfg.weight_decay)
+            self.optimizer = make_sgd(self.net.parameters(), cfg.lr, 0.9, cfg.weight_decay)
+            self.d_optimizer = make_adam(self.D.parameters(), cfg.lr, [self.beta1, self.beta2], cfg.weight_decay)
             self.g_reducer = parallel.GradAllReducer(self.net.parameters(), self.group)
             self.d_reducer = parallel.GradAllReducer(self.D.parameters(), self.group)
 

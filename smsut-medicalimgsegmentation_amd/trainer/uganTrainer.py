@@ -6,11 +6,11 @@ import random
 
 import numpy as np
 import torch
-from torch.optim import SGD, Adam
 
 from .. import config as cfg
 from .. import ops, parallel
 from ..network.ugan import UGAN, Discriminator
+from .baseTrainer import make_adam, make_sgd
 from .uganShp0Trainer import UGANShp0Trainer
 
 SCALARS = ("D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg", "G_shp")
@@ -28,8 +28,8 @@ class UGANTrainer(UGANShp0Trainer):
         parallel.broadcast_parameters(self.net, self.group)
         parallel.broadcast_parameters(self.D, self.group)
         if self.phase == "train":
-            self.optimizer = SGD(self.net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
-            self.d_optimizer = Adam(self.D.parameters(), cfg.lr, [self.beta1, self.beta2], weight_decay=cfg.weight_decay)
+            self.optimizer = make_sgd(self.net.parameters(), cfg.lr, 0.9, cfg.weight_decay)
+            self.d_optimizer = make_adam(self.D.parameters(), cfg.lr, [self.beta1, self.beta2], cfg.weight_decay)
             self.g_reducer = parallel.GradAllReducer(self.net.parameters(), self.group)
             self.d_reducer = parallel.GradAllReducer(self.D.parameters(), self.group)
 

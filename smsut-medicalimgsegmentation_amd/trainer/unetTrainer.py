@@ -5,12 +5,11 @@ import random
 
 import numpy as np
 import torch
-from torch.optim import SGD
 
 from .. import config as cfg
 from .. import graphs, parallel
 from ..network.unet import UNet
-from .baseTrainer import BaseTrainer
+from .baseTrainer import BaseTrainer, make_sgd
 
 
 class UnetTrainer(BaseTrainer):
@@ -19,7 +18,7 @@ class UnetTrainer(BaseTrainer):
         self.net.to(self.device)
         parallel.broadcast_parameters(self.net, self.group)
         if self.phase == "train":
-            self.optimizer = SGD(self.net.parameters(), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
+            self.optimizer = make_sgd(self.net.parameters(), cfg.lr, 0.9, cfg.weight_decay)
             self.reducer = parallel.GradAllReducer(self.net.parameters(), self.group)
         self._graph = None
 
