@@ -179,20 +179,36 @@ conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
   }
 }
 
+// out[e] = sum_s part[s][e]: 16 float4 columns x 16 split lanes per block, four independent accumulators per lane
+// (loads in flight), fixed-order LDS tree (deterministic); wsize = Cin * Cout is a multiple of 4 on this path
 __global__ void __launch_bounds__(TPB)
 sum_parts(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
-  __shared__ float sm[TPB];
+  __shared__ float4 sm[TPB];
   const int col = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int e = blockIdx.x * 16 + col;
-  float s = 0.f;
-  if (e < wsize)
-    for (int c = sl; c < splits; c += 16) s += part[(size_t)c * wsize + e];
-  sm[threadIdx.x] = s;
+  const int e = (blockIdx.x * 16 + col) * 4;
+  float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
+  if (e < wsize) {
+    int c = sl;
+    for (; c + 48 < splits; c += 64) {
+      const float4 v0 = *(const float4*)(part + (size_t)c * wsize + e);
+      const float4 v1 = *(const float4*)(part + (size_t)(c + 16) * wsize + e);
+      const float4 v2 = *(const float4*)(part + (size_t)(c + 32) * wsize + e);
+      const float4 v3 = *(const float4*)(part + (size_t)(c + 48) * wsize + e);
+      t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w; t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
+      t2.x += v2.x; t2.y += v2.y; t2.z += v2.z; t2.w += v2.w; t3.x += v3.x; t3.y += v3.y; t3.z += v3.z; t3.w += v3.w;
+    }
+    for (; c < splits; c += 16) {
+      const float4 v = *(const float4*)(part + (size_t)c * wsize + e);
+      t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
+    }
+  }
+  sm[threadIdx.x] = make_float4((t0.x + t1.x) + (t2.x + t3.x), (t0.y + t1.y) + (t2.y + t3.y), (t0.z + t1.z) + (t2.z + t3.z),
+                                (t0.w + t1.w) + (t2.w + t3.w));
   __syncthreads();
   if (sl == 0 && e < wsize) {
-    float t = 0.f;
-    for (int l = 0; l < 16; ++l) t += sm[l * 16 + col];
-    out[e] = t;
+    float4 t = sm[col];
+    for (int l = 1; l < 16; ++l) { const float4 v = sm[l * 16 + col]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    *(float4*)(out + e) = t;
   }
 }
 
@@ -264,7 +280,7 @@ int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* works
   else if (cot == 2) conv1x1_wgrad<1, 2><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
   else conv1x1_wgrad<1, 1><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
   const int wsize = Cin * Cout;
-  sum_parts<<<(wsize + 15) / 16, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  sum_parts<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
