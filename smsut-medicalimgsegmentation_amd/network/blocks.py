@@ -180,10 +180,14 @@ class BottleBlock(nn.Module):
         y = self.bn1(self.conv1(x, stats=True), slope=s)
         if self.stride == 2:
             y = ops.avg_pool2(y)
-        y = self.bn2(self.conv2(y, stats=True))
+        y2 = self.conv2(y, stats=True)
         if self.downsample is not None:
-            idn = self.downsample[1](self.downsample[0](idn, stats=True))
-        return ops.add_act(y, idn, s)
+            sc = self.downsample[0](idn, stats=True)
+            if ops.res_tail_fusable(y2, sc):          # first-order passes: IN2 + IN(shortcut) + add + act in one kernel
+                return ops.res_tail(y2, self.bn2.weight, self.bn2.bias, sc, self.downsample[1].weight,
+                                    self.downsample[1].bias, s)
+            idn = self.downsample[1](sc)
+        return ops.add_act(self.bn2(y2), idn, s)
 
 
 class Encoder(nn.Module):

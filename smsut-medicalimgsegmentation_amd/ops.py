@@ -44,6 +44,26 @@ def input_grads_only():
         _INPUT_GRADS_ONLY = prev
 
 
+_FIRST_ORDER = False
+
+
+@contextlib.contextmanager
+def first_order_pass():
+    """Forward passes inside this context are differentiated at most ONCE, so modules may use the first-order-only fused
+    forms (``res_tail`` in BottleBlock).  The default stays closed under differentiation: the discriminator's x_hat pass of
+    WGAN-GP (``autograd.grad(..., create_graph=True)``, reference uganShp0Trainer.py:127-134) must not take them."""
+    global _FIRST_ORDER
+    prev, _FIRST_ORDER = _FIRST_ORDER, True
+    try:
+        yield
+    finally:
+        _FIRST_ORDER = prev
+
+
+def first_order_only():
+    return _FIRST_ORDER
+
+
 # ------------------------------------------------------------------------------------------- layout helpers
 def nhwc(x: torch.Tensor) -> torch.Tensor:
     """Return ``x`` (logical NCHW, fp32) with dense NHWC memory."""
@@ -452,9 +472,68 @@ def instnorm_act(x, gamma, beta, slope: Optional[float]):
     return y
 
 
+# ------------------------------------------------------------------------------------------- residual tail
+class ResTailFn(Function):
+    """out = act(IN(y2; g2, b2) + IN(s; gs, bs))  -- the tail of BasicBlock / BottleBlock (network/blocks.py:74-79, 110-116)
+    as ONE pass forward (plus the statistics finalisation) and one reduce + one apply pass backward, instead of two
+    normalise kernels, an add and their separate backwards.  First-order only.  y2 / s may carry the statistics partials
+    of the conv epilogue that produced them (``_smsut_in_partials``)."""
+
+    @staticmethod
+    def forward(ctx, y2, g2, b2, s, gs, bs, slope):
+        y2, s = nhwc(y2), nhwc(s)
+        n, c, h, w = y2.shape
+        hw = h * w
+        st = _s()
+
+        def stats(t):
+            m = torch.empty(n, c, dtype=torch.float32, device=t.device)
+            r = torch.empty_like(m)
+            part, tiles = t._smsut_in_partials            # res_tail_fusable() checked that both inputs carry them
+            del t._smsut_in_partials
+            H.call("smsut_in_finalize_fwd", part, tiles, m, r, n, hw, c, IN_EPS, st)
+            return m, r
+        m2, r2 = stats(y2)
+        ms, rs = stats(s)
+        out = new_act(n, c, h, w, y2)
+        H.call("smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, c, float(slope), st)
+        ctx.save_for_backward(y2, s, out, m2, r2, ms, rs, g2, gs)
+        ctx.slope = float(slope)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g_out):
+        y2, s, out, m2, r2, ms, rs, g2, gs = ctx.saved_tensors
+        g_out = nhwc(g_out)
+        n, c, h, w = y2.shape
+        hw = h * w
+        dev = y2.device
+        vec = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
+        gy2, gs_t = new_act(n, c, h, w, y2), new_act(n, c, h, w, y2)
+        a_t, b2_t, bs_t = vec(n, c), vec(n, c), vec(n, c)
+        gg2, gb2, ggs, gbs = vec(c), vec(c), vec(c), vec(c)
+        chunks = H.call("smsut_in_chunks", n, hw, c)
+        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, s, ms, rs, gs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2, ggs, gbs,
+               _ws(n * chunks * c * 3, y2), n, hw, c, ctx.slope, _s())
+        return gy2, gg2, gb2, gs_t, ggs, gbs, None
+
+
+def res_tail_fusable(y2, s):
+    """Both raw conv outputs come with their statistics partials (MFMA / streaming 1x1 conv epilogues) and the pass will
+    be differentiated at most once."""
+    return (FUSED_BLOCK and FUSED_RES_TAIL and first_order_only() and hasattr(y2, "_smsut_in_partials") and hasattr(s, "_smsut_in_partials")
+            and y2.shape == s.shape)
+
+
+def res_tail(y2, g2, b2, s, gs, bs, slope):
+    return ResTailFn.apply(y2, g2, b2, s, gs, bs, slope)
+
+
 # ------------------------------------------------------------------------------------------- fused BasicBlock
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
+FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
 
 

@@ -72,12 +72,13 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def _d_phase(self, x_real, x_fake, modal_org, alpha):
         """D-step forward + backward (:129-144).  Returns [D_real, D_fake, D_cls, D_gp]."""
         b = x_real.size(0)
-        out_src, out_cls = self.D(torch.cat([x_real, x_fake], 0))
+        with ops.first_order_pass():
+            out_src, out_cls = self.D(torch.cat([x_real, x_fake], 0))
         d_real = ops.mean_all(out_src[:b], -1.0)
         d_cls = ops.cross_entropy_rows(out_cls[:b], modal_org)
         d_fake = ops.mean_all(out_src[b:], 1.0)
         x_hat = ops.row_lerp(x_real, x_fake, alpha).requires_grad_(True)
-        out_src, _ = self.D(x_hat)
+        out_src, _ = self.D(x_hat)                  # differentiated twice (gradient penalty): default op families
         d_gp = self.gradient_penalty(out_src, x_hat)
         d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
         d_loss.backward()
@@ -91,7 +92,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
         Returns [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]."""
         bs = y_real.size(0)
         y_fake, x_fake, feat_x = self._g1
-        out_src, out_cls = self.D(x_fake)
+        with ops.first_order_pass():
+            out_src, out_cls = self.D(x_fake)
         g_fake = ops.mean_all(out_src, -1.0)
         g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
         g_seg = self.loss(y_fake[:bs], y_real)

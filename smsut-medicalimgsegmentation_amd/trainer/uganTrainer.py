@@ -57,12 +57,13 @@ class UGANTrainer(UGANShp0Trainer):
         y_fake, x_fake = self.net(x_real, vec_ot)
 
         # ---- D-step (:155-174)
-        out_src, out_cls = self.D(torch.cat([x_real, x_fake.detach()], 0))
+        with ops.first_order_pass():
+            out_src, out_cls = self.D(torch.cat([x_real, x_fake.detach()], 0))
         d_real = ops.mean_all(out_src[:b], -1.0)
         d_cls = ops.cross_entropy_rows(out_cls[:b], modal_org)
         d_fake = ops.mean_all(out_src[b:], 1.0)
         x_hat = ops.row_lerp(x_real, x_fake.detach(), alpha).requires_grad_(True)
-        out_src, _ = self.D(x_hat)
+        out_src, _ = self.D(x_hat)                  # differentiated twice (gradient penalty): default op families
         d_gp = self.gradient_penalty(out_src, x_hat)
         d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
         self.d_optimizer.zero_grad(set_to_none=True)
@@ -73,7 +74,8 @@ class UGANTrainer(UGANShp0Trainer):
         # ---- G-step (:178-198), D frozen
         for p in d_params:
             p.requires_grad_(False)
-        out_src, out_cls = self.D(x_fake)
+        with ops.first_order_pass():
+            out_src, out_cls = self.D(x_fake)
         g_fake = ops.mean_all(out_src, -1.0)
         g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
         g_seg = self.loss(y_fake, y_real)

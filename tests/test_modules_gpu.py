@@ -197,6 +197,41 @@ def test_discriminator_and_gradient_penalty(pkg, golden):
             assert l2_rel(grads[k[6:]].grad.cpu().numpy(), g[k]) < 5e-3, k
 
 
+def test_discriminator_first_order_pass_matches_default(pkg, golden):
+    """BottleBlock's fused residual tail (ops.first_order_pass) against the default op families: same outputs and
+    parameter gradients; a double backward through a first-order pass must raise rather than return wrong numbers."""
+    from smsut_amd.network.ugan import Discriminator
+    from smsut_amd import ops
+    g = golden("disc_small")
+    B, S, nm, w, mw = (int(g[k]) for k in ("B", "S", "nm", "w", "mw"))
+    D = Discriminator(S, nm, w, max_width=mw)
+    D.load_state_dict(recipe.fill(recipe.disc_shapes(S, nm, w, mw), int(g["seed"])))
+    D.cuda().train()
+    x = torch.from_numpy(g["x"]).cuda()
+    out = {}
+    for fused in (False, True):
+        D.zero_grad(set_to_none=True)
+        xin = x.clone().requires_grad_(True)
+        if fused:
+            with ops.first_order_pass():
+                src, cls = D(xin)
+        else:
+            src, cls = D(xin)
+        (src.square().mean() + cls.square().mean()).backward()
+        out[fused] = (src.detach(), cls.detach(), xin.grad.clone(), {n: p.grad.clone() for n, p in D.named_parameters()})
+    assert rel_err(out[True][0].cpu().numpy(), g["out_src"]) < TOL
+    for a, b in zip(out[True][:3], out[False][:3]):
+        assert l2_rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+    for n in out[False][3]:
+        assert l2_rel(out[True][3][n].cpu().numpy(), out[False][3][n].cpu().numpy()) < 1e-3, n
+    xin = x.clone().requires_grad_(True)
+    with ops.first_order_pass():
+        src, _ = D(xin)
+    with pytest.raises(RuntimeError):
+        (dydx,) = torch.autograd.grad(src, xin, torch.ones_like(src), create_graph=True)
+        dydx.square().sum().backward()
+
+
 def test_ugannce_forward(pkg, golden):
     from smsut_amd.network.ugan import UGANnce
     g = golden("ugan_small")
