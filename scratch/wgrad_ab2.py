@@ -1,6 +1,6 @@
 """In-process A/B of two builds of the library on the 3x3 weight gradient (interleaved timing)."""
 import ctypes, sys, torch
-libs = {name: ctypes.CDLL(path) for name, path in (("A", sys.argv[1]), ("B", sys.argv[2]))}
+libs = {chr(65 + i): ctypes.CDLL(path) for i, path in enumerate(sys.argv[1:])}
 for l in libs.values():
     l.smsut_conv2d_wgrad_mfma_ws.restype = ctypes.c_int64
 P = lambda t: ctypes.c_void_p(t.data_ptr())

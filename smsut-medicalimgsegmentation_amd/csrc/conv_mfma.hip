@@ -664,6 +664,13 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
 // row-split kernel above (each wave 1/4 of the rows, all 36 tiles = 144 accumulator registers, one wave per SIMD,
 // three LDS combine rounds at the end) this needs 36 accumulator registers, keeps two workgroups per CU resident and
 // has no cross-wave combine: each wave stores its own tiles.  PMC r01 (64->64 @64^2): row-split 46 % MFMA busy.
+#ifdef WTS_F4
+typedef float4 wvec;
+#define WZERO make_float4(0.f, 0.f, 0.f, 0.f)
+#else
+typedef f32x4 wvec;
+#define WZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
+#endif
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                    int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split) {
@@ -704,7 +711,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   constexpr int NIN = (UIN + TPB - 1) / TPB;
   constexpr int NGY = (WTH * TW * (CO_T / 4) + TPB - 1) / TPB;
   static_assert(WTH * TW * (CO_T / 4) % TPB == 0, "gy tile units divide evenly");
-  float4 rin[NIN], rgy[NGY];
+  wvec rin[NIN], rgy[NGY];     // ext-vector values (HIP's float4 struct kept rgy in scratch memory)
   int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
@@ -735,10 +742,10 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       zero[i] = (in_flag[i] & flags) != 0;
-      rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : in_off[i]));
+      rin[i] = *(const wvec*)(xb + (zero[i] ? safe_off : in_off[i]));
     }
 #pragma unroll
-    for (int i = 0; i < NGY; ++i) rgy[i] = *(const float4*)(gb + gy_off[i]);
+    for (int i = 0; i < NGY; ++i) rgy[i] = *(const wvec*)(gb + gy_off[i]);
     if (++ptx == tiles_x) { ptx = 0; if (++pty == tiles_y) { pty = 0; ++pn; } }
   };
 
@@ -751,12 +758,12 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     if (t - t_begin < 2) { STAMP(2 + 4 * (t - t_begin)); }
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
-      float4 v = rin[i];
-      if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *(float4*)(in_s + in_lds[i]) = v;
+      wvec v = rin[i];
+      if (zero[i]) v = WZERO;
+      *(wvec*)(in_s + in_lds[i]) = v;
     }
 #pragma unroll
-    for (int i = 0; i < NGY; ++i) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
+    for (int i = 0; i < NGY; ++i) *(wvec*)(gy_s + gy_lds[i]) = rgy[i];
     __syncthreads();
     if (t - t_begin < 2) { STAMP(3 + 4 * (t - t_begin)); }
     if (t + 1 < t_end) prefetch();
@@ -785,13 +792,21 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     const int tap = ti >> 1, i = ti & 1;
     float* o = out + (tap * Cin + i * 16) * Cout;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r * Cout] = acc[k][r];
+    for (int r = 0; r < 4; ++r) {
+#ifdef WTS_NT_STORE
+      __builtin_nontemporal_store(acc[k][r], o + r * Cout);
+#else
+      o[r * Cout] = acc[k][r];
+#endif
+    }
   }
   STAMP(11);
 }
 
 // out[e] = sum_c part[c][e].  COLS float4 columns x (256/COLS) split-lanes per block: each thread strides over the
 // splits with 4 independent accumulators (loads in flight), then a fixed-order LDS tree over the lanes (deterministic).
+// wsize % 4 == 0 (checked at launch): every access is one aligned float4.  (A scalar tail path that indexed the float4
+// accumulator dynamically made the compiler move it to LDS -- 12 KB per block and a 4x slower kernel.)
 template <int COLS>
 __global__ void __launch_bounds__(TPB)
 sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, int splits) {
@@ -799,32 +814,27 @@ sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, i
   __shared__ float4 sm[TPB];
   const int col = threadIdx.x % COLS, sl = threadIdx.x / COLS;
   const int e = (blockIdx.x * COLS + col) * 4;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (e + 3 < wsize) {
-    float4 t0 = s, t1 = s, t2 = s, t3 = s;
+  float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), t1 = t0, t2 = t0, t3 = t0;
+  if (e < wsize) {
+    const float* p = part + e;
     int c = sl;
     for (; c + 3 * LANES < splits; c += 4 * LANES) {
-      const float4 v0 = *(const float4*)(part + (size_t)c * wsize + e);
-      const float4 v1 = *(const float4*)(part + (size_t)(c + LANES) * wsize + e);
-      const float4 v2 = *(const float4*)(part + (size_t)(c + 2 * LANES) * wsize + e);
-      const float4 v3 = *(const float4*)(part + (size_t)(c + 3 * LANES) * wsize + e);
+      const float4 v0 = *(const float4*)(p + (size_t)c * wsize);
+      const float4 v1 = *(const float4*)(p + (size_t)(c + LANES) * wsize);
+      const float4 v2 = *(const float4*)(p + (size_t)(c + 2 * LANES) * wsize);
+      const float4 v3 = *(const float4*)(p + (size_t)(c + 3 * LANES) * wsize);
       t0.x += v0.x; t0.y += v0.y; t0.z += v0.z; t0.w += v0.w;
       t1.x += v1.x; t1.y += v1.y; t1.z += v1.z; t1.w += v1.w;
       t2.x += v2.x; t2.y += v2.y; t2.z += v2.z; t2.w += v2.w;
       t3.x += v3.x; t3.y += v3.y; t3.z += v3.z; t3.w += v3.w;
     }
     for (; c < splits; c += LANES) {
-      const float4 v = *(const float4*)(part + (size_t)c * wsize + e);
+      const float4 v = *(const float4*)(p + (size_t)c * wsize);
       t0.x += v.x; t0.y += v.y; t0.z += v.z; t0.w += v.w;
     }
-    s.x = (t0.x + t1.x) + (t2.x + t3.x); s.y = (t0.y + t1.y) + (t2.y + t3.y);
-    s.z = (t0.z + t1.z) + (t2.z + t3.z); s.w = (t0.w + t1.w) + (t2.w + t3.w);
-  } else if (e < wsize) {
-    float* sp = (float*)&s;
-    for (int c = sl; c < splits; c += LANES)
-      for (int k = 0; k < wsize - e; ++k) sp[k] += part[(size_t)c * wsize + e + k];
   }
-  sm[threadIdx.x] = s;
+  sm[threadIdx.x] = make_float4((t0.x + t1.x) + (t2.x + t3.x), (t0.y + t1.y) + (t2.y + t3.y),
+                                (t0.z + t1.z) + (t2.z + t3.z), (t0.w + t1.w) + (t2.w + t3.w));
   __syncthreads();
   if (sl == 0 && e < wsize) {
     float4 t = sm[col];
@@ -832,17 +842,20 @@ sum_splits(const float* __restrict__ part, float* __restrict__ out, int wsize, i
       const float4 v = sm[l * COLS + col];
       t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
     }
-    if (e + 3 < wsize) *(float4*)(out + e) = t;
-    else for (int k = 0; k < wsize - e; ++k) out[e + k] = ((float*)&t)[k];
+    *(float4*)(out + e) = t;
   }
 }
 
-inline void launch_sum_splits(const float* part, float* out, int wsize, int splits, hipStream_t st) {
+inline void launch_sum_splits(const float* part, float* out, int wsize, int splits, hipStream_t st,
+                              [[maybe_unused]] bool dbg_force = false) {
   // COLS float4 columns (COLS*16 contiguous bytes per split row) x 256/COLS split-lanes per block, ~100-150 blocks:
   // in-process A/B on the layer shapes (scratch/wgrad_ab2.py) -- 4 columns x 64 lanes (the earlier choice for >= 128
   // splits) made the whole weight-gradient call 10-24 % slower at 256^2 / 128^2; 32 / 64 columns win from 32x32 / 64x64
   // weights on (longer contiguous rows per request).
   (void)splits;
+#ifdef WTS_SKIP_SUM
+  if (!dbg_force) return;
+#endif
   if (wsize >= 32768) sum_splits<64><<<(wsize + 255) / 256, TPB, 0, st>>>(part, out, wsize, splits);
   else if (wsize >= 8192) sum_splits<32><<<(wsize + 127) / 128, TPB, 0, st>>>(part, out, wsize, splits);
   else sum_splits<16><<<(wsize + 63) / 64, TPB, 0, st>>>(part, out, wsize, splits);
@@ -1062,6 +1075,12 @@ extern "C" {
 int smsut_dbg_set_stamps(void* buf, int base) {
   hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_base), &base, sizeof(base));
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf));
+}
+#endif
+#ifdef SMSUT_DBG_SUM   // scratch/ diagnostic builds only: the split-slab reduction as its own call
+int smsut_dbg_sum_splits(const float* part, float* out, int wsize, int splits, void* stream) {
+  launch_sum_splits(part, out, wsize, splits, (hipStream_t)stream, true);
+  return 0;
 }
 #endif
 
