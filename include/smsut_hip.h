@@ -127,8 +127,8 @@ int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const f
                       const float* ms /*nullable: identity*/, const float* rs, const float* gs, const float* bs, float* out,
                       int N, int HW, int C, float slope, void* stream);
 int smsut_restail_bwd(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
-                      const float* g2, const float* s, const float* ms /*nullable*/, const float* rs, const float* gs_,
-                      float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
+                      const float* g2, const float* b2 /*nullable*/, const float* s, const float* ms /*nullable*/,
+                      const float* rs, const float* gs_, const float* bs /*nullable*/, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
                       float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, int N, int HW, int C,
                       float slope, void* stream);
 int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta /*nullable: no activation*/, const float* mean,

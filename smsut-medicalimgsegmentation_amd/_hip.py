@@ -25,7 +25,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_in_finalize_bwd": "p i pp iii s",
     "smsut_in_apply_bwd": "pppppppp pp iii s",
     "smsut_restail_fwd": "pppppppppp p iii f s",
-    "smsut_restail_bwd": "pppppppppp pp ppp pppp p iii f s",
+    "smsut_restail_bwd": "pppppppppppp pp ppp pppp p iii f s",
     "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
     "smsut_instnorm_bwd2": "ppppppppppp ppp pp iii f s",
     # conv_naive.hip

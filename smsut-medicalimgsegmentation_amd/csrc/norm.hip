@@ -27,7 +27,7 @@ constexpr int TPB = 256;
 template <int MODE> struct NSums { static constexpr int n = (MODE == 2) ? 3 : 2; };
 
 template <int MODE, int VEC>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, 4)   // <= 128 VGPRs: 4 waves per SIMD (it sat at 172 = 2 waves)
 in_moments_partial(const float* __restrict__ t0,   // x | gy | v
                    const float* __restrict__ t1,   // - | x  | x
                    const float* __restrict__ t2,   // - | -  | gy
@@ -63,9 +63,11 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
       bt[j] = (MODE == 0 || !cv_ok || !beta) ? 0.f : beta[cv * VEC + j];
     }
     if (trow < rows && cv_ok) {
-      for (int p = p0 + trow; p < p1; p += rows) {
+      // U rows in flight per thread (one float4 per tensor per row): with a single row the loop was load -> wait ->
+      // accumulate, ~2 TB/s.  Rows are accumulated in the same order as before (bit-identical sums).
+      constexpr int U = (MODE == 0) ? 4 : 2;
+      auto load = [&](int p, float* a0, float* a1, float* a2) {
         const size_t off = base + (size_t)p * C + cv * VEC;
-        float a0[VEC], a1[VEC], a2[VEC];
         if constexpr (VEC == 4) {
           *(float4*)a0 = *(const float4*)(t0 + off);
           if (MODE >= 1) *(float4*)a1 = *(const float4*)(t1 + off);
@@ -75,6 +77,8 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
           if (MODE >= 1) a1[0] = t1[off];
           if (MODE == 2) a2[0] = t2[off];
         }
+      };
+      auto accum = [&](const float* a0, const float* a1, const float* a2) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
           if (MODE == 0) {
@@ -93,6 +97,19 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
             acc[NS - 1][j] += a0[j] * gz;
           }
         }
+      };
+      int p = p0 + trow;
+      for (; p + (U - 1) * rows < p1; p += U * rows) {
+        float a0[U][VEC], a1[U][VEC], a2[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) load(p + u * rows, a0[u], a1[u], a2[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) accum(a0[u], a1[u], a2[u]);
+      }
+      for (; p < p1; p += rows) {
+        float a0[VEC], a1[VEC], a2[VEC];
+        load(p, a0, a1, a2);
+        accum(a0, a1, a2);
       }
     }
     __syncthreads();
@@ -352,7 +369,7 @@ restail_fwd(TailRef t, float* __restrict__ out, int64_t total_vec, int HW, int C
 
 // partial [N][chunks][C][3] = {sum gz, sum gz*y2hat, sum gz*shat}
 template <int VEC>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, 4)
 restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
                     int HW, int C, int pix_per_chunk, float slope) {
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
@@ -372,32 +389,53 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int j = 0; j < VEC; ++j) acc[q][j] = 0.f;
-    float m2[VEC], r2[VEC], ms[VEC], rs[VEC];
+    // two-IN tail with both betas given: the activation mask is recomputed from y2 and s exactly as restail_fwd formed
+    // the pre-activation (no read of `out`: 3 tensor reads instead of 4)
+    const bool remask = t.ms && t.b2 && t.bs;
+    float m2[VEC], r2[VEC], ms[VEC], rs[VEC], g2[VEC], b2[VEC], gs[VEC], bs[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const int k = n * C + cv * VEC + j;
+      const int c = cv * VEC + j, k = n * C + c;
       m2[j] = cv_ok ? t.m2[k] : 0.f; r2[j] = cv_ok ? t.r2[k] : 1.f;
       ms[j] = (cv_ok && t.ms) ? t.ms[k] : 0.f; rs[j] = (cv_ok && t.ms) ? t.rs[k] : 1.f;
+      g2[j] = (cv_ok && remask) ? t.g2[c] : 1.f; b2[j] = (cv_ok && remask) ? t.b2[c] : 0.f;
+      gs[j] = (cv_ok && remask) ? t.gs[c] : 1.f; bs[j] = (cv_ok && remask) ? t.bs[c] : 0.f;
     }
     if (trow < rows && cv_ok) {
-      for (int p = p0 + trow; p < p1; p += rows) {
+      auto load = [&](int p, float* g, float* o, float* y, float* sv) {
         const size_t off = base + (size_t)p * C + cv * VEC;
-        float g[VEC], o[VEC], y[VEC], sv[VEC];
         if constexpr (VEC == 4) {
-          *(float4*)g = *(const float4*)(gout + off); *(float4*)o = *(const float4*)(out + off);
+          *(float4*)g = *(const float4*)(gout + off);
+          if (!remask) *(float4*)o = *(const float4*)(out + off);
           *(float4*)y = *(const float4*)(t.y2 + off);
           if (t.ms) *(float4*)sv = *(const float4*)(t.s + off);
         } else {
-          g[0] = gout[off]; o[0] = out[off]; y[0] = t.y2[off];
+          g[0] = gout[off]; y[0] = t.y2[off];
+          if (!remask) o[0] = out[off];
           if (t.ms) sv[0] = t.s[off];
         }
+      };
+      auto accum = [&](const float* g, const float* o, const float* y, const float* sv) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          const float gz = g[j] * lrelu_mask(o[j], slope);
+          const float pre = remask ? in_affine(y[j], m2[j], r2[j], g2[j], b2[j]) + in_affine(sv[j], ms[j], rs[j], gs[j], bs[j])
+                                   : o[j];
+          const float gz = g[j] * lrelu_mask(pre, slope);
           acc[0][j] += gz;
           acc[1][j] += gz * ((y[j] - m2[j]) * r2[j]);
           if (t.ms) acc[2][j] += gz * ((sv[j] - ms[j]) * rs[j]);
         }
+      };
+      int p = p0 + trow;
+      for (; p + rows < p1; p += 2 * rows) {         // two rows (8 float4 loads) in flight, accumulated in row order
+        float g[2][VEC], o[2][VEC], y[2][VEC], sv[2][VEC];
+        load(p, g[0], o[0], y[0], sv[0]); load(p + rows, g[1], o[1], y[1], sv[1]);
+        accum(g[0], o[0], y[0], sv[0]); accum(g[1], o[1], y[1], sv[1]);
+      }
+      for (; p < p1; p += rows) {
+        float g[VEC], o[VEC], y[VEC], sv[VEC];
+        load(p, g, o, y, sv);
+        accum(g, o, y, sv);
       }
     }
     __syncthreads();
@@ -455,6 +493,7 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
                   float* __restrict__ gs, int64_t total_vec, int HW, int C, float slope, int N, float* __restrict__ gg2,
                   float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs) {
   const int CV = C / VEC;
+  const bool remask = t.ms && t.b2 && t.bs;   // see restail_bwd_partial
   if (blockIdx.x == 0) {   // affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (both norms), ggs = sum_n M*bs
     for (int c = threadIdx.x; c < C; c += TPB) {
       double sa = 0.0, s2 = 0.0, ss = 0.0;
@@ -468,20 +507,25 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
     const int n = (int)(i / ((int64_t)CV * HW));
     float g[VEC], o[VEC], y[VEC], sv[VEC], o1[VEC], o2[VEC];
     if constexpr (VEC == 4) {
-      *(float4*)g = *(const float4*)(gout + i * 4); *(float4*)o = *(const float4*)(out + i * 4);
+      *(float4*)g = *(const float4*)(gout + i * 4);
+      if (!remask) *(float4*)o = *(const float4*)(out + i * 4);
       *(float4*)y = *(const float4*)(t.y2 + i * 4);
       if (t.ms) *(float4*)sv = *(const float4*)(t.s + i * 4);
     } else {
-      g[0] = gout[i]; o[0] = out[i]; y[0] = t.y2[i];
+      g[0] = gout[i]; y[0] = t.y2[i];
+      if (!remask) o[0] = out[i];
       if (t.ms) sv[0] = t.s[i];
     }
-    float av[VEC], b2v[VEC], bsv[VEC], m2[VEC], r2[VEC], g2[VEC], msv[VEC], rsv[VEC], gsv[VEC];
+    float av[VEC], b2v[VEC], bsv[VEC], m2[VEC], r2[VEC], g2[VEC], msv[VEC], rsv[VEC], gsv[VEC], be2[VEC], bes[VEC];
     const int c0 = cv * VEC, k0 = n * C + c0;
     ldv<VEC>(am, k0, av); ldv<VEC>(b2m, k0, b2v); ldv<VEC>(t.m2, k0, m2); ldv<VEC>(t.r2, k0, r2); ldv<VEC>(t.g2, c0, g2);
     if (t.ms) { ldv<VEC>(bsm, k0, bsv); ldv<VEC>(t.ms, k0, msv); ldv<VEC>(t.rs, k0, rsv); ldv<VEC>(t.gs, c0, gsv); }
+    if (remask) { ldv<VEC>(t.b2, c0, be2); ldv<VEC>(t.bs, c0, bes); }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      const float gz = g[j] * lrelu_mask(o[j], slope);
+      const float pre = remask ? in_affine(y[j], m2[j], r2[j], g2[j], be2[j]) + in_affine(sv[j], msv[j], rsv[j], gsv[j], bes[j])
+                               : o[j];
+      const float gz = g[j] * lrelu_mask(pre, slope);
       const float a = av[j];
       o1[j] = g2[j] * r2[j] * (gz - a - ((y[j] - m2[j]) * r2[j]) * b2v[j]);
       o2[j] = t.ms ? gsv[j] * rsv[j] * (gz - a - ((sv[j] - msv[j]) * rsv[j]) * bsv[j]) : gz;
@@ -657,15 +701,17 @@ int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const f
 }
 
 // Backward of the tail.  workspace: float[N * smsut_in_chunks(N,HW,C) * C * 3]; a/b2/bs: [N,C] scratch outputs;
+// b2 / bs (the two IN betas, nullable): with ms and both betas the activation mask is recomputed from y2 and s and `out`
+// is not read (8 tensor passes instead of 10); otherwise the mask is the sign of `out`.
 // gy2, gs: gradients w.r.t. the two raw conv outputs (gs = gradient of the identity when ms == null);
 // gg2/gb2/ggs/gbs: affine gradients (ggs/gbs nullable when ms == null).
 int smsut_restail_bwd(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
-                      const float* g2, const float* s, const float* ms, const float* rs, const float* gs_, float* gy2,
-                      float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
+                      const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
+                      const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
                       float* gbs, float* workspace, int N, int HW, int C, float slope, void* stream) {
   SMSUT_REQUIRE(gout && out && y2 && m2 && r2 && g2 && s && gy2 && gs && a_mean && b2_mean && bs_mean && gg2 && gb2 &&
                 workspace && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs_ && ggs && gbs)));
-  TailRef t{y2, m2, r2, g2, nullptr, s, ms, rs, gs_, nullptr};
+  TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs_, bs};
   hipStream_t st = (hipStream_t)stream;
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);

@@ -497,14 +497,16 @@ class ResTailFn(Function):
         ms, rs = stats(s)
         out = new_act(n, c, h, w, y2)
         H.call("smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, c, float(slope), st)
-        ctx.save_for_backward(y2, s, out, m2, r2, ms, rs, g2, gs)
+        ctx.save_for_backward(y2, s, out, m2, r2, ms, rs, g2, gs, b2, bs)
         ctx.slope = float(slope)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_out):
-        y2, s, out, m2, r2, ms, rs, g2, gs = ctx.saved_tensors
+        y2, s, out, m2, r2, ms, rs, g2, gs, b2, bs = ctx.saved_tensors
+        if not REMASK_TAIL:
+            b2 = bs = None
         g_out = nhwc(g_out)
         n, c, h, w = y2.shape
         hw = h * w
@@ -514,8 +516,8 @@ class ResTailFn(Function):
         a_t, b2_t, bs_t = vec(n, c), vec(n, c), vec(n, c)
         gg2, gb2, ggs, gbs = vec(c), vec(c), vec(c), vec(c)
         chunks = H.call("smsut_in_chunks", n, hw, c)
-        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, s, ms, rs, gs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2, ggs, gbs,
-               _ws(n * chunks * c * 3, y2), n, hw, c, ctx.slope, _s())
+        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
+               ggs, gbs, _ws(n * chunks * c * 3, y2), n, hw, c, ctx.slope, _s())
         return gy2, gg2, gb2, gs_t, ggs, gbs, None
 
 
@@ -534,6 +536,7 @@ def res_tail(y2, g2, b2, s, gs, bs, slope):
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
+REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
 
 
@@ -602,7 +605,7 @@ class BasicBlockFn(Function):
         ctx.has_sc = has_sc
         ctx.slope = slope
         if has_sc:
-            ctx.save_for_backward(x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs)
+            ctx.save_for_backward(x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs)
         else:
             ctx.save_for_backward(x, w1, w2, y1, a1, y2, out, m1, r1, m2, r2, g1, b1, g2)
         return out
@@ -611,10 +614,12 @@ class BasicBlockFn(Function):
     @once_differentiable
     def backward(ctx, g_out):
         if ctx.has_sc:
-            x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs = ctx.saved_tensors
+            x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs = ctx.saved_tensors
+            if not REMASK_TAIL:
+                b2 = bs = None
         else:
             x, w1, w2, y1, a1, y2, out, m1, r1, m2, r2, g1, b1, g2 = ctx.saved_tensors
-            ws = ms = rs = gs = None
+            ws = ms = rs = gs = b2 = bs = None
             s = x
         slope = ctx.slope
         g_out = nhwc(g_out)
@@ -633,8 +638,8 @@ class BasicBlockFn(Function):
         a_t, b2_t, bs_t = vec(n, co), vec(n, co), vec(n, co)
         gg2, gb2 = vec(co), vec(co)
         ggs, gbs = (vec(co), vec(co)) if ctx.has_sc else (None, None)
-        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, s, ms, rs, gs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2, ggs, gbs,
-               _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
+        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
+               ggs, gbs, _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
         # (forking the three weight-gradient launches to a second stream inside this node was measured 1-3 % SLOWER
         #  than the single-stream order below -- profiles/r01_notes.md)
         # ---- conv2 data-gradient + IN1 / LeakyReLU backward (mask recomputed from y1)
