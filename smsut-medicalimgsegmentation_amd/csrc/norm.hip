@@ -368,8 +368,8 @@ restail_fwd(TailRef t, float* __restrict__ out, int64_t total_vec, int HW, int C
 }
 
 // partial [N][chunks][C][3] = {sum gz, sum gz*y2hat, sum gz*shat}
-template <int VEC>
-__global__ void __launch_bounds__(TPB, 4)
+template <int VEC, bool REMASK>
+__global__ void __launch_bounds__(TPB)       // (a 128-VGPR cap spills here: 244 B scratch and +30 % time)
 restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
                     int HW, int C, int pix_per_chunk, float slope) {
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
@@ -391,7 +391,7 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
       for (int j = 0; j < VEC; ++j) acc[q][j] = 0.f;
     // two-IN tail with both betas given: the activation mask is recomputed from y2 and s exactly as restail_fwd formed
     // the pre-activation (no read of `out`: 3 tensor reads instead of 4)
-    const bool remask = t.ms && t.b2 && t.bs;
+    constexpr bool remask = REMASK;      // host: t.ms && t.b2 && t.bs
     float m2[VEC], r2[VEC], ms[VEC], rs[VEC], g2[VEC], b2[VEC], gs[VEC], bs[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -486,14 +486,14 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
   }
 }
 
-template <int VEC>
+template <int VEC, bool REMASK>
 __global__ void __launch_bounds__(TPB)
 restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
                   const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
                   float* __restrict__ gs, int64_t total_vec, int HW, int C, float slope, int N, float* __restrict__ gg2,
                   float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs) {
   const int CV = C / VEC;
-  const bool remask = t.ms && t.b2 && t.bs;   // see restail_bwd_partial
+  constexpr bool remask = REMASK;             // see restail_bwd_partial
   if (blockIdx.x == 0) {   // affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (both norms), ggs = sum_n M*bs
     for (int c = threadIdx.x; c < C; c += TPB) {
       double sa = 0.0, s2 = 0.0, ss = 0.0;
@@ -716,17 +716,20 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);
   dim3 g(chunks, N);
-  if (C % 4 == 0) restail_bwd_partial<4><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope);
-  else restail_bwd_partial<1><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope);
+  const bool remask = ms && b2 && bs;
+#define TAIL_PARTIAL(V, R) restail_bwd_partial<V, R><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope)
+  if (C % 4 == 0) { if (remask) TAIL_PARTIAL(4, true); else TAIL_PARTIAL(4, false); }
+  else { if (remask) TAIL_PARTIAL(1, true); else TAIL_PARTIAL(1, false); }
+#undef TAIL_PARTIAL
   in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
   // the affine gradients (and the copy gbs = gb2) are written by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
-  if (C % 4 == 0)
-    restail_bwd_apply<4><<<ew_grid(total / 4), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total / 4, HW, C, slope,
-                                                             N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr);
-  else
-    restail_bwd_apply<1><<<ew_grid(total), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total, HW, C, slope,
-                                                         N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr);
+#define TAIL_APPLY(V, R)                                                                                                \
+  restail_bwd_apply<V, R><<<ew_grid(total / V), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total / V, HW, C, \
+                                                              slope, N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr)
+  if (C % 4 == 0) { if (remask) TAIL_APPLY(4, true); else TAIL_APPLY(4, false); }
+  else { if (remask) TAIL_APPLY(1, true); else TAIL_APPLY(1, false); }
+#undef TAIL_APPLY
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
