@@ -78,6 +78,14 @@ int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout);
 int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
                         void* stream);
 
+/* thin 1x1 layers (Cout <= 8, Cin in {8,16,32,64}; reference: the nn.Conv2d heads at network/blocks.py:123-125 and
+   network/ugan.py:70): data-gradient gx[P][Cin] = gy[P][Cout] W^T and weight-gradient gw[Cin][Cout], both streaming. */
+int smsut_conv1x1_thin_supported(int Cin, int Cout);
+int smsut_conv1x1_thin_dgrad(const float* gy, const float* w, float* gx, int N, int HW, int Cin, int Cout, void* stream);
+int64_t smsut_conv1x1_thin_wgrad_ws(int Cin);
+int smsut_conv1x1_thin_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin,
+                             int Cout, void* stream);
+
 /* Tiny-channel convolutions (HBM-bound): 5x5 stems (blocks.py:123, ugan.py:26), D's k4 s2 stem (ugan.py:202), 1x1 heads
  * (blocks.py:166, ugan.py:70).  fwd/dgrad: direct, Cin <= 8, Cout in {4,8,12,16}; wgrad: MFMA with the flattened
  * (tap, ci) index as M, KS*KS*Cin <= 128, Cout <= 16. */

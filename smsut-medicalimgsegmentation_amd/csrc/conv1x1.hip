@@ -225,6 +225,109 @@ inline Plan1 plan_wgrad1(int64_t P, int Cin, int Cout, int cit, int cot) {
   return p;
 }
 
+
+// ---- "thin" 1x1 layers: <= 8 output channels (decoder.fc 16 -> n_label+1, the translator's 16 -> 1 head;
+// network/blocks.py:123-125, ugan.py:70).  Their data- and weight-gradients are pure streaming problems (16 -> 5 at
+// 32x256^2: 176 MB, 0.3 GFLOP) that the generic direct kernels ran at ~1.1 / 1.5 TB/s.  One work item = (pixel, 4
+// consecutive wide channels): the wide tensor moves as perfectly coalesced float4s, the thin tensor's <= 8 values per
+// pixel are shared by CI/4 neighbouring lanes, the weights sit in LDS as [8][CI] (zero beyond Cout).
+constexpr int THIN_MAX = 8;
+
+template <int CI>
+__global__ void __launch_bounds__(TPB)
+thin1x1_dgrad(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int64_t P, int CO) {
+  constexpr int Q = CI / 4;
+  __shared__ float wt[THIN_MAX * CI];                    // wt[k][ci] = w[ci][k]
+  for (int u = threadIdx.x; u < THIN_MAX * CI; u += TPB) {
+    const int k = u / CI, ci = u % CI;
+    wt[u] = k < CO ? w[ci * CO + k] : 0.f;
+  }
+  __syncthreads();
+  const int64_t total = P * Q;
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (int64_t)gridDim.x * TPB) {
+    const int c4 = (int)(i % Q);
+    const int64_t px = i / Q;
+    float g[THIN_MAX];
+#pragma unroll
+    for (int k = 0; k < THIN_MAX; ++k) g[k] = k < CO ? gy[px * CO + k] : 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < THIN_MAX; ++k) o += g[k] * *(const f32x4*)(wt + k * CI + c4 * 4);
+    *(f32x4*)(gx + i * 4) = o;
+  }
+}
+
+// partial[b][ci][8] = sum over the block's pixels of x[p][ci] * gy[p][k]
+template <int CI>
+__global__ void __launch_bounds__(TPB)
+thin1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int64_t P, int CO) {
+  constexpr int Q = CI / 4;
+  static_assert(Q <= 64 && (Q & (Q - 1)) == 0, "lanes sharing a channel group sit Q apart inside a wave");
+  __shared__ float sm[4 * Q * 4 * THIN_MAX];
+  f32x4 acc[THIN_MAX];
+#pragma unroll
+  for (int k = 0; k < THIN_MAX; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int64_t total = P * Q;
+  const int64_t stride = (int64_t)gridDim.x * TPB;       // multiple of Q: a thread keeps its channel group
+  auto step = [&](int64_t i) {
+    const int64_t px = i / Q;
+    const f32x4 xv = *(const f32x4*)(x + i * 4);
+#pragma unroll
+    for (int k = 0; k < THIN_MAX; ++k) {
+      const float g = k < CO ? gy[px * CO + k] : 0.f;
+      acc[k] += g * xv;
+    }
+  };
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  for (; i + stride < total; i += 2 * stride) { step(i); step(i + stride); }
+  for (; i < total; i += stride) step(i);
+  // lanes Q apart share the channel group: xor-tree in the wave, then the 4 waves through LDS (fixed order)
+  for (int off = Q; off < 64; off <<= 1) {
+#pragma unroll
+    for (int k = 0; k < THIN_MAX; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[k][j] += __shfl_xor(acc[k][j], off, 64);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane < Q) {
+#pragma unroll
+    for (int k = 0; k < THIN_MAX; ++k) *(f32x4*)(sm + ((wv * Q + lane) * THIN_MAX + k) * 4) = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < Q) {
+    const int c4 = threadIdx.x;                          // = (blockIdx.x*TPB + tid) % Q since TPB % Q == 0
+#pragma unroll
+    for (int k = 0; k < THIN_MAX; ++k) {
+      f32x4 t = *(const f32x4*)(sm + ((0 * Q + c4) * THIN_MAX + k) * 4);
+#pragma unroll
+      for (int w4 = 1; w4 < 4; ++w4) t += *(const f32x4*)(sm + ((w4 * Q + c4) * THIN_MAX + k) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[((size_t)blockIdx.x * CI + c4 * 4 + j) * THIN_MAX + k] = t[j];
+    }
+  }
+}
+
+// gw[ci][co] = sum_b part[b][ci][co] (co < CO): one wave per (ci, 4 k's), 64 lanes stride the blocks, xor-tree.
+__global__ void __launch_bounds__(TPB)
+thin1x1_wsum(const float* __restrict__ part, float* __restrict__ gw, int blocks, int CI, int CO) {
+  const int lane = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + (threadIdx.x >> 6);   // float4 column of the [CI][8] slab
+  if (col >= CI * THIN_MAX / 4) return;
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  for (int b = lane; b < blocks; b += 64) t += *(const f32x4*)(part + ((size_t)b * CI * THIN_MAX) + col * 4);
+  for (int off = 1; off < 64; off <<= 1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) t[j] += __shfl_xor(t[j], off, 64);
+  if (lane == 0) {
+    const int ci = col / 2, k0 = (col & 1) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < CO) gw[ci * CO + k0 + j] = t[j];
+  }
+}
+
+constexpr int THIN_WGRAD_BLOCKS = 1024;
+
 }  // namespace
 
 extern "C" {
@@ -285,4 +388,48 @@ int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* works
   return SMSUT_OK;
 }
 
+// ---- thin 1x1 layers (Cout <= 8, Cin in {8, 16, 32, 64}): data- and weight-gradient as streaming kernels
+int smsut_conv1x1_thin_supported(int Cin, int Cout) {
+  return (Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64) && Cout >= 1 && Cout <= THIN_MAX;
+}
+
+// gx [P][Cin] = gy [P][Cout] * W^T, W = [Cin][Cout] (HWIO memory of the forward weights)
+int smsut_conv1x1_thin_dgrad(const float* gy, const float* w, float* gx, int N, int HW, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(gy && w && gx && N > 0 && HW > 0 && smsut_conv1x1_thin_supported(Cin, Cout));
+  const int64_t P = (int64_t)N * HW;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid(P * (Cin / 4));
+  switch (Cin) {
+    case 8: thin1x1_dgrad<8><<<grid, TPB, 0, st>>>(gy, w, gx, P, Cout); break;
+    case 16: thin1x1_dgrad<16><<<grid, TPB, 0, st>>>(gy, w, gx, P, Cout); break;
+    case 32: thin1x1_dgrad<32><<<grid, TPB, 0, st>>>(gy, w, gx, P, Cout); break;
+    default: thin1x1_dgrad<64><<<grid, TPB, 0, st>>>(gy, w, gx, P, Cout); break;
+  }
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// workspace floats for smsut_conv1x1_thin_wgrad
+int64_t smsut_conv1x1_thin_wgrad_ws(int Cin) { return (int64_t)THIN_WGRAD_BLOCKS * Cin * THIN_MAX; }
+
+// gw [Cin][Cout] = sum_p x[p][:]^T gy[p][:]
+int smsut_conv1x1_thin_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin,
+                             int Cout, void* stream) {
+  SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && HW > 0 && smsut_conv1x1_thin_supported(Cin, Cout));
+  const int64_t P = (int64_t)N * HW;
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)cdiv64(P * (Cin / 4), 2 * TPB);
+  if (blocks > THIN_WGRAD_BLOCKS) blocks = THIN_WGRAD_BLOCKS;
+  switch (Cin) {
+    case 8: thin1x1_wgrad<8><<<blocks, TPB, 0, st>>>(x, gy, workspace, P, Cout); break;
+    case 16: thin1x1_wgrad<16><<<blocks, TPB, 0, st>>>(x, gy, workspace, P, Cout); break;
+    case 32: thin1x1_wgrad<32><<<blocks, TPB, 0, st>>>(x, gy, workspace, P, Cout); break;
+    default: thin1x1_wgrad<64><<<blocks, TPB, 0, st>>>(x, gy, workspace, P, Cout); break;
+  }
+  thin1x1_wsum<<<(Cin * THIN_MAX / 4 + 3) / 4, TPB, 0, st>>>(workspace, gw, blocks, Cin, Cout);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
 }  // extern "C"
+

@@ -182,6 +182,10 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
     co2, ci, kh, kw = w.shape
     assert co == co2
     gx = new_act(n, ci, h, wd, gy)
+    one_by_one = kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV
+    if one_by_one and THIN_1X1 and co % 4 != 0 and H.call("smsut_conv1x1_thin_supported", ci, co):   # heads: 1, 5 channels
+        H.call("smsut_conv1x1_thin_dgrad", gy, w, gx, n, h * wd, ci, co, _s())
+        return gx
     if kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV and H.call("smsut_conv1x1_supported", co, ci):
         H.call("smsut_conv1x1_fwd", gy, w, gx, None, n, h * wd, co, ci, 1, _s())
         return gx
@@ -198,6 +202,10 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
     n, ci, h, wd = x.shape
     _, co, ho, wo = gy.shape
     gw = new_weight(co, ci, kh, kw, device=x.device)
+    one_by_one = kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV
+    if one_by_one and THIN_1X1 and co % 4 != 0 and H.call("smsut_conv1x1_thin_supported", ci, co):
+        H.call("smsut_conv1x1_thin_wgrad", x, gy, gw, _ws(H.call("smsut_conv1x1_thin_wgrad_ws", ci), x), n, h * wd, ci, co, _s())
+        return gw
     if kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV and ci % 4 == 0 and co % 4 == 0:
         H.call("smsut_conv1x1_wgrad", x, gy, gw, _ws(H.call("smsut_conv1x1_wgrad_ws", n, h * wd, ci, co), x), n, h * wd, ci, co, _s())
         return gw
@@ -536,6 +544,7 @@ def res_tail(y2, g2, b2, s, gs, bs, slope):
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
+THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
 REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
 

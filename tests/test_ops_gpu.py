@@ -69,6 +69,11 @@ CONV_CASES = [
     (2, 32, 32, 2, 4, 5, 1, 2, False),
     (2, 24, 40, 16, 1, 1, 1, 0, True),
     (2, 72, 40, 16, 5, 1, 1, 0, False),
+    # thin 1x1 heads (streaming dgrad / wgrad): every wide-channel instantiation, grid-stride + 1024-block wgrad path
+    (2, 32, 32, 8, 3, 1, 1, 0, False),
+    (2, 32, 48, 32, 7, 1, 1, 0, True),
+    (1, 64, 64, 64, 2, 1, 1, 0, False),
+    (6, 256, 256, 16, 5, 1, 1, 0, True),
 ]
 
 
