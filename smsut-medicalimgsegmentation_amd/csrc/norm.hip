@@ -176,12 +176,29 @@ in_moments_final(const float* __restrict__ part, int chunks, int C, int HW, floa
   double s[NS];
 #pragma unroll
   for (int k = 0; k < NS; ++k) s[k] = 0.0;
-  if (c < C)
-    for (int ch = cl; ch < chunks; ch += 16) {
-      const float* p = part + (((size_t)n * chunks + ch) * C + c) * NS;
+  if (c < C) {
+    // 8 chunk rows in flight per thread (the one-row loop was a chain of dependent load latencies: 6 us for a 16-block
+    // grid that 150 launches per uganConsis step wait on); rows are added in the same order as before
+    constexpr int U = 8;
+    const float* p0 = part + ((size_t)n * chunks * C + c) * NS;
+    const size_t rstride = (size_t)C * NS;
+    int ch = cl;
+    for (; ch + (U - 1) * 16 < chunks; ch += U * 16) {
+      float v[U][NS];
 #pragma unroll
-      for (int k = 0; k < NS; ++k) s[k] += (double)p[k];
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[u][k] = p0[(size_t)(ch + u * 16) * rstride + k];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) s[k] += (double)v[u][k];
     }
+    for (; ch < chunks; ch += 16) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) s[k] += (double)p0[(size_t)ch * rstride + k];
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NS; ++k) sm[threadIdx.x * 3 + k] = s[k];
   __syncthreads();
