@@ -945,6 +945,23 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
          (int64_t)N * (H / 8) * (W / TW) * (Ndim / 16) >= 1024 && (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) < (1ll << 31);
 }
 
+// Variant table of the persistent kernel, from the late-r01 sweep (scratch/bench_conv.py 32: cfg 20..29 on the U-Net
+// shapes, forward and data-gradient): 16-channel reductions run ~10 % faster on 16-row items (109 vs 99 TF at 256^2
+// 16->16, 103 vs 88 at 128^2 16->32), 32-channel reductions ~8 % faster with 32 output channels per workgroup when
+// Ndim allows it (120 vs 111 TF at 128^2 32->32).  ONE selector for the plain, statistics, accumulate and BST forms,
+// so that smsut_conv2d_mfma_tiles() always describes the partials the launched variant writes.
+inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
+                        hipStream_t st, float* stats, int* tiles_out, const BstRef* bst) {
+#ifndef SMSUT_P_OLD_TABLE
+  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
+  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
+#endif
+  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
+  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
+  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
+  return -1;
+}
+
 template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
@@ -959,11 +976,7 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
     // small-Cin / large-image layers: persistent kernel with resident weights (see conv_mfma_fwd_p); it declines
     // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
     if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_p_eligible(N, H, W, Kdim, Ndim)) {
-      int rc = -1;
-      if (Kdim == 16) rc = launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
-      else if (Kdim == 32) rc = launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
-      else if (Kdim == 64) rc = launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out);
-      if (rc == 0) return 0;
+      if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr) == 0) return 0;
     }
   }
   const int nt = (Ndim + 15) / 16;
@@ -1162,10 +1175,7 @@ int smsut_conv2d_dgrad_mfma_bwdstats(const float* gy, const float* w, float* gz,
   SMSUT_REQUIRE(fwd_p_eligible(N, H, W, Kdim, Ndim));
   const BstRef b{y1, mean, rstd, gamma, beta, slope};
   hipStream_t st = (hipStream_t)stream;
-  int rc = -1;
-  if (Kdim == 16) rc = launch_fwd_p<3, 8, 1, 1>(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
-  else if (Kdim == 32) rc = launch_fwd_p<3, 8, 1, 2>(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
-  else if (Kdim == 64) rc = launch_fwd_p<3, 8, 1, 4>(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
+  const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
