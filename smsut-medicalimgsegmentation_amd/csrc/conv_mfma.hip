@@ -983,9 +983,14 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
   const int tx = (W + TW - 1) / TW;
   const int64_t wg16 = (int64_t)tx * ((H + 15) / 16) * N * ((nt + 1) / 2) * ntap_out;
   const int64_t wg8 = (int64_t)tx * ((H + 7) / 8) * N * ((nt + 1) / 2) * ntap_out;
+  // planes of <= 4 rows (discriminator 4x4 level): the 4-row tile halves the rows of padding every MFMA multiplies --
+  // scratch/bench_conv_small.py, 256->256: 19.4 vs 29.1 us forward, 25.1 vs 32.7 us data-gradient at B=16 (28.7 vs 48.2 at 32)
+  if (H <= 4 && isc == 1 && osc == 1) return launch_fwd<KS, 4, 4, 1, 1>(ARGS);
   if (nt == 1) return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
   if (wg16 >= 512) return launch_fwd<KS, 16, 4, 1, 2>(ARGS);       // >= 2 workgroups per CU with the big tile
-  if (wg8 >= 256) return launch_fwd<KS, 8, 4, 1, 2>(ARGS);
+  // mid-size grids: 32 output channels per workgroup for the forward form; the data-gradient form (float4 weight rows)
+  // runs 10-17 % faster with 16 (same sweep: 51.3 vs 60.0 us at 16x16 256->256, 49.4 vs 59.3 us at B32 8x8)
+  if (wg8 >= 256 && !(transposed & 1)) return launch_fwd<KS, 8, 4, 1, 2>(ARGS);
   return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
 #undef ARGS
 }

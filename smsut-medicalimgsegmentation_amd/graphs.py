@@ -16,13 +16,18 @@ from typing import Callable, Iterable, Sequence
 import torch
 
 
-def graphs_enabled(world: int) -> bool:
-    """Default: on for single-GPU runs, off under data parallelism (the in-graph Dice-statistics all-reduce over RCCL
-    has not been exercised on hardware yet).  ``SMSUT_GRAPH=0/1`` overrides."""
+def graphs_enabled(world: int, collective_free: bool = False) -> bool:
+    """Default: every phase on single-GPU runs; under data parallelism only the phases that contain no collective
+    (``collective_free``: the D-step of the GAN trainers -- its gradient all-reduce runs after the phase, outside the
+    graph).  A phase with the Dice-statistics all-reduce inside (G-step, U-Net step) stays
+    eager under DP: RCCL inside a captured hipGraph has not been exercised on hardware.  ``SMSUT_GRAPH=0/1`` overrides
+    (1 = every phase, whatever the world size; ``dp`` = the data-parallel policy on any world size)."""
     v = os.environ.get("SMSUT_GRAPH")
+    if v == "dp":                      # the data-parallel policy on any world size (to measure it on one GPU)
+        return collective_free
     if v is not None:
         return v not in ("0", "", "false", "False")
-    return world == 1
+    return world == 1 or collective_free
 
 
 class GraphedPhase:

@@ -121,10 +121,11 @@ class UGANConsisTrainer(UGANShp0Trainer):
             torch._foreach_add_(main, extra)
         return torch.stack([t.detach().float() for t in (g_fake, g_rec, g_cls, g_seg, g_semi, g_nce)])
 
-    def _run_phase(self, name, fn, inputs, params):
+    def _run_phase(self, name, fn, inputs, params, collective_free=False):
         """Eager call, or capture-once / replay as a hipGraph (graphs.GraphedPhase) when enabled.  The very first
         iteration always runs eagerly (it is the warm-up the capture needs)."""
-        use_graph = graphs.graphs_enabled(self.world) and not self._graphs.get("disabled") and self._eager_done
+        use_graph = (graphs.graphs_enabled(self.world, collective_free) and not self._graphs.get("disabled")
+                     and self._eager_done)
         if not use_graph:
             for p in params:
                 p.grad = None
@@ -138,7 +139,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
                 self.info(f"[graph] capture of {name} failed ({type(e).__name__}: {e}); running eagerly")
                 self._graphs["disabled"] = True
                 torch.cuda.synchronize()
-                return self._run_phase(name, fn, inputs, params)
+                return self._run_phase(name, fn, inputs, params, collective_free)
             return g.static_out                                          # the capture pass does not execute: replay it
         return g(*inputs)
 
@@ -173,10 +174,11 @@ class UGANConsisTrainer(UGANShp0Trainer):
         d_params = list(self.D.parameters())
 
         # ------------------------------------------------------------ G(x_real): once, shared by both steps
+        # (G1 shares G2's mode: G2's backward runs through G1's autograd graph, which a captured G1 builds only once)
         x_fake = self._run_phase("G1", self._g1_phase, (x_real, vec_ot, ids), [])
 
         # ------------------------------------------------------------ D-step (:129-146)
-        d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params)
+        d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params, collective_free=True)
         self.d_reducer.reduce()
         self.d_optimizer.step()
 
