@@ -230,26 +230,65 @@ __device__ __forceinline__ void ldv(const float* __restrict__ p, int idx, float 
   if constexpr (VEC == 4) *(float4*)o = *(const float4*)(p + idx); else o[0] = p[idx];
 }
 
+// ---- per-image walk of the apply kernels ------------------------------------------------------------------------------
+// grid = (blocks per image, N): the image index is blockIdx.y and a thread's vector units are li = x0 + k*stride inside
+// the image (32-bit).  When the stride is a multiple of CV = C/VEC (always, for power-of-two channel counts: the stride is
+// a multiple of 256), a thread keeps ONE channel group for the whole loop, so the per-(n, c) statistics and affine
+// parameters are loaded once per thread instead of once per float4 of data, and there is no per-element division.
+// (Before: i % CV and i / (CV*HW) in 64 bits per element -- ~250 integer instructions per 16 bytes, a VALU time equal
+// to the HBM time of these kernels.)
+inline dim3 img_grid(int64_t per_img_units, int N) {
+  int cap = SMSUT_EW_GRID_CAP / (N > 0 ? N : 1);
+  if (cap < 1) cap = 1;
+  int64_t bx = cdiv64(per_img_units, TPB);
+  if (bx > cap) bx = cap;
+  if (bx < 1) bx = 1;
+  return dim3((unsigned)bx, (unsigned)N);
+}
+
+template <class LoadP, class Body>
+__device__ __forceinline__ void img_walk(int HW, int CV, LoadP&& load_params, Body&& body) {
+  const int n = blockIdx.y;
+  const int per_img = HW * CV;
+  const int64_t ibase = (int64_t)n * per_img;
+  const int stride = gridDim.x * TPB;
+  const int x0 = blockIdx.x * TPB + threadIdx.x;
+  if (stride % CV == 0) {
+    if (x0 < per_img) {
+      auto prm = load_params(n, x0 % CV);
+      for (int li = x0; li < per_img; li += stride) body(ibase + li, prm);
+    }
+  } else {
+    for (int li = x0; li < per_img; li += stride) {
+      auto prm = load_params(n, li % CV);
+      body(ibase + li, prm);
+    }
+  }
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(TPB)
 in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-             int64_t total_vec, int HW, int C, float slope, int has_act) {
-  const int CV = C / VEC;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
-    const int cv = (int)(i % CV);
-    const int n = (int)(i / ((int64_t)CV * HW));
-    float v[VEC], mu[VEC], rs[VEC], gm[VEC], bt[VEC];
-    if constexpr (VEC == 4) *(float4*)v = *(const float4*)(x + i * 4); else v[0] = x[i];
-    ldv<VEC>(mean, n * C + cv * VEC, mu); ldv<VEC>(rstd, n * C + cv * VEC, rs);
-    ldv<VEC>(gamma, cv * VEC, gm); ldv<VEC>(beta, cv * VEC, bt);
+             int HW, int C, float slope, int has_act) {
+  struct Prm { float mu[VEC], rs[VEC], gm[VEC], bt[VEC]; };
+  img_walk(HW, C / VEC,
+    [&](int n, int cv) {
+      Prm p;
+      ldv<VEC>(mean, n * C + cv * VEC, p.mu); ldv<VEC>(rstd, n * C + cv * VEC, p.rs);
+      ldv<VEC>(gamma, cv * VEC, p.gm); ldv<VEC>(beta, cv * VEC, p.bt);
+      return p;
+    },
+    [&](int64_t i, const Prm& p) {
+      float v[VEC];
+      if constexpr (VEC == 4) *(float4*)v = *(const float4*)(x + i * 4); else v[0] = x[i];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const float r = in_affine(v[j], mu[j], rs[j], gm[j], bt[j]);
-      v[j] = has_act ? lrelu_f(r, slope) : r;
-    }
-    if constexpr (VEC == 4) *(float4*)(y + i * 4) = *(float4*)v; else y[i] = v[0];
-  }
+      for (int j = 0; j < VEC; ++j) {
+        const float r = in_affine(v[j], p.mu[j], p.rs[j], p.gm[j], p.bt[j]);
+        v[j] = has_act ? lrelu_f(r, slope) : r;
+      }
+      if constexpr (VEC == 4) *(float4*)(y + i * 4) = *(float4*)v; else y[i] = v[0];
+    });
 }
 
 template <int VEC>
@@ -257,9 +296,8 @@ __global__ void __launch_bounds__(TPB)
 in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
              const float* __restrict__ am, const float* __restrict__ bm, float* __restrict__ gx,
-             int64_t total_vec, int HW, int C, float slope, int N, float* __restrict__ ggamma, float* __restrict__ gbeta) {
-  const int CV = C / VEC;
-  if (ggamma && blockIdx.x == 0) {        // affine gradients ride along in block 0: ggamma = sum_n M*b, gbeta = sum_n M*a
+             int HW, int C, float slope, int N, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+  if (ggamma && blockIdx.x == 0 && blockIdx.y == 0) {   // affine gradients ride along in one block: ggamma = sum_n M*b, gbeta = sum_n M*a
     for (int c = threadIdx.x; c < C; c += TPB) {
       double sa = 0.0, sb = 0.0;
       for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; sb += (double)bm[n * C + c]; }
@@ -267,30 +305,33 @@ in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const fl
       gbeta[c] = (float)(sa * (double)HW);
     }
   }
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
-    const int cv = (int)(i % CV);
-    const int n = (int)(i / ((int64_t)CV * HW));
-    float g[VEC], xv[VEC];
-    if constexpr (VEC == 4) {
-      *(float4*)g = *(const float4*)(gy + i * 4);
-      *(float4*)xv = *(const float4*)(x + i * 4);
-    } else {
-      g[0] = gy[i]; xv[0] = x[i];
-    }
-    float mu[VEC], rs[VEC], gmv[VEC], btv[VEC], av[VEC], bv[VEC];
-    const int k0 = n * C + cv * VEC;
-    ldv<VEC>(mean, k0, mu); ldv<VEC>(rstd, k0, rs); ldv<VEC>(gamma, cv * VEC, gmv);
-    ldv<VEC>(am, k0, av); ldv<VEC>(bm, k0, bv);
-    if (beta) ldv<VEC>(beta, cv * VEC, btv);
+  struct Prm { float mu[VEC], rs[VEC], gm[VEC], bt[VEC], av[VEC], bv[VEC]; };
+  img_walk(HW, C / VEC,
+    [&](int n, int cv) {
+      Prm p;
+      const int k0 = n * C + cv * VEC;
+      ldv<VEC>(mean, k0, p.mu); ldv<VEC>(rstd, k0, p.rs); ldv<VEC>(gamma, cv * VEC, p.gm);
+      ldv<VEC>(am, k0, p.av); ldv<VEC>(bm, k0, p.bv);
+      if (beta) ldv<VEC>(beta, cv * VEC, p.bt);
+      return p;
+    },
+    [&](int64_t i, const Prm& p) {
+      float g[VEC], xv[VEC];
+      if constexpr (VEC == 4) {
+        *(float4*)g = *(const float4*)(gy + i * 4);
+        *(float4*)xv = *(const float4*)(x + i * 4);
+      } else {
+        g[0] = gy[i]; xv[0] = x[i];
+      }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const float r = rs[j], gm = gmv[j];
-      const float gz = beta ? g[j] * lrelu_mask(in_affine(xv[j], mu[j], r, gm, btv[j]), slope) : g[j];
-      const float xh = (xv[j] - mu[j]) * r;
-      g[j] = gm * r * (gz - av[j] - xh * bv[j]);
-    }
-    if constexpr (VEC == 4) *(float4*)(gx + i * 4) = *(float4*)g; else gx[i] = g[0];
-  }
+      for (int j = 0; j < VEC; ++j) {
+        const float r = p.rs[j], gm = p.gm[j];
+        const float gz = beta ? g[j] * lrelu_mask(in_affine(xv[j], p.mu[j], r, gm, p.bt[j]), slope) : g[j];
+        const float xh = (xv[j] - p.mu[j]) * r;
+        g[j] = gm * r * (gz - p.av[j] - xh * p.bv[j]);
+      }
+      if constexpr (VEC == 4) *(float4*)(gx + i * 4) = *(float4*)g; else gx[i] = g[0];
+    });
 }
 
 template <int VEC>
@@ -362,26 +403,28 @@ struct TailRef {
 
 template <int VEC>
 __global__ void __launch_bounds__(TPB)
-restail_fwd(TailRef t, float* __restrict__ out, int64_t total_vec, int HW, int C, float slope) {
-  const int CV = C / VEC;
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
-    const int cv = (int)(i % CV);
-    const int n = (int)(i / ((int64_t)CV * HW));
-    float a[VEC], b[VEC];
-    if constexpr (VEC == 4) { *(float4*)a = *(const float4*)(t.y2 + i * 4); *(float4*)b = *(const float4*)(t.s + i * 4); }
-    else { a[0] = t.y2[i]; b[0] = t.s[i]; }
-    float m2[VEC], r2[VEC], g2[VEC], b2[VEC], ms[VEC], rs[VEC], gs[VEC], bs[VEC];
-    const int c0 = cv * VEC, k0 = n * C + c0;
-    ldv<VEC>(t.m2, k0, m2); ldv<VEC>(t.r2, k0, r2); ldv<VEC>(t.g2, c0, g2); ldv<VEC>(t.b2, c0, b2);
-    if (t.ms) { ldv<VEC>(t.ms, k0, ms); ldv<VEC>(t.rs, k0, rs); ldv<VEC>(t.gs, c0, gs); ldv<VEC>(t.bs, c0, bs); }
+restail_fwd(TailRef t, float* __restrict__ out, int HW, int C, float slope) {
+  struct Prm { float m2[VEC], r2[VEC], g2[VEC], b2[VEC], ms[VEC], rs[VEC], gs[VEC], bs[VEC]; };
+  img_walk(HW, C / VEC,
+    [&](int n, int cv) {
+      Prm p;
+      const int c0 = cv * VEC, k0 = n * C + c0;
+      ldv<VEC>(t.m2, k0, p.m2); ldv<VEC>(t.r2, k0, p.r2); ldv<VEC>(t.g2, c0, p.g2); ldv<VEC>(t.b2, c0, p.b2);
+      if (t.ms) { ldv<VEC>(t.ms, k0, p.ms); ldv<VEC>(t.rs, k0, p.rs); ldv<VEC>(t.gs, c0, p.gs); ldv<VEC>(t.bs, c0, p.bs); }
+      return p;
+    },
+    [&](int64_t i, const Prm& p) {
+      float a[VEC], b[VEC];
+      if constexpr (VEC == 4) { *(float4*)a = *(const float4*)(t.y2 + i * 4); *(float4*)b = *(const float4*)(t.s + i * 4); }
+      else { a[0] = t.y2[i]; b[0] = t.s[i]; }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const float u = in_affine(a[j], m2[j], r2[j], g2[j], b2[j]);
-      const float v = t.ms ? in_affine(b[j], ms[j], rs[j], gs[j], bs[j]) : b[j];
-      a[j] = lrelu_f(u + v, slope);
-    }
-    if constexpr (VEC == 4) *(float4*)(out + i * 4) = *(float4*)a; else out[i] = a[0];
-  }
+      for (int j = 0; j < VEC; ++j) {
+        const float u = in_affine(a[j], p.m2[j], p.r2[j], p.g2[j], p.b2[j]);
+        const float v = t.ms ? in_affine(b[j], p.ms[j], p.rs[j], p.gs[j], p.bs[j]) : b[j];
+        a[j] = lrelu_f(u + v, slope);
+      }
+      if constexpr (VEC == 4) *(float4*)(out + i * 4) = *(float4*)a; else out[i] = a[0];
+    });
 }
 
 // partial [N][chunks][C][3] = {sum gz, sum gz*y2hat, sum gz*shat}
@@ -507,11 +550,10 @@ template <int VEC, bool REMASK>
 __global__ void __launch_bounds__(TPB)
 restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
                   const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
-                  float* __restrict__ gs, int64_t total_vec, int HW, int C, float slope, int N, float* __restrict__ gg2,
+                  float* __restrict__ gs, int HW, int C, float slope, int N, float* __restrict__ gg2,
                   float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs) {
-  const int CV = C / VEC;
   constexpr bool remask = REMASK;             // see restail_bwd_partial
-  if (blockIdx.x == 0) {   // affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (both norms), ggs = sum_n M*bs
+  if (blockIdx.x == 0 && blockIdx.y == 0) {   // affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (both norms), ggs = sum_n M*bs
     for (int c = threadIdx.x; c < C; c += TPB) {
       double sa = 0.0, s2 = 0.0, ss = 0.0;
       for (int n = 0; n < N; ++n) { sa += (double)am[n * C + c]; s2 += (double)b2m[n * C + c]; if (ggs) ss += (double)bsm[n * C + c]; }
@@ -519,37 +561,40 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
       if (ggs) { ggs[c] = (float)(ss * HW); gbs[c] = (float)(sa * HW); }
     }
   }
-  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * TPB) {
-    const int cv = (int)(i % CV);
-    const int n = (int)(i / ((int64_t)CV * HW));
-    float g[VEC], o[VEC], y[VEC], sv[VEC], o1[VEC], o2[VEC];
-    if constexpr (VEC == 4) {
-      *(float4*)g = *(const float4*)(gout + i * 4);
-      if (!remask) *(float4*)o = *(const float4*)(out + i * 4);
-      *(float4*)y = *(const float4*)(t.y2 + i * 4);
-      if (t.ms) *(float4*)sv = *(const float4*)(t.s + i * 4);
-    } else {
-      g[0] = gout[i]; y[0] = t.y2[i];
-      if (!remask) o[0] = out[i];
-      if (t.ms) sv[0] = t.s[i];
-    }
-    float av[VEC], b2v[VEC], bsv[VEC], m2[VEC], r2[VEC], g2[VEC], msv[VEC], rsv[VEC], gsv[VEC], be2[VEC], bes[VEC];
-    const int c0 = cv * VEC, k0 = n * C + c0;
-    ldv<VEC>(am, k0, av); ldv<VEC>(b2m, k0, b2v); ldv<VEC>(t.m2, k0, m2); ldv<VEC>(t.r2, k0, r2); ldv<VEC>(t.g2, c0, g2);
-    if (t.ms) { ldv<VEC>(bsm, k0, bsv); ldv<VEC>(t.ms, k0, msv); ldv<VEC>(t.rs, k0, rsv); ldv<VEC>(t.gs, c0, gsv); }
-    if (remask) { ldv<VEC>(t.b2, c0, be2); ldv<VEC>(t.bs, c0, bes); }
+  struct Prm { float av[VEC], b2v[VEC], bsv[VEC], m2[VEC], r2[VEC], g2[VEC], msv[VEC], rsv[VEC], gsv[VEC], be2[VEC], bes[VEC]; };
+  img_walk(HW, C / VEC,
+    [&](int n, int cv) {
+      Prm p;
+      const int c0 = cv * VEC, k0 = n * C + c0;
+      ldv<VEC>(am, k0, p.av); ldv<VEC>(b2m, k0, p.b2v); ldv<VEC>(t.m2, k0, p.m2); ldv<VEC>(t.r2, k0, p.r2); ldv<VEC>(t.g2, c0, p.g2);
+      if (t.ms) { ldv<VEC>(bsm, k0, p.bsv); ldv<VEC>(t.ms, k0, p.msv); ldv<VEC>(t.rs, k0, p.rsv); ldv<VEC>(t.gs, c0, p.gsv); }
+      if (remask) { ldv<VEC>(t.b2, c0, p.be2); ldv<VEC>(t.bs, c0, p.bes); }
+      return p;
+    },
+    [&](int64_t i, const Prm& p) {
+      float g[VEC], o[VEC], y[VEC], sv[VEC], o1[VEC], o2[VEC];
+      if constexpr (VEC == 4) {
+        *(float4*)g = *(const float4*)(gout + i * 4);
+        if (!remask) *(float4*)o = *(const float4*)(out + i * 4);
+        *(float4*)y = *(const float4*)(t.y2 + i * 4);
+        if (t.ms) *(float4*)sv = *(const float4*)(t.s + i * 4);
+      } else {
+        g[0] = gout[i]; y[0] = t.y2[i];
+        if (!remask) o[0] = out[i];
+        if (t.ms) sv[0] = t.s[i];
+      }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      const float pre = remask ? in_affine(y[j], m2[j], r2[j], g2[j], be2[j]) + in_affine(sv[j], msv[j], rsv[j], gsv[j], bes[j])
-                               : o[j];
-      const float gz = g[j] * lrelu_mask(pre, slope);
-      const float a = av[j];
-      o1[j] = g2[j] * r2[j] * (gz - a - ((y[j] - m2[j]) * r2[j]) * b2v[j]);
-      o2[j] = t.ms ? gsv[j] * rsv[j] * (gz - a - ((sv[j] - msv[j]) * rsv[j]) * bsv[j]) : gz;
-    }
-    if constexpr (VEC == 4) { *(float4*)(gy2 + i * 4) = *(float4*)o1; *(float4*)(gs + i * 4) = *(float4*)o2; }
-    else { gy2[i] = o1[0]; gs[i] = o2[0]; }
-  }
+      for (int j = 0; j < VEC; ++j) {
+        const float pre = remask ? in_affine(y[j], p.m2[j], p.r2[j], p.g2[j], p.be2[j]) + in_affine(sv[j], p.msv[j], p.rsv[j], p.gsv[j], p.bes[j])
+                                 : o[j];
+        const float gz = g[j] * lrelu_mask(pre, slope);
+        const float a = p.av[j];
+        o1[j] = p.g2[j] * p.r2[j] * (gz - a - ((y[j] - p.m2[j]) * p.r2[j]) * p.b2v[j]);
+        o2[j] = t.ms ? p.gsv[j] * p.rsv[j] * (gz - a - ((sv[j] - p.msv[j]) * p.rsv[j]) * p.bsv[j]) : gz;
+      }
+      if constexpr (VEC == 4) { *(float4*)(gy2 + i * 4) = *(float4*)o1; *(float4*)(gs + i * 4) = *(float4*)o2; }
+      else { gy2[i] = o1[0]; gs[i] = o2[0]; }
+    });
 }
 
 inline int pick_chunk(int HW, int C, int N) {
@@ -583,10 +628,11 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
     in_moments_partial<0, 1><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
   in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, eps, mean, rstd, nullptr);
   const int64_t total = (int64_t)N * HW * C;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   if (C % 4 == 0)
-    in_apply_fwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total / 4, HW, C, slope, has_act);
+    in_apply_fwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
   else
-    in_apply_fwd<1><<<ew_grid(total), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total, HW, C, slope, has_act);
+    in_apply_fwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -600,10 +646,11 @@ int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float*
   hipStream_t st = (hipStream_t)stream;
   in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(partials, chunks, C, HW, eps, mean, rstd, nullptr);
   const int64_t total = (int64_t)N * HW * C;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   if (C % 4 == 0)
-    in_apply_fwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total / 4, HW, C, slope, has_act);
+    in_apply_fwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
   else
-    in_apply_fwd<1><<<ew_grid(total), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, total, HW, C, slope, has_act);
+    in_apply_fwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -625,11 +672,12 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta, const
   in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
   float* gg = (ggamma && gbeta) ? ggamma : nullptr;       // affine gradients: computed by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   if (C % 4 == 0)
-    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, slope,
+    in_apply_bwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, slope,
                                                         N, gg, gbeta);
   else
-    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, slope,
+    in_apply_bwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, slope,
                                                     N, gg, gbeta);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
@@ -655,6 +703,7 @@ int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const 
   in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, cvm, dvm, em);
   in_bwd2_gamma<<<(C + 63) / 64, 64, 0, st>>>(rstd, a_mean, b_mean, cvm, dvm, em, N, C, HW, d_gamma);
   const int64_t total = (int64_t)N * HW * C;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   if (C % 4 == 0)
     in_apply_bwd2<4><<<ew_grid(total / 4), TPB, 0, st>>>(v, x, gy, beta, mean, rstd, gamma, a_mean, b_mean, cvm, dvm, em,
                                                           ug, ub, d_gy, d_x, total / 4, HW, C, slope);
@@ -693,11 +742,12 @@ int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const
   hipStream_t st = (hipStream_t)stream;
   float* gg = (ggamma && gbeta) ? ggamma : nullptr;
   const int64_t total = (int64_t)N * HW * C;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   if (C % 4 == 0)
-    in_apply_bwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total / 4, HW, C, 0.f,
+    in_apply_bwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, 0.f,
                                                         N, gg, gbeta);
   else
-    in_apply_bwd<1><<<ew_grid(total), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, total, HW, C, 0.f,
+    in_apply_bwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, 0.f,
                                                     N, gg, gbeta);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
@@ -710,9 +760,10 @@ int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const f
   SMSUT_REQUIRE(y2 && m2 && r2 && g2 && b2 && s && out && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs && bs)));
   TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs, bs};
   const int64_t total = (int64_t)N * HW * C;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   hipStream_t st = (hipStream_t)stream;
-  if (C % 4 == 0) restail_fwd<4><<<ew_grid(total / 4), TPB, 0, st>>>(t, out, total / 4, HW, C, slope);
-  else restail_fwd<1><<<ew_grid(total), TPB, 0, st>>>(t, out, total, HW, C, slope);
+  if (C % 4 == 0) restail_fwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(t, out, HW, C, slope);
+  else restail_fwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(t, out, HW, C, slope);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -741,8 +792,9 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
   in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
   // the affine gradients (and the copy gbs = gb2) are written by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
 #define TAIL_APPLY(V, R)                                                                                                \
-  restail_bwd_apply<V, R><<<ew_grid(total / V), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, total / V, HW, C, \
+  restail_bwd_apply<V, R><<<img_grid((int64_t)HW * (C / V), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, HW, C, \
                                                               slope, N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr)
   if (C % 4 == 0) { if (remask) TAIL_APPLY(4, true); else TAIL_APPLY(4, false); }
   else { if (remask) TAIL_APPLY(1, true); else TAIL_APPLY(1, false); }
