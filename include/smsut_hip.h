@@ -78,6 +78,16 @@ int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout);
 int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
                         void* stream);
 
+/* split-output forms: result channels [0, split) -> ya (pixel stride split), [split, Ndim) -> yb (stride Ndim - split).
+   They write the data-gradient of a block whose input was cat([up, skip]) (network/blocks.py:49) straight into the two
+   gradient tensors.  conv2d form: persistent kernel shapes only (ask _split_supported), any `transposed` form of
+   smsut_conv2d_fwd_mfma; conv1x1 form: split % 16 == 0. */
+int smsut_conv2d_mfma_split_supported(int N, int H, int W, int Kdim, int Ndim, int split);
+int smsut_conv2d_fwd_mfma_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int H, int W,
+                                int Kdim, int Ndim, int transposed, void* stream);
+int smsut_conv1x1_fwd_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int HW, int Kdim,
+                            int Ndim, int transposed, void* stream);
+
 /* thin 1x1 layers (Cout <= 8, Cin in {8,16,32,64}; reference: the nn.Conv2d heads at network/blocks.py:123-125 and
    network/ugan.py:70): data-gradient gx[P][Cin] = gy[P][Cout] W^T and weight-gradient gw[Cin][Cout], both streaming. */
 int smsut_conv1x1_thin_supported(int Cin, int Cout);

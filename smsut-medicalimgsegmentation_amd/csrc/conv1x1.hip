@@ -26,7 +26,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 template <int MR, int NR>
 __global__ void __launch_bounds__(TPB)
 conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ stats,
-            int64_t P, int HW, int Kdim, int Ndim, int transposed) {
+            int64_t P, int HW, int Kdim, int Ndim, int transposed, float* __restrict__ y2 = nullptr, int split = 0) {
   constexpr int CO_T = 16 * NR;
   extern __shared__ float w_s[];                 // [chunks][4 kq][CO_T][4]: k = 16*chunk + 4*kq + j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -85,6 +85,11 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     const int co = co0 + j * 16 + lm;
+    // split output (y2 != null, split % 16 == 0): channels >= split go to y2 [P][Ndim - split] (see conv_mfma_fwd_p)
+    const bool hi = y2 && co0 + j * 16 >= split;
+    float* const yo = hi ? y2 : y;
+    const int os = !y2 ? Ndim : (hi ? Ndim - split : split);
+    const int oc = hi ? co - split : co;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -93,7 +98,7 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
         const int64_t p = p0 + i * 16 + 4 * kq + r;
         if (p < P && co < Ndim) {
           const float v = acc[i][j][r];
-          y[(size_t)p * Ndim + co] = v;
+          yo[(size_t)p * os + oc] = v;
           s1 += v; s2 += v * v;
         }
       }
@@ -345,9 +350,10 @@ int smsut_conv1x1_tiles(int N, int HW, int Ndim) {
 }
 
 // y = x * W (+ optional InstanceNorm statistics partials [N][tiles][Ndim][2]); transposed = 1: data-gradient
-int smsut_conv1x1_fwd(const float* x, const float* w, float* y, float* stats, int N, int HW, int Kdim, int Ndim,
-                      int transposed, void* stream) {
+static int conv1x1_fwd_launch(const float* x, const float* w, float* y, float* stats, int N, int HW, int Kdim, int Ndim,
+                              int transposed, void* stream, float* y2, int split) {
   SMSUT_REQUIRE(x && w && y && N > 0 && HW > 0 && smsut_conv1x1_supported(Kdim, Ndim));
+  SMSUT_REQUIRE(!y2 || (!stats && split > 0 && split < Ndim && split % 16 == 0));
   const int64_t P = (int64_t)N * HW;
   const int mr = (P / 256 >= 512) ? 4 : 1;
   SMSUT_REQUIRE(!stats || HW % (16 * mr) == 0);
@@ -356,12 +362,25 @@ int smsut_conv1x1_fwd(const float* x, const float* w, float* y, float* stats, in
   const size_t sh = (size_t)chunks * 4 * 16 * nr * 4 * sizeof(float);
   dim3 grid((unsigned)cdiv64(P, 64 * mr), (Ndim + 16 * nr - 1) / (16 * nr));
   hipStream_t st = (hipStream_t)stream;
-  if (mr == 4 && nr == 2) conv1x1_fwd<4, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
-  else if (mr == 4) conv1x1_fwd<4, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
-  else if (nr == 2) conv1x1_fwd<1, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
-  else conv1x1_fwd<1, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed);
+  if (mr == 4 && nr == 2) conv1x1_fwd<4, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
+  else if (mr == 4) conv1x1_fwd<4, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
+  else if (nr == 2) conv1x1_fwd<1, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
+  else conv1x1_fwd<1, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+
+int smsut_conv1x1_fwd(const float* x, const float* w, float* y, float* stats, int N, int HW, int Kdim, int Ndim,
+                      int transposed, void* stream) {
+  return conv1x1_fwd_launch(x, w, y, stats, N, HW, Kdim, Ndim, transposed, stream, nullptr, 0);
+}
+
+// Same product with the result channels [0, split) written to ya [P][split] and [split, Ndim) to yb [P][Ndim - split]
+// (split % 16 == 0): the shortcut's data-gradient of a block fed by cat([up, skip]).
+int smsut_conv1x1_fwd_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int HW, int Kdim,
+                            int Ndim, int transposed, void* stream) {
+  SMSUT_REQUIRE(yb);
+  return conv1x1_fwd_launch(x, w, ya, nullptr, N, HW, Kdim, Ndim, transposed, stream, yb, split);
 }
 
 int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout) {

@@ -264,7 +264,7 @@ template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = fal
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
-                BstRef bst = BstRef{}) {
+                BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0) {
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -283,6 +283,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, kq = lane >> 4;
   const int co0 = blockIdx.y * CO_T;
+  // split output (y2 != null; plain / accumulate forms only): channels [0, split) of the result live in y with pixel
+  // stride `split`, channels [split, Ndim) in y2 with stride Ndim - split -- the data-gradient of a block whose input was
+  // cat([up, skip]) lands in the two gradient tensors directly (no split-copy pass).  split % CO_T == 0 (host).
+  float* const yo = (y2 && co0 >= split) ? y2 : y;
+  const int os = !y2 ? Ndim : (co0 >= split ? Ndim - split : split);      // pixel stride of the tensor this workgroup writes
+  const int oc0 = (y2 && co0 >= split) ? co0 - split : co0;
   const int total_items = N * tiles_img;
   // workgroups go to the 8 XCDs round-robin (MICROARCH "Workgroup dispatch"): give XCD k the k-th contiguous eighth of
   // the items, so that the halo rows a strip shares with the strips above / below are hits in that XCD's own L2
@@ -372,7 +378,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     for (int j = 0; j < NR; ++j) { ng[j] = bst.gamma[co0 + j * 16 + lm]; nb[j] = bst.beta[co0 + j * 16 + lm]; }
   }
   // per-lane output offset of (row wave*MR, col 4*kq, channel lm) inside a tile; red[] slot of this lane
-  const int o_lane = ((wave * MR) * W + 4 * kq) * Ndim + lm;
+  const int o_lane = ((wave * MR) * W + 4 * kq) * os + lm;
   const int red_slot = (wave * CO_T + lm) * 2;
 
   // statistics + stores of the item in pacc / (en, ety, etx); straight-line, no branches
@@ -400,13 +406,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         *(float2*)rd = make_float2(s1, s2);
       }
     }
-    float* yb = y + (((size_t)en * H + ety * TH) * W + etx * TW) * Ndim + co0;
+    float* yb = yo + (((size_t)en * H + ety * TH) * W + etx * TW) * os + oc0;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
       for (int j = 0; j < NR; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yb[o_lane + (i * W + r) * Ndim + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
+        for (int r = 0; r < 4; ++r) yb[o_lane + (i * W + r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
   };
   // ACC: the values the outputs of item (n_, ty_, tx_) hold now (loaded one region before they are added and stored)
   auto load_old = [&](int n_, int ty_, int tx_) {
@@ -418,13 +424,14 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       }
     }
     if (ACC || BST) {
-      const float* yb = (BST ? bst.y1 : y) + (((size_t)n_ * H + ty_ * TH) * W + tx_ * TW) * Ndim + co0;
+      // (BST never has a split output: os == Ndim, oc0 == co0 there)
+      const float* yb = (BST ? bst.y1 : yo) + (((size_t)n_ * H + ty_ * TH) * W + tx_ * TW) * os + oc0;
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pold[i][j][r] = yb[o_lane + (i * W + r) * Ndim + j * 16];
+          for (int r = 0; r < 4; ++r) pold[i][j][r] = yb[o_lane + (i * W + r) * os + j * 16];
     }
   };
   auto stats_out = [&](int par) {                     // after the barrier that completes red[par]
@@ -896,7 +903,8 @@ constexpr size_t fwd_p_lds() {
 
 template <int KS, int TH, int NTN, int NCH>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-                 hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr) {
+                 hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
+                 float* y2 = nullptr, int split = 0) {
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
   if constexpr (sh > 64 * 1024) return -1;
   else {
@@ -905,6 +913,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     return -1;
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int tiles_img = tiles_x * tiles_y;
+  if (y2 && (split <= 0 || split >= Ndim || split % (16 * NTN) != 0 || stats || bst)) return -1;
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = Ndim / (16 * NTN);
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
@@ -922,7 +931,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   dim3 grid((unsigned)((items + ipw - 1) / ipw), nz);
   const int tr = transposed & 1;
 #define P_LAUNCH(ST, AC) conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, \
-                                                                                        tiles_img, ipw, tr, stats)
+                                                                                        tiles_img, ipw, tr, stats, BstRef{}, y2, split)
   if (bst) {
     if (!stats || (transposed & 2)) return -1;
     conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
@@ -951,14 +960,14 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
 // Ndim allows it (120 vs 111 TF at 128^2 32->32).  ONE selector for the plain, statistics, accumulate and BST forms,
 // so that smsut_conv2d_mfma_tiles() always describes the partials the launched variant writes.
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-                        hipStream_t st, float* stats, int* tiles_out, const BstRef* bst) {
+                        hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0) {
 #ifndef SMSUT_P_OLD_TABLE
-  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
-  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
+  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
+  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
 #endif
-  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
-  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
-  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst);
+  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
+  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
+  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
   return -1;
 }
 
@@ -1118,6 +1127,26 @@ int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H
   hipStream_t st = (hipStream_t)stream;
   if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
   else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// 3x3 conv (any `transposed` form of smsut_conv2d_fwd_mfma) whose result channels [0, split) go to ya [N,H,W,split] and
+// [split, Ndim) to yb [N,H,W,Ndim-split]: the data-gradient of a block fed by cat([up, skip]) (network/blocks.py:49)
+// written straight into the two gradients.  Persistent kernel only: _supported tells whether this shape is covered.
+int smsut_conv2d_mfma_split_supported(int N, int H, int W, int Kdim, int Ndim, int split) {
+  if (N <= 0 || H <= 0 || W <= 0 || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  int tiles = 0;
+  float dummy;
+  return select_fwd_p(nullptr, nullptr, &dummy, N, H, W, Kdim, Ndim, 1, nullptr, nullptr, &tiles, nullptr, &dummy, split) == 0;
+}
+
+int smsut_conv2d_fwd_mfma_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int H, int W,
+                                int Kdim, int Ndim, int transposed, void* stream) {
+  SMSUT_REQUIRE(x && w && ya && yb && N > 0 && H > 0 && W > 0 && (transposed & ~3) == 0);
+  SMSUT_REQUIRE(smsut_conv2d_mfma_split_supported(N, H, W, Kdim, Ndim, split));
+  const int rc = select_fwd_p(x, w, ya, N, H, W, Kdim, Ndim, transposed, (hipStream_t)stream, nullptr, nullptr, nullptr, yb, split);
+  SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

@@ -544,6 +544,7 @@ def res_tail(y2, g2, b2, s, gs, bs, slope):
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
+SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-after-concat: gradient written into the two parts
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
 REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
@@ -567,7 +568,10 @@ class BasicBlockFn(Function):
     VGPRs, cost the MFMA kernels more than the memory passes they remove.)  First-order only (generator / U-Net)."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, xa=None, xb=None):
+        # xa, xb (optional): x is cat([xa, xb], 1), already materialised and passed detached; the backward then writes the
+        # block-input gradient straight into the two parts (split-output data-gradients) instead of returning d/dx
+        ctx.cat_split = (xa.shape[1], xb.shape[1]) if xa is not None else None
         x, w1, w2 = nhwc(x), hwio(w1), hwio(w2)
         has_sc = ws is not None
         if has_sc:
@@ -678,6 +682,25 @@ class BasicBlockFn(Function):
             gws = new_weight(co, ci, 1, 1, device=dev)
             H.call("smsut_conv1x1_wgrad", x, gs_t, gws, _ws(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), x), n, hw, ci, co, st)
         gx = None
+        if ctx.cat_split is not None:
+            ga = gb = None
+            if ctx.needs_input_grad[11] or ctx.needs_input_grad[12]:
+                ca, cb = ctx.cat_split
+                ga, gb = new_act(n, ca, h, w, x), new_act(n, cb, h, w, x)
+                if (ctx.has_sc and ca % 16 == 0 and H.call("smsut_conv1x1_supported", co, ci)
+                        and H.call("smsut_conv2d_mfma_split_supported", n, h, w, co, ci, ca)):
+                    # shortcut gradient first, the 3x3 data-gradient accumulates on top -- both straight into (ga, gb)
+                    H.call("smsut_conv1x1_fwd_split", gs_t, ws, ga, gb, ca, n, hw, co, ci, 1, st)
+                    H.call("smsut_conv2d_fwd_mfma_split", gy1, w1, ga, gb, ca, n, h, w, co, ci, 3, st)
+                else:
+                    gx = new_act(n, ci, h, w, x)
+                    if H.call("smsut_conv1x1_supported", co, ci):
+                        H.call("smsut_conv1x1_fwd", gs_t, ws, gx, None, n, hw, co, ci, 1, st)
+                    else:
+                        H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gx, n, h, w, co, ci, 1, 1, st)
+                    H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
+                    H.call("smsut_concat2", ga, ca, gb, cb, gx, n * hw, 1, st)
+            return None, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, ga, gb
         if ctx.needs_input_grad[0]:
             # the shortcut's gradient lands in gx first; the 3x3 data-gradient then accumulates into it in its store
             # epilogue (transposed | 2), which replaces a separate 3-pass add
@@ -690,10 +713,14 @@ class BasicBlockFn(Function):
             else:
                 gx = gs_t
             H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
-        return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None
+        return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
 
 
 def basic_block(x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):
+    parts = getattr(x, "_smsut_cat_parts", None)
+    if parts is not None and SPLIT_DGRAD and ws is not None and torch.is_grad_enabled():
+        # x = cat([up, skip]) (UpSampleAndConcat): gradients go to the two parts directly, the ConcatFn node is bypassed
+        return BasicBlockFn.apply(cl(x).detach(), w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, parts[0], parts[1])
     return BasicBlockFn.apply(cl(x), w1, g1, b1, w2, g2, b2, ws, gs, bs, slope)
 
 
@@ -953,7 +980,10 @@ class ConcatFn(Function):
 
 
 def concat_channels(a, b):
-    return ConcatFn.apply(a, b)
+    y = ConcatFn.apply(a, b)
+    if SPLIT_DGRAD and torch.is_grad_enabled() and (a.requires_grad or b.requires_grad) and a.shape[1] % 16 == 0:
+        y._smsut_cat_parts = (a, b)        # side channel: a fused BasicBlock consuming y writes d/da, d/db itself
+    return y
 
 
 class ModalPlanesFn(Function):

@@ -377,3 +377,44 @@ def test_fused_basic_block_vs_torch(ops, n, h, ci, co):
                 assert np.quantile(d, 0.999) < 5e-3, (tuple(ref.shape), float(np.quantile(d, 0.999)))
         else:
             assert rel_err(got.grad.cpu().numpy(), ref.grad.numpy()) < 5e-3, tuple(ref.shape)
+
+
+@pytest.mark.parametrize("n,h,ca,cb,co", [(8, 128, 16, 16, 16), (16, 64, 32, 32, 32), (32, 32, 64, 64, 64),      # split-output kernels
+                                          (2, 32, 16, 16, 16), (4, 64, 32, 32, 32), (2, 16, 128, 128, 128)])    # contiguous + split copy
+def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
+    """BasicBlock fed by cat([up, skip]) (UpSampleAndConcat, network/blocks.py:37-50): the data-gradients written straight
+    into d/d(up), d/d(skip) (split-output kernels) must equal, bit for bit, the contiguous gradient followed by the split
+    copy -- same kernels, same accumulation order -- and match torch autograd of the reference composition."""
+    slope = 0.01
+    ci = ca + cb
+    a = rnd(n, ca, h, h, seed=1); b = rnd(n, cb, h, h, seed=2)
+    w1 = rnd(co, ci, 3, 3, seed=3) / np.sqrt(9 * ci); w2 = rnd(co, co, 3, 3, seed=4) / np.sqrt(9 * co)
+    ws = rnd(co, ci, 1, 1, seed=5) / np.sqrt(ci)
+    aff = [1 + 0.1 * rnd(co, seed=6 + k) if k % 2 == 0 else 0.1 * rnd(co, seed=6 + k) for k in range(6)]
+    gout = rnd(n, co, h, h, seed=20)
+    res = {}
+    for split in (True, False):
+        ops.SPLIT_DGRAD = split
+        try:
+            ad, bd = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+            x = ops.concat_channels(ad, bd)
+            assert hasattr(x, "_smsut_cat_parts") == split
+            prm = [to_hwio(ops, w1).requires_grad_(True), *[dev(t).requires_grad_(True) for t in aff[:2]],
+                   to_hwio(ops, w2).requires_grad_(True), *[dev(t).requires_grad_(True) for t in aff[2:4]],
+                   to_hwio(ops, ws).requires_grad_(True), *[dev(t).requires_grad_(True) for t in aff[4:]]]
+            out = ops.basic_block(x, *prm, slope)
+            out.backward(dev(gout))
+            res[split] = (out.detach().cpu().numpy(), ad.grad.cpu().numpy(), bd.grad.cpu().numpy(), prm[0].grad.cpu().numpy())
+        finally:
+            ops.SPLIT_DGRAD = True
+    for u, v in zip(res[True], res[False]):
+        assert np.array_equal(u, v)
+    at, bt = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    xt = torch.cat([at, bt], 1)
+    y = F.leaky_relu(F.instance_norm(F.conv2d(xt, w1, padding=1), weight=aff[0], bias=aff[1]), slope)
+    y = F.instance_norm(F.conv2d(y, w2, padding=1), weight=aff[2], bias=aff[3])
+    ref = F.leaky_relu(y + F.instance_norm(F.conv2d(xt, ws), weight=aff[4], bias=aff[5]), slope)
+    ref.backward(gout)
+    from conftest import l2_rel
+    assert rel_err(res[True][0], ref.detach().numpy()) < 2e-5
+    assert l2_rel(res[True][1], at.grad.numpy()) < 5e-3 and l2_rel(res[True][2], bt.grad.numpy()) < 5e-3
