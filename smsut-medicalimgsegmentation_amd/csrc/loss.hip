@@ -13,33 +13,46 @@ constexpr int MAXC = 32;
 
 // stats layout per group g (g = n when per-sample dice, g = 0 when batch dice):
 //   part[block][G][C][3] = {tp, sum_p, count}; part_ce[block]
+// CT > 0: the class count as a compile-time constant (loops unrolled, per-class arrays in registers); CT = 0: runtime C.
+// (With runtime bounds the per-class arrays were indexed dynamically: 1.2 TB/s on a 59 MB pass.)
+template <int CT>
 __global__ void __launch_bounds__(TPB)
 k_dicece_partial(const float* __restrict__ logits, const int64_t* __restrict__ labels, float* __restrict__ part,
                  float* __restrict__ part_ce, int N, int64_t HW, int C, int G) {
   __shared__ float sm4[4];
   __shared__ float acc_sm[MAXC * 3];
+  constexpr int CC = CT ? CT : MAXC;
+  if (CT) C = CT;
   const int n = blockIdx.y;
   const int g = G == 1 ? 0 : n;
-  float tp[MAXC], sp[MAXC], cnt[MAXC];
-  for (int c = 0; c < C; ++c) { tp[c] = 0.f; sp[c] = 0.f; cnt[c] = 0.f; }
+  float tp[CC], sp[CC], cnt[CC];
+#pragma unroll
+  for (int c = 0; c < (CT ? CT : C); ++c) { tp[c] = 0.f; sp[c] = 0.f; cnt[c] = 0.f; }
   float ce = 0.f;
   for (int64_t p = (int64_t)blockIdx.x * TPB + threadIdx.x; p < HW; p += (int64_t)gridDim.x * TPB) {
     const float* z = logits + ((size_t)n * HW + p) * C;
     const int lab = (int)labels[(size_t)n * HW + p];
-    float m = z[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
-    float e[MAXC], s = 0.f;
-    for (int c = 0; c < C; ++c) { e[c] = __expf(z[c] - m); s += e[c]; }
+    float zc[CC];
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : C); ++c) zc[c] = z[c];
+    float m = zc[0], zl = zc[0];
+#pragma unroll
+    for (int c = 1; c < (CT ? CT : C); ++c) { m = fmaxf(m, zc[c]); zl = c == lab ? zc[c] : zl; }
+    float e[CC], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : C); ++c) { e[c] = __expf(zc[c] - m); s += e[c]; }
     const float inv = 1.f / s;
-    for (int c = 0; c < C; ++c) {
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : C); ++c) {
       const float pc = e[c] * inv;
       sp[c] += pc;
       if (c == lab) { tp[c] += pc; cnt[c] += 1.f; }
     }
-    ce += (m + __logf(s)) - z[lab];
+    ce += (m + __logf(s)) - zl;
   }
   // block reduce each statistic
-  for (int c = 0; c < C; ++c) {
+#pragma unroll
+  for (int c = 0; c < (CT ? CT : C); ++c) {
     const float a = block_sum_256(tp[c], sm4);
     const float b = block_sum_256(sp[c], sm4);
     const float d = block_sum_256(cnt[c], sm4);
@@ -95,10 +108,13 @@ __global__ void k_dicece_final(const float* __restrict__ stats, const float* __r
   out[2] = (float)ce;
 }
 
+template <int CT>
 __global__ void __launch_bounds__(TPB)
 k_dicece_bwd(const float* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ stats,
              const float* __restrict__ gout, float* __restrict__ glogits, int N, int64_t HW, int C, int G,
              double npix_total, float w_dc, float w_ce, float smooth, float eps) {
+  constexpr int CC = CT ? CT : MAXC;
+  if (CT) C = CT;
   __shared__ float A[MAXC], Bc[MAXC];
   const int n = blockIdx.y;
   const int g = G == 1 ? 0 : n;
@@ -118,18 +134,24 @@ k_dicece_bwd(const float* __restrict__ logits, const int64_t* __restrict__ label
     const float* z = logits + ((size_t)n * HW + p) * C;
     float* gz = glogits + ((size_t)n * HW + p) * C;
     const int lab = (int)labels[(size_t)n * HW + p];
-    float m = z[0];
-    for (int c = 1; c < C; ++c) m = fmaxf(m, z[c]);
-    float pr[MAXC], s = 0.f;
-    for (int c = 0; c < C; ++c) { pr[c] = __expf(z[c] - m); s += pr[c]; }
+    float pr[CC], s = 0.f;
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : C); ++c) pr[c] = z[c];
+    float m = pr[0];
+#pragma unroll
+    for (int c = 1; c < (CT ? CT : C); ++c) m = fmaxf(m, pr[c]);
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : C); ++c) { pr[c] = __expf(pr[c] - m); s += pr[c]; }
     const float inv = 1.f / s;
-    float dot = 0.f, dp[MAXC];
-    for (int c = 0; c < C; ++c) {
+    float dot = 0.f, dp[CC];
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : C); ++c) {
       pr[c] *= inv;
       dp[c] = Bc[c] - (c == lab ? A[c] : 0.f);
       dot += pr[c] * dp[c];
     }
-    for (int c = 0; c < C; ++c)
+#pragma unroll
+    for (int c = 0; c < (CT ? CT : C); ++c)
       gz[c] = go * (pr[c] * (dp[c] - dot) + cew * (pr[c] - (c == lab ? 1.f : 0.f)));
   }
 }
@@ -422,7 +444,10 @@ int smsut_dicece_stats(const float* logits, const int64_t* labels, float* stats,
   const int nblk = N * pb;
   float* part = workspace;
   float* part_ce = workspace + (size_t)nblk * G * C * 3;
-  k_dicece_partial<<<dim3(pb, N), TPB, 0, ST>>>(logits, labels, part, part_ce, N, HW, C, G);
+#define DICE_P(CT) k_dicece_partial<CT><<<dim3(pb, N), TPB, 0, ST>>>(logits, labels, part, part_ce, N, HW, C, G)
+  switch (C) { case 2: DICE_P(2); break; case 3: DICE_P(3); break; case 4: DICE_P(4); break; case 5: DICE_P(5); break;
+               default: DICE_P(0); }
+#undef DICE_P
   k_dicece_reduce<<<G * C * 3 + 1, TPB, 0, ST>>>(part, part_ce, nblk, G * C * 3, stats, ce_sum);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
@@ -436,8 +461,11 @@ int smsut_dicece_final(const float* stats, const float* ce_sum, float* out, int 
 int smsut_dicece_bwd(const float* logits, const int64_t* labels, const float* stats, const float* gout, float* glogits,
                      int N, int64_t HW, int C, int G, double npix_total, float w_dc, float w_ce, void* stream) {
   SMSUT_REQUIRE(logits && labels && stats && gout && glogits && N > 0 && HW > 0 && C >= 2 && C <= MAXC);
-  k_dicece_bwd<<<dim3(pix_blocks(HW) * 4, N), TPB, 0, ST>>>(logits, labels, stats, gout, glogits, N, HW, C, G,
-                                                             npix_total, w_dc, w_ce, 1e-5f, 1e-8f);
+#define DICE_B(CT) k_dicece_bwd<CT><<<dim3(pix_blocks(HW) * 4, N), TPB, 0, ST>>>(logits, labels, stats, gout, glogits, N, HW, C, G, \
+                                                                          npix_total, w_dc, w_ce, 1e-5f, 1e-8f)
+  switch (C) { case 2: DICE_B(2); break; case 3: DICE_B(3); break; case 4: DICE_B(4); break; case 5: DICE_B(5); break;
+               default: DICE_B(0); }
+#undef DICE_B
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 
