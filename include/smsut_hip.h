@@ -78,6 +78,19 @@ int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout);
 int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
                         void* stream);
 
+/* virtual-cat input forms: the logical input is cat([xa, xb], channel) (UpSampleAndConcat, network/blocks.py:49-50) read
+   from the two tensors in place -- same chunk order and arithmetic as on a materialised cat, so results are bit-identical.
+   ca % 16 == 0.  conv2d forward: persistent kernel, Kdim in {32, 64}, xa and xb of Kdim/2 channels each (ask _cat_supported). */
+int smsut_conv2d_mfma_cat_supported(int N, int H, int W, int Kdim, int Ndim);
+int smsut_conv2d_fwd_mfma_stats_cat(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
+                                    int W, int Kdim, int Ndim, void* stream);
+int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace,
+                                int N, int H, int W, int Cin, int Cout, int KS, void* stream);
+int smsut_conv1x1_fwd_cat(const float* xa, const float* xb, int ca, const float* w, float* y, float* stats /*nullable*/,
+                          int N, int HW, int Kdim, int Ndim, void* stream);
+int smsut_conv1x1_wgrad_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace, int N,
+                            int HW, int Cin, int Cout, void* stream);
+
 /* split-output forms: result channels [0, split) -> ya (pixel stride split), [split, Ndim) -> yb (stride Ndim - split).
    They write the data-gradient of a block whose input was cat([up, skip]) (network/blocks.py:49) straight into the two
    gradient tensors.  conv2d form: persistent kernel shapes only (ask _split_supported), any `transposed` form of

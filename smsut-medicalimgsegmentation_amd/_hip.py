@@ -57,6 +57,11 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv1x1_fwd": "pppp iiii i s",
     "smsut_conv1x1_wgrad_ws": "iiii",
     "smsut_conv1x1_wgrad": "pppp iiii s",
+    "smsut_conv2d_mfma_cat_supported": "iiiii",
+    "smsut_conv2d_fwd_mfma_stats_cat": "ppppp iiiii s",
+    "smsut_conv2d_wgrad_mfma_cat": "pp i ppp iiiiii s",
+    "smsut_conv1x1_fwd_cat": "pp i ppp iiii s",
+    "smsut_conv1x1_wgrad_cat": "pp i ppp iiii s",
     "smsut_conv2d_mfma_split_supported": "iiiiii",
     "smsut_conv2d_fwd_mfma_split": "pppp iiiiiii s",
     "smsut_conv1x1_fwd_split": "pppp iiiiii s",
@@ -123,7 +128,7 @@ _RET_I64 = {"smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws
 _NO_STATUS = _RET_I64 | {"smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
                          "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
-                         "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported"}
+                         "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported"}
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

@@ -79,3 +79,13 @@ __device__ __forceinline__ float in_affine(float x, float mean, float rstd, floa
   return __fmaf_rn(x - mean, rstd * gamma, beta);
 }
 
+
+// ---- virtual channel concat ------------------------------------------------------------------------------------------------
+// A kernel input that is logically cat([xa, xb], channel) (UpSampleAndConcat, network/blocks.py:49-50) can be read from
+// the two tensors in place: channel c of the cat lives in xa [.., ca] for c < ca, else in xb [.., Ctot - ca] at c - ca.
+// Every kernel below picks the source per 4- or 16-channel unit, which never straddles the seam (ca % 16 == 0).
+struct CatSrc { const float* p; int stride; int coff; };      // element (pix, c) = p[pix * stride + c - coff]
+__device__ __forceinline__ CatSrc cat_src(const float* x, const float* x2, int Ctot, int ca, int c) {
+  if (!x2) return CatSrc{x, Ctot, 0};
+  return c < ca ? CatSrc{x, ca, 0} : CatSrc{x2, Ctot - ca, ca};
+}

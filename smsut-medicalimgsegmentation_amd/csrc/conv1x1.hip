@@ -26,7 +26,8 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 template <int MR, int NR>
 __global__ void __launch_bounds__(TPB)
 conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ stats,
-            int64_t P, int HW, int Kdim, int Ndim, int transposed, float* __restrict__ y2 = nullptr, int split = 0) {
+            int64_t P, int HW, int Kdim, int Ndim, int transposed, float* __restrict__ y2 = nullptr, int split = 0,
+            const float* __restrict__ x2 = nullptr, int ca = 0) {
   constexpr int CO_T = 16 * NR;
   extern __shared__ float w_s[];                 // [chunks][4 kq][CO_T][4]: k = 16*chunk + 4*kq + j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,21 +58,27 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // x2 != null: the input is the virtual cat([x, x2]) (common.h): 16-channel chunks below ca come from x [P][ca], the
+  // rest from x2 [P][Kdim - ca]
   const float* xp[MR];
+  const float* xq[MR];
   bool pok[MR];
+  const int sa = x2 ? ca : Kdim;
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
     const int64_t p = p0 + i * 16 + lm;
     pok[i] = p < P;
-    xp[i] = x + (size_t)(pok[i] ? p : 0) * Kdim + 4 * kq;
+    xp[i] = x + (size_t)(pok[i] ? p : 0) * sa + 4 * kq;
+    xq[i] = x2 ? x2 + (size_t)(pok[i] ? p : 0) * (Kdim - ca) + 4 * kq - ca : xp[i];
   }
 // (runtime trip count: the partial unroll request is not honoured for every instantiation)
   for (int c = 0; c < chunks; ++c) {
     const bool kok = c * 16 + 4 * kq < Kdim;
+    const bool second = x2 && c * 16 >= ca;
     f32x4 a[MR], b[NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i)
-      a[i] = (pok[i] && kok) ? *(const f32x4*)(xp[i] + c * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      a[i] = (pok[i] && kok) ? *(const f32x4*)((second ? xq[i] : xp[i]) + c * 16) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < NR; ++j) b[j] = *(const f32x4*)(w_s + ((size_t)(c * 4 + kq) * CO_T + j * 16 + lm) * 4);
 #pragma unroll
@@ -120,7 +127,7 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
 template <int CIT, int COT>
 __global__ void __launch_bounds__(TPB)
 conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int64_t P, int Cin,
-              int Cout, int64_t pix_per_split) {
+              int Cout, int64_t pix_per_split, const float* __restrict__ x2 = nullptr, int ca = 0) {
   __shared__ float red[CIT * COT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, kq = lane >> 4;
@@ -137,14 +144,16 @@ conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
   for (int i = 0; i < CIT; ++i) iok[i] = ci0 + i * 16 + lm < Cin;
 #pragma unroll
   for (int j = 0; j < COT; ++j) jok[j] = co0 + j * 16 + lm < Cout;
-  const float* xb = x + ci0 + lm;
+  CatSrc xs[CIT];                                  // per 16-channel tile: which tensor of the (virtual) cat holds it
+#pragma unroll
+  for (int i = 0; i < CIT; ++i) xs[i] = cat_src(x, x2, Cin, ca, ci0 + i * 16);
   const float* gb = gy + co0 + lm;
 // (runtime trip count)
   for (int64_t p = pb + 4 * wave + kq; p - kq < pe; p += 16) {      // this lane's pixel (the MFMA k index)
     const bool ok = p < pe;
     float a[CIT], b[COT];
 #pragma unroll
-    for (int i = 0; i < CIT; ++i) a[i] = (ok && iok[i]) ? xb[(size_t)p * Cin + i * 16] : 0.f;
+    for (int i = 0; i < CIT; ++i) a[i] = (ok && iok[i]) ? xs[i].p[(size_t)p * xs[i].stride + ci0 + i * 16 + lm - xs[i].coff] : 0.f;
 #pragma unroll
     for (int j = 0; j < COT; ++j) b[j] = (ok && jok[j]) ? gb[(size_t)p * Cout + j * 16] : 0.f;
 #pragma unroll
@@ -351,9 +360,10 @@ int smsut_conv1x1_tiles(int N, int HW, int Ndim) {
 
 // y = x * W (+ optional InstanceNorm statistics partials [N][tiles][Ndim][2]); transposed = 1: data-gradient
 static int conv1x1_fwd_launch(const float* x, const float* w, float* y, float* stats, int N, int HW, int Kdim, int Ndim,
-                              int transposed, void* stream, float* y2, int split) {
+                              int transposed, void* stream, float* y2, int split, const float* x2 = nullptr, int ca = 0) {
   SMSUT_REQUIRE(x && w && y && N > 0 && HW > 0 && smsut_conv1x1_supported(Kdim, Ndim));
   SMSUT_REQUIRE(!y2 || (!stats && split > 0 && split < Ndim && split % 16 == 0));
+  SMSUT_REQUIRE(!x2 || (!transposed && ca > 0 && ca < Kdim && ca % 16 == 0 && (Kdim - ca) % 4 == 0));
   const int64_t P = (int64_t)N * HW;
   const int mr = (P / 256 >= 512) ? 4 : 1;
   SMSUT_REQUIRE(!stats || HW % (16 * mr) == 0);
@@ -362,10 +372,10 @@ static int conv1x1_fwd_launch(const float* x, const float* w, float* y, float* s
   const size_t sh = (size_t)chunks * 4 * 16 * nr * 4 * sizeof(float);
   dim3 grid((unsigned)cdiv64(P, 64 * mr), (Ndim + 16 * nr - 1) / (16 * nr));
   hipStream_t st = (hipStream_t)stream;
-  if (mr == 4 && nr == 2) conv1x1_fwd<4, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
-  else if (mr == 4) conv1x1_fwd<4, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
-  else if (nr == 2) conv1x1_fwd<1, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
-  else conv1x1_fwd<1, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split);
+  if (mr == 4 && nr == 2) conv1x1_fwd<4, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
+  else if (mr == 4) conv1x1_fwd<4, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
+  else if (nr == 2) conv1x1_fwd<1, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
+  else conv1x1_fwd<1, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -373,6 +383,13 @@ static int conv1x1_fwd_launch(const float* x, const float* w, float* y, float* s
 int smsut_conv1x1_fwd(const float* x, const float* w, float* y, float* stats, int N, int HW, int Kdim, int Ndim,
                       int transposed, void* stream) {
   return conv1x1_fwd_launch(x, w, y, stats, N, HW, Kdim, Ndim, transposed, stream, nullptr, 0);
+}
+
+// y = cat([xa, xb]) * W without materialising the cat (xa [P][ca], xb [P][Kdim - ca], ca % 16 == 0); forward form only.
+int smsut_conv1x1_fwd_cat(const float* xa, const float* xb, int ca, const float* w, float* y, float* stats, int N, int HW,
+                          int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(xb);
+  return conv1x1_fwd_launch(xa, w, y, stats, N, HW, Kdim, Ndim, 0, stream, nullptr, 0, xb, ca);
 }
 
 // Same product with the result channels [0, split) written to ya [P][split] and [split, Ndim) to yb [P][Ndim - split]
@@ -389,22 +406,35 @@ int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout) {
 }
 
 // gw [Cin][Cout] = sum_p x[p][:]^T gy[p][:]
-int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
-                        void* stream) {
+static int conv1x1_wgrad_launch(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin,
+                                int Cout, void* stream, const float* x2, int ca) {
   SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && HW > 0 && Cin > 0 && Cout > 0);
+  SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0));
   const int64_t P = (int64_t)N * HW;
   const int cit = Cin > 16 ? 2 : 1, cot = Cout > 16 ? 2 : 1;
   const Plan1 p = plan_wgrad1(P, Cin, Cout, cit, cot);
   dim3 grid(p.splits, (Cin + 16 * cit - 1) / (16 * cit), (Cout + 16 * cot - 1) / (16 * cot));
   hipStream_t st = (hipStream_t)stream;
-  if (cit == 2 && cot == 2) conv1x1_wgrad<2, 2><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
-  else if (cit == 2) conv1x1_wgrad<2, 1><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
-  else if (cot == 2) conv1x1_wgrad<1, 2><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
-  else conv1x1_wgrad<1, 1><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps);
+  if (cit == 2 && cot == 2) conv1x1_wgrad<2, 2><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps, x2, ca);
+  else if (cit == 2) conv1x1_wgrad<2, 1><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps, x2, ca);
+  else if (cot == 2) conv1x1_wgrad<1, 2><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps, x2, ca);
+  else conv1x1_wgrad<1, 1><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Cout, p.pps, x2, ca);
   const int wsize = Cin * Cout;
   sum_parts<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+
+int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
+                        void* stream) {
+  return conv1x1_wgrad_launch(x, gy, gw, workspace, N, HW, Cin, Cout, stream, nullptr, 0);
+}
+
+// weight gradient with x = cat([xa, xb]) read in place (same workspace size as smsut_conv1x1_wgrad_ws)
+int smsut_conv1x1_wgrad_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace, int N,
+                            int HW, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(xb);
+  return conv1x1_wgrad_launch(xa, gy, gw, workspace, N, HW, Cin, Cout, stream, xb, ca);
 }
 
 // ---- thin 1x1 layers (Cout <= 8, Cin in {8, 16, 32, 64}): data- and weight-gradient as streaming kernels

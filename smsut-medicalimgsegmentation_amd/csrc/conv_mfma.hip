@@ -260,12 +260,17 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 // reduction pass over (g, y1) disappears (in_moments_partial<1>: 4.5 % of the uganConsis iteration).
 struct BstRef { const float* y1; const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
 
-template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false>
+template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
-                BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0) {
+                BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0,
+                const float* __restrict__ x2 = nullptr) {
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
+  static_assert(!DUAL || NCH % 2 == 0, "virtual cat input: two equal halves of whole 16-channel chunks");
+  // DUAL: the input is the virtual cat([x, x2]) of two [N,H,W,Kdim/2] tensors (common.h): chunks [0, NCH/2) are staged
+  // from x, the rest from x2 -- same chunk order, same arithmetic as on the materialised cat.
+  constexpr int KST = DUAL ? 8 * NCH : 16 * NCH;             // pixel stride of the tensor(s) the input is read from
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
@@ -328,12 +333,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     const int uu = real ? u : 0;
     const int q = uu & 3, pix = uu >> 2;
     const int iy = pix / IW, ix = pix % IW;
-    u_off[i] = (iy * W + ix) * Kdim + 4 * q;
+    u_off[i] = (iy * W + ix) * KST + 4 * q;
     u_lds[i] = real ? pix * SPIX + 4 * q : IH * IW * SPIX;
     u_flag[i] = (iy < PAD ? 1 : 0) | (iy >= TH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
   }
   // a unit outside the image reads the tile's first interior pixel instead (always valid) and is zeroed at publish
-  const int safe_off = (PAD * W + PAD) * Kdim;
+  const int safe_off = (PAD * W + PAD) * KST;
 
   // ---- cursors: item being prefetched (p*), item being computed (c*), item whose results are being written (e*)
   int pn = item0 / tiles_img, pty, ptx;
@@ -345,8 +350,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 
   auto prefetch = [&](int c) {                       // chunk c of item (pn, pty, ptx)
     if (c == 0) pflags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
-    const int base = (((pn * H + pty * TH - PAD) * W) + ptx * TW - PAD) * Kdim + c * 16;   // may be "negative": only
-    const float* xb = x + base;                                                          // used with in-image offsets
+    const int cl = DUAL ? c % (NCH / 2 > 0 ? NCH / 2 : 1) : c;                          // chunk inside its source tensor
+    const int base = (((pn * H + pty * TH - PAD) * W) + ptx * TW - PAD) * KST + cl * 16;   // may be "negative": only
+    const float* xb = ((DUAL && c >= NCH / 2) ? x2 : x) + base;                          // used with in-image offsets
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       zero[i] = (u_flag[i] & pflags) != 0;
@@ -523,7 +529,8 @@ constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the t
 template <int KS, int CIT, int COT>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
-                int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci) {
+                int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci,
+                const float* __restrict__ x2 = nullptr, int ca = 0) {
   // gsc = 2 / 4 tap groups in blockIdx.y: weight-gradient of ConvTranspose2x2 (gy is the 2x larger tensor).
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -576,18 +583,20 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
     gy_lds[i] = pix * SO + 4 * q;
   }
 
+  // x2 != null: x is the virtual cat([x, x2]); a thread's units share one channel quad (see conv_mfma_wgrad_ts)
+  const CatSrc xsrc = cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4)));
   auto prefetch = [&](int t) {
     const int n_img = t / tiles_img;
     const int rem = t % tiles_img;
     const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * TW;
-    const float* xin = x + (size_t)n_img * H * W * Cin;
+    const float* xin = xsrc.p + (size_t)n_img * H * W * xsrc.stride - xsrc.coff;
     const float* gin = gy + (size_t)n_img * H * gsc * Wg * Cout;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int gy_ = y0 + (in_yx[i] >> 8) - PAD, gx_ = x0 + (in_yx[i] & 255) - PAD;
       if (in_yx[i] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W)
-        v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * Cin + in_c[i]);
+        v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * xsrc.stride + in_c[i]);
       rin[i] = v;
     }
 #pragma unroll
@@ -680,7 +689,8 @@ typedef f32x4 wvec;
 #endif
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
-                   int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split) {
+                   int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split,
+                   const float* __restrict__ x2 = nullptr, int ca = 0) {
   constexpr int KS = 3, KK = 9, PAD = 1, CIT = 2, COT = 2;
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int CI_T = 32, CO_T = 32, SI = WTS_STRIDE, SO = WTS_STRIDE;
@@ -720,14 +730,17 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   static_assert(WTH * TW * (CO_T / 4) % TPB == 0, "gy tile units divide evenly");
   wvec rin[NIN], rgy[NGY];     // ext-vector values (HIP's float4 struct kept rgy in scratch memory)
   int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
+  // x2 != null: x is the virtual cat([x, x2]) (common.h).  A thread's units all carry the same channel quad
+  // (TPB % (CI_T/4) == 0; padding units keep it too), so its source tensor, pixel stride and channel offset are fixed.
+  const CatSrc xsrc = cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4)));
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
     const int u = tid + i * TPB;
     const bool real = u < UIN;
-    const int uu = real ? u : 0;
+    const int uu = real ? u : tid % (CI_T / 4);              // padding unit: pixel 0, this thread's channel quad
     const int q = uu % (CI_T / 4), pix = uu / (CI_T / 4);
     const int iy = pix / IW, ix = pix % IW;
-    in_off[i] = (iy * W + ix) * Cin + 4 * q;
+    in_off[i] = (iy * W + ix) * xsrc.stride + 4 * q;
     in_lds[i] = real ? pix * SI + 4 * q : (IH * IW * SI + WTH * TW * SO);          // dummy slot behind both tiles
     in_flag[i] = (iy < PAD ? 1 : 0) | (iy >= WTH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
   }
@@ -738,13 +751,13 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     gy_off[i] = ((pix / TW) * W + (pix % TW)) * Cout + 4 * q;
     gy_lds[i] = pix * SO + 4 * q;
   }
-  const int safe_off = (PAD * W + PAD) * Cin;              // first interior pixel of the tile: always inside the image
+  const int safe_off = (PAD * W + PAD) * xsrc.stride;     // first interior pixel of the tile: always inside the image
   int pn = t_begin / tiles_img, pty, ptx;                  // cursor of the tile being prefetched
   { const int t = t_begin - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
   bool zero[NIN];
   auto prefetch = [&]() {
     const int flags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
-    const float* xb = x + (((pn * H + pty * WTH - PAD) * W) + ptx * TW - PAD) * Cin + ci0;
+    const float* xb = xsrc.p + (((pn * H + pty * WTH - PAD) * W) + ptx * TW - PAD) * xsrc.stride + ci0 - xsrc.coff;
     const float* gb = gy + (((pn * H + pty * WTH) * W) + ptx * TW) * Cout + co0;
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
@@ -904,7 +917,7 @@ constexpr size_t fwd_p_lds() {
 template <int KS, int TH, int NTN, int NCH>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
-                 float* y2 = nullptr, int split = 0) {
+                 float* y2 = nullptr, int split = 0, const float* x2 = nullptr) {
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
   if constexpr (sh > 64 * 1024) return -1;
   else {
@@ -914,6 +927,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int tiles_img = tiles_x * tiles_y;
   if (y2 && (split <= 0 || split >= Ndim || split % (16 * NTN) != 0 || stats || bst)) return -1;
+  if (x2 && (NCH % 2 != 0 || !stats || bst || y2 || transposed)) return -1;     // virtual-cat input: forward statistics form
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = Ndim / (16 * NTN);
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
@@ -932,7 +946,11 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   const int tr = transposed & 1;
 #define P_LAUNCH(ST, AC) conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, \
                                                                                         tiles_img, ipw, tr, stats, BstRef{}, y2, split)
-  if (bst) {
+  if (x2) {
+    if constexpr (NCH % 2 == 0)
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img,
+                                                                                         ipw, tr, stats, BstRef{}, nullptr, 0, x2);
+  } else if (bst) {
     if (!stats || (transposed & 2)) return -1;
     conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
                                                                                  tr, stats, *bst);
@@ -960,14 +978,15 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
 // Ndim allows it (120 vs 111 TF at 128^2 32->32).  ONE selector for the plain, statistics, accumulate and BST forms,
 // so that smsut_conv2d_mfma_tiles() always describes the partials the launched variant writes.
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-                        hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0) {
+                        hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
+                        const float* x2 = nullptr) {
 #ifndef SMSUT_P_OLD_TABLE
-  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
-  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
+  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
+  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
 #endif
-  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
-  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
-  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split);
+  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
+  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
+  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
   return -1;
 }
 
@@ -1078,7 +1097,7 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
 
 template <int KS, int CIT, int COT>
 int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int W, int Cin, int Cout,
-                 const WgradPlan& p, int gsc, int ntaps, hipStream_t st) {
+                 const WgradPlan& p, int gsc, int ntaps, hipStream_t st, const float* x2 = nullptr, int ca = 0) {
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
   constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;
@@ -1090,7 +1109,7 @@ int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int
   const int nci = (Cin + CI_T - 1) / CI_T;
   dim3 grid(p.splits, nci * ntaps, (Cout + CO_T - 1) / CO_T);
   conv_mfma_wgrad<KS, CIT, COT><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
-                                                      p.tiles_per_split, gsc, nci);
+                                                      p.tiles_per_split, gsc, nci, x2, ca);
   return 0;
 }
 
@@ -1127,6 +1146,25 @@ int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H
   hipStream_t st = (hipStream_t)stream;
   if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
   else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Forward 3x3 conv + InstanceNorm partials (as smsut_conv2d_fwd_mfma_stats) of the virtual cat([xa, xb]) of two
+// [N,H,W,Kdim/2] tensors, read in place.  Persistent kernel, Kdim in {32, 64}: _supported says whether the shape is covered;
+// the statistics tiles are those of smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3).
+int smsut_conv2d_mfma_cat_supported(int N, int H, int W, int Kdim, int Ndim) {
+  if (N <= 0 || H <= 0 || W <= 0 || (Kdim != 32 && Kdim != 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  int tiles = 0;
+  float dummy;
+  return select_fwd_p(nullptr, nullptr, &dummy, N, H, W, Kdim, Ndim, 0, nullptr, &dummy, &tiles, nullptr, nullptr, 0, &dummy) == 0;
+}
+
+int smsut_conv2d_fwd_mfma_stats_cat(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
+                                    int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(xa && xb && w && y && stats && smsut_conv2d_mfma_cat_supported(N, H, W, Kdim, Ndim));
+  const int rc = select_fwd_p(xa, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb);
+  SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -1237,33 +1275,47 @@ int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int K
 }
 
 // gw [KS*KS][Cin][Cout] = sum over pixels of x (x) gy
-int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
-                            int Cout, int KS, void* stream) {
+static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                             int Cout, int KS, void* stream, const float* x2, int ca) {
   SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0);
   SMSUT_REQUIRE(smsut_conv2d_wgrad_mfma_supported(KS, 1, (KS - 1) / 2, Cin, Cout));
+  SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0 && (Cin - ca) % 4 == 0));
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
   if (KS == 1) {
-    if (p.cit == 1 && p.cot == 1) launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
-    else if (p.cit == 1) launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
-    else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
-    else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    if (p.cit == 1 && p.cot == 1) launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else if (p.cit == 1) launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
   } else {
-    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
-    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
-    else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
     else if (H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
              (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {
       constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE + 4) * sizeof(float);
       dim3 grid(p.splits, Cin / 32, Cout / 32);
       conv_mfma_wgrad_ts<<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
-                                                p.tiles_per_split);
-    } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st);
+                                                p.tiles_per_split, x2, ca);
+    } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
   }
   const int wsize = KS * KS * Cin * Cout;
   launch_sum_splits(workspace, gw, wsize, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+
+int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                            int Cout, int KS, void* stream) {
+  return wgrad_mfma_launch(x, gy, gw, workspace, N, H, W, Cin, Cout, KS, stream, nullptr, 0);
+}
+
+// Weight gradient with x = the virtual cat([xa, xb]) (xa [N,H,W,ca], xb [N,H,W,Cin-ca], ca % 16 == 0) read in place;
+// workspace as smsut_conv2d_wgrad_mfma_ws(N, H, W, Cin, Cout, KS).
+int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace,
+                                int N, int H, int W, int Cin, int Cout, int KS, void* stream) {
+  SMSUT_REQUIRE(xb);
+  return wgrad_mfma_launch(xa, gy, gw, workspace, N, H, W, Cin, Cout, KS, stream, xb, ca);
 }
 
 int64_t smsut_convT2x2_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout) {

@@ -129,8 +129,8 @@ class UpSampleAndConcat(nn.Module):
             # bilinear interpolation (per channel, spatial) and a 1x1 conv (per pixel, across channels) are both
             # linear and commute exactly in real arithmetic: run the conv at the LOW resolution (4x fewer FLOPs
             # and bytes), then upsample its half-as-wide output.  fp32 rounding differs at the 1e-7 level.
-            return ops.concat_channels(self.up[0](self.up[1](x)), skip)
-        return ops.concat_channels(self.up(x), skip)
+            return ops.concat_channels_deferred(self.up[0](self.up[1](x)), skip)
+        return ops.concat_channels_deferred(self.up(x), skip)
 
 
 class BasicBlock(nn.Module):
@@ -149,6 +149,11 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         s = self.relu.slope
         ws = self.shortcut1.weight if self.downsample else None
+        if isinstance(x, ops.CatParts):            # cat([up, skip]) not built yet (UpSampleAndConcat)
+            if ops.basic_block_cat_fusable(x, self.conv1.weight, ws):
+                return ops.basic_block_cat(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
+                                           self.bn2.weight, self.bn2.bias, ws, self.shortcut2.weight, self.shortcut2.bias, s)
+            x = x.tensor()
         if ops.basic_block_fusable(x, self.conv1.weight, ws):
             sc = (ws, self.shortcut2.weight, self.shortcut2.bias) if self.downsample else (None, None, None)
             return ops.basic_block(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,

@@ -544,6 +544,7 @@ def res_tail(y2, g2, b2, s, gs, bs, slope):
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
+VIRTUAL_CAT = bool(int(_os.environ.get("SMSUT_VIRTUAL_CAT", "1")))   # block-after-concat reads [up, skip] in place (no cat tensor)
 SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-after-concat: gradient written into the two parts
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
 REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
@@ -571,12 +572,22 @@ class BasicBlockFn(Function):
     def forward(ctx, x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, xa=None, xb=None):
         # xa, xb (optional): x is cat([xa, xb], 1), already materialised and passed detached; the backward then writes the
         # block-input gradient straight into the two parts (split-output data-gradients) instead of returning d/dx
+        # x None (with xa, xb): the cat is never materialised -- conv1, the shortcut and their weight gradients read the two
+        # parts in place (virtual-cat entry points; chunk order and arithmetic of the materialised cat: same bits)
         ctx.cat_split = (xa.shape[1], xb.shape[1]) if xa is not None else None
-        x, w1, w2 = nhwc(x), hwio(w1), hwio(w2)
+        virtual = x is None
+        ctx.virtual = virtual
+        if virtual:
+            xa, xb = nhwc(xa), nhwc(xb)
+            x = xa                                   # device / allocation hints below
+        w1, w2 = hwio(w1), hwio(w2)
+        x = nhwc(x)
         has_sc = ws is not None
         if has_sc:
             ws = hwio(ws)
         n, ci, h, w = x.shape
+        if virtual:
+            ci = xa.shape[1] + xb.shape[1]
         co = w1.shape[0]
         hw = h * w
         st = _s()
@@ -590,7 +601,10 @@ class BasicBlockFn(Function):
         t3b = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
         y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
-        H.call("smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
+        if virtual:
+            H.call("smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w1, y1, p1, n, h, w, ci, co, st)
+        else:
+            H.call("smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
         m1, r1 = stat(co)
         a1 = new_act(n, co, h, w, x)
         H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
@@ -602,7 +616,10 @@ class BasicBlockFn(Function):
         if has_sc:
             s = new_act(n, co, h, w, x)
             t1 = H.call("smsut_conv1x1_tiles", n, hw, co) if H.call("smsut_conv1x1_supported", ci, co) else 0
-            if t1:
+            if virtual:                                      # (basic_block_cat_fusable checked t1 > 0)
+                ps = _ws(n * t1 * co * 2, x)
+                H.call("smsut_conv1x1_fwd_cat", xa, xb, xa.shape[1], ws, s, ps, n, hw, ci, co, st)
+            elif t1:
                 ps = _ws(n * t1 * co * 2, x)
                 H.call("smsut_conv1x1_fwd", x, ws, s, ps, n, hw, ci, co, 0, st)
             else:
@@ -617,7 +634,9 @@ class BasicBlockFn(Function):
         H.call("smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, co, slope, st)
         ctx.has_sc = has_sc
         ctx.slope = slope
-        if has_sc:
+        if virtual:
+            ctx.save_for_backward(xa, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs, xb)
+        elif has_sc:
             ctx.save_for_backward(x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs)
         else:
             ctx.save_for_backward(x, w1, w2, y1, a1, y2, out, m1, r1, m2, r2, g1, b1, g2)
@@ -626,7 +645,12 @@ class BasicBlockFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, g_out):
-        if ctx.has_sc:
+        xb_part = None
+        if ctx.virtual:
+            x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs, xb_part = ctx.saved_tensors
+            if not REMASK_TAIL:
+                b2 = bs = None
+        elif ctx.has_sc:
             x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs = ctx.saved_tensors
             if not REMASK_TAIL:
                 b2 = bs = None
@@ -637,6 +661,8 @@ class BasicBlockFn(Function):
         slope = ctx.slope
         g_out = nhwc(g_out)
         n, ci, h, w = x.shape
+        if ctx.virtual:
+            ci = x.shape[1] + xb_part.shape[1]           # x is the first part here
         co = w1.shape[0]
         hw = h * w
         st = _s()
@@ -675,12 +701,19 @@ class BasicBlockFn(Function):
                n, h, w, co, co, 3, st)
         # ---- conv1 and the shortcut
         gw1 = new_weight(co, ci, 3, 3, device=dev)
-        H.call("smsut_conv2d_wgrad_mfma", x, gy1, gw1, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), x),
-               n, h, w, ci, co, 3, st)
+        wws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), x)
+        if ctx.virtual:
+            H.call("smsut_conv2d_wgrad_mfma_cat", x, xb_part, x.shape[1], gy1, gw1, wws, n, h, w, ci, co, 3, st)
+        else:
+            H.call("smsut_conv2d_wgrad_mfma", x, gy1, gw1, wws, n, h, w, ci, co, 3, st)
         gws = None
         if ctx.has_sc:
             gws = new_weight(co, ci, 1, 1, device=dev)
-            H.call("smsut_conv1x1_wgrad", x, gs_t, gws, _ws(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), x), n, hw, ci, co, st)
+            wws1 = _ws(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), x)
+            if ctx.virtual:
+                H.call("smsut_conv1x1_wgrad_cat", x, xb_part, x.shape[1], gs_t, gws, wws1, n, hw, ci, co, st)
+            else:
+                H.call("smsut_conv1x1_wgrad", x, gs_t, gws, wws1, n, hw, ci, co, st)
         gx = None
         if ctx.cat_split is not None:
             ga = gb = None
@@ -714,6 +747,48 @@ class BasicBlockFn(Function):
                 gx = gs_t
             H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
         return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
+
+
+class CatParts:
+    """Deferred ``torch.cat([a, b], 1)`` (UpSampleAndConcat, network/blocks.py:49-50).  A fused BasicBlock reads the two parts in
+    place (``basic_block_cat``) and never builds the cat; any other consumer calls ``tensor()``."""
+    __slots__ = ("a", "b", "_t")
+
+    def __init__(self, a, b):
+        self.a, self.b, self._t = a, b, None
+
+    @property
+    def shape(self):
+        return torch.Size((self.a.shape[0], self.a.shape[1] + self.b.shape[1], self.a.shape[2], self.a.shape[3]))
+
+    def tensor(self):
+        if self._t is None:
+            self._t = concat_channels(self.a, self.b)
+        return self._t
+
+
+def concat_channels_deferred(a, b):
+    """cat([a, b], 1) whose materialisation is left to the consumer (see CatParts); a plain tensor when the virtual-cat
+    kernels cannot apply (unequal or non-16-multiple halves, CPU tensors, switches off)."""
+    if (VIRTUAL_CAT and SPLIT_DGRAD and FUSED_BLOCK and not FORCE_GENERIC_CONV and a.is_cuda and a.shape[1] == b.shape[1]
+            and a.shape[1] % 16 == 0 and a.shape[0] == b.shape[0] and a.shape[2:] == b.shape[2:]):
+        return CatParts(a, b)
+    return concat_channels(a, b)
+
+
+def basic_block_cat_fusable(parts, w1, ws):
+    """Every consumer of the cat has a virtual-cat kernel for this shape: persistent 3x3 forward (Kdim 32 / 64), streaming
+    1x1 shortcut with statistics tiles, MFMA weight gradients."""
+    n, ca, h, w = parts.a.shape
+    ci, co = 2 * ca, w1.shape[0]
+    return (ws is not None and w1.shape[1] == ci and co % 4 == 0
+            and H.call("smsut_conv2d_mfma_cat_supported", n, h, w, ci, co)
+            and H.call("smsut_conv1x1_supported", ci, co) and H.call("smsut_conv1x1_tiles", n, h * w, co) > 0
+            and H.call("smsut_conv2d_wgrad_mfma_supported", 3, 1, 1, ci, co))
+
+
+def basic_block_cat(parts, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):
+    return BasicBlockFn.apply(None, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, cl(parts.a), cl(parts.b))
 
 
 def basic_block(x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):

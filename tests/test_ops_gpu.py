@@ -392,7 +392,7 @@ def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
     ws = rnd(co, ci, 1, 1, seed=5) / np.sqrt(ci)
     aff = [1 + 0.1 * rnd(co, seed=6 + k) if k % 2 == 0 else 0.1 * rnd(co, seed=6 + k) for k in range(6)]
     gout = rnd(n, co, h, h, seed=20)
-    res = {}
+    res, res_ws = {}, None
     for split in (True, False):
         ops.SPLIT_DGRAD = split
         try:
@@ -405,10 +405,29 @@ def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
             out = ops.basic_block(x, *prm, slope)
             out.backward(dev(gout))
             res[split] = (out.detach().cpu().numpy(), ad.grad.cpu().numpy(), bd.grad.cpu().numpy(), prm[0].grad.cpu().numpy())
+            res_ws = prm[6].grad.cpu().numpy()
         finally:
             ops.SPLIT_DGRAD = True
     for u, v in zip(res[True], res[False]):
         assert np.array_equal(u, v)
+    # virtual cat: the cat tensor is never built (persistent-kernel shapes only); same bits again
+    ad, bd = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    parts = ops.concat_channels_deferred(ad, bd)
+    prm = [to_hwio(ops, w1).requires_grad_(True), *[dev(t).requires_grad_(True) for t in aff[:2]],
+           to_hwio(ops, w2).requires_grad_(True), *[dev(t).requires_grad_(True) for t in aff[2:4]],
+           to_hwio(ops, ws).requires_grad_(True), *[dev(t).requires_grad_(True) for t in aff[4:]]]
+    assert isinstance(parts, ops.CatParts)
+    if ops.basic_block_cat_fusable(parts, prm[0], prm[6]):
+        assert (n, h) in ((8, 128), (16, 64), (32, 32))
+        out = ops.basic_block_cat(parts, *prm, slope)
+        out.backward(dev(gout))
+        got = (out.detach().cpu().numpy(), ad.grad.cpu().numpy(), bd.grad.cpu().numpy(), prm[0].grad.cpu().numpy())
+        for u, v in zip(got, res[True]):
+            assert np.array_equal(u, v)
+        assert np.array_equal(prm[6].grad.cpu().numpy(), np.asarray(res_ws)) if res_ws is not None else True
+    else:
+        assert (n, h) not in ((8, 128), (16, 64))
+        assert torch.equal(parts.tensor(), ops.concat_channels(ad, bd))
     at, bt = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
     xt = torch.cat([at, bt], 1)
     y = F.leaky_relu(F.instance_norm(F.conv2d(xt, w1, padding=1), weight=aff[0], bias=aff[1]), slope)
@@ -418,3 +437,43 @@ def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
     from conftest import l2_rel
     assert rel_err(res[True][0], ref.detach().numpy()) < 2e-5
     assert l2_rel(res[True][1], at.grad.numpy()) < 5e-3 and l2_rel(res[True][2], bt.grad.numpy()) < 5e-3
+
+
+@pytest.mark.parametrize("n,h,ca,co", [(8, 128, 16, 16), (16, 64, 32, 32), (4, 256, 16, 16), (6, 128, 32, 64)])
+def test_virtual_cat_entries_bit_identical(ops, n, h, ca, co):
+    """The *_cat entry points read cat([xa, xb]) from the two tensors in place; chunk order and arithmetic are those of the
+    materialised cat, so every result must be bit-identical to the plain entry point on torch.cat's output."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    ci = 2 * ca
+    g = torch.Generator(device="cpu").manual_seed(7)
+    xa = torch.randn(n, h, h, ca, generator=g).cuda(); xb = torch.randn(n, h, h, ca, generator=g).cuda()
+    cat = torch.cat([xa, xb], 3).contiguous()
+    w3 = (torch.randn(9 * ci * co, generator=g) / np.sqrt(9 * ci)).cuda(); w1 = (torch.randn(ci * co, generator=g) / np.sqrt(ci)).cuda()
+    gy = torch.randn(n, h, h, co, generator=g).cuda()
+    hw = h * h
+    # 3x3 forward + statistics
+    assert H.call("smsut_conv2d_mfma_cat_supported", n, h, h, ci, co) == 1
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3)
+    y0, y1 = torch.empty(n, h, h, co, device="cuda"), torch.empty(n, h, h, co, device="cuda")
+    p0, p1 = torch.zeros(n * tiles * co * 2, device="cuda"), torch.zeros(n * tiles * co * 2, device="cuda")
+    H.call("smsut_conv2d_fwd_mfma_stats", cat, w3, y0, p0, n, h, h, ci, co, 3, st)
+    H.call("smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w3, y1, p1, n, h, h, ci, co, st)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    # 1x1 forward (+ statistics)
+    t1 = H.call("smsut_conv1x1_tiles", n, hw, co)
+    q0, q1 = torch.zeros(n * max(t1, 1) * co * 2, device="cuda"), torch.zeros(n * max(t1, 1) * co * 2, device="cuda")
+    H.call("smsut_conv1x1_fwd", cat, w1, y0, q0 if t1 else None, n, hw, ci, co, 0, st)
+    H.call("smsut_conv1x1_fwd_cat", xa, xb, ca, w1, y1, q1 if t1 else None, n, hw, ci, co, st)
+    assert torch.equal(y0, y1) and torch.equal(q0, q1)
+    # 3x3 and 1x1 weight gradients
+    ws = torch.empty(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, h, ci, co, 3), device="cuda")
+    g0, g1 = torch.empty(9 * ci * co, device="cuda"), torch.empty(9 * ci * co, device="cuda")
+    H.call("smsut_conv2d_wgrad_mfma", cat, gy, g0, ws, n, h, h, ci, co, 3, st)
+    H.call("smsut_conv2d_wgrad_mfma_cat", xa, xb, ca, gy, g1, ws, n, h, h, ci, co, 3, st)
+    assert torch.equal(g0, g1)
+    ws1 = torch.empty(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), device="cuda")
+    k0, k1 = torch.empty(ci * co, device="cuda"), torch.empty(ci * co, device="cuda")
+    H.call("smsut_conv1x1_wgrad", cat, gy, k0, ws1, n, hw, ci, co, st)
+    H.call("smsut_conv1x1_wgrad_cat", xa, xb, ca, gy, k1, ws1, n, hw, ci, co, st)
+    assert torch.equal(k0, k1)
