@@ -23,7 +23,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // MR x 16 pixels per wave step, NR x 16 output channels per workgroup.
-template <int MR, int NR>
+template <int MR, int NR, bool DUAL = false>
 __global__ void __launch_bounds__(TPB)
 conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ stats,
             int64_t P, int HW, int Kdim, int Ndim, int transposed, float* __restrict__ y2 = nullptr, int split = 0,
@@ -63,18 +63,18 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
   const float* xp[MR];
   const float* xq[MR];
   bool pok[MR];
-  const int sa = x2 ? ca : Kdim;
+  const int sa = DUAL ? ca : Kdim;                 // (template flag: the plain form keeps one pointer set and no select)
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
     const int64_t p = p0 + i * 16 + lm;
     pok[i] = p < P;
     xp[i] = x + (size_t)(pok[i] ? p : 0) * sa + 4 * kq;
-    xq[i] = x2 ? x2 + (size_t)(pok[i] ? p : 0) * (Kdim - ca) + 4 * kq - ca : xp[i];
+    xq[i] = DUAL ? x2 + (size_t)(pok[i] ? p : 0) * (Kdim - ca) + 4 * kq - ca : xp[i];
   }
 // (runtime trip count: the partial unroll request is not honoured for every instantiation)
   for (int c = 0; c < chunks; ++c) {
     const bool kok = c * 16 + 4 * kq < Kdim;
-    const bool second = x2 && c * 16 >= ca;
+    const bool second = DUAL && c * 16 >= ca;
     f32x4 a[MR], b[NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -372,10 +372,16 @@ static int conv1x1_fwd_launch(const float* x, const float* w, float* y, float* s
   const size_t sh = (size_t)chunks * 4 * 16 * nr * 4 * sizeof(float);
   dim3 grid((unsigned)cdiv64(P, 64 * mr), (Ndim + 16 * nr - 1) / (16 * nr));
   hipStream_t st = (hipStream_t)stream;
-  if (mr == 4 && nr == 2) conv1x1_fwd<4, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
-  else if (mr == 4) conv1x1_fwd<4, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
-  else if (nr == 2) conv1x1_fwd<1, 2><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
-  else conv1x1_fwd<1, 1><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca);
+#define LAUNCH1X1(M, R)                                                                                                      \
+  do {                                                                                                                       \
+    if (x2) conv1x1_fwd<M, R, true><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, x2, ca); \
+    else conv1x1_fwd<M, R, false><<<grid, TPB, sh, st>>>(x, w, y, stats, P, HW, Kdim, Ndim, transposed, y2, split, nullptr, 0); \
+  } while (0)
+  if (mr == 4 && nr == 2) LAUNCH1X1(4, 2);
+  else if (mr == 4) LAUNCH1X1(4, 1);
+  else if (nr == 2) LAUNCH1X1(1, 2);
+  else LAUNCH1X1(1, 1);
+#undef LAUNCH1X1
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

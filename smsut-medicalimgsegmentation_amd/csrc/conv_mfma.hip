@@ -526,7 +526,7 @@ constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows 
 #endif
 constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
-template <int KS, int CIT, int COT>
+template <int KS, int CIT, int COT, bool DUAL = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                 int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci,
@@ -583,8 +583,9 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
     gy_lds[i] = pix * SO + 4 * q;
   }
 
-  // x2 != null: x is the virtual cat([x, x2]); a thread's units share one channel quad (see conv_mfma_wgrad_ts)
-  const CatSrc xsrc = cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4)));
+  // DUAL: x is the virtual cat([x, x2]); a thread's units share one channel quad (see conv_mfma_wgrad_ts).  A template
+  // flag, so the plain form keeps its uniform (scalar-register) base and stride: a runtime select cost it 15 % at 16->16.
+  const CatSrc xsrc = DUAL ? cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4))) : CatSrc{x, Cin, 0};
   auto prefetch = [&](int t) {
     const int n_img = t / tiles_img;
     const int rem = t % tiles_img;
@@ -687,6 +688,7 @@ typedef float4 wvec;
 typedef f32x4 wvec;
 #define WZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
 #endif
+template <bool DUAL = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                    int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split,
@@ -732,7 +734,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
   // x2 != null: x is the virtual cat([x, x2]) (common.h).  A thread's units all carry the same channel quad
   // (TPB % (CI_T/4) == 0; padding units keep it too), so its source tensor, pixel stride and channel offset are fixed.
-  const CatSrc xsrc = cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4)));
+  const CatSrc xsrc = DUAL ? cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4))) : CatSrc{x, Cin, 0};
 #pragma unroll
   for (int i = 0; i < NIN; ++i) {
     const int u = tid + i * TPB;
@@ -1108,8 +1110,12 @@ int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int
   static_assert(sh <= 64 * 1024, "LDS budget");
   const int nci = (Cin + CI_T - 1) / CI_T;
   dim3 grid(p.splits, nci * ntaps, (Cout + CO_T - 1) / CO_T);
-  conv_mfma_wgrad<KS, CIT, COT><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
-                                                      p.tiles_per_split, gsc, nci, x2, ca);
+  if (x2)
+    conv_mfma_wgrad<KS, CIT, COT, true><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                              p.tiles_per_split, gsc, nci, x2, ca);
+  else
+    conv_mfma_wgrad<KS, CIT, COT, false><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                               p.tiles_per_split, gsc, nci, nullptr, 0);
   return 0;
 }
 
@@ -1295,8 +1301,12 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
              (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {
       constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE + 4) * sizeof(float);
       dim3 grid(p.splits, Cin / 32, Cout / 32);
-      conv_mfma_wgrad_ts<<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
-                                                p.tiles_per_split, x2, ca);
+      if (x2)
+        conv_mfma_wgrad_ts<true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                        p.tiles_per_split, x2, ca);
+      else
+        conv_mfma_wgrad_ts<false><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                         p.tiles_per_split, nullptr, 0);
     } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
   }
   const int wsize = KS * KS * Cin * Cout;
