@@ -53,7 +53,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 template <int KS, int TH, int WM, int WN, int NTN>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Kdim,
-              int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz, float* __restrict__ stats) {
+              int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz, float* __restrict__ stats,
+              const float* __restrict__ x2 = nullptr, float* __restrict__ y2 = nullptr, int split = 0) {
+  // x2 (nullable, regular conv only): the input is the virtual cat([x, x2]) of two Kdim/2-channel tensors (common.h); the
+  // select is per 16-channel chunk, i.e. uniform.  y2 / split (nullable): result channels >= split go to y2 (see
+  // conv_mfma_fwd_p).
   // stats (nullable): per-workgroup InstanceNorm partials [n][tile][Ndim][2] = {sum, sum of squares} of this tile's
   // outputs, in the layout in_moments_final<0> (norm.hip) consumes -- the statistics pass over y is then not needed.
   // (H, W) is the compute grid.  Regular conv: isc = osc = G = 1.  ConvTranspose2x2 forward: osc = 2 and
@@ -82,7 +86,9 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   const int co0 = (blockIdx.z % nz) * CO_T;
   const int y0 = ty * TH, x0 = tx * TW;
   const int Wi = W * isc;
-  const float* xin = x + (size_t)n_img * H * isc * Wi * Kdim;
+  const int KSTR = x2 ? Kdim / 2 : Kdim;       // pixel stride of the input tensor(s)
+  const float* xin = x + (size_t)n_img * H * isc * Wi * KSTR;
+  const float* xin2 = x2 ? x2 + (size_t)n_img * H * isc * Wi * KSTR : xin;
   w += (size_t)tapo * KK * Kdim * Ndim;
 
   f32x4 acc[MR][NR];
@@ -108,7 +114,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     const int iy = pix / IW, ix = pix % IW;
     const int gy_ = y0 + iy - PAD, gx_ = x0 + ix - PAD;
     const bool ok = u < IH * IW * 4 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
-    in_off[i] = ok ? ((gy_ * isc) * Wi + gx_ * isc) * Kdim + 4 * q : -1;
+    in_off[i] = ok ? ((gy_ * isc) * Wi + gx_ * isc) * KSTR + 4 * q : -1;
     in_q[i] = 4 * q;
   }
 #pragma unroll
@@ -126,7 +132,8 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   auto prefetch = [&](int step) {
     const int g = step / nchunk, c0 = (step % nchunk) * CK;
     const float* wg = w + (size_t)g * KK * Kdim * Ndim + (transposed ? c0 : c0 * Ndim);
-    const float* xg = xin + ((size_t)(g >> 1) * Wi + (g & 1)) * Kdim + c0;
+    const bool second = x2 && c0 >= KSTR;
+    const float* xg = (second ? xin2 : xin) + ((size_t)(g >> 1) * Wi + (g & 1)) * KSTR + (second ? c0 - KSTR : c0);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -219,7 +226,6 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   }
   STAMP(10);
   const int Wo = W * osc;
-  float* yout = y + (size_t)n_img * H * osc * Wo * Ndim;
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
     const int gy_ = y0 + wm * MR + i;
@@ -228,11 +234,14 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     for (int j = 0; j < NR; ++j) {
       const int co = co0 + (wn * NR + j) * 16 + lm;
       if (co >= Ndim) continue;
+      const bool hi = y2 && co0 + (wn * NR + j) * 16 >= split;           // uniform per (workgroup, j)
+      const int os = !y2 ? Ndim : (hi ? Ndim - split : split);
+      float* yout = (hi ? y2 : y) + (size_t)n_img * H * osc * Wo * os + (hi ? co - split : co);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int gx_ = x0 + 4 * kq + r;
         if (gx_ < W) {
-          float* o = yout + ((size_t)(gy_ * osc + (tapo >> 1)) * Wo + gx_ * osc + (tapo & 1)) * Ndim + co;
+          float* o = yout + ((size_t)(gy_ * osc + (tapo >> 1)) * Wo + gx_ * osc + (tapo & 1)) * os;
           *o = accum ? acc[i][j][r] + *o : acc[i][j][r];
         }
       }
@@ -885,7 +894,8 @@ inline void launch_sum_splits(const float* part, float* out, int wsize, int spli
 
 template <int KS, int TH, int WM, int WN, int NTN>
 int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-               int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
+               int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr,
+               const float* x2 = nullptr, float* y2 = nullptr, int split = 0) {
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
   constexpr size_t sh = (size_t)(IH * IW * SPIX + KS * KS * CK * 16 * NTN) * sizeof(float);
   static_assert(sh <= 64 * 1024, "LDS budget");
@@ -893,8 +903,11 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
   const int nz = (Ndim + 16 * NTN - 1) / (16 * NTN);
   if (tiles_out) { *tiles_out = tiles_x * tiles_y; return 0; }          // planning query only
   dim3 grid(tiles_x * tiles_y, N, nz * ntap_out);
+  if ((x2 && (isc != 1 || osc != 1 || G != 1 || ntap_out != 1 || (transposed & 1) || Kdim % 32 != 0)) ||
+      (y2 && (osc != 1 || ntap_out != 1 || stats || split <= 0 || split >= Ndim || split % 16 != 0)))
+    return -1;
   conv_mfma_fwd<KS, TH, WM, WN, NTN><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc, G,
-                                                            nz, stats);
+                                                            nz, stats, x2, y2, split);
   return 0;
 }
 
@@ -994,8 +1007,9 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
 
 template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
-                 int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr) {
-#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out
+                 int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr,
+                 const float* x2 = nullptr, float* y2 = nullptr, int split = 0) {
+#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out, x2, y2, split
   // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
   // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
   static const bool log_shapes = getenv("SMSUT_LOG_CONV") != nullptr;      // shape census for tuning (stderr)
@@ -1006,7 +1020,7 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
     // small-Cin / large-image layers: persistent kernel with resident weights (see conv_mfma_fwd_p); it declines
     // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
     if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_p_eligible(N, H, W, Kdim, Ndim)) {
-      if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr) == 0) return 0;
+      if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr, y2, split, x2) == 0) return 0;
     }
   }
   const int nt = (Ndim + 15) / 16;
@@ -1160,16 +1174,15 @@ int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H
 // [N,H,W,Kdim/2] tensors, read in place.  Persistent kernel, Kdim in {32, 64}: _supported says whether the shape is covered;
 // the statistics tiles are those of smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3).
 int smsut_conv2d_mfma_cat_supported(int N, int H, int W, int Kdim, int Ndim) {
-  if (N <= 0 || H <= 0 || W <= 0 || (Kdim != 32 && Kdim != 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
-  int tiles = 0;
-  float dummy;
-  return select_fwd_p(nullptr, nullptr, &dummy, N, H, W, Kdim, Ndim, 0, nullptr, &dummy, &tiles, nullptr, nullptr, 0, &dummy) == 0;
+  // persistent kernel (Kdim 32 / 64) or the per-tile kernel: two halves of whole 16-channel chunks
+  return N > 0 && H > 0 && W > 0 && Kdim % 32 == 0 && smsut_conv2d_mfma_supported(3, 1, 1, Kdim, Ndim) &&
+         (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) < (1ll << 31);
 }
 
 int smsut_conv2d_fwd_mfma_stats_cat(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
                                     int W, int Kdim, int Ndim, void* stream) {
   SMSUT_REQUIRE(xa && xb && w && y && stats && smsut_conv2d_mfma_cat_supported(N, H, W, Kdim, Ndim));
-  const int rc = select_fwd_p(xa, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb);
+  const int rc = dispatch_fwd<3>(xa, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, (hipStream_t)stream, stats, nullptr, xb);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
@@ -1179,17 +1192,19 @@ int smsut_conv2d_fwd_mfma_stats_cat(const float* xa, const float* xb, const floa
 // [split, Ndim) to yb [N,H,W,Ndim-split]: the data-gradient of a block fed by cat([up, skip]) (network/blocks.py:49)
 // written straight into the two gradients.  Persistent kernel only: _supported tells whether this shape is covered.
 int smsut_conv2d_mfma_split_supported(int N, int H, int W, int Kdim, int Ndim, int split) {
-  if (N <= 0 || H <= 0 || W <= 0 || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
-  int tiles = 0;
-  float dummy;
-  return select_fwd_p(nullptr, nullptr, &dummy, N, H, W, Kdim, Ndim, 1, nullptr, nullptr, &tiles, nullptr, &dummy, split) == 0;
+  // 16-channel output tiles never straddle the seam
+  if (N <= 0 || H <= 0 || W <= 0 || split <= 0 || split >= Ndim || split % 16 != 0 ||
+      !smsut_conv2d_mfma_supported(3, 1, 1, Kdim, Ndim) || Kdim % 4 != 0)
+    return 0;
+  return 1;          // a persistent variant that cannot split at `split` declines and the per-tile kernel takes over
 }
 
 int smsut_conv2d_fwd_mfma_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int H, int W,
                                 int Kdim, int Ndim, int transposed, void* stream) {
   SMSUT_REQUIRE(x && w && ya && yb && N > 0 && H > 0 && W > 0 && (transposed & ~3) == 0);
   SMSUT_REQUIRE(smsut_conv2d_mfma_split_supported(N, H, W, Kdim, Ndim, split));
-  const int rc = select_fwd_p(x, w, ya, N, H, W, Kdim, Ndim, transposed, (hipStream_t)stream, nullptr, nullptr, nullptr, yb, split);
+  const int rc = dispatch_fwd<3>(x, w, ya, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, (hipStream_t)stream, nullptr, nullptr,
+                                 nullptr, yb, split);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

@@ -418,7 +418,6 @@ def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
            to_hwio(ops, ws).requires_grad_(True), *[dev(t).requires_grad_(True) for t in aff[4:]]]
     assert isinstance(parts, ops.CatParts)
     if ops.basic_block_cat_fusable(parts, prm[0], prm[6]):
-        assert (n, h) in ((8, 128), (16, 64), (32, 32))
         out = ops.basic_block_cat(parts, *prm, slope)
         out.backward(dev(gout))
         got = (out.detach().cpu().numpy(), ad.grad.cpu().numpy(), bd.grad.cpu().numpy(), prm[0].grad.cpu().numpy())
@@ -426,7 +425,7 @@ def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
             assert np.array_equal(u, v)
         assert np.array_equal(prm[6].grad.cpu().numpy(), np.asarray(res_ws)) if res_ws is not None else True
     else:
-        assert (n, h) not in ((8, 128), (16, 64))
+        assert ca % 16 != 0 or co % 4 != 0
         assert torch.equal(parts.tensor(), ops.concat_channels(ad, bd))
     at, bt = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
     xt = torch.cat([at, bt], 1)
@@ -439,7 +438,8 @@ def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
     assert l2_rel(res[True][1], at.grad.numpy()) < 5e-3 and l2_rel(res[True][2], bt.grad.numpy()) < 5e-3
 
 
-@pytest.mark.parametrize("n,h,ca,co", [(8, 128, 16, 16), (16, 64, 32, 32), (4, 256, 16, 16), (6, 128, 32, 64)])
+@pytest.mark.parametrize("n,h,ca,co", [(8, 128, 16, 16), (16, 64, 32, 32), (4, 256, 16, 16), (6, 128, 32, 64),   # persistent
+                                       (8, 64, 64, 64), (4, 32, 128, 128), (2, 24, 16, 20), (3, 8, 64, 32)])      # per-tile kernel
 def test_virtual_cat_entries_bit_identical(ops, n, h, ca, co):
     """The *_cat entry points read cat([xa, xb]) from the two tensors in place; chunk order and arithmetic are those of the
     materialised cat, so every result must be bit-identical to the plain entry point on torch.cat's output."""
@@ -452,8 +452,16 @@ def test_virtual_cat_entries_bit_identical(ops, n, h, ca, co):
     w3 = (torch.randn(9 * ci * co, generator=g) / np.sqrt(9 * ci)).cuda(); w1 = (torch.randn(ci * co, generator=g) / np.sqrt(ci)).cuda()
     gy = torch.randn(n, h, h, co, generator=g).cuda()
     hw = h * h
-    # 3x3 forward + statistics
+    # 3x3 forward + statistics, and the split-output data-gradient form (Kdim = co, Ndim = ci)
     assert H.call("smsut_conv2d_mfma_cat_supported", n, h, h, ci, co) == 1
+    assert H.call("smsut_conv2d_mfma_split_supported", n, h, h, co, ci, ca) == 1
+    gfull = torch.empty(n, h, h, ci, device="cuda"); ga = torch.empty(n, h, h, ca, device="cuda"); gb = torch.empty(n, h, h, ca, device="cuda")
+    H.call("smsut_conv2d_fwd_mfma", gy, w3, gfull, n, h, h, co, ci, 3, 1, st)
+    H.call("smsut_conv2d_fwd_mfma_split", gy, w3, ga, gb, ca, n, h, h, co, ci, 1, st)
+    assert torch.equal(gfull[..., :ca].contiguous(), ga) and torch.equal(gfull[..., ca:].contiguous(), gb)
+    H.call("smsut_conv2d_fwd_mfma", gy, w3, gfull, n, h, h, co, ci, 3, 3, st)           # accumulate forms on top
+    H.call("smsut_conv2d_fwd_mfma_split", gy, w3, ga, gb, ca, n, h, h, co, ci, 3, st)
+    assert torch.equal(gfull[..., :ca].contiguous(), ga) and torch.equal(gfull[..., ca:].contiguous(), gb)
     tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3)
     y0, y1 = torch.empty(n, h, h, co, device="cuda"), torch.empty(n, h, h, co, device="cuda")
     p0, p1 = torch.zeros(n * tiles * co * 2, device="cuda"), torch.zeros(n * tiles * co * 2, device="cuda")
