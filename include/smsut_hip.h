@@ -78,6 +78,17 @@ int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout);
 int smsut_conv1x1_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int HW, int Cin, int Cout,
                         void* stream);
 
+/* input-side InstanceNorm + LeakyReLU: the operand is a = lrelu(IN(x; mean[N,C], rstd[N,C], gamma[C], beta[C])) of the tensor
+   passed, normalised while the tiles are staged -- conv2 of a BasicBlock (network/blocks.py:70-72) and its weight gradient
+   read the raw conv1 output, so the activation a1 is never written to or read from HBM.  Same in_affine() fma as the IN
+   kernels: results equal the two-pass path bit for bit.  Forward: persistent-kernel shapes (smsut_conv2d_mfma_persistent). */
+int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, float* stats, const float* mean,
+                                      const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
+                                      int W, int Kdim, int Ndim, void* stream);
+int smsut_conv2d_wgrad_mfma_inaff(const float* x, const float* gy, float* gw, float* workspace, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, float slope, int N, int H, int W,
+                                  int Cin, int Cout, void* stream);
+
 /* virtual-cat input forms: the logical input is cat([xa, xb], channel) (UpSampleAndConcat, network/blocks.py:49-50) read
    from the two tensors in place -- same chunk order and arithmetic as on a materialised cat, so results are bit-identical.
    ca % 16 == 0.  conv2d forward: persistent kernel, Kdim in {32, 64}, xa and xb of Kdim/2 channels each (ask _cat_supported). */

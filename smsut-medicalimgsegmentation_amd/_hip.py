@@ -57,6 +57,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv1x1_fwd": "pppp iiii i s",
     "smsut_conv1x1_wgrad_ws": "iiii",
     "smsut_conv1x1_wgrad": "pppp iiii s",
+    "smsut_conv2d_fwd_mfma_stats_inaff": "pppp pppp f iiiii s",
+    "smsut_conv2d_wgrad_mfma_inaff": "pppp pppp f iiiii s",
     "smsut_conv2d_mfma_cat_supported": "iiiii",
     "smsut_conv2d_fwd_mfma_stats_cat": "ppppp iiiii s",
     "smsut_conv2d_wgrad_mfma_cat": "pp i ppp iiiiii s",

@@ -267,15 +267,24 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 // a1 = LeakyReLU(IN(y1)); the epilogue multiplies it by the activation mask recomputed from y1 (in_affine), stores
 // gz = g * mask, and emits the per-tile partials {sum gz, sum gz * xhat} of the InstanceNorm backward -- the separate
 // reduction pass over (g, y1) disappears (in_moments_partial<1>: 4.5 % of the uganConsis iteration).
+// Input-side InstanceNorm + LeakyReLU ("INAFF"): the conv input is a = lrelu(in_affine(x; mean[n,c], rstd[n,c], gamma[c],
+// beta[c])) of the tensor actually read -- conv2 of a BasicBlock and its weight gradient read the raw conv1 output y1 and
+// normalise it while staging, so a1 is never written to or read from HBM.  Same in_affine() fma as norm.hip: same bits.
+struct AffRef { const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
+__device__ __forceinline__ float aff1(float v, float m, float r, float g, float b, float slope) {
+  return lrelu_f(in_affine(v, m, r, g, b), slope);
+}
+
 struct BstRef { const float* y1; const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
 
-template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false>
+template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
                 BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0,
-                const float* __restrict__ x2 = nullptr) {
+                const float* __restrict__ x2 = nullptr, AffRef aff = AffRef{}) {
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
+  static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
   static_assert(!DUAL || NCH % 2 == 0, "virtual cat input: two equal halves of whole 16-channel chunks");
   // DUAL: the input is the virtual cat([x, x2]) of two [N,H,W,Kdim/2] tensors (common.h): chunks [0, NCH/2) are staged
   // from x, the rest from x2 -- same chunk order, same arithmetic as on the materialised cat.
@@ -356,6 +365,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   int en = pn, ety = pty, etx = ptx;
   int pflags = 0;      // borders the prefetched tile touches
   bool zero[NI];       // per unit: outside the image for the chunk currently in rin
+  [[maybe_unused]] float4 a_m, a_r, a_g, a_b;     // INAFF: statistics / affine of (image, this thread's channel quad) for rin
 
   auto prefetch = [&](int c) {                       // chunk c of item (pn, pty, ptx)
     if (c == 0) pflags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
@@ -367,6 +377,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       zero[i] = (u_flag[i] & pflags) != 0;
       rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : u_off[i]));
     }
+    if (INAFF) {                                     // every unit of a thread carries the channel quad tid & 3
+      const int ch = c * 16 + 4 * (tid & 3);
+      a_m = *(const float4*)(aff.mean + (size_t)pn * Kdim + ch);
+      a_r = *(const float4*)(aff.rstd + (size_t)pn * Kdim + ch);
+      a_g = *(const float4*)(aff.gamma + ch);
+      a_b = *(const float4*)(aff.beta + ch);
+    }
   };
   auto advance = [&](int& n_, int& ty_, int& tx_) {
     if (++tx_ == tiles_x) { tx_ = 0; if (++ty_ == tiles_y) { ty_ = 0; ++n_; } }
@@ -375,7 +392,11 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       float4 v = rin[i];
-      if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (INAFF) {
+        v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+        v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
+      }
+      if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);          // the zero padding applies to a, not to x
       *(float4*)(in_s + u_lds[i]) = v;
     }
   };
@@ -535,11 +556,12 @@ constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows 
 #endif
 constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
-template <int KS, int CIT, int COT, bool DUAL = false>
+template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                 int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci,
-                const float* __restrict__ x2 = nullptr, int ca = 0) {
+                const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{}) {
+  // INAFF: x is the raw conv output whose lrelu(IN(.)) is the operand (see AffRef); applied when a tile is published.
   // gsc = 2 / 4 tap groups in blockIdx.y: weight-gradient of ConvTranspose2x2 (gy is the 2x larger tensor).
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
@@ -595,6 +617,13 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   // DUAL: x is the virtual cat([x, x2]); a thread's units share one channel quad (see conv_mfma_wgrad_ts).  A template
   // flag, so the plain form keeps its uniform (scalar-register) base and stride: a runtime select cost it 15 % at 16->16.
   const CatSrc xsrc = DUAL ? cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4))) : CatSrc{x, Cin, 0};
+  [[maybe_unused]] unsigned inimg = 0;                          // INAFF: units of rin that lie inside the image
+  [[maybe_unused]] float4 a_m, a_r, a_g, a_b;
+  [[maybe_unused]] const int aq = ci0 + 4 * (tid % (CI_T / 4));   // this thread's channel quad (same for all its units)
+  if (INAFF) {
+    a_g = a_b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (aq < Cin) { a_g = *(const float4*)(aff.gamma + aq); a_b = *(const float4*)(aff.beta + aq); }
+  }
   auto prefetch = [&](int t) {
     const int n_img = t / tiles_img;
     const int rem = t % tiles_img;
@@ -605,9 +634,15 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
     for (int i = 0; i < NIN; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int gy_ = y0 + (in_yx[i] >> 8) - PAD, gx_ = x0 + (in_yx[i] & 255) - PAD;
-      if (in_yx[i] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W)
+      if (in_yx[i] >= 0 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W) {
         v = *(const float4*)(xin + ((size_t)gy_ * W + gx_) * xsrc.stride + in_c[i]);
+        if (INAFF) inimg |= 1u << i;
+      } else if (INAFF) inimg &= ~(1u << i);
       rin[i] = v;
+    }
+    if (INAFF && aq < Cin) {
+      a_m = *(const float4*)(aff.mean + (size_t)n_img * Cin + aq);
+      a_r = *(const float4*)(aff.rstd + (size_t)n_img * Cin + aq);
     }
 #pragma unroll
     for (int i = 0; i < NGY; ++i) {
@@ -624,7 +659,14 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NIN; ++i)
-      if (tid + i * TPB < IH * IW * (CI_T / 4)) *(float4*)(in_s + in_lds[i]) = rin[i];
+      if (tid + i * TPB < IH * IW * (CI_T / 4)) {
+        float4 v = rin[i];
+        if (INAFF && ((inimg >> i) & 1u)) {
+          v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+          v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
+        }
+        *(float4*)(in_s + in_lds[i]) = v;
+      }
 #pragma unroll
     for (int i = 0; i < NGY; ++i)
       if (tid + i * TPB < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
@@ -697,11 +739,11 @@ typedef float4 wvec;
 typedef f32x4 wvec;
 #define WZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
 #endif
-template <bool DUAL = false>
+template <bool DUAL = false, bool INAFF = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                    int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split,
-                   const float* __restrict__ x2 = nullptr, int ca = 0) {
+                   const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{}) {
   constexpr int KS = 3, KK = 9, PAD = 1, CIT = 2, COT = 2;
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int CI_T = 32, CO_T = 32, SI = WTS_STRIDE, SO = WTS_STRIDE;
@@ -766,6 +808,9 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   int pn = t_begin / tiles_img, pty, ptx;                  // cursor of the tile being prefetched
   { const int t = t_begin - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
   bool zero[NIN];
+  [[maybe_unused]] float4 a_m, a_r, a_g, a_b;                      // INAFF (see conv_mfma_wgrad)
+  [[maybe_unused]] const int aq = ci0 + 4 * (tid % (CI_T / 4));
+  if (INAFF) { a_g = *(const float4*)(aff.gamma + aq); a_b = *(const float4*)(aff.beta + aq); }
   auto prefetch = [&]() {
     const int flags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
     const float* xb = xsrc.p + (((pn * H + pty * WTH - PAD) * W) + ptx * TW - PAD) * xsrc.stride + ci0 - xsrc.coff;
@@ -777,6 +822,10 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     }
 #pragma unroll
     for (int i = 0; i < NGY; ++i) rgy[i] = *(const wvec*)(gb + gy_off[i]);
+    if (INAFF) {
+      a_m = *(const float4*)(aff.mean + (size_t)pn * Cin + aq);
+      a_r = *(const float4*)(aff.rstd + (size_t)pn * Cin + aq);
+    }
     if (++ptx == tiles_x) { ptx = 0; if (++pty == tiles_y) { pty = 0; ++pn; } }
   };
 
@@ -790,6 +839,10 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
 #pragma unroll
     for (int i = 0; i < NIN; ++i) {
       wvec v = rin[i];
+      if (INAFF) {
+        v[0] = aff1(v[0], a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v[1] = aff1(v[1], a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+        v[2] = aff1(v[2], a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v[3] = aff1(v[3], a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
+      }
       if (zero[i]) v = WZERO;
       *(wvec*)(in_s + in_lds[i]) = v;
     }
@@ -932,7 +985,7 @@ constexpr size_t fwd_p_lds() {
 template <int KS, int TH, int NTN, int NCH>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
-                 float* y2 = nullptr, int split = 0, const float* x2 = nullptr) {
+                 float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr) {
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
   if constexpr (sh > 64 * 1024) return -1;
   else {
@@ -943,6 +996,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   const int tiles_img = tiles_x * tiles_y;
   if (y2 && (split <= 0 || split >= Ndim || split % (16 * NTN) != 0 || stats || bst)) return -1;
   if (x2 && (NCH % 2 != 0 || !stats || bst || y2 || transposed)) return -1;     // virtual-cat input: forward statistics form
+  if (aff && (!stats || bst || y2 || x2 || transposed)) return -1;              // input-side IN: forward statistics form
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = Ndim / (16 * NTN);
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
@@ -961,7 +1015,10 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   const int tr = transposed & 1;
 #define P_LAUNCH(ST, AC) conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, \
                                                                                         tiles_img, ipw, tr, stats, BstRef{}, y2, split)
-  if (x2) {
+  if (aff) {
+    conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, true><<<grid, TPB, sh, st>>>(
+        x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, BstRef{}, nullptr, 0, nullptr, *aff);
+  } else if (x2) {
     if constexpr (NCH % 2 == 0)
       conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img,
                                                                                          ipw, tr, stats, BstRef{}, nullptr, 0, x2);
@@ -994,14 +1051,14 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
 // so that smsut_conv2d_mfma_tiles() always describes the partials the launched variant writes.
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
-                        const float* x2 = nullptr) {
+                        const float* x2 = nullptr, const AffRef* aff = nullptr) {
 #ifndef SMSUT_P_OLD_TABLE
-  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
-  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
+  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
+  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
 #endif
-  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
-  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
-  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2);
+  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
+  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
+  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
   return -1;
 }
 
@@ -1113,7 +1170,8 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
 
 template <int KS, int CIT, int COT>
 int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int W, int Cin, int Cout,
-                 const WgradPlan& p, int gsc, int ntaps, hipStream_t st, const float* x2 = nullptr, int ca = 0) {
+                 const WgradPlan& p, int gsc, int ntaps, hipStream_t st, const float* x2 = nullptr, int ca = 0,
+                 const AffRef* aff = nullptr) {
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
   constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;
@@ -1124,7 +1182,11 @@ int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int
   static_assert(sh <= 64 * 1024, "LDS budget");
   const int nci = (Cin + CI_T - 1) / CI_T;
   dim3 grid(p.splits, nci * ntaps, (Cout + CO_T - 1) / CO_T);
-  if (x2)
+  if (aff) {
+    if (x2 || gsc != 1) return -1;
+    conv_mfma_wgrad<KS, CIT, COT, false, true><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                                     p.tiles_per_split, gsc, nci, nullptr, 0, *aff);
+  } else if (x2)
     conv_mfma_wgrad<KS, CIT, COT, true><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
                                                               p.tiles_per_split, gsc, nci, x2, ca);
   else
@@ -1166,6 +1228,21 @@ int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H
   hipStream_t st = (hipStream_t)stream;
   if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
   else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// conv2 of a BasicBlock on the RAW conv1 output: y = conv3x3(lrelu(IN(x; mean, rstd, gamma, beta))) + statistics of y, the
+// normalisation applied while the tiles are staged (a1 never exists in HBM).  Persistent-kernel shapes only
+// (smsut_conv2d_mfma_persistent); statistics tiles as smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3).
+int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, float* stats, const float* mean,
+                                      const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
+                                      int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(x && w && y && stats && mean && rstd && gamma && beta && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(fwd_p_eligible(N, H, W, Kdim, Ndim));
+  const AffRef a{mean, rstd, gamma, beta, slope};
+  const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, nullptr, &a);
+  SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -1297,10 +1374,11 @@ int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int K
 
 // gw [KS*KS][Cin][Cout] = sum over pixels of x (x) gy
 static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
-                             int Cout, int KS, void* stream, const float* x2, int ca) {
+                             int Cout, int KS, void* stream, const float* x2, int ca, const AffRef* aff = nullptr) {
   SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0);
   SMSUT_REQUIRE(smsut_conv2d_wgrad_mfma_supported(KS, 1, (KS - 1) / 2, Cin, Cout));
   SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0 && (Cin - ca) % 4 == 0));
+  SMSUT_REQUIRE(!aff || (KS == 3 && !x2));
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
   if (KS == 1) {
@@ -1309,20 +1387,23 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
     else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
     else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
   } else {
-    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
-    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
-    else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
+    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
+    else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
     else if (H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
              (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {
       constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE + 4) * sizeof(float);
       dim3 grid(p.splits, Cin / 32, Cout / 32);
-      if (x2)
+      if (aff)
+        conv_mfma_wgrad_ts<false, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                               p.tiles_per_split, nullptr, 0, *aff);
+      else if (x2)
         conv_mfma_wgrad_ts<true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
                                                         p.tiles_per_split, x2, ca);
       else
         conv_mfma_wgrad_ts<false><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
                                                          p.tiles_per_split, nullptr, 0);
-    } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
   }
   const int wsize = KS * KS * Cin * Cout;
   launch_sum_splits(workspace, gw, wsize, p.splits, st);
@@ -1333,6 +1414,16 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
 int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
                             int Cout, int KS, void* stream) {
   return wgrad_mfma_launch(x, gy, gw, workspace, N, H, W, Cin, Cout, KS, stream, nullptr, 0);
+}
+
+// 3x3 weight gradient whose x operand is lrelu(IN(x)) of the tensor passed (see smsut_conv2d_fwd_mfma_stats_inaff);
+// workspace as smsut_conv2d_wgrad_mfma_ws(N, H, W, Cin, Cout, 3).
+int smsut_conv2d_wgrad_mfma_inaff(const float* x, const float* gy, float* gw, float* workspace, const float* mean,
+                                  const float* rstd, const float* gamma, const float* beta, float slope, int N, int H, int W,
+                                  int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(mean && rstd && gamma && beta);
+  const AffRef a{mean, rstd, gamma, beta, slope};
+  return wgrad_mfma_launch(x, gy, gw, workspace, N, H, W, Cin, Cout, 3, stream, nullptr, 0, &a);
 }
 
 // Weight gradient with x = the virtual cat([xa, xb]) (xa [N,H,W,ca], xb [N,H,W,Cin-ca], ca % 16 == 0) read in place;

@@ -544,6 +544,7 @@ def res_tail(y2, g2, b2, s, gs, bs, slope):
 FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
+INAFF_CONV2 = bool(int(_os.environ.get("SMSUT_INAFF_CONV2", "1")))   # conv2 / wgrad2 of a fused block normalise y1 while staging
 VIRTUAL_CAT = bool(int(_os.environ.get("SMSUT_VIRTUAL_CAT", "1")))   # block-after-concat reads [up, skip] in place (no cat tensor)
 SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-after-concat: gradient written into the two parts
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
@@ -606,11 +607,21 @@ class BasicBlockFn(Function):
         else:
             H.call("smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
         m1, r1 = stat(co)
-        a1 = new_act(n, co, h, w, x)
-        H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
         y2 = new_act(n, co, h, w, x)
         p2 = _ws(n * t3b * co * 2, x)
-        H.call("smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
+        # (co % 32: the tap-split weight-gradient kernel takes the transform for +4 us; on the 16-channel kernel it cost
+        #  +55 us at 32x256^2, more than the apply pass it removes -- scratch/inaff_ab.py)
+        inaff = INAFF_CONV2 and co % 32 == 0 and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3))
+        ctx.inaff = inaff
+        if inaff:
+            # conv2 (and later its weight gradient) normalise the raw conv1 output while staging their tiles: a1 is never built
+            a1 = None
+            H.call("smsut_in_finalize_fwd", p1, t3, m1, r1, n, hw, co, IN_EPS, st)
+            H.call("smsut_conv2d_fwd_mfma_stats_inaff", y1, w2, y2, p2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+        else:
+            a1 = new_act(n, co, h, w, x)
+            H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
+            H.call("smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
         H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
         if has_sc:
@@ -697,8 +708,11 @@ class BasicBlockFn(Function):
             H.call("smsut_instnorm_bwd", ga1, y1, b1, m1, r1, g1, gy1, a1m, b1m, gg1, gb1, _ws(n * chunks * co * 3, x),
                    n, hw, co, slope, st)
         gw2 = new_weight(co, co, 3, 3, device=dev)
-        H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x),
-               n, h, w, co, co, 3, st)
+        wws2 = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x)
+        if ctx.inaff:
+            H.call("smsut_conv2d_wgrad_mfma_inaff", y1, gy2, gw2, wws2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+        else:
+            H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, wws2, n, h, w, co, co, 3, st)
         # ---- conv1 and the shortcut
         gw1 = new_weight(co, ci, 3, 3, device=dev)
         wws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), x)

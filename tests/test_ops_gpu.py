@@ -485,3 +485,34 @@ def test_virtual_cat_entries_bit_identical(ops, n, h, ca, co):
     H.call("smsut_conv1x1_wgrad", cat, gy, k0, ws1, n, hw, ci, co, st)
     H.call("smsut_conv1x1_wgrad_cat", xa, xb, ca, gy, k1, ws1, n, hw, ci, co, st)
     assert torch.equal(k0, k1)
+
+
+@pytest.mark.parametrize("n,h,c", [(8, 128, 16), (4, 256, 16), (8, 128, 32), (16, 64, 64), (9, 128, 16)])
+def test_input_side_instnorm_conv_bit_identical(ops, n, h, c):
+    """conv2 of a BasicBlock and its weight gradient on the RAW conv1 output (InstanceNorm + LeakyReLU applied while the
+    tiles are staged, *_inaff entry points) against the two-pass path (normalise to a1, then the plain kernels): the same
+    in_affine() fma on the same values, so outputs, statistics and gradients must be bit-identical."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x0 = torch.randn(n, h, h, c, generator=g).cuda()
+    w1 = (torch.randn(9 * c * c, generator=g) / np.sqrt(9 * c)).cuda(); w2 = (torch.randn(9 * c * c, generator=g) / np.sqrt(9 * c)).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(c, generator=g)).cuda(), (0.1 * torch.randn(c, generator=g)).cuda()
+    gy = torch.randn(n, h, h, c, generator=g).cuda()
+    hw = h * h
+    assert H.call("smsut_conv2d_mfma_persistent", n, h, h, c, c, 3) == 1
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3)
+    E = lambda *s: torch.empty(*s, device="cuda")
+    y1, a1, p1 = E(n, h, h, c), E(n, h, h, c), torch.zeros(n * tiles * c * 2, device="cuda")
+    H.call("smsut_conv2d_fwd_mfma_stats", x0, w1, y1, p1, n, h, h, c, c, 3, st)
+    m1, r1 = E(n, c), E(n, c)
+    H.call("smsut_instnorm_fwd_partials", y1, gam, bet, a1, m1, r1, p1, tiles, n, hw, c, 1e-5, 0.01, 1, st)
+    ya, yb, pa, pb = E(n, h, h, c), E(n, h, h, c), torch.zeros_like(p1), torch.zeros_like(p1)
+    H.call("smsut_conv2d_fwd_mfma_stats", a1, w2, ya, pa, n, h, h, c, c, 3, st)
+    H.call("smsut_conv2d_fwd_mfma_stats_inaff", y1, w2, yb, pb, m1, r1, gam, bet, 0.01, n, h, h, c, c, st)
+    assert torch.equal(ya, yb) and torch.equal(pa, pb)
+    ws = E(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, h, c, c, 3))
+    ga, gb = E(9 * c * c), E(9 * c * c)
+    H.call("smsut_conv2d_wgrad_mfma", a1, gy, ga, ws, n, h, h, c, c, 3, st)
+    H.call("smsut_conv2d_wgrad_mfma_inaff", y1, gy, gb, ws, m1, r1, gam, bet, 0.01, n, h, h, c, c, st)
+    assert torch.equal(ga, gb)
