@@ -249,6 +249,16 @@ def main():
                       "parallelism": f"dp{world}", "weights": "random init (reference initialisers)"},
            "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])]}
     log(f"timed region done: {ms:.2f} ms/step")
+    # whole-step arithmetic rate (all ops of the step, memory-bound ones included) against the fp32 MFMA peak: algorithmic conv
+    # FLOPs per slice, fwd + dgrad + wgrad counted once each (U-Net(1,5,16)@256^2 19.61 GFLOP,
+    # uganConsis iteration 1.71 TFLOP per 16 slices as the REFERENCE executes it -- G(x_real) twice)
+    gflop_slice = 19.61 if args.workload == "unet" else 1710.0 / 16
+    tf = value / world * gflop_slice / 1e3
+    out["whole_step"] = {"algorithmic_gflop_per_slice": gflop_slice, "achieved_tflops_per_gpu": round(tf, 2),
+                         "frac_of_fp32_mfma_peak": round(tf / 157.3, 4), "peak_tflops": 157.3}
+    if args.workload != "unet":
+        out["whole_step"]["note"] = ("FLOPs of the reference iteration (3 generator forwards); this build computes G(x_real) "
+                                     "once, i.e. executes ~12 % fewer")
     if not args.no_roofline:
         out["roofline"] = measure_dominant_conv(dev, B)
     if world == 1 and not args.no_cpu_baseline:
