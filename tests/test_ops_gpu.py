@@ -1,4 +1,6 @@
 """Op-level parity of every HIP kernel family (called through the C-ABI) against plain PyTorch fp32/fp64 on CPU."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -335,6 +337,8 @@ def test_fused_in_statistics_match_standalone_pass(ops, n, h, ci, co, k):
 def test_fused_basic_block_vs_torch(ops, n, h, ci, co):
     """The fused BasicBlock (forward + hand-written backward) against torch autograd of the reference
     composition (network/blocks.py:53-80), incl. the identity-shortcut form and ragged tiles."""
+    if not ops.FUSED_BLOCK:
+        pytest.skip("SMSUT_FUSED_BLOCK=0 in the environment")
     slope = 0.01
     x = rnd(n, ci, h, h, seed=1).requires_grad_(True)
     w1 = (rnd(co, ci, 3, 3, seed=2) / np.sqrt(9 * ci)).requires_grad_(True)
@@ -385,6 +389,8 @@ def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):
     """BasicBlock fed by cat([up, skip]) (UpSampleAndConcat, network/blocks.py:37-50): the data-gradients written straight
     into d/d(up), d/d(skip) (split-output kernels) must equal, bit for bit, the contiguous gradient followed by the split
     copy -- same kernels, same accumulation order -- and match torch autograd of the reference composition."""
+    if not (ops.FUSED_BLOCK and ops.VIRTUAL_CAT):
+        pytest.skip("SMSUT_FUSED_BLOCK / SMSUT_VIRTUAL_CAT switched off in the environment")
     slope = 0.01
     ci = ca + cb
     a = rnd(n, ca, h, h, seed=1); b = rnd(n, cb, h, h, seed=2)
@@ -500,6 +506,8 @@ def test_input_side_instnorm_conv_bit_identical(ops, n, h, c):
     gam, bet = (1 + 0.1 * torch.randn(c, generator=g)).cuda(), (0.1 * torch.randn(c, generator=g)).cuda()
     gy = torch.randn(n, h, h, c, generator=g).cuda()
     hw = h * h
+    if os.environ.get("SMSUT_CONV_PERSISTENT", "1") == "0":
+        pytest.skip("SMSUT_CONV_PERSISTENT=0 in the environment")
     assert H.call("smsut_conv2d_mfma_persistent", n, h, h, c, c, 3) == 1
     tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3)
     E = lambda *s: torch.empty(*s, device="cuda")
