@@ -1137,6 +1137,83 @@ int dispatch_fwd_cfg(int cfg, const float* x, const float* w, float* y, int N, i
   return -1;
 }
 
+
+// ---- weight gradient on tiny planes (the discriminator's 8x8 / 4x4 levels, 256 -> 256: ugan.py:205-215) -----------------------
+// The tiled kernels give every image its own 8x16-pixel tile: on a 4x4 plane 7/8 of each staged tile and of every MFMA is
+// padding, and the result still goes through the split-slab sum (56 us for 0.3 GFLOP).  Here the whole batch is the GEMM K
+// dimension: gw[tap][ci][co] = sum over ALL N*H*W pixels of x[pixel + tap][ci] * gy[pixel][co]; a wave owns one 16x16 tile
+// of one tap split over its pixels, reads its operands straight from global memory (they are L2-resident: <= 2 MB) with
+// PW_UNR pixel groups in flight, and the workgroup writes the final value -- no workspace, no second kernel.  W % 4 == 0 (the pixel cursor advances by 4).
+constexpr int PW_UNR = 8;
+__global__ void __launch_bounds__(TPB)
+plane_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gw, int N, int H, int W, int Cin,
+            int Cout, const float* __restrict__ x2 = nullptr, int ca = 0) {
+  // one workgroup = one 32x32 (ci, co) slab of one tap; every wave computes all four 16x16 tiles of it (two x and two gy
+  // loads feed four MFMAs: the kernel is bound by L2 operand traffic, not by latency) on its interleaved share of the
+  // pixels; the four waves are combined through LDS in a fixed order
+  __shared__ float red[3 * 4 * 64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tap = blockIdx.z, dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int HW = H * W, P = N * HW;
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // x2 != null: x is the virtual cat([x, x2]); each 16-channel tile picks its tensor (uniform per workgroup)
+  const CatSrc s0 = cat_src(x, x2, Cin, ca, ci0), s1 = cat_src(x, x2, Cin, ca, ci0 + 16);
+  const float* xa0 = s0.p + ci0 + lm - s0.coff;
+  const float* xa1 = s1.p + ci0 + 16 + lm - s1.coff;
+  const float* gb = gy + co0 + lm;
+  constexpr int BLK = 4 * PW_UNR;                            // pixels per wave per round
+  for (int p0 = wave * BLK; p0 < P; p0 += 4 * BLK) {
+    // pixel cursor of this lane: (n, y, x) of pixel p0 + kq, advanced by 4 pixels per group without divisions
+    // (W % 4 == 0: the column wraps at most once per step); three divisions per round, none per group
+    const int pk = p0 + kq;
+    int cn = pk / HW;
+    const int r = pk - cn * HW;
+    int cy = r / W, cx = r - cy * W;
+    float a[PW_UNR][2], b[PW_UNR][2];
+#pragma unroll
+    for (int u = 0; u < PW_UNR; ++u) {
+      const int p = p0 + 4 * u + kq;                         // this lane's pixel (the MFMA k index) of group u
+      const int yy = cy + dy, xx = cx + dx;
+      const bool ok = p < P;
+      const bool in = ok && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      const size_t pix = (size_t)((cn * H + yy) * W + xx);
+      const float* gp = gb + (size_t)p * Cout;
+      a[u][0] = in ? xa0[pix * s0.stride] : 0.f; a[u][1] = in ? xa1[pix * s1.stride] : 0.f;
+      b[u][0] = ok ? gp[0] : 0.f; b[u][1] = ok ? gp[16] : 0.f;
+      cx += 4;
+      if (cx >= W) { cx -= W; if (++cy == H) { cy = 0; ++cn; } }
+    }
+#pragma unroll
+    for (int u = 0; u < PW_UNR; ++u)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(a[u][i], b[u][j], acc[i][j]);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *(f32x4*)(red + (((wave - 1) * 4 + t) * 64 + lane) * 4) = acc[t >> 1][t & 1];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      f32x4 v = acc[t >> 1][t & 1];
+#pragma unroll
+      for (int w4 = 0; w4 < 3; ++w4) v += *(const f32x4*)(red + ((w4 * 4 + t) * 64 + lane) * 4);
+      float* o = gw + ((size_t)tap * Cin + ci0 + (t >> 1) * 16 + 4 * kq) * Cout + co0 + (t & 1) * 16 + lm;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[(size_t)r * Cout] = v[r];
+    }
+  }
+}
+
 struct WgradPlan { int cit, cot, splits, tiles_per_split, tiles_x, tiles_y; };
 
 WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
@@ -1373,6 +1450,16 @@ int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int K
 }
 
 // gw [KS*KS][Cin][Cout] = sum over pixels of x (x) gy
+#ifndef PLANE_WGRAD_MAX_HW
+#define PLANE_WGRAD_MAX_HW 64      // 8x8 planes too: 57 -> 35 us at B16 256->256 vs the tap-split kernel (scratch/plane_wgrad_ab.py)
+#endif
+// planes small enough for the whole-batch GEMM form
+inline bool plane_wgrad_applies(int N, int H, int W, int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("SMSUT_PLANE_WGRAD"); return !e || atoi(e) != 0; }();
+  return on && H * W <= PLANE_WGRAD_MAX_HW && W % 4 == 0 && Cin % 32 == 0 && Cout % 32 == 0 && (int64_t)N * H * W <= 4096 &&
+         (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31);
+}
+
 static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
                              int Cout, int KS, void* stream, const float* x2, int ca, const AffRef* aff = nullptr) {
   SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0);
@@ -1386,6 +1473,10 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
     else if (p.cit == 1) launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
     else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
     else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+  } else if (plane_wgrad_applies(N, H, W, Cin, Cout) && !aff) {
+    plane_wgrad<<<dim3(Cin / 32, Cout / 32, 9), TPB, 0, st>>>(x, gy, gw, N, H, W, Cin, Cout, x2, ca);
+    SMSUT_LAUNCH_CHECK();
+    return SMSUT_OK;                                 // final values written directly: no split-slab sum
   } else {
     if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
     else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);

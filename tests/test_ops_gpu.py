@@ -71,6 +71,12 @@ CONV_CASES = [
     (2, 32, 32, 2, 4, 5, 1, 2, False),
     (2, 24, 40, 16, 1, 1, 1, 0, True),
     (2, 72, 40, 16, 5, 1, 1, 0, False),
+    # whole-batch-GEMM weight gradient on tiny planes (H < 8: discriminator 4x4 level)
+    (16, 4, 4, 256, 256, 3, 1, 1, False),
+    (32, 4, 4, 64, 32, 3, 1, 1, True),
+    (3, 4, 8, 32, 64, 3, 1, 1, False),
+    (16, 8, 8, 256, 256, 3, 1, 1, False),
+    (5, 8, 8, 64, 32, 3, 1, 1, False),
     # thin 1x1 heads (streaming dgrad / wgrad): every wide-channel instantiation, grid-stride + 1024-block wgrad path
     (2, 32, 32, 8, 3, 1, 1, 0, False),
     (2, 32, 48, 32, 7, 1, 1, 0, True),
