@@ -198,6 +198,9 @@ int smsut_fill(float* out, float v, int64_t n, void* stream);
 int smsut_scale(const float* x, const float* scale_dev /*nullable*/, float mul, float* out, int64_t n, void* stream);
 int smsut_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_maxpool2_bwd(const float* gy, const float* x, float* gx, int N, int H, int W, int C, void* stream);
+/* gx = maxpool2_bwd(gy; x) + add: pooled-path and skip-connection gradients of an encoder level (blocks.py:131-133) in one pass */
+int smsut_maxpool2_bwd_add(const float* gy, const float* x, const float* add, float* gx, int N, int H, int W, int C,
+                           void* stream);
 int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
 /* Device-side joint augmentation (rotate + elastic + random-resized-crop of data_loader/externalTransforms.py:45-90 as one

@@ -89,6 +89,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_scale": "pp f p l s",
     "smsut_maxpool2_fwd": "pp iiii s",
     "smsut_maxpool2_bwd": "ppp iiii s",
+    "smsut_maxpool2_bwd_add": "pppp iiii s",
     "smsut_avgpool2_fwd": "pp iiii s",
     "smsut_avgpool2_bwd": "pp iiii s",
     "smsut_bilinear2_fwd": "pp iiii s",

@@ -111,7 +111,9 @@ k_maxpool_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, 
 template <int VEC>
 __global__ void __launch_bounds__(TPB)
 k_maxpool_bwd(const float* __restrict__ gy, const float* __restrict__ x, float* __restrict__ gx, int N, int H, int W,
-              int C) {
+              int C, const float* __restrict__ add = nullptr) {
+  // add (nullable): a second gradient of x (the skip connection of the encoder level, network/blocks.py:131-133) summed in
+  // the same pass -- replaces autograd's separate accumulation kernel (read 2, write 1 full-resolution tensors)
   const int Ho = H >> 1, Wo = W >> 1, CV = C / VEC;
   const int64_t total = (int64_t)N * Ho * Wo * CV;
   GRID_STRIDE(i, total) {
@@ -132,6 +134,12 @@ k_maxpool_bwd(const float* __restrict__ gy, const float* __restrict__ x, float* 
       if (v2[j] > m || v2[j] != v2[j]) { m = v2[j]; k = 2; }
       if (v3[j] > m || v3[j] != v3[j]) { m = v3[j]; k = 3; }
       v0[j] = k == 0 ? g[j] : 0.f; v1[j] = k == 1 ? g[j] : 0.f; v2[j] = k == 2 ? g[j] : 0.f; v3[j] = k == 3 ? g[j] : 0.f;
+    }
+    if (add) {
+      float a0[VEC], a1[VEC], a2[VEC], a3[VEC];
+      ldp<VEC>(add + o, a0); ldp<VEC>(add + o1, a1); ldp<VEC>(add + o2, a2); ldp<VEC>(add + o3, a3);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) { v0[j] += a0[j]; v1[j] += a1[j]; v2[j] += a2[j]; v3[j] += a3[j]; }
     }
     stp<VEC>(gx + o, v0); stp<VEC>(gx + o1, v1); stp<VEC>(gx + o2, v2); stp<VEC>(gx + o3, v3);
   }
@@ -529,6 +537,14 @@ int smsut_maxpool2_bwd(const float* gy, const float* x, float* gx, int N, int H,
   SMSUT_REQUIRE(gy && x && gx && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
   if (C % 4 == 0) k_maxpool_bwd<4><<<ew_grid(((int64_t)N * H * W * C / 4) / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C);
   else k_maxpool_bwd<1><<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// gx = maxpool2_bwd(gy; x) + add: the pooled path's and the skip connection's gradients of an encoder level in one pass
+int smsut_maxpool2_bwd_add(const float* gy, const float* x, const float* add, float* gx, int N, int H, int W, int C,
+                           void* stream) {
+  SMSUT_REQUIRE(gy && x && add && gx && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
+  if (C % 4 == 0) k_maxpool_bwd<4><<<ew_grid(((int64_t)N * H * W * C / 4) / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C, add);
+  else k_maxpool_bwd<1><<<ew_grid((int64_t)N * H * W * C / 4), TPB, 0, ST>>>(gy, x, gx, N, H, W, C, add);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_avgpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {

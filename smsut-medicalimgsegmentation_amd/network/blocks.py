@@ -212,8 +212,8 @@ class Encoder(nn.Module):
         x = self.pre_bn(self.pre_conv(x, stats=True), slope=self.pre_relu.slope)
         for i in range(1, 5):
             x = getattr(self, f"layer{i}")(x)
-            skips.append(x)
-            x = getattr(self, f"pool{i}")(x)
+            x, skip = getattr(self, f"pool{i}").pool_skip(x)
+            skips.append(skip)
         return self.layer5(x), skips
 
 
@@ -222,6 +222,10 @@ class MaxPool2x2(nn.Module):
 
     def forward(self, x):
         return ops.max_pool2(x)
+
+    def pool_skip(self, x):
+        """(pooled, skip): the level's two uses of x in one autograd node (skip gradient summed in the pooling backward)."""
+        return ops.max_pool2_skip(x)
 
 
 class Decoder(nn.Module):

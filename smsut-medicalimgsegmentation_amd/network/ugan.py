@@ -35,8 +35,8 @@ class Encoder(nn.Module):
         x = self.pre(x)
         for i in range(1, 5):
             x = getattr(self, f"enc{i}")(x)
-            skips.append(x)
-            x = getattr(self, f"pool{i}")(x)
+            x, skip = getattr(self, f"pool{i}").pool_skip(x)
+            skips.append(skip)
         skips.reverse()                    # deepest first (ugan.py:54)
         return x, skips
 

@@ -545,6 +545,7 @@ FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
 INAFF_CONV2 = bool(int(_os.environ.get("SMSUT_INAFF_CONV2", "1")))   # conv2 / wgrad2 of a fused block normalise y1 while staging
+POOL_SKIP = bool(int(_os.environ.get("SMSUT_POOL_SKIP", "1")))       # encoder level: skip gradient summed inside the pooling backward
 VIRTUAL_CAT = bool(int(_os.environ.get("SMSUT_VIRTUAL_CAT", "1")))   # block-after-concat reads [up, skip] in place (no cat tensor)
 SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-after-concat: gradient written into the two parts
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
@@ -908,6 +909,43 @@ class MaxPool2Fn(Function):
         gx = new_act(n, c, h, w, x)
         H.call("smsut_maxpool2_bwd", gy, x, gx, n, h, w, c, _s())
         return gx
+
+
+class MaxPool2SkipFn(Function):
+    """An encoder level's two uses of its block output x (network/blocks.py:131-133, ugan.py:50-52): returns
+    (max_pool2(x), x) and sums the two incoming gradients inside the pooling backward kernel -- autograd's separate
+    accumulation kernel over the full-resolution tensor (read 2, write 1) disappears."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = new_act(n, c, h // 2, w // 2, x)
+        H.call("smsut_maxpool2_fwd", x, y, n, h, w, c, _s())
+        ctx.save_for_backward(x)
+        return y, x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy, gskip):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        if gy is None:
+            return gskip
+        gy = nhwc(gy)
+        gx = new_act(n, c, h, w, x)
+        if gskip is None:
+            H.call("smsut_maxpool2_bwd", gy, x, gx, n, h, w, c, _s())
+        else:
+            H.call("smsut_maxpool2_bwd_add", gy, x, nhwc(gskip), gx, n, h, w, c, _s())
+        return gx
+
+
+def max_pool2_skip(x):
+    """(pooled, skip) of an encoder level; plain (max_pool2(x), x) when the fused form is switched off."""
+    if POOL_SKIP and x.is_cuda and x.requires_grad and torch.is_grad_enabled():
+        return MaxPool2SkipFn.apply(x)
+    return max_pool2(x), x
 
 
 class AvgPool2Fn(Function):

@@ -530,3 +530,23 @@ def test_input_side_instnorm_conv_bit_identical(ops, n, h, c):
     H.call("smsut_conv2d_wgrad_mfma", a1, gy, ga, ws, n, h, h, c, c, 3, st)
     H.call("smsut_conv2d_wgrad_mfma_inaff", y1, gy, gb, ws, m1, r1, gam, bet, 0.01, n, h, h, c, c, st)
     assert torch.equal(ga, gb)
+
+
+@pytest.mark.parametrize("n,c,h,w", [(2, 16, 32, 48), (3, 5, 8, 8), (4, 64, 64, 64)])
+def test_max_pool_skip_fused_backward(ops, n, c, h, w):
+    """(pooled, skip) of an encoder level as one autograd node: the skip gradient is summed inside the pooling backward."""
+    x = rnd(n, c, h, w, seed=1).requires_grad_(True)
+    gp, gs = rnd(n, c, h // 2, w // 2, seed=2), rnd(n, c, h, w, seed=3)
+    (F.max_pool2d(x, 2) * gp).sum().backward(retain_graph=False)
+    ref_pool_only = x.grad.clone(); x.grad = None
+    ((F.max_pool2d(x, 2) * gp).sum() + (x * gs).sum()).backward()
+    xd = dev(x.detach()).requires_grad_(True)
+    y, skip = ops.max_pool2_skip(xd)
+    assert rel_err(y.detach().cpu().numpy(), F.max_pool2d(x, 2).detach().numpy()) == 0
+    assert skip.data_ptr() == xd.data_ptr() or torch.equal(skip.detach(), xd.detach())
+    ((y * dev(gp)).sum() + (skip * dev(gs)).sum()).backward()
+    assert rel_err(xd.grad.cpu().numpy(), x.grad.numpy()) < 1e-6
+    xd2 = dev(x.detach()).requires_grad_(True)
+    y2, skip2 = ops.max_pool2_skip(xd2)
+    (y2 * dev(gp)).sum().backward()                       # skip unused: plain pooling backward
+    assert rel_err(xd2.grad.cpu().numpy(), ref_pool_only.numpy()) < 1e-6
