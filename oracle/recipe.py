@@ -151,3 +151,20 @@ def synth_labels(b, h, w, n_cls, seed, block=16):
     small = rs.randint(0, n_cls, size=(b, bh, bw))
     lab = np.repeat(np.repeat(small, h // bh, axis=1), w // bw, axis=2)
     return torch.from_numpy(lab.astype(np.int64))
+
+
+def trace_inputs(step: int, b: int = 16, size: int = 256, n_cls: int = 5, n_modal: int = 4, base: int = 3000):
+    """Inputs and RNG-dependent draws of iteration ``step`` of the multi-step uganConsis trace fixture
+    (tests/golden/iter_trace.npz): images, labels of the labeled half, source modalities (one per half-batch,
+    data_loader/inTurnLoader.py:37-57), target modality ``mj`` (uganConsisTrainer.py:114), ``alpha ~ randn``
+    (:138) and the 64 shared patch ids (ugan.py:321-323).  Shared by the generator (reference modules), the CPU
+    oracle test and the GPU test, so all three replay identical draws."""
+    bs = b // 2
+    x = synth_images((b, 1, size, size), base + step)
+    y = synth_labels(bs, size, size, n_cls, base + 1000 + step)
+    modal = torch.tensor([step % n_modal] * bs + [(step + 1) % n_modal] * bs)
+    mj = int(np.random.RandomState(base + 2000 + step).randint(0, n_modal))
+    alpha = torch.from_numpy(np.random.RandomState(base + 3000 + step).standard_normal((b, 1, 1, 1))).float()
+    hw = (size // 16) ** 2
+    ids = torch.from_numpy(np.random.RandomState(base + 4000 + step).permutation(hw)[:64].astype(np.int64))
+    return x, y, modal, mj, alpha, ids

@@ -279,6 +279,14 @@ k_scatter_rows(const float* __restrict__ gout, const int64_t* __restrict__ ids, 
   }
 }
 
+__global__ void __launch_bounds__(TPB) k_zero_f32(float* __restrict__ p, int64_t n) {
+  const int64_t n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB)
+    p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
+}
+
 // y = x / (||x||_2 + 1e-7) per row; one wave per row
 __global__ void __launch_bounds__(TPB)
 k_l2norm_fwd(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ norms, int rows, int C) {
@@ -542,8 +550,10 @@ int smsut_gather_rows(const float* feat, const int64_t* ids, float* out, int B, 
 int smsut_scatter_rows(const float* gout, const int64_t* ids, float* gfeat, int B, int64_t HW, int C, int P,
                        void* stream) {
   SMSUT_REQUIRE(gout && ids && gfeat && B > 0 && HW > 0 && C > 0 && P > 0);
-  hipError_t e = hipMemsetAsync(gfeat, 0, (size_t)B * HW * C * sizeof(float), ST);
-  if (e != hipSuccess) return (int)e;
+  // zero-fill by a KERNEL, not hipMemsetAsync: under stream capture the memset became a hipGraph memset node that was
+  // not ordered against the kernel nodes around it on replay (r01: the un-sampled rows of d/dfeat kept whatever the
+  // block held before -- 1e10-scale garbage into enc5 / tsl_encoder gradients from the first replayed iteration on)
+  k_zero_f32<<<ew_grid(((int64_t)B * HW * C + 3) / 4), TPB, 0, ST>>>(gfeat, (int64_t)B * HW * C);
   k_scatter_rows<<<ew_grid((int64_t)B * P * C), TPB, 0, ST>>>(gout, ids, gfeat, B, HW, C, P);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }

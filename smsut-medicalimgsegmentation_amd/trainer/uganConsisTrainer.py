@@ -13,6 +13,7 @@ MI355X-first choices that do not change the arithmetic:
   * RNG-dependent inputs (target modality, alpha ~ randn, patch ids ~ randperm) may be passed in for replay.
 """
 import argparse
+import os
 import random
 import time
 from os.path import join as pjoin
@@ -38,6 +39,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._g1 = None
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
+        self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
+        self.finite_log = []
+        self.taps = {}
 
     def consistency_loss(self, source, target):
         return self.loss(source, ops.argmax_channels(target))                    # :45-53
@@ -47,6 +51,18 @@ class UGANConsisTrainer(UGANShp0Trainer):
         for f_f, f_x, crit in zip(feat_f_pool, feat_x_pool, self.criterionNCE):     # :55-64
             total = total + ops.mean_all(crit(f_f, f_x), 1.0)
         return total / len(cfg.nce_layers)
+
+    def _finite_probe(self, tag, named):
+        """``SMSUT_DEBUG_FINITE=1``: after each phase, record the first non-finite tensor (scalars, gradients, parameters,
+        translated images) together with the iteration and the RNG draws that led to it.  One host sync per probe --
+        a diagnosis mode, never on in timed runs."""
+        for name, t in named:
+            if t is None:
+                continue
+            if not bool(torch.isfinite(t).all()):
+                self.finite_log.append((self.iter, tag, name))
+                return False
+        return True
 
     def _to_device_async(self, t):
         if t.is_cuda:
@@ -107,6 +123,12 @@ class UGANConsisTrainer(UGANShp0Trainer):
         g_nce = self.nce_loss(feat_x, feat_f)
         g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg \
             + lambda_semi * g_semi + 1.0 * g_nce
+        if self._probe:                                   # gradient taps (diagnosis): persistent copies, graph-safe
+            for nm, t in (("x_rec", x_rec), ("x_fake", x_fake), ("y_rec", y_rec), ("y_fake", y_fake),
+                          ("feat_f", feat_f[0]), ("out_src", out_src), ("out_cls", out_cls)):
+                if t.requires_grad:
+                    buf = self.taps.setdefault(nm, torch.zeros_like(t))
+                    t.register_hook(lambda g, buf=buf: (buf.copy_(g), None)[1])
         g_loss.backward()
         self._g1 = None
         main, extra = [], []
@@ -176,11 +198,17 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # ------------------------------------------------------------ G(x_real): once, shared by both steps
         # (G1 shares G2's mode: G2's backward runs through G1's autograd graph, which a captured G1 builds only once)
         x_fake = self._run_phase("G1", self._g1_phase, (x_real, vec_ot, ids), [])
+        if self._probe:
+            self._finite_probe("G1", [("x_fake", x_fake)])
 
         # ------------------------------------------------------------ D-step (:129-146)
         d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params, collective_free=True)
+        if self._probe:
+            self._finite_probe("D", [("d_scalars", d_scal)] + [("grad " + k, p.grad) for k, p in self.D.named_parameters()])
         self.d_reducer.reduce()
         self.d_optimizer.step()
+        if self._probe:
+            self._finite_probe("D.step", list(self.D.named_parameters()))
 
         # ------------------------------------------------------------ G-step (:150-180), D frozen
         for p in d_params:
@@ -189,8 +217,12 @@ class UGANConsisTrainer(UGANShp0Trainer):
                                  g_params + list(self._alias.values()))
         for p in d_params:
             p.requires_grad_(True)
+        if self._probe:
+            self._finite_probe("G2", [("g_scalars", g_scal)] + [("grad " + k, p.grad) for k, p in self.net.named_parameters()])
         self.g_reducer.reduce()
         self.optimizer.step()
+        if self._probe:
+            self._finite_probe("G.step", list(self.net.named_parameters()))
 
         lr_ = self.poly_lr()                                                                   # :198-202
         for grp in list(self.optimizer.param_groups) + list(self.d_optimizer.param_groups):

@@ -461,6 +461,96 @@ def gen_siblings():
     save("siblings", **rec)
 
 
+def gen_iter_trace(n_steps=None, dtype=torch.float32, name="iter_trace"):
+    """A 32-iteration trajectory of the hot loop (uganConsisTrainer.py:110-203) at the BASELINE config-3 size:
+    8 labeled + 8 unlabeled 256x256 slices, UGANnce(1,5,4,16) + Discriminator(256,4,16,256), PatchNCELoss(8) fed 16,
+    iter >= 1000 (consistency on), SGD / Adam as uganShp0Trainer.py:72-74, poly LR.  Inputs and draws per step come from
+    ``recipe.trace_inputs``; only the 10 scalars per step and a few weight norms are stored.  ``dtype=float64`` (name
+    ``iter_trace_f64``) is the same replay in double precision: the spread between the two is the reference's OWN
+    sensitivity to rounding, which is what bounds how closely any fp32 implementation can track the trace."""
+    n_steps = int(os.environ.get("SMSUT_TRACE_STEPS", n_steps or 32))
+    bs, H, nm = 8, 256, 4
+    B = 2 * bs
+    torch.set_default_dtype(dtype)
+    G = load(UGANnce(1, 5, nm, 16), recipe.ugan_shapes(1, 5, nm, 16), 2020).to(dtype)
+    D = load(Discriminator(H, nm, 16, max_width=256), recipe.disc_shapes(H, nm, 16, 256), 2021).to(dtype)
+    G.train(); D.train()
+    crit = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)
+    nce = PatchNCELoss(bs)
+    g_opt = torch.optim.SGD(G.parameters(), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    d_opt = torch.optim.Adam(D.parameters(), 1e-2, [0.9, 0.999], weight_decay=1e-3)
+    epoch, it0 = 100, 1000
+    ph = 1.0 - epoch / 200.0
+    lam_semi = 10.0 * float(np.exp(-5.0 * ph * ph))
+
+    def onehot(idx):
+        o = torch.zeros(idx.size(0), nm)
+        o[np.arange(idx.size(0)), idx.long()] = 1
+        return o
+
+    import time
+    logs_all, norms = [], []
+    t0 = time.time()
+    for step in range(n_steps):
+        it = it0 + step
+        x_real, y_real, modal_org, mj, alpha, ids = recipe.trace_inputs(step)
+        x_real, alpha = x_real.to(dtype), alpha.to(dtype)
+        modal_trg = torch.zeros_like(modal_org).fill_(mj)
+        vec_org, vec_trg = onehot(modal_org), onehot(modal_trg)
+        vec_ot, vec_to = vec_trg - vec_org, vec_org - vec_trg
+
+        out_src, out_cls = D(x_real)
+        d_real = -torch.mean(out_src)
+        d_cls = F.cross_entropy(out_cls, modal_org)
+        _, x_fake, _, _ = G(x_real, vec_ot, sample_ids=[ids])
+        out_src, out_cls = D(x_fake.detach())
+        d_fake = torch.mean(out_src)
+        x_hat = (alpha * x_real.data + (1 - alpha) * x_fake.data).requires_grad_(True)
+        out_src, _ = D(x_hat)
+        dydx = torch.autograd.grad(out_src, x_hat, torch.ones(out_src.size()), retain_graph=True,
+                                   create_graph=True, only_inputs=True)[0]
+        d_gp = torch.mean((torch.sqrt(torch.sum(dydx.view(B, -1) ** 2, dim=1)) - 1) ** 2)
+        d_loss = d_real + d_fake + 1.0 * d_cls + 10.0 * d_gp
+        d_opt.zero_grad(); g_opt.zero_grad()
+        d_loss.backward()
+        d_opt.step()
+
+        y_fake, x_fake, feat_x, _ = G(x_real, vec_ot, sample_ids=[ids])
+        out_src, out_cls = D(x_fake)
+        g_fake = -torch.mean(out_src)
+        g_cls = F.cross_entropy(out_cls, modal_trg)
+        g_seg = crit(y_fake[:bs], y_real)
+        y_rec, x_rec, feat_f, _ = G(x_fake, vec_to, sample_ids=[ids])
+        g_rec = torch.mean(torch.abs(x_real - x_rec))
+        g_semi = crit(y_rec, torch.argmax(y_fake, dim=1))
+        g_nce = sum((nce(ff, fx) * 1.0).mean() for ff, fx in zip(feat_f, feat_x)) / 1
+        g_loss = g_fake + 10.0 * g_rec + 1.0 * g_cls + 10.0 * g_seg + lam_semi * g_semi + g_nce
+        d_opt.zero_grad(); g_opt.zero_grad()
+        g_loss.backward()
+        gn = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in G.parameters() if p.grad is not None)))
+        g_opt.step()
+        lr_ = 1e-2 * (1.0 - it / 30000) ** 0.9
+        for grp in list(g_opt.param_groups) + list(d_opt.param_groups):
+            grp["lr"] = lr_
+        logs_all.append([d_real.item(), d_fake.item(), d_cls.item(), d_gp.item(), g_fake.item(), g_rec.item(),
+                         g_cls.item(), g_seg.item(), g_semi.item(), g_nce.item()])
+        norms.append([float(torch.sqrt(sum(p.double().pow(2).sum() for p in G.parameters()))),
+                      float(torch.sqrt(sum(p.double().pow(2).sum() for p in D.parameters()))), gn,
+                      float(x_fake.abs().max())])
+        print(f"trace[{name}] step {step}: " + " ".join(f"{v:.4g}" for v in logs_all[-1]) +
+              f" | |G| {norms[-1][0]:.3f} |D| {norms[-1][1]:.3f} |gG| {gn:.3g}  ({time.time() - t0:.0f} s)", flush=True)
+        # written after every step: a partial trace is still a usable fixture if the run is cut short
+        save(name, scalars=np.array(logs_all, dtype=np.float64), norms=np.array(norms, dtype=np.float64),
+             norm_names=np.array(["G_param_l2", "D_param_l2", "G_grad_l2", "x_fake_absmax"]),
+             scalar_names=np.array(["D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg",
+                                    "G_semi", "G_nce"]), it0=it0, epoch=epoch, bs=bs, H=H, g_seed=2020, d_seed=2021)
+    torch.set_default_dtype(torch.float32)
+
+
+def gen_iter_trace_f64():
+    gen_iter_trace(dtype=torch.float64, name="iter_trace_f64")
+
+
 if __name__ == "__main__":
     random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
     which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small", "networks_zoo", "siblings"]
