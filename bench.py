@@ -17,6 +17,7 @@ dominant kernel (the 3x3 conv at the layer shape that carries most FLOPs); ``cpu
 import argparse
 import json
 import os
+import random
 import sys
 import time
 import types
@@ -29,6 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 HBM_PEAK_GBS = 8000.0
+PMC_FILE = "r02_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
 
 
 def host_cores():
@@ -49,37 +51,47 @@ def conv_flops(n, h, w, cin, cout, k):
 
 
 def pmc_traffic_per_slice():
-    """HBM bytes per slice of the dominant kernel from the committed PMC passes (profiles/r01_pmc_dominant.json:
+    """HBM bytes per slice of the dominant kernel from the committed PMC passes (profiles/r02_pmc_dominant.json:
     FETCH_SIZE and WRITE_SIZE collected in two separate ``rocprofv3 --pmc`` runs of ``bench.py --roofline-only``,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  Counters cannot be read from
     inside the process, so the live line carries the profiled per-slice figure scaled to this run's batch; the
     launch is linear in slices (weights are 18 KB)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")) as f:
+        with open(os.path.join(ROOT, "profiles", PMC_FILE)) as f:
             return float(json.load(f)["hbm_bytes_per_slice"])
     except (OSError, KeyError, ValueError):
         return None
 
 
 def measure_dominant_conv(dev, batch):
-    """HIP-event timing of the dominant kernel: conv3x3 s1 p1 on the decoder-level-1 shape
-    ([B,32,256,256] -> 16 ch, blocks.py dec layer1.conv1; 9.2 % of the U-Net MACs on its own and the layer
-    class -- 3x3 @256^2 -- that holds the largest share).  Returns the roofline dict."""
-    from smsut_amd import ops, _hip
+    """HIP-event timing of the dominant kernel AS THE STEP LAUNCHES IT: conv3x3 s1 p1 of the decoder-level-1 block
+    (blocks.py dec layer1.conv1: cat([up, skip]) [B,16+16,256,256] -> 16 ch), i.e. the persistent resident-weight kernel
+    with the InstanceNorm-statistics epilogue and the virtual-cat input (``smsut_conv2d_fwd_mfma_stats_cat`` ->
+    ``conv_mfma_fwd_p<3,8,1,2,STATS,..,DUAL>``); the 3x3 @256^2 layer class holds the largest share of the step's FLOPs.
+    Returns the roofline dict."""
+    from smsut_amd import ops, _hip as H
     cin, cout, h = 32, 16, 256
-    x = torch.randn(batch, cin, h, h, device=dev).contiguous(memory_format=torch.channels_last)
+    cl = torch.channels_last
+    xa = torch.randn(batch, cin // 2, h, h, device=dev).contiguous(memory_format=cl)
+    xb = torch.randn(batch, cin // 2, h, h, device=dev).contiguous(memory_format=cl)
     w = ops.new_weight(cout, cin, 3, 3, device=dev)
     w.copy_(torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5)
-    name, kind = ops.conv_fwd_kernel_name(cin, cout, 3, 1, 1, batch, h, h)
+    y = ops.new_act(batch, cout, h, h, xa)
+    tiles = H.call("smsut_conv2d_mfma_tiles", batch, h, h, cin, cout, 3)
+    part = torch.empty(batch * tiles * cout * 2, device=dev)
+    assert H.call("smsut_conv2d_mfma_cat_supported", batch, h, h, cin, cout), "virtual-cat form not available for this shape"
+    st = torch.cuda.current_stream()
+
+    def launch():
+        H.call("smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y, part, batch, h, h, cin, cout, st.cuda_stream)
     for _ in range(3):
-        ops.conv2d(x, w, None, 1, 1)
+        launch()
     torch.cuda.synchronize()
     reps = 20
-    st = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(reps):
-        ops.conv2d(x, w, None, 1, 1)
+        launch()
     e1.record(st)
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
@@ -90,11 +102,71 @@ def measure_dominant_conv(dev, batch):
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": None if per_slice is None else round(per_slice * batch),
-            "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_dominant.json)",
-            "kernel": name, "kernel_kind": kind, "shape": f"N{batch} 256x256 {cin}->{cout} k3",
+            "traffic_unit": f"HBM bytes per launch (PMC, profiles/{PMC_FILE})",
+            "kernel": "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL> via smsut_conv2d_fwd_mfma_stats_cat", "kernel_kind": "mfma",
+            "shape": f"N{batch} 256x256 (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
             "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
+
+
+def measure_step_conv(step, label):
+    """Per-shape replay profile of ONE eager step (smsut_amd.profiling): conv FLOPs / conv kernel time over the step."""
+    from smsut_amd import profiling
+    prev = os.environ.get("SMSUT_GRAPH")
+    os.environ["SMSUT_GRAPH"] = "0"                      # record an eager pass (same kernels, same shapes)
+    try:
+        step(); step()
+        torch.cuda.synchronize()
+        rec = profiling.record_step(step)
+    finally:
+        if prev is None:
+            os.environ.pop("SMSUT_GRAPH", None)
+        else:
+            os.environ["SMSUT_GRAPH"] = prev
+    rows = profiling.replay(rec)
+    out = profiling.summarize(rows, FP32_MFMA_PEAK_TFLOPS)
+    out["calls"] = len(rec)
+    log(f"{label}: per-shape replay of one step ({len(rec)} C-ABI calls)\n" + profiling.table(rows, 0.012))
+    return out
+
+
+def time_unet_step(dev, rank, B=32, warmup=10, steps=30):
+    """BASELINE config 2 in the same run: U-Net(1,5,16) fwd + DiceCE + bwd + SGD at 32x1x256x256 (north_star's >= 40 % of the
+    fp32 MFMA roofline target is stated on this step)."""
+    import types as _t
+    from smsut_amd import config as cfg
+    from smsut_amd.trainer.unetTrainer import UnetTrainer
+    from smsut_amd.misc.synthetic import SyntheticSliceLoader
+    old_bs = cfg.batch_size
+    cfg.batch_size = B
+    try:
+        tr = UnetTrainer("train", _t.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+        tr.net.train()
+        ld = iter(SyntheticSliceLoader(B, device=dev, rank=rank, n_batches=warmup + steps + 4))
+        batches = [next(ld)[:2] for _ in range(warmup + steps + 4)]
+        it = iter(batches)
+        for _ in range(warmup):
+            tr.train_step(*next(it))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = None
+        for _ in range(steps):
+            loss = tr.train_step(*next(it))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        lv = float(loss.item())
+        tf = B / dt * 19.61 / 1e3
+        out = {"config": f"U-Net(1,5,16) fwd + DiceCE + bwd + SGD, {B}x1x256x256, fp32 (BASELINE config 2)", "steps": steps,
+               "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "slices_per_s": round(B / dt, 1),
+               "algorithmic_gflop_per_slice": 19.61, "achieved_tflops": round(tf, 2),
+               "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "last_loss": round(lv, 5),
+               "graph": tr.graph_report()}
+        img, msk = batches[-1]
+        out["step_conv"] = measure_step_conv(lambda: tr.train_step(img, msk), "unet")
+        return out
+    finally:
+        cfg.batch_size = old_bs
 
 
 def cpu_baseline_ugan(sample_b=16, timed=3):
@@ -152,12 +224,14 @@ def cpu_baseline_unet(sample_b=32, timed=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=("ugan", "unet"), default="ugan")
     ap.add_argument("--per-gpu-batch", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-unet-step", action="store_true", help="skip the BASELINE config-2 (U-Net step) leg")
+    ap.add_argument("--no-step-profile", action="store_true", help="skip the per-shape replay profile (roofline.step_conv_frac)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel leg (the command the rocprofv3 stats / PMC passes profile)")
     args = ap.parse_args()
@@ -172,6 +246,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(cfg.seed + rank)
+    random.seed(cfg.seed + rank)                       # target-modality draws (uganConsisTrainer.py:114)
     if args.roofline_only:
         B = args.per_gpu_batch or (16 if args.workload == "ugan" else 32)
         print(json.dumps({"roofline": measure_dominant_conv(dev, B)}))
@@ -197,6 +272,9 @@ def main():
         def step():
             x_real, y1, modal = next(it_batches)
             return tr.train_iteration(x_real, y1, modal)
+
+        def step_again():
+            return tr.train_iteration(*batches[-1])
         workload = f"uganConsisTrainer iteration (D-step + G-step, WGAN-GP, cycle, DiceCE, consistency, PatchNCE), " \
                    f"{B // 2} labeled + {B // 2} unlabeled 1x256x256 slices per GPU, 5 classes, 4 modalities"
         metric = "slices/sec uganConsisTrainer step @256x256"
@@ -213,6 +291,9 @@ def main():
         def step():
             img, msk = next(it_batches)
             return tr.train_step(img, msk)
+
+        def step_again():
+            return tr.train_step(*batches[-1])
         workload = f"U-Net(1,5,16) fwd + DiceCE + bwd + SGD, {B}x1x256x256 per GPU (BASELINE config 2)"
         metric = "slices/sec U-Net train step @256x256"
 
@@ -249,6 +330,17 @@ def main():
                       "parallelism": f"dp{world}", "weights": "random init (reference initialisers)"},
            "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])]}
     log(f"timed region done: {ms:.2f} ms/step")
+    out["graph"] = tr.graph_report()
+    finite = all(v == v and abs(v) != float("inf") for v in out["last_step_scalars"])
+    if not finite:
+        # a throughput number of a numerically dead trajectory is not a measurement (r01's driver line ended all-NaN)
+        out["error"] = "non-finite loss scalars at the end of the timed region"
+        print(json.dumps(out), flush=True)
+        log("FAILED: " + out["error"])
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        sys.exit(3)
     # whole-step arithmetic rate (all ops of the step, memory-bound ones included) against the fp32 MFMA peak: algorithmic conv
     # FLOPs per slice, fwd + dgrad + wgrad counted once each (U-Net(1,5,16)@256^2 19.61 GFLOP,
     # uganConsis iteration 1.71 TFLOP per 16 slices as the REFERENCE executes it -- G(x_real) twice)
@@ -261,6 +353,12 @@ def main():
                                      "once, i.e. executes ~12 % fewer")
     if not args.no_roofline:
         out["roofline"] = measure_dominant_conv(dev, B)
+        if not args.no_step_profile and world == 1:      # (an eager step holds collectives: single-rank runs only)
+            prof = measure_step_conv(step_again, args.workload)
+            out["roofline"]["step_conv_frac"] = prof["step_conv_frac"]
+            out["roofline"]["step_conv"] = prof
+    if world == 1 and args.workload == "ugan" and not args.no_unet_step:
+        out["unet_step"] = time_unet_step(dev, rank)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_ugan() if args.workload == "ugan" else cpu_baseline_unet()
     print(json.dumps(out), flush=True)

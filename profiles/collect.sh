@@ -9,9 +9,9 @@ tag=${1:-r01}
 out=gpurun_out
 common="--output-format csv"
 rm -rf $out/${tag}_ugan $out/${tag}_unet $out/${tag}_roof $out/${tag}_pmc_fetch $out/${tag}_pmc_write
-rocprofv3 --kernel-trace --stats $common -d $out/${tag}_ugan -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $out/${tag}_ugan.log 2>&1
+rocprofv3 --kernel-trace --stats $common -d $out/${tag}_ugan -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-unet-step > $out/${tag}_ugan.log 2>&1
 tail -1 $out/${tag}_ugan.log | cut -c1-160
-rocprofv3 --kernel-trace --stats $common -d $out/${tag}_unet -- python3 bench.py --workload unet --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $out/${tag}_unet.log 2>&1
+rocprofv3 --kernel-trace --stats $common -d $out/${tag}_unet -- python3 bench.py --workload unet --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-unet-step > $out/${tag}_unet.log 2>&1
 tail -1 $out/${tag}_unet.log | cut -c1-160
 rocprofv3 --kernel-trace --stats $common -d $out/${tag}_roof -- python3 bench.py --roofline-only > $out/${tag}_roof.log 2>&1
 tail -1 $out/${tag}_roof.log | cut -c1-400

@@ -1,0 +1,153 @@
+"""Per-shape replay profile of one training step (measurement tooling, used by ``bench.py`` and ``scratch/``).
+
+rocprofv3's per-kernel-name averages hide shapes (one template instantiation serves a dozen layer sizes), so the step is
+profiled from the C-ABI side instead: every ``_hip.call`` of ONE eager step is recorded (entry point + converted
+arguments), then each distinct (entry point, integer/float arguments) is replayed alone between HIP events on the
+pointers it ran with (still owned by torch's caching allocator -- the replay happens before anything is freed back to
+the driver).  Convolution-like entry points get their algorithmic FLOPs from the integer arguments
+(2 * N * Ho * Wo * Cin * Cout * k^2), which gives
+
+    step_conv_frac = sum(conv FLOPs of the step) / sum(conv kernel time of the step) / fp32 MFMA peak
+
+-- the roofline fraction of the WHOLE conv side of the step, not of one hand-picked instantiation.
+"""
+from __future__ import annotations
+
+import collections
+from typing import Callable, Dict, List, Tuple
+
+import torch
+
+from . import _hip as H
+
+
+def _k2(ints, i):
+    return ints[i] * ints[i]
+
+
+# entry point -> (flops(ints), kind); ``ints`` = the call's integer arguments in declaration order (include/smsut_hip.h)
+_CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
+    "smsut_conv2d_fwd_generic": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * a[7] * a[8], "direct"),
+    "smsut_conv2d_dgrad_generic": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * a[7] * a[8], "direct"),
+    "smsut_conv2d_wgrad_generic": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * a[7] * a[8], "direct"),
+    "smsut_conv2d_fwd_mfma": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
+    "smsut_conv2d_fwd_mfma_stats": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
+    "smsut_conv2d_dgrad_mfma_bwdstats": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_wgrad_mfma": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
+    "smsut_conv2d_fwd_mfma_stats_inaff": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_wgrad_mfma_inaff": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_fwd_mfma_stats_cat": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_wgrad_mfma_cat": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * _k2(a, 6), "mfma"),
+    "smsut_conv2d_fwd_mfma_split": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
+    "smsut_conv1x1_fwd": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "mfma"),
+    "smsut_conv1x1_wgrad": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "mfma"),
+    "smsut_conv1x1_fwd_cat": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4], "mfma"),
+    "smsut_conv1x1_wgrad_cat": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4], "mfma"),
+    "smsut_conv1x1_fwd_split": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4], "mfma"),
+    "smsut_conv1x1_thin_dgrad": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "direct"),
+    "smsut_conv1x1_thin_wgrad": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "direct"),
+    "smsut_conv2d_small_fwd": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * _k2(a, 7), "direct"),
+    "smsut_conv2d_small_dgrad": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * _k2(a, 7), "direct"),
+    "smsut_conv2d_flat_wgrad": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * _k2(a, 7), "mfma"),
+    "smsut_convT2x2_fwd_mfma": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
+    "smsut_convT2x2_dgrad_mfma": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
+    "smsut_convT2x2_wgrad_mfma": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
+}
+
+
+def conv_flops_of(name: str, conv_args) -> float:
+    """Algorithmic FLOPs of one recorded call (0 for non-conv entry points)."""
+    ent = _CONV_FLOPS.get(name)
+    if ent is None:
+        return 0.0
+    sig = H.SIGNATURES[name].replace(" ", "")
+    ints = [a for c, a in zip(sig, conv_args) if c in "il"]
+    return float(ent[0](ints))
+
+
+class Row(collections.namedtuple("Row", "name args calls us flops")):
+    @property
+    def total_us(self):
+        return self.us * self.calls
+
+
+def record_step(step: Callable[[], object]):
+    """Run ``step()`` once with every status-returning C-ABI call recorded: [(entry point, converted args)]."""
+    rec = []
+    orig = H.call
+
+    def spy(name, *args):
+        if name not in H._NO_STATUS:
+            rec.append((name, [H.ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args]))
+        return orig(name, *args)
+    H.call = spy
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        H.call = orig
+    return rec
+
+
+def replay(rec, reps: int = 8) -> List[Row]:
+    """Replay each distinct (entry point, non-pointer arguments) ``reps`` times between HIP events."""
+    lib = H.load()
+    groups = collections.OrderedDict()
+    for name, conv in rec:
+        sig = H.SIGNATURES[name].replace(" ", "")
+        key = (name, tuple(a for c, a in zip(sig, conv) if c in "ilfd"))
+        groups.setdefault(key, []).append(conv)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream()
+    rows = []
+    for (name, shp), calls in groups.items():
+        conv = list(calls[0])
+        conv[-1] = st.cuda_stream                        # the recorded stream may have been a capture stream
+        fn = getattr(lib, name)
+        for _ in range(2):
+            fn(*conv)
+        torch.cuda.synchronize()
+        e0.record(st)
+        for _ in range(reps):
+            fn(*conv)
+        e1.record(st)
+        torch.cuda.synchronize()
+        rows.append(Row(name, shp, len(calls), e0.elapsed_time(e1) / reps * 1e3, conv_flops_of(name, calls[0])))
+    return rows
+
+
+def summarize(rows: List[Row], peak_tflops: float) -> dict:
+    """Conv-side roofline of the step and the per-family split."""
+    conv = [r for r in rows if r.flops > 0]
+    mfma = [r for r in conv if _CONV_FLOPS[r.name][1] == "mfma"]
+    t_all = sum(r.total_us for r in rows)
+    t_conv = sum(r.total_us for r in conv)
+    f_conv = sum(r.flops * r.calls for r in conv)
+    t_mfma = sum(r.total_us for r in mfma)
+    f_mfma = sum(r.flops * r.calls for r in mfma)
+    fam = collections.OrderedDict()
+    for r in conv:
+        k = ("wgrad" if "wgrad" in r.name else "fwd/dgrad") + (" 1x1" if "1x1" in r.name else (" convT" if "convT" in r.name else ""))
+        t, f = fam.get(k, (0.0, 0.0))
+        fam[k] = (t + r.total_us, f + r.flops * r.calls)
+    return {
+        "kernel_ms_all": round(t_all / 1e3, 3), "kernel_ms_conv": round(t_conv / 1e3, 3),
+        "conv_gflop": round(f_conv / 1e9, 2),
+        "step_conv_tflops": round(f_conv / (t_conv * 1e-6) / 1e12, 2) if t_conv else None,
+        "step_conv_frac": round(f_conv / (t_conv * 1e-6) / 1e12 / peak_tflops, 4) if t_conv else None,
+        "mfma_conv_frac": round(f_mfma / (t_mfma * 1e-6) / 1e12 / peak_tflops, 4) if t_mfma else None,
+        "conv_share_of_kernel_time": round(t_conv / t_all, 4) if t_all else None,
+        "families": {k: {"ms": round(t / 1e3, 3), "tflops": round(f / (t * 1e-6) / 1e12, 1)} for k, (t, f) in fam.items()},
+    }
+
+
+def table(rows: List[Row], min_share: float = 0.007) -> str:
+    tot = sum(r.total_us for r in rows) or 1.0
+    out = []
+    for r in sorted(rows, key=lambda r: -r.total_us):
+        if r.total_us / tot < min_share:
+            break
+        tf = f"{r.flops / (r.us * 1e-6) / 1e12:6.1f} TF" if r.flops else "         "
+        out.append(f"{r.total_us / 1e3:7.3f} ms {100 * r.total_us / tot:5.1f}%  {r.calls:3d} x {r.us:7.1f} us {tf}  "
+                   f"{r.name.replace('smsut_', '')} {r.args}")
+    return "\n".join(out)

@@ -67,11 +67,12 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def _to_device_async(self, t):
         if t.is_cuda:
             return t.to(torch.int64)
-        n = t.numel()
-        if getattr(self, "_pin", None) is None or self._pin.numel() != n:
-            self._pin = torch.empty(n, dtype=torch.int64).pin_memory()
-        self._pin.copy_(t.reshape(-1))
-        return self._pin.to(self.device, non_blocking=True).clone()
+        # a fresh pinned tensor per call: the caching host allocator records the copy's stream event and does not hand
+        # the block out again before the copy has run (one shared staging buffer could be overwritten by the host for
+        # iteration k+1 while iteration k's copy was still queued behind ~30 ms of GPU work)
+        pin = torch.empty(t.numel(), dtype=torch.int64, pin_memory=True)
+        pin.copy_(t.reshape(-1))
+        return pin.to(self.device, non_blocking=True)
 
     # ------------------------------------------------------------------ the three phases of one iteration
     # The reference runs G(x_real) twice per iteration with the SAME generator weights: once in the D-step (detached,
@@ -146,8 +147,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def _run_phase(self, name, fn, inputs, params, collective_free=False):
         """Eager call, or capture-once / replay as a hipGraph (graphs.GraphedPhase) when enabled.  The very first
         iteration always runs eagerly (it is the warm-up the capture needs)."""
-        use_graph = (graphs.graphs_enabled(self.world, collective_free) and not self._graphs.get("disabled")
-                     and self._eager_done)
+        use_graph = graphs.graphs_enabled(self.world, collective_free) and self._eager_done
         if not use_graph:
             for p in params:
                 p.grad = None
@@ -155,15 +155,20 @@ class UGANConsisTrainer(UGANShp0Trainer):
         key = (name, self._semi_on) + tuple(tuple(t.shape) for t in inputs)
         g = self._graphs.get(key)
         if g is None:
-            try:
-                g = self._graphs[key] = graphs.GraphedPhase(fn, inputs, params, warmup=0)
-            except Exception as e:                                       # capture refused: stay eager, loudly
-                self.info(f"[graph] capture of {name} failed ({type(e).__name__}: {e}); running eagerly")
-                self._graphs["disabled"] = True
-                torch.cuda.synchronize()
-                return self._run_phase(name, fn, inputs, params, collective_free)
+            # A refused capture raises (r01 swallowed it and ran eagerly forever: after a partial capture p.grad points
+            # into an aborted pool and G1's autograd graph may already be consumed -- there is nothing safe to fall back
+            # to, and a silent eager run is a performance cliff nobody sees).  SMSUT_GRAPH=0 is the explicit eager mode.
+            g = self._graphs[key] = graphs.GraphedPhase(fn, inputs, params, warmup=0)
             return g.static_out                                          # the capture pass does not execute: replay it
         return g(*inputs)
+
+    def graph_report(self):
+        """What actually ran: which phases are captured hipGraphs (bench.py prints this next to the timing)."""
+        captured = sorted({k[0] for k in self._graphs if isinstance(k, tuple)})
+        mode = "graph" if len(captured) == 3 else ("graph(D only)" if captured == ["D"] else
+                                                   ("eager" if not captured else "graph(" + ",".join(captured) + ")"))
+        return {"mode": mode, "captured": captured, "fallback": False,
+                "policy": os.environ.get("SMSUT_GRAPH", "default")}
 
     def train_iteration(self, x_real, y_real, modal_org, mj=None, alpha=None, sample_ids=None):
         """One iteration; returns a float32 device tensor with the 10 scalars in ``SCALARS`` order."""

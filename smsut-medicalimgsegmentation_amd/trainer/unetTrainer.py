@@ -1,6 +1,7 @@
 """``UnetTrainer`` (reference trainer/unetTrainer.py:35-85): supervised U-Net, SGD(0.9, wd 1e-3), poly LR --
 BASELINE configs 1-2."""
 import argparse
+import os
 import random
 
 import numpy as np
@@ -29,24 +30,21 @@ class UnetTrainer(BaseTrainer):
         loss.backward()
         return loss.detach()
 
+    def graph_report(self):
+        return {"mode": "graph" if self._graph else "eager", "captured": ["step"] if self._graph else [], "fallback": False,
+                "policy": os.environ.get("SMSUT_GRAPH", "default")}
+
     def train_step(self, img, msk):
         """One iteration of unetTrainer.py:66-83 (forward, DiceCE, zero_grad, backward, step, poly LR).
         Returns the loss as a 0-dim device tensor (no host sync)."""
-        if graphs.graphs_enabled(self.world) and self._graph is not False:
+        if graphs.graphs_enabled(self.world):
             key = tuple(img.shape)
-            fresh = False
             if self._graph is None or self._graph[0] != key:
-                try:
-                    self._graph = (key, graphs.GraphedPhase(self._phase, (img, msk), self.net.parameters()))
-                    fresh = True                                         # the constructor already replayed it once
-                except Exception as e:                                   # capture refused: stay eager, loudly
-                    self.info(f"[graph] capture failed ({type(e).__name__}: {e}); running eagerly")
-                    self._graph = False
-                    torch.cuda.synchronize()
-            if self._graph:
-                loss = self._graph[1].static_out if fresh else self._graph[1](img, msk)
+                # a refused capture raises (no silent eager fallback; SMSUT_GRAPH=0 is the explicit eager mode)
+                self._graph = (key, graphs.GraphedPhase(self._phase, (img, msk), self.net.parameters()))
+                loss = self._graph[1].static_out                         # the constructor already replayed it once
             else:
-                return self.train_step(img, msk)
+                loss = self._graph[1](img, msk)
         else:
             self.optimizer.zero_grad(set_to_none=True)
             loss = self._phase(img, msk)
