@@ -168,3 +168,19 @@ def trace_inputs(step: int, b: int = 16, size: int = 256, n_cls: int = 5, n_moda
     hw = (size // 16) ** 2
     ids = torch.from_numpy(np.random.RandomState(base + 4000 + step).permutation(hw)[:64].astype(np.int64))
     return x, y, modal, mj, alpha, ids
+
+
+def validation_batches(batch_size=4, size=64, n_cls=5, base=5200):
+    """The ragged test loader of the validation-pass fixture (tests/golden/validate.npz): two volumes, ``ct_001`` with
+    5 slices and ``t2_007`` with 6, served as single-modality batches of ``batch_size`` whose LAST batch per volume is
+    short (1 and 2 slices) -- the case the reference pads (trainer/uganShp0Trainer.py:259-263).  Yields the reference's
+    loader contract ``(img, msk, modality ids, names 'm_pid_z')`` (data_loader/balanceLoader.py:59-69)."""
+    out = []
+    for vi, (m, mid, pid, nz) in enumerate((("ct", 0, "001", 5), ("t2", 3, "007", 6))):
+        img = synth_images((nz, 1, size, size), base + vi)
+        msk = synth_labels(nz, size, size, n_cls, base + 10 + vi, block=8)
+        for z0 in range(0, nz, batch_size):
+            z1 = min(z0 + batch_size, nz)
+            out.append((img[z0:z1], msk[z0:z1], torch.full((z1 - z0,), mid, dtype=torch.int64),
+                        [f"{m}_{pid}_{z}" for z in range(z0, z1)]))
+    return out

@@ -56,7 +56,6 @@ for step in range(n):
     rec = {"step": step, "scalars": dict(zip(SCALARS, [round(v, 5) for v in vals])),
            "G_l2": l2(tr.net.parameters()), "D_l2": l2(tr.D.parameters()),
            "gG_l2": l2(p.grad for p in tr.net.parameters()), "gD_l2": l2(p.grad for p in tr.D.parameters()),
-           "taps": {k: float(v.double().norm()) for k, v in tr.taps.items()},
            "graphs": sorted(str(k[0]) for k in tr._graphs if isinstance(k, tuple)), "nonfinite": tr.finite_log[:3]}
     print(json.dumps(rec), flush=True)
     if not (rec["gG_l2"] < 1e6):

@@ -17,21 +17,21 @@ import torch
 
 
 def graphs_enabled(world: int, collective_free: bool = False) -> bool:
-    """Default: every phase on single-GPU runs; under data parallelism only the phases that contain no collective
-    (``collective_free``: the D-step of the GAN trainers -- its gradient all-reduce runs after the phase, outside the
-    graph).  A phase with the Dice-statistics all-reduce inside (G-step, U-Net step) stays
-    eager under DP: RCCL inside a captured hipGraph has not been exercised on hardware.  ``SMSUT_GRAPH=0/1`` overrides
-    (1 = every phase, whatever the world size; ``dp`` = the data-parallel policy on any world size)."""
+    """Default: every phase is captured, on one GPU and under data parallelism alike -- the trainers split their steps
+    at the collectives (gradient all-reduce, Dice-statistics all-reduce), which run eagerly BETWEEN replays, so no
+    RCCL call ever sits inside a captured region.  ``SMSUT_GRAPH=0`` is the explicit eager mode (``world`` and
+    ``collective_free`` are kept for callers that want a per-phase policy)."""
     v = os.environ.get("SMSUT_GRAPH")
-    if v == "dp":                      # the data-parallel policy on any world size (to measure it on one GPU)
-        return collective_free
     if v is not None:
         return v not in ("0", "", "false", "False")
-    return world == 1 or collective_free
+    return True
 
 
 class GraphedPhase:
-    """Captures ``fn(*tensors) -> tensor`` (which ends in ``.backward()``) and replays it on new inputs."""
+    """Captures ``fn(*tensors) -> tensor | tuple of tensors`` and replays it on new inputs.  A phase may end in
+    ``.backward()`` (its parameters' ``.grad`` then live in the graph's pool and are rewritten by every replay) or leave
+    an autograd graph behind for a LATER phase to differentiate through (the later phase's capture walks it once; on
+    replay only the recorded kernels run, in capture order, on the same addresses)."""
 
     def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor],
                  grad_params: Iterable[torch.nn.Parameter], warmup: int = 2):

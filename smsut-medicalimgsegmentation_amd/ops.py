@@ -1145,47 +1145,93 @@ def modal_planes(x, m):
 
 
 # ------------------------------------------------------------------------------------------- losses
-class DiceCEFn(Function):
-    """weight_dc * SoftDice + weight_ce * CE on logits [N,C,H,W] / int64 labels [N,H,W] (misc/loss.py:8-63).
+def dice_ce_stats(logits, labels, batch_dice):
+    """Stage 1 of Dice+CE: one pass over the logits -> (stats [G, C, 3] = {tp, sum_p, count}, ce_sum [1]).  No autograd:
+    the differentiable stage is ``DiceCEFromStatsFn``.  Under data parallelism the caller all-reduces both tensors
+    between the stages, which is also where a captured step is split (no collective inside a hipGraph)."""
+    logits = nhwc(logits.detach())
+    n, c, h, w = logits.shape
+    labels = labels.contiguous()
+    if labels.dtype != torch.int64:
+        raise TypeError("labels must be int64")
+    g = 1 if batch_dice else n
+    stats = torch.empty(g, c, 3, dtype=torch.float32, device=logits.device)
+    ce_sum = torch.empty(1, dtype=torch.float32, device=logits.device)
+    H.call("smsut_dicece_stats", logits, labels, stats, ce_sum, _ws(H.call("smsut_dicece_ws", n, h * w, c, g), logits),
+           n, h * w, c, g, _s())
+    return stats, ce_sum
 
-    ``group``: optional torch.distributed process group; when given, the Dice statistics and the CE sum
-    are all-reduced so the loss equals the single-process global-batch value."""
+
+class DiceCEFromStatsFn(Function):
+    """Stage 2: loss value from (already global) statistics, and the gradient w.r.t. the local logits.
+
+    ``world`` > 1: the statistics are sums over ``world`` ranks and ``npix`` is the global pixel count, so the value is the
+    single-process global-batch loss on every rank and this rank's backward is ITS SHARE of that loss' gradient.  The
+    gradient all-reduce that follows AVERAGES over ranks (parallel.GradAllReducer), which is right for the per-rank
+    mean losses of the step but would divide this share by ``world`` once too often -- so the backward is scaled by
+    ``world`` (r01 left that out: lambda_seg was effectively 10 / world)."""
 
     @staticmethod
-    def forward(ctx, logits, labels, w_ce, w_dc, batch_dice, group):
+    def forward(ctx, logits, labels, stats, ce_sum, w_ce, w_dc, world):
         logits = nhwc(logits)
         n, c, h, w = logits.shape
-        labels = labels.contiguous()
-        if labels.dtype != torch.int64:
-            raise TypeError("labels must be int64")
-        g = 1 if batch_dice else n
-        stats = torch.empty(g, c, 3, dtype=torch.float32, device=logits.device)
-        ce_sum = torch.empty(1, dtype=torch.float32, device=logits.device)
-        H.call("smsut_dicece_stats", logits, labels, stats, ce_sum, _ws(H.call("smsut_dicece_ws", n, h * w, c, g), logits),
-               n, h * w, c, g, _s())
-        npix = float(n * h * w)
-        if group is not None:
-            import torch.distributed as dist
-            world = dist.get_world_size(group)
-            if batch_dice:
-                dist.all_reduce(stats, group=group)
-            dist.all_reduce(ce_sum, group=group)
-            npix *= world
+        g = stats.shape[0]
+        npix = float(n * h * w) * world
         out = torch.empty(3, dtype=torch.float32, device=logits.device)
         H.call("smsut_dicece_final", stats, ce_sum, out, g, c, npix, float(w_dc), float(w_ce), _s())
-        ctx.save_for_backward(logits, labels, stats)
-        ctx.cfg = (g, npix, float(w_dc), float(w_ce))
+        ctx.save_for_backward(logits, labels.contiguous(), stats)
+        ctx.cfg = (g, npix, float(w_dc), float(w_ce), int(world))
         return out[0]
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gout):
         logits, labels, stats = ctx.saved_tensors
-        g, npix, w_dc, w_ce = ctx.cfg
+        g, npix, w_dc, w_ce, world = ctx.cfg
         n, c, h, w = logits.shape
         gl = new_act(n, c, h, w, logits)
-        H.call("smsut_dicece_bwd", logits, labels, stats, gout.contiguous(), gl, n, h * w, c, g, npix, w_dc, w_ce, _s())
-        return gl, None, None, None, None, None
+        gout = gout.contiguous()
+        if world > 1:
+            gout = gout * float(world)
+        H.call("smsut_dicece_bwd", logits, labels, stats, gout, gl, n, h * w, c, g, npix, w_dc, w_ce, _s())
+        return gl, None, None, None, None, None, None
+
+
+def dice_ce_from_stats(logits, labels, stats, ce_sum, weight_ce, weight_dc, world=1):
+    return DiceCEFromStatsFn.apply(logits, labels, stats, ce_sum, weight_ce, weight_dc, world)
+
+
+def all_reduce_dice_stats(pairs, group):
+    """ONE all-reduce for any number of (stats, ce_sum) pairs (16 floats each at 5 classes): packed into a flat buffer,
+    summed over ``group``, unpacked in place."""
+    import torch.distributed as dist
+    flat = torch.cat([t.reshape(-1) for pair in pairs for t in pair])
+    dist.all_reduce(flat, group=group)
+    off = 0
+    for pair in pairs:
+        for t in pair:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class DiceCEFn:
+    """weight_dc * SoftDice + weight_ce * CE on logits [N,C,H,W] / int64 labels [N,H,W] (misc/loss.py:8-63): the two
+    stages back to back.  ``group``: optional torch.distributed process group; when given, the Dice statistics and the CE
+    sum are all-reduced between the stages so the loss equals the single-process global-batch value."""
+
+    @staticmethod
+    def apply(logits, labels, w_ce, w_dc, batch_dice, group):
+        stats, ce_sum = dice_ce_stats(logits, labels, batch_dice)
+        world = 1
+        # per-sample Dice (batch_dice False) is a mean over samples like CE: the local loss + gradient averaging IS the
+        # global-batch loss, nothing to exchange
+        if group is not None and batch_dice:
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+            if world > 1:
+                all_reduce_dice_stats([(stats, ce_sum)], group)
+        return DiceCEFromStatsFn.apply(logits, labels, stats, ce_sum, w_ce, w_dc, world)
 
 
 def dice_ce(logits, labels, weight_ce=1.0, weight_dc=1.0, batch_dice=False, group=None):

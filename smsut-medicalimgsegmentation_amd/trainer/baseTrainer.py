@@ -96,7 +96,45 @@ class BaseTrainer(abc.ABC):
             return
         path = pjoin(self.expr_root, self.model_idx, "ckpt", f"{prefix}.ckpt")
         torch.save({k: v.contiguous() for k, v in self.net.state_dict().items()}, path)
+        self.save_train_state(prefix)
         self.info(f"Save model to {path}.")
+
+    # ------------------------------------------------------------------ resume (the reference saves
+    # state_dicts only -- uganShp0Trainer.py:94-107, baseTrainer.py:120-123 -- and cannot continue a run)
+    _OPTIMIZERS = ("optimizer", "d_optimizer", "optimizer1", "optimizer2")
+
+    def save_train_state(self, prefix):
+        """``{prefix}_state.ckpt`` next to the weight files: every optimizer's state (momentum / Adam moments, current LR),
+        ``iter`` / ``epoch`` (poly LR, consistency ramp-up and the ``iter >= 1000`` switch depend on them) and the host +
+        device RNG states.  Optimizer state tensors keep the parameters' HWIO strides (the fused optimizers need the
+        layouts to agree), so they are saved as they are, not ``.contiguous()``."""
+        if self.rank != 0 or self.phase != "train" or self.model_idx is None:
+            return None
+        import random as _random
+        state = {"iter": self.iter, "epoch": self.epoch,
+                 "optimizers": {n: getattr(self, n).state_dict() for n in self._OPTIMIZERS if hasattr(self, n)},
+                 "rng": {"python": _random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
+                         "cuda": torch.cuda.get_rng_state(self.device)}}
+        path = pjoin(self.expr_root, self.model_idx, "ckpt", f"{prefix}_state.ckpt")
+        torch.save(state, path)
+        return path
+
+    def resume(self, model_idx, which_ckpt="last", restore_rng=True):
+        """Continue a run: weights (``load_model``), optimizer states, ``iter`` / ``epoch`` and RNG streams.  Call before the
+        first training step (captured graphs bind gradient buffers at capture time)."""
+        import random as _random
+        self.load_model(model_idx, which_ckpt)
+        self.net.to(self.device)
+        path = pjoin(self.expr_root, model_idx, "ckpt", f"{which_ckpt}_state.ckpt")
+        state = torch.load(path, map_location="cpu", weights_only=False)
+        for n, sd in state["optimizers"].items():
+            getattr(self, n).load_state_dict(sd)
+        self.iter, self.epoch = int(state["iter"]), int(state["epoch"])
+        if restore_rng:
+            _random.setstate(state["rng"]["python"]); np.random.set_state(state["rng"]["numpy"])
+            torch.set_rng_state(state["rng"]["torch"]); torch.cuda.set_rng_state(state["rng"]["cuda"], self.device)
+        self.model_idx = self.model_idx or model_idx
+        self.info(f"[*] Resumed from {path}: iter {self.iter}, epoch {self.epoch}.")
 
     # ------------------------------------------------------------------ loaders
     def get_loaders(self, loader_type):
@@ -123,7 +161,7 @@ class BaseTrainer(abc.ABC):
         train_meter = Meter(keys_min, [], alpha=cfg.exp_alpha)
         test_meter = Meter(keys_min, keys_max, alpha=1.0)
         tic = time.time()
-        for epoch in range(max_epoch or cfg.max_epoch):
+        for epoch in range(self.epoch, max_epoch or cfg.max_epoch):          # (self.epoch > 0 after resume())
             train_meter.reset_cur()
             self.train_epoch(lb, ul, train_meter)
             self.epoch += 1

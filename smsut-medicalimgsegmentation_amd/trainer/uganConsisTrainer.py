@@ -36,12 +36,12 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._semi_on = False
         self._graphs = {}
         self._alias = None
-        self._g1 = None
+        self._g1 = self._g2 = None
+        self._side = None
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
         self.finite_log = []
-        self.taps = {}
 
     def consistency_loss(self, source, target):
         return self.loss(source, ops.argmax_channels(target))                    # :45-53
@@ -74,17 +74,25 @@ class UGANConsisTrainer(UGANShp0Trainer):
         pin.copy_(t.reshape(-1))
         return pin.to(self.device, non_blocking=True)
 
-    # ------------------------------------------------------------------ the three phases of one iteration
+    # ------------------------------------------------------------------ the four phases of one iteration
     # The reference runs G(x_real) twice per iteration with the SAME generator weights: once in the D-step (detached,
     # :133-135) and again in the G-step (:151) -- D is updated in between, G is not, so both calls produce identical
     # values.  Here it is computed ONCE (phase G1, with its autograd graph kept), the D-step consumes the detached
     # result, and the G-step continues from the stored graph.  D(x_real) and D(x_fake) of the D-step share one batched
     # pass (InstanceNorm is per sample, so the values are unchanged).
-    def _g1_phase(self, x_real, vec_ot, ids):
-        """G(x_real -> x_fake) with the autograd graph retained for the G-step; returns x_fake detached."""
+    #
+    # Phase boundaries sit exactly where data parallelism needs a collective, so every phase is collective-free and is
+    # captured as a hipGraph on one GPU and under DP alike (r01 ran G1 / G2 eagerly under DP):
+    #   G1   G(x_real)                      + Dice statistics of (y_fake[:bs], y_real)
+    #   D    D-step forward / backward      -> [all-reduce of D's gradients + Adam: side stream, overlapped with G2gen]
+    #   G2gen  cycle pass G(x_fake), L1, PatchNCE, pseudo labels + Dice statistics of (y_rec, argmax y_fake)
+    #                                       -> [ONE all-reduce of both statistics sets]
+    #   G2   D(x_fake) through the UPDATED frozen D, both DiceCE values from the global statistics, g_loss.backward()
+    def _g1_phase(self, x_real, vec_ot, ids, y_real):
+        """G(x_real -> x_fake) with the autograd graph retained for the G-step; returns (x_fake detached, seg statistics)."""
         y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
         self._g1 = (y_fake, x_fake, feat_x)
-        return x_fake.detach()
+        return x_fake.detach(), self.loss.stats(y_fake[:y_real.size(0)], y_real)
 
     def _d_phase(self, x_real, x_fake, modal_org, alpha):
         """D-step forward + backward (:129-144).  Returns [D_real, D_fake, D_cls, D_gp]."""
@@ -101,37 +109,45 @@ class UGANConsisTrainer(UGANShp0Trainer):
         d_loss.backward()
         return torch.stack([t.detach().float() for t in (d_real, d_fake, d_cls, d_gp)])
 
-    def _g2_phase(self, x_real, y_real, vec_to, modal_trg, ids, lambda_semi):
-        """Rest of the G-step (:152-179) with D frozen: D(x_fake), the cycle pass, the losses, backward through both
-        generator passes.  ``lambda_semi`` is a 0-dim device tensor (it changes every epoch and must not be baked into a
-        captured graph).  The second generator pass runs on parameter ALIASES (same storage, separate ``.grad``) so the
-        two passes' weight gradients are summed by one multi-tensor add instead of one add kernel per parameter.
+    def _g2gen_phase(self, x_real, vec_to, ids):
+        """The cycle pass of the G-step (:159-168) -- everything that does not need the updated D: G(x_fake -> x_rec) on
+        parameter ALIASES (same storage, separate ``.grad``, so the two passes' weight gradients are summed by one
+        multi-tensor add instead of one add kernel per parameter), L1, PatchNCE, the pseudo labels and the consistency
+        term's Dice statistics.  Leaves its autograd graph for phase G2; returns the (local) statistics."""
+        y_fake, x_fake, feat_x = self._g1
+        y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
+                                                             {"sample_ids": [ids]})
+        g_rec = ops.l1_mean(x_real, x_rec)
+        g_nce = self.nce_loss(feat_x, feat_f)
+        if self._semi_on:
+            pseudo = ops.argmax_channels(y_fake)                                     # :45-53
+            st = self.loss.stats(y_rec, pseudo)
+        else:
+            pseudo, st = None, torch.zeros(1, device=self.device)
+        self._g2 = (y_rec, pseudo, g_rec, g_nce)
+        return st
+
+    def _g2_phase(self, y_real, modal_trg, st_seg, st_semi, lambda_semi):
+        """Rest of the G-step (:152-179) with D frozen: D(x_fake), the losses, backward through both generator passes.
+        ``lambda_semi`` is a 0-dim device tensor (it changes every epoch and must not be baked into a captured graph);
+        ``st_*`` are the Dice statistics, already summed over the ranks.
         Returns [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]."""
         bs = y_real.size(0)
-        y_fake, x_fake, feat_x = self._g1
+        y_fake, x_fake, _ = self._g1
+        y_rec, pseudo, g_rec, g_nce = self._g2
         with ops.first_order_pass():
             out_src, out_cls = self.D(x_fake)
         g_fake = ops.mean_all(out_src, -1.0)
         g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
-        g_seg = self.loss(y_fake[:bs], y_real)
-        y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
-                                                             {"sample_ids": [ids]})
-        g_rec = ops.l1_mean(x_real, x_rec)
+        g_seg = self.loss.from_stats(y_fake[:bs], y_real, st_seg)
         if self._semi_on:
-            g_semi = self.consistency_loss(y_rec, y_fake)
+            g_semi = self.loss.from_stats(y_rec, pseudo, st_semi)
         else:
             g_semi = torch.zeros((), device=self.device)
-        g_nce = self.nce_loss(feat_x, feat_f)
         g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg \
             + lambda_semi * g_semi + 1.0 * g_nce
-        if self._probe:                                   # gradient taps (diagnosis): persistent copies, graph-safe
-            for nm, t in (("x_rec", x_rec), ("x_fake", x_fake), ("y_rec", y_rec), ("y_fake", y_fake),
-                          ("feat_f", feat_f[0]), ("out_src", out_src), ("out_cls", out_cls)):
-                if t.requires_grad:
-                    buf = self.taps.setdefault(nm, torch.zeros_like(t))
-                    t.register_hook(lambda g, buf=buf: (buf.copy_(g), None)[1])
         g_loss.backward()
-        self._g1 = None
+        self._g1 = self._g2 = None
         main, extra = [], []
         for name, p in self.net.named_parameters():
             a = self._alias[name]
@@ -165,8 +181,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def graph_report(self):
         """What actually ran: which phases are captured hipGraphs (bench.py prints this next to the timing)."""
         captured = sorted({k[0] for k in self._graphs if isinstance(k, tuple)})
-        mode = "graph" if len(captured) == 3 else ("graph(D only)" if captured == ["D"] else
-                                                   ("eager" if not captured else "graph(" + ",".join(captured) + ")"))
+        mode = "graph" if len(captured) == 4 else ("eager" if not captured else "graph(" + ",".join(captured) + ")")
         return {"mode": mode, "captured": captured, "fallback": False,
                 "policy": os.environ.get("SMSUT_GRAPH", "default")}
 
@@ -201,25 +216,36 @@ class UGANConsisTrainer(UGANShp0Trainer):
         d_params = list(self.D.parameters())
 
         # ------------------------------------------------------------ G(x_real): once, shared by both steps
-        # (G1 shares G2's mode: G2's backward runs through G1's autograd graph, which a captured G1 builds only once)
-        x_fake = self._run_phase("G1", self._g1_phase, (x_real, vec_ot, ids), [])
+        x_fake, st_seg = self._run_phase("G1", self._g1_phase, (x_real, vec_ot, ids, y_real), [])
         if self._probe:
             self._finite_probe("G1", [("x_fake", x_fake)])
 
         # ------------------------------------------------------------ D-step (:129-146)
-        d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params, collective_free=True)
+        d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params)
         if self._probe:
             self._finite_probe("D", [("d_scalars", d_scal)] + [("grad " + k, p.grad) for k, p in self.D.named_parameters()])
-        self.d_reducer.reduce()
-        self.d_optimizer.step()
+        cur = torch.cuda.current_stream()
+        if self.world > 1:
+            # D's gradient all-reduce + Adam on a side stream: the cycle pass below does not touch D
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self.d_reducer.reduce()
+                self.d_optimizer.step()
+        else:
+            self.d_optimizer.step()
         if self._probe:
             self._finite_probe("D.step", list(self.D.named_parameters()))
 
-        # ------------------------------------------------------------ G-step (:150-180), D frozen
-        for p in d_params:
+        # ------------------------------------------------------------ G-step (:150-180)
+        st_semi = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids), list(self._alias.values()))
+        self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
+        if self.world > 1:
+            cur.wait_stream(self._side)
+        for p in d_params:                                    # D frozen: its unused gradients are neither computed nor reduced
             p.requires_grad_(False)
-        g_scal = self._run_phase("G2", self._g2_phase, (x_real, y_real, vec_to, modal_trg, ids, lam_t),
-                                 g_params + list(self._alias.values()))
+        g_scal = self._run_phase("G2", self._g2_phase, (y_real, modal_trg, st_seg, st_semi, lam_t), g_params)
         for p in d_params:
             p.requires_grad_(True)
         if self._probe:

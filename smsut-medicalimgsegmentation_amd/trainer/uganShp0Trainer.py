@@ -38,6 +38,7 @@ class UGANShp0Trainer(BaseTrainer):
         root = pjoin(self.expr_root, model_idx, "ckpt")
         self.net.load_state_dict(torch.load(pjoin(root, f"{which_ckpt}_G.ckpt"), map_location="cpu"))
         self.D.load_state_dict(torch.load(pjoin(root, f"{which_ckpt}_D.ckpt"), map_location="cpu"))
+        self.net.to(self.device); self.D.to(self.device)
         self.info(f"[*] Load G and D from {root}.")
 
     def save_model(self, prefix):
@@ -47,6 +48,7 @@ class UGANShp0Trainer(BaseTrainer):
         # .contiguous(): checkpoints hold plain OIHW tensors, loadable by the reference's nn.Modules
         torch.save({k: v.contiguous() for k, v in self.net.state_dict().items()}, pjoin(root, f"{prefix}_G.ckpt"))
         torch.save({k: v.contiguous() for k, v in self.D.state_dict().items()}, pjoin(root, f"{prefix}_D.ckpt"))
+        self.save_train_state(prefix)
         self.info(f"[*] Save G and D to {root}.")
 
     def label2onehot(self, modals, dim=cfg.n_modal):

@@ -23,15 +23,24 @@ class UnetTrainer(BaseTrainer):
             self.reducer = parallel.GradAllReducer(self.net.parameters(), self.group)
         self._graph = None
 
-    def _phase(self, img, msk):
-        """forward + DiceCE + backward (the part that is captured into a hipGraph)."""
+    # The step is two collective-free phases, split where data parallelism exchanges the Dice statistics
+    # (batch_dice sums tp / fp / fn over the GLOBAL batch, misc/loss.py:52); each is captured as a hipGraph, the 16-float
+    # all-reduce runs eagerly between the two replays (a no-op on one GPU).
+    def _fwd_phase(self, img, msk):
+        """forward + Dice/CE statistics; leaves the autograd graph for the second phase."""
         out = self.net(img)
-        loss = self.loss(out, msk)
+        self._out = out
+        return self.loss.stats(out, msk)
+
+    def _bwd_phase(self, msk, stats):
+        """loss from the (global) statistics + backward."""
+        loss = self.loss.from_stats(self._out, msk, stats)
         loss.backward()
+        self._out = None
         return loss.detach()
 
     def graph_report(self):
-        return {"mode": "graph" if self._graph else "eager", "captured": ["step"] if self._graph else [], "fallback": False,
+        return {"mode": "graph" if self._graph else "eager", "captured": ["fwd", "bwd"] if self._graph else [], "fallback": False,
                 "policy": os.environ.get("SMSUT_GRAPH", "default")}
 
     def train_step(self, img, msk):
@@ -41,13 +50,25 @@ class UnetTrainer(BaseTrainer):
             key = tuple(img.shape)
             if self._graph is None or self._graph[0] != key:
                 # a refused capture raises (no silent eager fallback; SMSUT_GRAPH=0 is the explicit eager mode)
-                self._graph = (key, graphs.GraphedPhase(self._phase, (img, msk), self.net.parameters()))
-                loss = self._graph[1].static_out                         # the constructor already replayed it once
+                # warm-up outside any capture (first launches load code objects, the allocator sizes its pools): one
+                # forward + backward whose gradients are dropped -- the weights do not move
+                self._bwd_phase(msk, self._fwd_phase(img, msk))
+                self.optimizer.zero_grad(set_to_none=True)
+                torch.cuda.synchronize()
+                ga = graphs.GraphedPhase(self._fwd_phase, (img, msk), [], warmup=0)
+                self.loss.reduce_stats([ga.static_out])
+                gb = graphs.GraphedPhase(self._bwd_phase, (msk, ga.static_out), self.net.parameters(), warmup=0)
+                self._graph = (key, ga, gb)
+                loss = gb.static_out                                     # the constructors already replayed them once
             else:
-                loss = self._graph[1](img, msk)
+                stats = self._graph[1](img, msk)
+                self.loss.reduce_stats([stats])
+                loss = self._graph[2](msk, stats)
         else:
             self.optimizer.zero_grad(set_to_none=True)
-            loss = self._phase(img, msk)
+            stats = self._fwd_phase(img, msk)
+            self.loss.reduce_stats([stats])
+            loss = self._bwd_phase(msk, stats)
         self.reducer.reduce()
         self.optimizer.step()
         lr_ = self.poly_lr()

@@ -551,6 +551,54 @@ def gen_iter_trace_f64():
     gen_iter_trace(dtype=torch.float64, name="iter_trace_f64")
 
 
+def gen_validate():
+    """The padded validation pass, replayed line by line with the reference's modules (trainer/uganShp0Trainer.py:250-287:
+    eval mode, last batch zero-padded to cfg.batch_size, ``val_phase=True`` forward, crop, DiceCE per batch, argmax, volume
+    assembly by name 'm_pid_z', meter accumulation with the PADDED batch size :270).  Stores the predicted volumes, the
+    per-batch losses and the meter sums; the Dice matrix on top is medpy's ``dc`` (not installed: parity unpinned there)."""
+    bs, H = 4, 64
+    G = load(UGANnce(1, 5, 4, 16), recipe.ugan_shapes(1, 5, 4, 16), 77)
+    G.eval()
+    crit = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)
+    batches = recipe.validation_batches(bs, H)
+    gt = {}
+    for _, msk, _, names in batches:
+        for i, nm in enumerate(names):
+            m, pid, z = nm.split("_")
+            gt.setdefault(f"{m}_{pid}", {})[int(z)] = msk[i].numpy()
+    gt = {k: np.stack([v[z] for z in sorted(v)]) for k, v in gt.items()}
+    prd = {k: np.zeros(v.shape, dtype=v.dtype) for k, v in gt.items()}
+    losses, n_prd, meter_sum, meter_n = [], 0, {}, {}
+    logits_keep = None
+    with torch.no_grad():
+        for x_real, y_real, mdl, inm in batches:
+            b, c, h, w = x_real.shape
+            if b != bs:
+                x_real = torch.cat([x_real, torch.zeros((bs - b, c, h, w), dtype=x_real.dtype)], dim=0)
+            m = mdl[0].item()
+            y_fake, x_fake = G(x_real, val_phase=True)
+            if b != bs:
+                y_fake, x_fake = y_fake[:b], x_fake[:b]
+            sample_loss = crit(y_fake, y_real)
+            losses.append(sample_loss.item())
+            meter_sum[m] = meter_sum.get(m, 0.0) + sample_loss.item() * x_real.size(0)      # :270 -- padded size
+            meter_n[m] = meter_n.get(m, 0) + x_real.size(0)
+            pred = torch.argmax(y_fake, dim=1).numpy()
+            if logits_keep is None:
+                logits_keep = npy(y_fake[:, :, ::4, ::4])
+            for i in range(b):
+                mm, pid, z = inm[i].split("_")
+                prd[f"{mm}_{pid}"][int(z)] = pred[i]
+                n_prd += 1
+    rec = dict(bs=bs, H=H, g_seed=77, n_prd=n_prd, losses=np.array(losses), logits0_s4=logits_keep,
+               meter_keys=np.array(sorted(meter_sum)), meter_sum=np.array([meter_sum[k] for k in sorted(meter_sum)]),
+               meter_n=np.array([meter_n[k] for k in sorted(meter_sum)]))
+    for k in gt:
+        rec["prd::" + k] = prd[k].astype(np.uint8)
+        rec["gt::" + k] = gt[k].astype(np.uint8)
+    save("validate", **rec)
+
+
 if __name__ == "__main__":
     random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
     which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small", "networks_zoo", "siblings"]

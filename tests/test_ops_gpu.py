@@ -241,18 +241,19 @@ def test_convT_concat_planes(ops):
     assert rel_err(ops.modal_planes(dev(xi), dev(m)).cpu().numpy(), ref.numpy()) < 1e-7
 
 
+@pytest.mark.parametrize("n_cls", [2, 3, 4, 5, 7])          # 2-5: compile-time class counts (config 1 is 2-class); 7: runtime C
 @pytest.mark.parametrize("batch_dice", [True, False])
-def test_dice_ce(ops, batch_dice):
+def test_dice_ce(ops, batch_dice, n_cls):
     from oracle import smsut_oracle as O
-    lg = (rnd(3, 5, 16, 16, seed=1) * 2).requires_grad_(True)
-    lb = torch.from_numpy(np.random.RandomState(2).randint(0, 5, size=(3, 16, 16)).astype(np.int64))
+    lg = (rnd(3, n_cls, 16, 16, seed=1) * 2).requires_grad_(True)
+    lb = torch.from_numpy(np.random.RandomState(2).randint(0, n_cls, size=(3, 16, 16)).astype(np.int64))
     ref = O.dice_ce(lg, lb, 0.5, 0.5, batch_dice)
     ref.backward()
     ld = dev(lg.detach()).requires_grad_(True)
     out = ops.dice_ce(ld, dev(lb), 0.5, 0.5, batch_dice)
-    out.backward()
+    (out * 1.7).backward()                                  # a non-unit upstream gradient
     assert abs(out.item() - ref.item()) < 1e-6
-    assert rel_err(ld.grad.cpu().numpy(), lg.grad.numpy()) < 1e-5
+    assert rel_err(ld.grad.cpu().numpy(), 1.7 * lg.grad.numpy()) < 1e-5
 
 
 def test_small_losses(ops):

@@ -182,3 +182,67 @@ def test_medpy_dc_formula_selfcheck():
     assert O.medpy_dc(a, b) == 0.0
     b[:] = 0; b[1:3] = 1
     assert abs(O.medpy_dc(a, b) - 0.5) < 1e-12
+
+
+def test_validation_pass_replay(golden):
+    """The oracle's forward / DiceCE / argmax on the ragged validation loader vs the replay of
+    trainer/uganShp0Trainer.py:250-287 with the reference's modules (tests/golden/validate.npz)."""
+    g = golden("validate")
+    bs, H = int(g["bs"]), int(g["H"])
+    sd = recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), int(g["g_seed"]))
+    losses, agree, total = [], 0, 0
+    with torch.no_grad():
+        for bi, (x, y, mdl, names) in enumerate(recipe.validation_batches(bs, H)):
+            b = x.shape[0]
+            if b != bs:
+                x = torch.cat([x, torch.zeros(bs - b, *x.shape[1:])], 0)
+            seg, _ = O.ugan_forward(sd, x, val_phase=True)
+            seg = seg[:b]
+            if bi == 0:
+                assert rel_err(seg[:, :, ::4, ::4].numpy(), g["logits0_s4"]) < TOL
+            losses.append(O.dice_ce(seg, y).item())
+            pred = seg.argmax(1).numpy()
+            for i, nm in enumerate(names):
+                m, pid, z = nm.split("_")
+                ref = g[f"prd::{m}_{pid}"][int(z)]
+                agree += int((pred[i] == ref).sum()); total += ref.size
+    assert np.allclose(losses, g["losses"], rtol=1e-5)
+    assert agree / total > 0.9995, agree / total          # argmax ties at round-off level only
+
+
+def test_trace_first_iteration_replay(golden):
+    """Iteration 0 of the 32-iteration trajectory fixture (256^2, 8 + 8 slices) through the oracle: pins
+    ``recipe.trace_inputs`` + the oracle at the BASELINE config-3 size to the reference's own numbers."""
+    g = golden("iter_trace")
+    names = [str(s) for s in g["scalar_names"]]
+    gsd = leaf(recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), int(g["g_seed"])))
+    dsd = leaf(recipe.fill(recipe.disc_shapes(256, 4, 16, 256), int(g["d_seed"])))
+    g_opt = torch.optim.SGD(list(gsd.values()), lr=1e-2, momentum=0.9, weight_decay=1e-3)
+    d_opt = torch.optim.Adam(list(dsd.values()), 1e-2, (0.9, 0.999), weight_decay=1e-3)
+    x, y, modal, mj, alpha, ids = recipe.trace_inputs(0)
+    logs, _ = O.ugan_consis_iteration(gsd, dsd, g_opt, d_opt, x, y, modal, mj, alpha, [ids], it=int(g["it0"]),
+                                      epoch=int(g["epoch"]), nce_batch=int(g["bs"]))
+    got = np.array([logs[k] for k in names])
+    ref = g["scalars"][0]
+    # G_fake / G_cls pass through D after its first Adam step (+-lr on every weight): 2e-3; the rest at round-off
+    assert np.allclose(got, ref, rtol=2e-3, atol=1e-5), dict(zip(names, zip(got, ref)))
+    tight = [names.index(k) for k in ("D_real", "D_fake", "D_cls", "G_rec", "G_seg", "G_semi", "G_nce")]
+    assert np.allclose(got[tight], ref[tight], rtol=1e-4, atol=1e-6)
+
+
+def test_trace_bands_cover_reference_fp_spread(golden):
+    """The bands of tests/test_graph_gpu.py's trajectory test against the reference's OWN sensitivity to rounding: the
+    same 32 iterations replayed with the reference modules in fp32 (iter_trace) and fp64 (iter_trace_f64).  A band may
+    not be tighter than that spread (no fp32 implementation could meet it) nor looser than 4x the spread + 1e-2."""
+    from trace_bands import TRACE_BANDS
+    a, b = golden("iter_trace"), golden("iter_trace_f64")
+    names = [str(s) for s in a["scalar_names"]]
+    n = min(a["scalars"].shape[0], b["scalars"].shape[0])
+    assert n >= 24
+    for name, band in TRACE_BANDS.items():
+        i = names.index(name)
+        spread = float((np.abs(a["scalars"][:n, i] - b["scalars"][:n, i]) / np.abs(b["scalars"][:n, i])).max())
+        assert spread <= band <= 4 * spread + 1e-2, (name, spread, band)
+    # and the D-side really is chaotic in the reference itself (why it is not banded at all past iteration 0)
+    i = names.index("G_fake")
+    assert float(np.abs(a["scalars"][3:n, i] - b["scalars"][3:n, i]).max()) > 0.3
