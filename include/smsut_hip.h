@@ -112,6 +112,36 @@ int smsut_conv2d_fwd_mfma_split(const float* x, const float* w, float* ya, float
 int smsut_conv1x1_fwd_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int HW, int Kdim,
                             int Ndim, int transposed, void* stream);
 
+/* fp16-operand convolutions (BASELINE config 5: 512x512 slices, "fp16 MFMA conv path with fp32 IN / loss accumulators"; the
+ * reference has no AMP -- SURVEY.md 2.2 -- so these replace the same nn.Conv2d sites as the fp32 entry points: network/blocks.py:10-16,
+ * 53-80 at the shapes of network/ugan.py:205-215, config.py:50).  Tensors stay fp32 in HBM; operands are converted to fp16 while a tile
+ * is staged into LDS, products accumulate in fp32 (v_mfma_f32_16x16x16_f16), statistics / epilogues / outputs are the fp32 ones.
+ * gsc (nullable): device float[2] = {s, 1/s} from smsut_absmax_scale -- a per-tensor power-of-two scale for a GRADIENT input operand
+ * (it would underflow fp16 otherwise); the operand is multiplied by s before the conversion, the fp32 result by 1/s.
+ * Tile selection, statistics layout (smsut_conv2d_mfma_tiles) and the `transposed` flags are those of the fp32 entry points. */
+int smsut_conv2d_f16_supported(int KS, int Kdim, int Ndim);
+int smsut_conv2d_fwd_mfma_f16(const float* x, const float* w, float* y, const float* gsc /*nullable*/, int N, int H, int W,
+                              int Kdim, int Ndim, int KS, int transposed, void* stream);
+int smsut_conv2d_fwd_mfma_stats_f16(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
+                                    int Ndim, int KS, void* stream);
+int smsut_conv2d_fwd_mfma_stats_cat_f16(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
+                                        int W, int Kdim, int Ndim, void* stream);
+int smsut_conv2d_fwd_mfma_split_f16(const float* x, const float* w, float* ya, float* yb, const float* gsc /*nullable*/,
+                                    int split, int N, int H, int W, int Kdim, int Ndim, int transposed, void* stream);
+int smsut_conv2d_dgrad_mfma_bwdstats_f16(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                         const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                         const float* gsc /*nullable*/, float slope, int N, int H, int W, int Kdim, int Ndim,
+                                         void* stream);
+/* 3x3 weight gradient, fp16 operands read transposed from LDS (ds_read_b64_tr_b16): H % 8 == 0, W % 16 == 0, Cin % 16 == 0,
+ * Cout % 16 == 0.  x2 (nullable): x is the virtual cat([x, x2]) with ca channels in x.  workspace: _ws floats. */
+int smsut_conv2d_wgrad_f16_supported(int N, int H, int W, int Cin, int Cout);
+int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout);
+int smsut_conv2d_wgrad_f16(const float* x, const float* x2 /*nullable*/, int ca, const float* gy, float* gw, float* workspace,
+                           const float* gsc /*nullable*/, int N, int H, int W, int Cin, int Cout, void* stream);
+/* out2[2] = {s, 1/s}, s = 2^k with max|x| * s in [2^13, 2^14] (s = 1 for an all-zero tensor); workspace: _ws floats */
+int64_t smsut_absmax_scale_ws(int64_t n);
+int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace, void* stream);
+
 /* thin 1x1 layers (Cout <= 8, Cin in {8,16,32,64}; reference: the nn.Conv2d heads at network/blocks.py:123-125 and
    network/ugan.py:70): data-gradient gx[P][Cin] = gy[P][Cout] W^T and weight-gradient gw[Cin][Cout], both streaming. */
 int smsut_conv1x1_thin_supported(int Cin, int Cout);

@@ -62,6 +62,18 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_mfma_cat_supported": "iiiii",
     "smsut_conv2d_fwd_mfma_stats_cat": "ppppp iiiii s",
     "smsut_conv2d_wgrad_mfma_cat": "pp i ppp iiiiii s",
+    # fp16-operand forms (config 5)
+    "smsut_conv2d_f16_supported": "iii",
+    "smsut_conv2d_fwd_mfma_f16": "pppp iiiiii i s",
+    "smsut_conv2d_fwd_mfma_stats_f16": "pppp iiiiii s",
+    "smsut_conv2d_fwd_mfma_stats_cat_f16": "ppppp iiiii s",
+    "smsut_conv2d_fwd_mfma_split_f16": "ppppp iiiiiii s",
+    "smsut_conv2d_dgrad_mfma_bwdstats_f16": "pppppppppp f iiiii s",
+    "smsut_conv2d_wgrad_f16_supported": "iiiii",
+    "smsut_conv2d_wgrad_f16_ws": "iiiii",
+    "smsut_conv2d_wgrad_f16": "pp i pppp iiiii s",
+    "smsut_absmax_scale_ws": "l",
+    "smsut_absmax_scale": "p l pp s",
     "smsut_conv1x1_fwd_cat": "pp i ppp iiii s",
     "smsut_conv1x1_wgrad_cat": "pp i ppp iiii s",
     "smsut_conv2d_mfma_split_supported": "iiiiii",
@@ -125,10 +137,10 @@ SIGNATURES: Dict[str, str] = {
     "smsut_patchnce_fwd": "pppp iii f s",
     "smsut_patchnce_bwd": "pppp iii f s",
 }
-_RET_I64 = {"smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
+_RET_I64 = {"smsut_conv2d_wgrad_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws",
             "smsut_conv1x1_thin_wgrad_ws"}
-_NO_STATUS = _RET_I64 | {"smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
+_NO_STATUS = _RET_I64 | {"smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
                          "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported"}

@@ -50,11 +50,34 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int KS, int TH, int WM, int WN, int NTN>
+// ---- fp16-operand mode (BASELINE config 5: 512x512 slices, "fp16 MFMA conv path with fp32 IN / loss accumulators") ----------
+// Tensors stay fp32 in HBM; a kernel instantiated with F16 converts its operands to fp16 WHILE STAGING them into LDS and
+// multiplies with v_mfma_f32_16x16x16_f16 -- one instruction per 16-channel chunk and tap instead of four fp32 ones, fp32
+// accumulators, statistics, epilogues and outputs unchanged (the C/D register layout is dtype-independent on gfx950).
+// LDS images: input tile [pixel][24 halves] (16 used; 48-B pixel stride makes the ds_read_b64 of lane (pixel lm, 4kq..4kq+3)
+// conflict-free: banks 12*lm + 2*kq + {0,1} are all distinct within a 32-lane half), weights [tap][chunk][n][24 halves].
+// Gradient operands (gy of the data- and weight-gradient passes) would underflow fp16 (|gy| ~ 1e-7 at 512^2): the caller
+// passes gsc = {s, 1/s}, a per-tensor power-of-two scale from smsut_absmax_scale; gy*s is what is converted, the fp32
+// result is multiplied by 1/s -- exact, no loss-scale bookkeeping outside the kernel.
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int SPIXH = 24;    // halves between consecutive pixels of the staged fp16 input tile
+constexpr int WROWH = 24;    // halves between consecutive output channels of the staged fp16 weights ([n][16 k] + pad)
+__device__ __forceinline__ f32x4 mfma16h(h4 a, h4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ h4 to_h4(float4 v) { return (h4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
+__device__ __forceinline__ h4 to_h4s(float4 v, float s) {
+  return (h4){(_Float16)(v.x * s), (_Float16)(v.y * s), (_Float16)(v.z * s), (_Float16)(v.w * s)};
+}
+
+template <int KS, int TH, int WM, int WN, int NTN, bool F16 = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Kdim,
               int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz, float* __restrict__ stats,
-              const float* __restrict__ x2 = nullptr, float* __restrict__ y2 = nullptr, int split = 0) {
+              const float* __restrict__ x2 = nullptr, float* __restrict__ y2 = nullptr, int split = 0,
+              const float* __restrict__ gsc = nullptr) {
+  // F16: fp16 operands, converted while staging (block comment above mfma16h); gsc (nullable) = {s, 1/s} of a gradient input.
   // x2 (nullable, regular conv only): the input is the virtual cat([x, x2]) of two Kdim/2-channel tensors (common.h); the
   // select is per 16-channel chunk, i.e. uniform.  y2 / split (nullable): result channels >= split go to y2 (see
   // conv_mfma_fwd_p).
@@ -71,6 +94,9 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   extern __shared__ float smem[];
   float* in_s = smem;                        // [IH][IW][SPIX]
   float* w_s = smem + IH * IW * SPIX;        // [KK][4][CO_T][4]
+  [[maybe_unused]] _Float16* in_h = reinterpret_cast<_Float16*>(smem);      // F16: [IH][IW][SPIXH]
+  [[maybe_unused]] _Float16* w_h = reinterpret_cast<_Float16*>(w_s);        // F16: [KK][CO_T][WROWH]
+  [[maybe_unused]] const float gs = (F16 && gsc) ? gsc[0] : 1.f, gi = (F16 && gsc) ? gsc[1] : 1.f;
 
   const bool accum = (transposed & 2) != 0;     // y += conv(x) instead of y = conv(x) (second gradient path of a block)
   transposed &= 1;
@@ -161,18 +187,42 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int u = tid + i * TPB;
-      if (u < IH * IW * 4) *(float4*)(in_s + (u >> 2) * SPIX + 4 * (u & 3)) = rin[i];
+      if (u < IH * IW * 4) {
+        if (F16) *(h4*)(in_h + (u >> 2) * SPIXH + 4 * (u & 3)) = to_h4s(rin[i], gs);
+        else *(float4*)(in_s + (u >> 2) * SPIX + 4 * (u & 3)) = rin[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int u = tid + i * TPB;
-      if (u < KK * 4 * CO_T) *(float4*)(w_s + (size_t)u * 4) = rw[i];
+      if (u < KK * 4 * CO_T) {
+        // unit u = (tap, k4, n): four consecutive k of output channel n
+        if (F16) *(h4*)(w_h + ((size_t)(u / (4 * CO_T)) * CO_T + u % CO_T) * WROWH + 4 * ((u / CO_T) & 3)) = to_h4(rw[i]);
+        else *(float4*)(w_s + (size_t)u * 4) = rw[i];
+      }
     }
     __syncthreads();
     if (step < 2) { STAMP(3 + 4 * step); }
     if (step + 1 < nsteps) prefetch(step + 1);
     if (step < 2) { STAMP(4 + 4 * step); }
     // ---- MFMA over taps
+    if constexpr (F16) {
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) {
+        const int kh = tap / KS, kw = tap % KS;
+        h4 a[MR], b[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+          a[i] = *(const h4*)(in_h + ((wm * MR + i + kh) * IW + lm + kw) * SPIXH + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          b[j] = *(const h4*)(w_h + ((size_t)tap * CO_T + (wn * NR + j) * 16 + lm) * WROWH + 4 * kq);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma16h(a[i], b[j], acc[i][j]);
+      }
+    } else
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
       const int kh = tap / KS, kw = tap % KS;
@@ -193,6 +243,12 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     if (step < 2) { STAMP(5 + 4 * step); }
   }
   // ---- epilogue: acc[i][j][r] is pixel (row wm*MR+i, col 4*kq + r), channel (wn*NR+j)*16 + lm
+  if (F16) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) acc[i][j] *= gi;
+  }
   if (stats) {
     __syncthreads();                          // LDS is free again: reuse it for the cross-wave combine
     float* red = smem;                        // [WM][CO_T][2]
@@ -277,12 +333,14 @@ __device__ __forceinline__ float aff1(float v, float m, float r, float g, float 
 
 struct BstRef { const float* y1; const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
 
-template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false>
+template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
+          bool F16 = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
                 BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0,
-                const float* __restrict__ x2 = nullptr, AffRef aff = AffRef{}) {
+                const float* __restrict__ x2 = nullptr, AffRef aff = AffRef{}, const float* __restrict__ gsc = nullptr) {
+  // F16: fp16 operands (see the block comment above mfma16h); gsc (nullable) = {s, 1/s} for a gradient input.
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
   static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
   static_assert(!DUAL || NCH % 2 == 0, "virtual cat input: two equal halves of whole 16-channel chunks");
@@ -301,6 +359,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   float* in_s = smem;                         // [IH][IW][SPIX] + one dummy pixel (sink for the padding units)
   float* red = smem + (IH * IW + 1) * SPIX;   // [2][4][CO_T][2] + dummy
   float* w_s = red + 2 * 4 * CO_T * 2 + 8;    // [KK][K4][CO_T][4]
+  [[maybe_unused]] _Float16* in_h = reinterpret_cast<_Float16*>(smem);       // F16: [IH][IW][SPIXH] + dummy pixel
+  [[maybe_unused]] _Float16* w_h = reinterpret_cast<_Float16*>(w_s);         // F16: [KK][NCH][CO_T][WROWH]
+  [[maybe_unused]] const float gs = (F16 && gsc) ? gsc[0] : 1.f, gi = (F16 && gsc) ? gsc[1] : 1.f;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -337,7 +398,8 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     } else {
       v = *(const float4*)(w + ((size_t)(KK - 1 - tap) * Ndim + ng) * Kdim + 4 * k4);
     }
-    *(float4*)(w_s + (size_t)u * 4) = v;
+    if (F16) *(h4*)(w_h + ((size_t)(tap * NCH + (k4 >> 2)) * CO_T + n) * WROWH + 4 * (k4 & 3)) = to_h4(v);
+    else *(float4*)(w_s + (size_t)u * 4) = v;
   }
 
   // ---- per-thread staging descriptors (tile-independent): element offset relative to the tile's first halo pixel,
@@ -352,7 +414,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     const int q = uu & 3, pix = uu >> 2;
     const int iy = pix / IW, ix = pix % IW;
     u_off[i] = (iy * W + ix) * KST + 4 * q;
-    u_lds[i] = real ? pix * SPIX + 4 * q : IH * IW * SPIX;
+    u_lds[i] = real ? pix * (F16 ? SPIXH : SPIX) + 4 * q : IH * IW * (F16 ? SPIXH : SPIX);
     u_flag[i] = (iy < PAD ? 1 : 0) | (iy >= TH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
   }
   // a unit outside the image reads the tile's first interior pixel instead (always valid) and is zeroed at publish
@@ -397,7 +459,8 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
       }
       if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);          // the zero padding applies to a, not to x
-      *(float4*)(in_s + u_lds[i]) = v;
+      if (F16) *(h4*)(in_h + u_lds[i]) = to_h4s(v, gs);
+      else *(float4*)(in_s + u_lds[i]) = v;
     }
   };
 
@@ -419,6 +482,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 
   // statistics + stores of the item in pacc / (en, ety, etx); straight-line, no branches
   auto epilogue = [&](int par) {
+    if (F16) {                                          // undo the gradient-operand scale (1 for forward passes)
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) pacc[i][j] *= gi;
+    }
     if (STATS || BST) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -480,6 +549,24 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     }
   };
   auto mma_chunk = [&](int c) {
+    if constexpr (F16) {
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) {
+        const int kh = tap / KS, kw = tap % KS;
+        h4 a[MR], b[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+          a[i] = *(const h4*)(in_h + ((wave * MR + i + kh) * IW + lm + kw) * SPIXH + 4 * kq);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          b[j] = *(const h4*)(w_h + ((size_t)(tap * NCH + c) * CO_T + j * 16 + lm) * WROWH + 4 * kq);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma16h(a[i], b[j], acc[i][j]);
+      }
+      return;
+    }
     const float* wc = w_s + (size_t)(c * 4) * CO_T * 4;
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
@@ -804,7 +891,10 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     gy_off[i] = ((pix / TW) * W + (pix % TW)) * Cout + 4 * q;
     gy_lds[i] = pix * SO + 4 * q;
   }
-  const int safe_off = (PAD * W + PAD) * xsrc.stride;     // first interior pixel of the tile: always inside the image
+  // first interior pixel of the tile (always inside the image), THIS thread's channel quad: with a virtual-cat source the
+  // base pointer carries -coff, which only the quad offset brings back inside the tensor (without it the second part was
+  // read 64 B before its first element for the tile at the image origin -- out of bounds when the tensor starts a segment)
+  const int safe_off = (PAD * W + PAD) * xsrc.stride + 4 * (tid % (CI_T / 4));
   int pn = t_begin / tiles_img, pty, ptx;                  // cursor of the tile being prefetched
   { const int t = t_begin - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
   bool zero[NIN];
@@ -887,6 +977,217 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   STAMP(11);
 }
 
+// ---- fp16-operand weight gradient (config 5) ------------------------------------------------------------------------------
+// gW[tap][ci][co] = sum_p x[p + off(tap)][ci] * gy[p][co] with the PIXELS as the MFMA K dimension: v_mfma_f32_16x16x16_f16
+// wants, per lane, four consecutive k (= pixels) of one channel -- the transpose of the pixel-major tiles the staging
+// produces.  gfx950's ds_read_b64_tr_b16 does that transpose in the LDS read: per 16-lane group it fetches a block of
+// 4 rows (pixels) x 16 columns (channels) and hands lane i column i.  So both operands are staged as fp16 planes
+// [16-channel tile][pixel][16] (32-B pixel stride: the 8 pixels a 32-lane half touches fall on 8 x 8 distinct banks) and
+// read transposed; one MFMA covers a whole 16-pixel tile row of one tap.  x is staged with its halo, so a tap is a pixel
+// offset in the read address.  gy is multiplied by gsc[0] (power of two, smsut_absmax_scale) before the conversion and the
+// slab by gsc[1] at the store.
+//   TS  (2 x 2 tiles of 16 channels): the 36 accumulator tiles are dealt to the 4 waves, each wave walks all 8 tile rows;
+//   !TS (1 x 1, 1 x 2, 2 x 1): every wave keeps all 9*CIT*COT tiles for 2 of the 8 rows, fixed-order combine at the end.
+// Full tiles only (H % 8 == 0, W % 16 == 0), Cin % (16*CIT) == 0, Cout % (16*COT) == 0 -- checked by the host.
+template <int CIT, int COT, bool DUAL>
+__global__ void __launch_bounds__(TPB)
+conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H, int W,
+               int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, const float* __restrict__ x2, int ca,
+               const float* __restrict__ gsc) {
+  constexpr int KS = 3, KK = 9, PAD = 1;
+  constexpr bool TS = (CIT == 2 && COT == 2);
+  constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
+  constexpr int NPX = IH * IW, NPG = WTH * TW;              // pixels of the haloed x tile / of the gy tile
+  constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
+  constexpr int NACC = TS ? 9 : KK * CIT * COT;
+  extern __shared__ float smem[];
+  _Float16* x_h = reinterpret_cast<_Float16*>(smem);       // [CIT][NPX][16]
+  _Float16* g_h = x_h + CIT * NPX * 16;                    // [COT][NPG][16]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x;
+  const int ci0 = blockIdx.y * CI_T, co0 = blockIdx.z * CO_T;
+  const int tiles_img = tiles_x * tiles_y;
+  const int total_tiles = N * tiles_img;
+  const int t_begin = split * tiles_per_split;
+  const int t_end = min(t_begin + tiles_per_split, total_tiles);
+  const float gs = gsc ? gsc[0] : 1.f, gi = gsc ? gsc[1] : 1.f;
+
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read lane address inside a 16-channel plane: group kq takes pixels 4kq .. 4kq+3 of the row segment, lane
+  // 4q+p of the group supplies pixel 4kq+q, channels 4p .. 4p+3 (8 bytes)
+  const int tr_off = (4 * kq + ((lane >> 2) & 3)) * 16 + 4 * (lane & 3);
+
+  constexpr int UIN = NPX * (CI_T / 4), NIN = (UIN + TPB - 1) / TPB;
+  constexpr int UGY = NPG * (CO_T / 4), NGY = UGY / TPB;
+  static_assert(UGY % TPB == 0, "gy tile units divide evenly");
+  f32x4 rin[NIN], rgy[NGY];
+  int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
+  const CatSrc xsrc = DUAL ? cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4))) : CatSrc{x, Cin, 0};
+#pragma unroll
+  for (int i = 0; i < NIN; ++i) {
+    const int u = tid + i * TPB;
+    const bool real = u < UIN;
+    const int uu = real ? u : tid % (CI_T / 4);
+    const int q = uu % (CI_T / 4), pix = uu / (CI_T / 4);
+    const int iy = pix / IW, ix = pix % IW;
+    in_off[i] = (iy * W + ix) * xsrc.stride + 4 * q;
+    in_lds[i] = real ? ((q >> 2) * NPX + pix) * 16 + 4 * (q & 3) : (CIT * NPX + COT * NPG) * 16;      // dummy slot behind both images
+    in_flag[i] = (iy < PAD ? 1 : 0) | (iy >= WTH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
+  }
+#pragma unroll
+  for (int i = 0; i < NGY; ++i) {
+    const int u = tid + i * TPB;
+    const int q = u % (CO_T / 4), pix = u / (CO_T / 4);
+    gy_off[i] = ((pix / TW) * W + (pix % TW)) * Cout + 4 * q;
+    gy_lds[i] = ((q >> 2) * NPG + pix) * 16 + 4 * (q & 3);
+  }
+  const int safe_off = (PAD * W + PAD) * xsrc.stride + 4 * (tid % (CI_T / 4));     // (see conv_mfma_wgrad_ts)
+  int pn = t_begin / tiles_img, pty, ptx;
+  { const int t = t_begin - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
+  bool zero[NIN];
+  auto prefetch = [&]() {
+    const int flags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
+    const float* xb = xsrc.p + (((pn * H + pty * WTH - PAD) * W) + ptx * TW - PAD) * xsrc.stride + ci0 - xsrc.coff;
+    const float* gb = gy + (((pn * H + pty * WTH) * W) + ptx * TW) * Cout + co0;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      zero[i] = (in_flag[i] & flags) != 0;
+      rin[i] = *(const f32x4*)(xb + (zero[i] ? safe_off : in_off[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < NGY; ++i) rgy[i] = *(const f32x4*)(gb + gy_off[i]);
+    if (++ptx == tiles_x) { ptx = 0; if (++pty == tiles_y) { pty = 0; ++pn; } }
+  };
+  auto tr_read = [&](const _Float16* plane_pix) -> h4 {       // plane_pix: first pixel of the 16-pixel row segment
+    typedef s16x4 __attribute__((address_space(3))) lds_s16x4;
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane_pix + tr_off));
+    return __builtin_bit_cast(h4, v);
+  };
+
+  if (t_begin < t_end) prefetch();
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const f32x4 v = zero[i] ? (f32x4){0.f, 0.f, 0.f, 0.f} : rin[i];
+      *(h4*)(x_h + in_lds[i]) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+#pragma unroll
+    for (int i = 0; i < NGY; ++i) {
+      const f32x4 v = rgy[i] * gs;
+      *(h4*)(g_h + gy_lds[i]) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    }
+    __syncthreads();
+    if (t + 1 < t_end) prefetch();
+    if constexpr (TS) {
+      const int jt = wave & 1;
+#pragma unroll
+      for (int r = 0; r < WTH; ++r) {
+        const h4 b = tr_read(g_h + (jt * NPG + r * TW) * 16);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const int ti = (wave + 4 * k) >> 1;                  // tap * CIT + i   (wave-uniform)
+          const int tap = ti >> 1, i = ti & 1;
+          const h4 a = tr_read(x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16);
+          acc[k] = mfma16h(a, b, acc[k]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < WTH / 4; ++rr) {
+        const int r = wave * (WTH / 4) + rr;
+        h4 b[COT];
+#pragma unroll
+        for (int j = 0; j < COT; ++j) b[j] = tr_read(g_h + (j * NPG + r * TW) * 16);
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+          for (int i = 0; i < CIT; ++i) {
+            const h4 a = tr_read(x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16);
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[(tap * CIT + i) * COT + j] = mfma16h(a, b[j], acc[(tap * CIT + i) * COT + j]);
+          }
+      }
+    }
+  }
+  // ---- store: acc[.][r] is (ci = tile*16 + 4*kq + r, co = tile*16 + lm)
+  if constexpr (TS) {
+    const int jt = wave & 1;
+    float* out = part + (size_t)split * KK * Cin * Cout + (size_t)(ci0 + 4 * kq) * Cout + co0 + jt * 16 + lm;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int ti = (wave + 4 * k) >> 1;
+      float* o = out + ((ti >> 1) * Cin + (ti & 1) * 16) * Cout;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r * Cout] = acc[k][r] * gi;
+    }
+  } else {
+    float* red = smem;      // NACC * 64 * 4 floats; combine the 4 waves in a fixed order (wave 0 += 1, 2, 3)
+    for (int src = 1; src < 4; ++src) {
+      __syncthreads();
+      if (wave == src) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) *(f32x4*)(red + ((size_t)k * 64 + lane) * 4) = acc[k];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < NACC; ++k) acc[k] += *(const f32x4*)(red + ((size_t)k * 64 + lane) * 4);
+      }
+    }
+    if (wave == 0) {
+      float* out = part + (size_t)split * KK * Cin * Cout;
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+        for (int i = 0; i < CIT; ++i)
+#pragma unroll
+          for (int j = 0; j < COT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              out[((size_t)tap * Cin + ci0 + i * 16 + 4 * kq + r) * Cout + co0 + j * 16 + lm] = acc[(tap * CIT + i) * COT + j][r] * gi;
+    }
+  }
+}
+
+// per-tensor power-of-two scale for an fp16 gradient operand: out2 = {s, 1/s}, s = 2^(14 - ceil(log2(max|x|))) so that the
+// largest element lands in [2^13, 2^14] (fp16 max is 65504; what underflows is < 2^-38 of the largest element).
+__global__ void __launch_bounds__(TPB) k_absmax_partial(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+  __shared__ float sm4[4];
+  float m = 0.f;
+  const int64_t n4 = n >> 2;
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+    const float4 v = x4[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+  m = block_max_256(m, sm4);
+  if (threadIdx.x == 0) part[blockIdx.x] = m;
+}
+__global__ void __launch_bounds__(TPB) k_absmax_final(const float* __restrict__ part, int nparts, float* __restrict__ out2) {
+  __shared__ float sm4[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += TPB) m = fmaxf(m, part[i]);
+  m = block_max_256(m, sm4);
+  if (threadIdx.x == 0) {
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);                          // m = f * 2^e, f in [0.5, 1)  ->  m <= 2^e
+      int k = 14 - e;
+      k = k > 120 ? 120 : (k < -120 ? -120 : k);
+      s = ldexpf(1.f, k);
+    }
+    out2[0] = s; out2[1] = 1.f / s;
+  }
+}
+
 // out[e] = sum_c part[c][e].  COLS float4 columns x (256/COLS) split-lanes per block: each thread strides over the
 // splits with 4 independent accumulators (loads in flight), then a fixed-order LDS tree over the lanes (deterministic).
 // wsize % 4 == 0 (checked at launch): every access is one aligned float4.  (A scalar tail path that indexed the float4
@@ -948,7 +1249,7 @@ inline void launch_sum_splits(const float* part, float* out, int wsize, int spli
 template <int KS, int TH, int WM, int WN, int NTN>
 int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr,
-               const float* x2 = nullptr, float* y2 = nullptr, int split = 0) {
+               const float* x2 = nullptr, float* y2 = nullptr, int split = 0, bool f16 = false, const float* gsc = nullptr) {
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
   constexpr size_t sh = (size_t)(IH * IW * SPIX + KS * KS * CK * 16 * NTN) * sizeof(float);
   static_assert(sh <= 64 * 1024, "LDS budget");
@@ -959,8 +1260,12 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
   if ((x2 && (isc != 1 || osc != 1 || G != 1 || ntap_out != 1 || (transposed & 1) || Kdim % 32 != 0)) ||
       (y2 && (osc != 1 || ntap_out != 1 || stats || split <= 0 || split >= Ndim || split % 16 != 0)))
     return -1;
-  conv_mfma_fwd<KS, TH, WM, WN, NTN><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc, G,
-                                                            nz, stats, x2, y2, split);
+  if (f16)
+    conv_mfma_fwd<KS, TH, WM, WN, NTN, true><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc,
+                                                                    G, nz, stats, x2, y2, split, gsc);
+  else
+    conv_mfma_fwd<KS, TH, WM, WN, NTN><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc, G,
+                                                              nz, stats, x2, y2, split);
   return 0;
 }
 
@@ -985,7 +1290,8 @@ constexpr size_t fwd_p_lds() {
 template <int KS, int TH, int NTN, int NCH>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
-                 float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr) {
+                 float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
+                 bool f16 = false, const float* gsc = nullptr) {
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
   if constexpr (sh > 64 * 1024) return -1;
   else {
@@ -1013,25 +1319,31 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (ipw < 1) ipw = 1;
   dim3 grid((unsigned)((items + ipw - 1) / ipw), nz);
   const int tr = transposed & 1;
-#define P_LAUNCH(ST, AC) conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, \
-                                                                                        tiles_img, ipw, tr, stats, BstRef{}, y2, split)
+  const BstRef bstv = bst ? *bst : BstRef{};
+  const AffRef affv = aff ? *aff : AffRef{};
+  // one launch site for every form; the fp16-operand twin of each form is chosen at run time (f16)
+#define P_GO(ST, AC, BS, DU, IA)                                                                                             \
+  do {                                                                                                                       \
+    if (f16)                                                                                                                 \
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, true><<<grid, TPB, sh, st>>>(                                     \
+          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, gsc);                       \
+    else                                                                                                                     \
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false><<<grid, TPB, sh, st>>>(                                    \
+          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
+  } while (0)
   if (aff) {
-    conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, true><<<grid, TPB, sh, st>>>(
-        x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, BstRef{}, nullptr, 0, nullptr, *aff);
+    P_GO(true, false, false, false, true);
   } else if (x2) {
-    if constexpr (NCH % 2 == 0)
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img,
-                                                                                         ipw, tr, stats, BstRef{}, nullptr, 0, x2);
+    if constexpr (NCH % 2 == 0) P_GO(true, false, false, true, false);
   } else if (bst) {
     if (!stats || (transposed & 2)) return -1;
-    conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, true><<<grid, TPB, sh, st>>>(x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw,
-                                                                                 tr, stats, *bst);
+    P_GO(false, false, true, false, false);
   } else if (transposed & 2) {
     if (stats) return -1;
-    P_LAUNCH(false, true);
-  } else if (stats) P_LAUNCH(true, false);
-  else P_LAUNCH(false, false);
-#undef P_LAUNCH
+    P_GO(false, true, false, false, false);
+  } else if (stats) P_GO(true, false, false, false, false);
+  else P_GO(false, false, false, false, false);
+#undef P_GO
   return 0;
   }
 }
@@ -1051,22 +1363,24 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
 // so that smsut_conv2d_mfma_tiles() always describes the partials the launched variant writes.
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
-                        const float* x2 = nullptr, const AffRef* aff = nullptr) {
+                        const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr) {
+#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc
 #ifndef SMSUT_P_OLD_TABLE
-  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
-  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
+  if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
+  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(PARGS);
 #endif
-  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
-  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
-  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff);
+  if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(PARGS);
+  if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(PARGS);
+  if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(PARGS);
+#undef PARGS
   return -1;
 }
 
 template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr,
-                 const float* x2 = nullptr, float* y2 = nullptr, int split = 0) {
-#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out, x2, y2, split
+                 const float* x2 = nullptr, float* y2 = nullptr, int split = 0, bool f16 = false, const float* gsc = nullptr) {
+#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out, x2, y2, split, f16, gsc
   // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
   // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
   static const bool log_shapes = getenv("SMSUT_LOG_CONV") != nullptr;      // shape census for tuning (stderr)
@@ -1077,7 +1391,9 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
     // small-Cin / large-image layers: persistent kernel with resident weights (see conv_mfma_fwd_p); it declines
     // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
     if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_p_eligible(N, H, W, Kdim, Ndim)) {
-      if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr, y2, split, x2) == 0) return 0;
+      if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr, y2, split, x2, nullptr, f16,
+                       gsc) == 0)
+        return 0;
     }
   }
   const int nt = (Ndim + 15) / 16;
@@ -1523,6 +1839,119 @@ int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const 
                                 int N, int H, int W, int Cin, int Cout, int KS, void* stream) {
   SMSUT_REQUIRE(xb);
   return wgrad_mfma_launch(xa, gy, gw, workspace, N, H, W, Cin, Cout, KS, stream, xb, ca);
+}
+
+// ---- fp16-operand entry points (BASELINE config 5; see the block comment above mfma16h) -----------------------------------
+// Same tensors (fp32 in HBM), same tile selection and statistics layout as the fp32 entry points of the same name; operands
+// are converted to fp16 while they are staged.  gsc (nullable): device float[2] = {s, 1/s} from smsut_absmax_scale for a
+// GRADIENT input operand (x of a data-gradient form, gy of the weight gradient).
+int smsut_conv2d_f16_supported(int KS, int Kdim, int Ndim) {
+  return (KS == 1 || KS == 3) && Kdim >= 16 && Kdim % 16 == 0 && Ndim >= 1;
+}
+int smsut_conv2d_fwd_mfma_f16(const float* x, const float* w, float* y, const float* gsc, int N, int H, int W, int Kdim,
+                              int Ndim, int KS, int transposed, void* stream) {
+  SMSUT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && smsut_conv2d_f16_supported(KS, Kdim, Ndim));
+  hipStream_t st = (hipStream_t)stream;
+  if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st, nullptr, nullptr, nullptr, nullptr, 0, true, gsc);
+  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st, nullptr, nullptr, nullptr, nullptr, 0, true, gsc);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats_f16(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
+                                    int Ndim, int KS, void* stream) {
+  SMSUT_REQUIRE(x && w && y && stats && N > 0 && H > 0 && W > 0 && smsut_conv2d_f16_supported(KS, Kdim, Ndim));
+  hipStream_t st = (hipStream_t)stream;
+  if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats, nullptr, nullptr, nullptr, 0, true, nullptr);
+  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats, nullptr, nullptr, nullptr, 0, true, nullptr);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats_cat_f16(const float* xa, const float* xb, const float* w, float* y, float* stats, int N,
+                                        int H, int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(xa && xb && w && y && stats && smsut_conv2d_mfma_cat_supported(N, H, W, Kdim, Ndim));
+  const int rc = dispatch_fwd<3>(xa, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, (hipStream_t)stream, stats, nullptr, xb, nullptr,
+                                 0, true, nullptr);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_split_f16(const float* x, const float* w, float* ya, float* yb, const float* gsc, int split, int N,
+                                    int H, int W, int Kdim, int Ndim, int transposed, void* stream) {
+  SMSUT_REQUIRE(x && w && ya && yb && N > 0 && H > 0 && W > 0 && (transposed & ~3) == 0 && Kdim % 16 == 0);
+  SMSUT_REQUIRE(smsut_conv2d_mfma_split_supported(N, H, W, Kdim, Ndim, split));
+  const int rc = dispatch_fwd<3>(x, w, ya, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, (hipStream_t)stream, nullptr, nullptr,
+                                 nullptr, yb, split, true, gsc);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+int smsut_conv2d_dgrad_mfma_bwdstats_f16(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                         const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                         const float* gsc, float slope, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(gy && w && gz && stats && y1 && mean && rstd && gamma && beta && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(fwd_p_eligible(N, H, W, Kdim, Ndim));
+  const BstRef b{y1, mean, rstd, gamma, beta, slope};
+  const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, (hipStream_t)stream, stats, nullptr, &b, nullptr, 0, nullptr,
+                              nullptr, true, gsc);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// 3x3 weight gradient with fp16 operands (conv_f16_wgrad): full 8x16-pixel tiles and whole 16-channel tiles only
+int smsut_conv2d_wgrad_f16_supported(int N, int H, int W, int Cin, int Cout) {
+  return N > 0 && H > 0 && W > 0 && H % WTH == 0 && W % TW == 0 && Cin % 16 == 0 && Cout % 16 == 0 &&
+         (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31);
+}
+static WgradPlan plan_wgrad_f16(int N, int H, int W, int Cin, int Cout) {
+  WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
+  p.cit = (Cin % 32 == 0) ? 2 : 1;
+  p.cot = (Cout % 32 == 0) ? 2 : 1;
+  return p;
+}
+int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout) {
+  return (int64_t)plan_wgrad_f16(N, H, W, Cin, Cout).splits * 9 * Cin * Cout;
+}
+// x2 (nullable): x is the virtual cat([x, x2]) with ca channels in x (ca % 16 == 0)
+int smsut_conv2d_wgrad_f16(const float* x, const float* x2, int ca, const float* gy, float* gw, float* workspace,
+                           const float* gsc, int N, int H, int W, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(x && gy && gw && workspace && smsut_conv2d_wgrad_f16_supported(N, H, W, Cin, Cout));
+  SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0));
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
+  constexpr int NPX = (WTH + 2) * (TW + 2), NPG = WTH * TW;
+#define F16_WGRAD(CI, CO)                                                                                                   \
+  do {                                                                                                                      \
+    constexpr size_t stage = (size_t)((CI * NPX + CO * NPG) * 16 + 8) * sizeof(_Float16);                                   \
+    constexpr size_t red = (CI == 2 && CO == 2) ? 0 : (size_t)9 * CI * CO * 64 * 4 * sizeof(float);                         \
+    constexpr size_t sh = stage > red ? stage : red;                                                                        \
+    dim3 grid(p.splits, Cin / (16 * CI), Cout / (16 * CO));                                                                 \
+    if (x2) conv_f16_wgrad<CI, CO, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,  \
+                                                               p.tiles_per_split, x2, ca, gsc);                            \
+    else conv_f16_wgrad<CI, CO, false><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,    \
+                                                             p.tiles_per_split, nullptr, 0, gsc);                         \
+  } while (0)
+  if (p.cit == 2 && p.cot == 2) F16_WGRAD(2, 2);
+  else if (p.cit == 2) F16_WGRAD(2, 1);
+  else if (p.cot == 2) F16_WGRAD(1, 2);
+  else F16_WGRAD(1, 1);
+#undef F16_WGRAD
+  launch_sum_splits(workspace, gw, 9 * Cin * Cout, p.splits, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int64_t smsut_absmax_scale_ws(int64_t n) { (void)n; return 1024; }
+// out2 (device float[2]) = {s, 1/s}: the power-of-two scale that brings max|x| into [2^13, 2^14] (1 for an all-zero tensor)
+int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace, void* stream) {
+  SMSUT_REQUIRE(x && out2 && workspace && n > 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)cdiv64(n >> 2, TPB * 4);
+  blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+  k_absmax_partial<<<blocks, TPB, 0, st>>>(x, n, workspace);
+  k_absmax_final<<<1, TPB, 0, st>>>(workspace, blocks, out2);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
 }
 
 int64_t smsut_convT2x2_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout) {

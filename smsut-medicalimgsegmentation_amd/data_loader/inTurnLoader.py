@@ -21,38 +21,49 @@ from .gpu_augment import GpuJointAugment
 
 
 class InTurnTrainBatchSampler:
-    """inTurnLoader.py:15-59."""
+    """inTurnLoader.py:15-59.
 
-    def __init__(self, samples: List[List[int]], batch_size: int, shuffle: bool):
-        self.samples = samples
+    Data parallelism (one process per GPU; the reference has none): every rank builds the SAME sampler over a global batch
+    of ``world * batch_size`` slices of one modality -- drawn from a private generator seeded identically on all ranks --
+    and keeps its own ``batch_size``-slice share, so the ranks train on disjoint slices while the modality turn-taking
+    stays aligned (r01 had every rank draw identical batches).  With ``world == 1`` the draws come from Python's global
+    ``random`` in the reference's order."""
+
+    def __init__(self, samples: List[List[int]], batch_size: int, shuffle: bool, rank: int = 0, world: int = 1, seed=None):
+        self.samples = [list(s) for s in samples]
         self.num_modality = len(samples)
         self.batch_size = batch_size
+        self.rank, self.world = rank, world
+        self.global_batch = batch_size * world
+        self.rng = random if world == 1 else random.Random(cfg.seed if seed is None else seed)
         self.starts = [0 for _ in range(self.num_modality)]
         self.shuffle = shuffle
         self.queue = list(range(self.num_modality))
         self.cur_modality = 0
         max_batch_per_modality = 0
+        gb = self.global_batch
         for i, spl in enumerate(self.samples):
-            n = len(spl) // batch_size - 1 if len(spl) % batch_size else len(spl) // batch_size      # :31
+            n = len(spl) // gb - 1 if len(spl) % gb else len(spl) // gb                          # :31
             max_batch_per_modality = max(n, max_batch_per_modality)
-            random.shuffle(self.samples[i])
+            self.rng.shuffle(self.samples[i])
         self.n = self.num_modality * max_batch_per_modality
 
     def __iter__(self):
+        gb = self.global_batch
         for _ in range(self.n):
             cur = self.queue[self.cur_modality] if self.shuffle else self.cur_modality
             s = self.starts[cur]
-            if s + self.batch_size >= len(self.samples[cur]):            # wrap: restart this modality, reshuffled (:44-47)
+            if s + gb >= len(self.samples[cur]):                         # wrap: restart this modality, reshuffled (:44-47)
                 self.starts[cur] = 0
                 s = 0
-                random.shuffle(self.samples[cur])
+                self.rng.shuffle(self.samples[cur])
             else:
-                self.starts[cur] += self.batch_size
-            batch = self.samples[cur][s: s + self.batch_size]
-            if len(batch) == self.batch_size:
-                yield batch
+                self.starts[cur] += gb
+            batch = self.samples[cur][s: s + gb]
+            if len(batch) == gb:
+                yield batch[self.rank * self.batch_size: (self.rank + 1) * self.batch_size]
             if self.shuffle and self.cur_modality + 1 == self.num_modality:
-                random.shuffle(self.queue)
+                self.rng.shuffle(self.queue)
             self.cur_modality = (self.cur_modality + 1) % self.num_modality
 
     def __len__(self):
@@ -136,11 +147,11 @@ class InTurnLoader:
 
 
 def get_loader(data_root, phase, fold, batch_size, data_aug=None, load_in_ram: bool = True, device="cuda",
-               split_yaml="semi-1910.yaml"):
+               split_yaml="semi-1910.yaml", rank: int = 0, world: int = 1):
     """inTurnLoader.py:82-97 (``load_in_ram`` is always on here; ``data_aug`` is the dict of config.py:60-71)."""
     ds = BalanceDataset(data_root, phase, fold, split_yaml)
     if phase in ("train", "val"):
-        sampler = InTurnTrainBatchSampler(ds.modal_sample_ids, batch_size, shuffle=False)
+        sampler = InTurnTrainBatchSampler(ds.modal_sample_ids, batch_size, shuffle=False, rank=rank, world=world)
         aug = GpuJointAugment(data_aug, cfg.input_size) if data_aug else None
     else:
         sampler = InTurnTestBatchSampler(ds.modal_sample_ids, batch_size)

@@ -130,6 +130,35 @@ def new_linear_weight(out_f, in_f, device=None) -> torch.Tensor:
     return torch.empty_strided((out_f, in_f), (1, out_f), dtype=torch.float32, device=device)
 
 
+# ------------------------------------------------------------------------------------------- fp16-operand convolutions
+# BASELINE config 5 (512 x 512 slices): the 3x3 MFMA convolutions convert their operands to fp16 while staging them into
+# LDS (v_mfma_f32_16x16x16_f16, fp32 accumulate); tensors, InstanceNorm statistics, losses and optimizers stay fp32.
+# ``SMSUT_CONV_DTYPE=f16`` or ``set_conv_dtype("f16")``.  Applies to the fused BasicBlock (generator, U-Net) and to generic
+# convs inside ``first_order_pass()`` (the discriminator passes that are differentiated once); the WGAN-GP x_hat pass, which
+# is differentiated twice, keeps fp32 operands.  Layers whose channel counts are not multiples of 16 (stems, heads, the 8-channel
+# first block) and every 1x1 conv (HBM-bound streaming kernels) stay fp32 as well.
+CONV_F16 = _os.environ.get("SMSUT_CONV_DTYPE", "f32").lower() in ("f16", "fp16", "half")
+
+
+def set_conv_dtype(name: str):
+    global CONV_F16
+    if name not in ("f32", "f16"):
+        raise ValueError("conv operand dtype is 'f32' or 'f16'")
+    CONV_F16 = name == "f16"
+
+
+def conv_dtype() -> str:
+    return "f16" if CONV_F16 else "f32"
+
+
+def _grad_scale(t: torch.Tensor) -> torch.Tensor:
+    """Device float[2] = {s, 1/s}: power-of-two scale that brings max|t| into [2^13, 2^14] -- gradient tensors sit far below
+    fp16's normal range (|gy| ~ 1e-7 at 512^2); the f16 kernels multiply by s before converting and by 1/s after."""
+    out = torch.empty(2, dtype=torch.float32, device=t.device)
+    H.call("smsut_absmax_scale", t, t.numel(), out, _ws(H.call("smsut_absmax_scale_ws", t.numel()), t), _s())
+    return out
+
+
 def _ws(numel: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(max(int(numel), 1), dtype=torch.float32, device=like.device)
 
@@ -143,7 +172,7 @@ def _out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False):
+def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False, f16=False):
     n, ci, h, wd = x.shape
     co, ci2, kh, kw = w.shape
     assert ci == ci2, f"conv: Cin mismatch {ci} vs {ci2}"
@@ -159,15 +188,20 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False):
             y._smsut_in_partials = (part, tiles)
         return y
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, ci, co):
+        f16 = f16 and bool(H.call("smsut_conv2d_f16_supported", kh, ci, co))
         if want_stats and bias is None:
             # fused InstanceNorm statistics: the conv epilogue leaves {sum, sum^2} partials that the following
             # instnorm_act picks up from the tensor object (side channel; autograd is unaffected)
             tiles = H.call("smsut_conv2d_mfma_tiles", n, h, wd, ci, co, kh)
             part = _ws(n * tiles * co * 2, x)
-            H.call("smsut_conv2d_fwd_mfma_stats", x, w, y, part, n, h, wd, ci, co, kh, _s())
+            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", x, w, y, part, n, h, wd, ci, co,
+                   kh, _s())
             y._smsut_in_partials = (part, tiles)
             return y
-        H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, wd, ci, co, kh, 0, _s())
+        if f16:
+            H.call("smsut_conv2d_fwd_mfma_f16", x, w, y, None, n, h, wd, ci, co, kh, 0, _s())
+        else:
+            H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, wd, ci, co, kh, 0, _s())
         if bias is not None:
             H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
     elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_small_supported", kh, ci, co):
@@ -177,7 +211,7 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False):
     return y
 
 
-def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
+def _conv_dgrad_launch(gy, w, h, wd, stride, pad, f16=False):
     n, co, ho, wo = gy.shape
     co2, ci, kh, kw = w.shape
     assert co == co2
@@ -190,7 +224,10 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
         H.call("smsut_conv1x1_fwd", gy, w, gx, None, n, h * wd, co, ci, 1, _s())
         return gx
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_mfma_supported", kh, stride, pad, co, ci):
-        H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
+        if f16 and H.call("smsut_conv2d_f16_supported", kh, co, ci):
+            H.call("smsut_conv2d_fwd_mfma_f16", gy, w, gx, _grad_scale(gy), n, h, wd, co, ci, kh, 1, _s())
+        else:
+            H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
     elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_small_supported", kh, ci, co):
         H.call("smsut_conv2d_small_dgrad", gy, w, gx, n, h, wd, ci, ho, wo, co, kh, stride, pad, _s())
     else:
@@ -198,7 +235,7 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad):
     return gx
 
 
-def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
+def _conv_wgrad_launch(x, gy, kh, kw, stride, pad, f16=False):
     n, ci, h, wd = x.shape
     _, co, ho, wo = gy.shape
     gw = new_weight(co, ci, kh, kw, device=x.device)
@@ -208,6 +245,11 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad):
         return gw
     if kh == 1 and kw == 1 and stride == 1 and pad == 0 and not FORCE_GENERIC_CONV and ci % 4 == 0 and co % 4 == 0:
         H.call("smsut_conv1x1_wgrad", x, gy, gw, _ws(H.call("smsut_conv1x1_wgrad_ws", n, h * wd, ci, co), x), n, h * wd, ci, co, _s())
+        return gw
+    if (f16 and kh == 3 and kw == 3 and stride == 1 and pad == 1 and not FORCE_GENERIC_CONV
+            and H.call("smsut_conv2d_wgrad_f16_supported", n, h, wd, ci, co)):
+        ws = _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, wd, ci, co), x)
+        H.call("smsut_conv2d_wgrad_f16", x, None, 0, gy, gw, ws, _grad_scale(gy), n, h, wd, ci, co, _s())
         return gw
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_wgrad_mfma_supported", kh, stride, pad, ci, co):
         ws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, wd, ci, co, kh), x)
@@ -239,7 +281,8 @@ class Conv2dFn(Function):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         ctx.geom = (stride, pad)
-        return _conv_fwd_launch(x, w, bias, stride, pad, want_stats)
+        ctx.f16 = CONV_F16 and _FIRST_ORDER          # passes differentiated once only; the WGAN-GP x_hat pass stays fp32
+        return _conv_fwd_launch(x, w, bias, stride, pad, want_stats, ctx.f16)
 
     @staticmethod
     def backward(ctx, gy):
@@ -247,10 +290,10 @@ class Conv2dFn(Function):
         stride, pad = ctx.geom
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = Conv2dDgradFn.apply(gy, w, x.shape[2], x.shape[3], stride, pad)
+            gx = Conv2dDgradFn.apply(gy, w, x.shape[2], x.shape[3], stride, pad, ctx.f16)
         if not _INPUT_GRADS_ONLY:
             if ctx.needs_input_grad[1]:
-                gw = Conv2dWgradFn.apply(x, gy, w.shape[2], w.shape[3], stride, pad)
+                gw = Conv2dWgradFn.apply(x, gy, w.shape[2], w.shape[3], stride, pad, ctx.f16)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = SumPerChannelFn.apply(gy)
         return gx, gw, gb, None, None, None
@@ -260,11 +303,11 @@ class Conv2dDgradFn(Function):
     """gx = conv2d_backward_data(gy, w); bilinear in (gy, w) so its backward is a conv and a wgrad."""
 
     @staticmethod
-    def forward(ctx, gy, w, h, wd, stride, pad):
+    def forward(ctx, gy, w, h, wd, stride, pad, f16=False):
         gy, w = nhwc(gy), hwio(w)
         ctx.save_for_backward(gy, w)
         ctx.geom = (h, wd, stride, pad)
-        return _conv_dgrad_launch(gy, w, h, wd, stride, pad)
+        return _conv_dgrad_launch(gy, w, h, wd, stride, pad, f16)
 
     @staticmethod
     def backward(ctx, ggx):
@@ -275,18 +318,18 @@ class Conv2dDgradFn(Function):
             d_gy = Conv2dFn.apply(ggx, w, None, stride, pad, False)
         if ctx.needs_input_grad[1]:
             d_w = Conv2dWgradFn.apply(ggx, gy, w.shape[2], w.shape[3], stride, pad)
-        return d_gy, d_w, None, None, None, None
+        return d_gy, d_w, None, None, None, None, None
 
 
 class Conv2dWgradFn(Function):
     """gw = conv2d_backward_weight(x, gy); bilinear in (x, gy)."""
 
     @staticmethod
-    def forward(ctx, x, gy, kh, kw, stride, pad):
+    def forward(ctx, x, gy, kh, kw, stride, pad, f16=False):
         x, gy = nhwc(x), nhwc(gy)
         ctx.save_for_backward(x, gy)
         ctx.geom = (kh, kw, stride, pad)
-        return _conv_wgrad_launch(x, gy, kh, kw, stride, pad)
+        return _conv_wgrad_launch(x, gy, kh, kw, stride, pad, f16)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -297,7 +340,7 @@ class Conv2dWgradFn(Function):
             d_x = Conv2dDgradFn.apply(gy, ggw, x.shape[2], x.shape[3], stride, pad)
         if ctx.needs_input_grad[1]:
             d_gy = Conv2dFn.apply(x, ggw, None, stride, pad, False)
-        return d_x, d_gy, None, None, None, None
+        return d_x, d_gy, None, None, None, None, None
 
 
 class SumPerChannelFn(Function):
@@ -601,18 +644,24 @@ class BasicBlockFn(Function):
 
         t3 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 3)        # tile shape depends on (N, H, W, Cin, Cout)
         t3b = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
+        # fp16 operands (config 5): both 3x3 convs of the block and their gradients, when every reduction is whole 16-channel
+        # chunks; same tile selection / statistics layout as the fp32 forms
+        f16 = CONV_F16 and ci % 16 == 0 and co % 16 == 0
+        ctx.f16 = f16
         y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
         if virtual:
-            H.call("smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w1, y1, p1, n, h, w, ci, co, st)
+            H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16 else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w1, y1, p1, n, h, w,
+                   ci, co, st)
         else:
-            H.call("smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
+            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
         m1, r1 = stat(co)
         y2 = new_act(n, co, h, w, x)
         p2 = _ws(n * t3b * co * 2, x)
         # (co % 32: the tap-split weight-gradient kernel takes the transform for +4 us; on the 16-channel kernel it cost
         #  +55 us at 32x256^2, more than the apply pass it removes -- scratch/inaff_ab.py)
-        inaff = INAFF_CONV2 and co % 32 == 0 and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3))
+        inaff = (INAFF_CONV2 and not f16 and co % 32 == 0
+                 and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3)))
         ctx.inaff = inaff
         if inaff:
             # conv2 (and later its weight gradient) normalise the raw conv1 output while staging their tiles: a1 is never built
@@ -622,7 +671,7 @@ class BasicBlockFn(Function):
         else:
             a1 = new_act(n, co, h, w, x)
             H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
-            H.call("smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
+            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
         H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
         if has_sc:
@@ -697,30 +746,52 @@ class BasicBlockFn(Function):
         ga1 = new_act(n, co, h, w, x)
         gy1 = new_act(n, co, h, w, x)
         a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
+        f16 = ctx.f16
+        sc2 = _grad_scale(gy2) if f16 else None              # one absmax pass serves conv2's data- and weight-gradient
         if FUSED_BWD_STATS and H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3):
             # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
             tb = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
             pb = _ws(n * tb * co * 2, x)
-            H.call("smsut_conv2d_dgrad_mfma_bwdstats", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+            if f16:
+                H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, sc2, slope, n, h, w, co, co, st)
+            else:
+                H.call("smsut_conv2d_dgrad_mfma_bwdstats", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
             H.call("smsut_in_finalize_bwd", pb, tb, a1m, b1m, n, hw, co, st)
             H.call("smsut_in_apply_bwd", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, n, hw, co, st)
         else:
-            H.call("smsut_conv2d_fwd_mfma", gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
+            if f16:
+                H.call("smsut_conv2d_fwd_mfma_f16", gy2, w2, ga1, sc2, n, h, w, co, co, 3, 1, st)
+            else:
+                H.call("smsut_conv2d_fwd_mfma", gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
             H.call("smsut_instnorm_bwd", ga1, y1, b1, m1, r1, g1, gy1, a1m, b1m, gg1, gb1, _ws(n * chunks * co * 3, x),
                    n, hw, co, slope, st)
         gw2 = new_weight(co, co, 3, 3, device=dev)
-        wws2 = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x)
-        if ctx.inaff:
-            H.call("smsut_conv2d_wgrad_mfma_inaff", y1, gy2, gw2, wws2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+        f16w2 = f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, co, co))
+        f16w1 = f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, ci, co))
+        if f16w2:
+            H.call("smsut_conv2d_wgrad_f16", a1, None, 0, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x),
+                   sc2, n, h, w, co, co, st)
         else:
-            H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, wws2, n, h, w, co, co, 3, st)
+            wws2 = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x)
+            if ctx.inaff:
+                H.call("smsut_conv2d_wgrad_mfma_inaff", y1, gy2, gw2, wws2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+            else:
+                H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, wws2, n, h, w, co, co, 3, st)
         # ---- conv1 and the shortcut
+        sc1 = _grad_scale(gy1) if f16 else None
         gw1 = new_weight(co, ci, 3, 3, device=dev)
-        wws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), x)
-        if ctx.virtual:
-            H.call("smsut_conv2d_wgrad_mfma_cat", x, xb_part, x.shape[1], gy1, gw1, wws, n, h, w, ci, co, 3, st)
+        if f16w1:
+            wws = _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, ci, co), x)
+            if ctx.virtual:
+                H.call("smsut_conv2d_wgrad_f16", x, xb_part, x.shape[1], gy1, gw1, wws, sc1, n, h, w, ci, co, st)
+            else:
+                H.call("smsut_conv2d_wgrad_f16", x, None, 0, gy1, gw1, wws, sc1, n, h, w, ci, co, st)
         else:
-            H.call("smsut_conv2d_wgrad_mfma", x, gy1, gw1, wws, n, h, w, ci, co, 3, st)
+            wws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), x)
+            if ctx.virtual:
+                H.call("smsut_conv2d_wgrad_mfma_cat", x, xb_part, x.shape[1], gy1, gw1, wws, n, h, w, ci, co, 3, st)
+            else:
+                H.call("smsut_conv2d_wgrad_mfma", x, gy1, gw1, wws, n, h, w, ci, co, 3, st)
         gws = None
         if ctx.has_sc:
             gws = new_weight(co, ci, 1, 1, device=dev)
@@ -739,14 +810,20 @@ class BasicBlockFn(Function):
                         and H.call("smsut_conv2d_mfma_split_supported", n, h, w, co, ci, ca)):
                     # shortcut gradient first, the 3x3 data-gradient accumulates on top -- both straight into (ga, gb)
                     H.call("smsut_conv1x1_fwd_split", gs_t, ws, ga, gb, ca, n, hw, co, ci, 1, st)
-                    H.call("smsut_conv2d_fwd_mfma_split", gy1, w1, ga, gb, ca, n, h, w, co, ci, 3, st)
+                    if f16:
+                        H.call("smsut_conv2d_fwd_mfma_split_f16", gy1, w1, ga, gb, sc1, ca, n, h, w, co, ci, 3, st)
+                    else:
+                        H.call("smsut_conv2d_fwd_mfma_split", gy1, w1, ga, gb, ca, n, h, w, co, ci, 3, st)
                 else:
                     gx = new_act(n, ci, h, w, x)
                     if H.call("smsut_conv1x1_supported", co, ci):
                         H.call("smsut_conv1x1_fwd", gs_t, ws, gx, None, n, hw, co, ci, 1, st)
                     else:
                         H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gx, n, h, w, co, ci, 1, 1, st)
-                    H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
+                    if f16:
+                        H.call("smsut_conv2d_fwd_mfma_f16", gy1, w1, gx, sc1, n, h, w, co, ci, 3, 3, st)
+                    else:
+                        H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
                     H.call("smsut_concat2", ga, ca, gb, cb, gx, n * hw, 1, st)
             return None, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, ga, gb
         if ctx.needs_input_grad[0]:
@@ -760,7 +837,10 @@ class BasicBlockFn(Function):
                     H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gx, n, h, w, co, ci, 1, 1, st)
             else:
                 gx = gs_t
-            H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
+            if f16:
+                H.call("smsut_conv2d_fwd_mfma_f16", gy1, w1, gx, sc1, n, h, w, co, ci, 3, 3, st)
+            else:
+                H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
         return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
 
 

@@ -24,6 +24,19 @@ from ..misc.synthetic import SyntheticSliceLoader
 from ..misc.utils import Meter, get_mo_matrix, maybe_mkdir
 
 
+def seed_all(seed=None):
+    """The reference seeds random / numpy / torch with config.seed (uganConsisTrainer.py:317-320).  One process per GPU:
+    rank r seeds with ``seed + r`` so the ranks draw different target modalities, interpolation weights and augmentation
+    parameters (the weights themselves are broadcast from rank 0 in ``build_network``; the train sampler keeps its own
+    rank-independent generator, data_loader/inTurnLoader.py)."""
+    import random as _random
+    s = (cfg.seed if seed is None else seed) + int(os.environ.get("RANK", "0"))
+    _random.seed(s); np.random.seed(s); torch.manual_seed(s)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(s)
+    return s
+
+
 def make_sgd(params, lr, momentum, weight_decay):
     """torch.optim.SGD with the single-kernel ("fused") multi-tensor step: same update rule as the reference's optimizer
     (baseline trainers: SGD(lr, momentum=0.9, weight_decay)), ~3 launches instead of ~12 per step.  The parameters, their
@@ -146,7 +159,9 @@ class BaseTrainer(abc.ABC):
         if loader_type == "inTurn" and cfg.base_root and os.path.isdir(cfg.base_root):
             from ..data_loader import inTurnLoader as inlod
             mk = lambda phase, fold, aug: inlod.get_loader(cfg.base_root, phase, fold, cfg.batch_size, aug,
-                                                           device=self.device, split_yaml=cfg.split_yaml)
+                                                           device=self.device, split_yaml=cfg.split_yaml,
+                                                           rank=self.rank if phase != "test" else 0,
+                                                           world=self.world if phase != "test" else 1)
             return mk("train", self.fold, cfg.data_aug), mk("val", self.fold, cfg.data_aug), mk("test", 0, None)
         n = getattr(self.args, "iters_per_epoch", None) or cfg.num_iter_per_epoch
         mk = lambda labeled, nb: SyntheticSliceLoader(cfg.batch_size, n_batches=nb, device=self.device,

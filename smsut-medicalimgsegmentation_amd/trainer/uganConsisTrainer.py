@@ -23,6 +23,7 @@ import torch
 
 from .. import config as cfg
 from .. import graphs, ops
+from .baseTrainer import seed_all
 from .uganShp0Trainer import UGANShp0Trainer
 
 SCALARS = ("D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg", "G_semi", "G_nce")
@@ -320,7 +321,7 @@ def main(argv=None):
     p.add_argument("-i", "--model_id", type=str, help="only for test")
     p.add_argument("-wh", "--which_ckpt", type=str, default="last")
     args = p.parse_args(argv)
-    random.seed(cfg.seed); np.random.seed(cfg.seed); torch.manual_seed(cfg.seed); torch.cuda.manual_seed(cfg.seed)
+    seed_all()
     trainer = UGANConsisTrainer(args.phase, args)
     if args.phase == "train":
         trainer.fit("synthetic")

@@ -10,7 +10,7 @@ import torch
 from .. import config as cfg
 from .. import ops, parallel
 from ..network.ugan import UGAN, Discriminator
-from .baseTrainer import make_adam, make_sgd
+from .baseTrainer import seed_all, make_adam, make_sgd
 from .uganShp0Trainer import UGANShp0Trainer
 
 SCALARS = ("D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg", "G_shp")
@@ -124,7 +124,7 @@ def main(argv=None):
     p.add_argument("-i", "--model_id", type=str)
     p.add_argument("-wh", "--which_ckpt", type=str, default="last")
     args = p.parse_args(argv)
-    random.seed(cfg.seed); np.random.seed(cfg.seed); torch.manual_seed(cfg.seed); torch.cuda.manual_seed(cfg.seed)
+    seed_all()
     t = UGANTrainer(args.phase, args)
     if args.phase == "train":
         t.fit("synthetic")

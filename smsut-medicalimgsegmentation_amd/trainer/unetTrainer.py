@@ -10,7 +10,7 @@ import torch
 from .. import config as cfg
 from .. import graphs, parallel
 from ..network.unet import UNet
-from .baseTrainer import BaseTrainer, make_sgd
+from .baseTrainer import seed_all, BaseTrainer, make_sgd
 
 
 class UnetTrainer(BaseTrainer):
@@ -99,7 +99,7 @@ def main(argv=None):
     p.add_argument("-i", "--model_id", type=str)
     p.add_argument("-wh", "--which_ckpt", type=str, default="last")
     args = p.parse_args(argv)
-    random.seed(cfg.seed); np.random.seed(cfg.seed); torch.manual_seed(cfg.seed); torch.cuda.manual_seed(cfg.seed)
+    seed_all()
     t = UnetTrainer(args.phase, args)
     if args.phase == "train":
         t.fit("synthetic")

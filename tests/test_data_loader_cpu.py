@@ -96,3 +96,25 @@ def test_balance_dataset_reads_split_and_pngs(tmp_path):
     img, msk, mdl, names = next(iter(loader))
     assert tuple(img.shape) == (2, 1, 16, 16) and img.dtype == torch.float32 and float(img.min()) >= -1 and float(img.max()) <= 1
     assert msk.dtype == torch.int64 and tuple(msk.shape) == (2, 16, 16) and mdl.tolist() == [0, 0] and names[0].startswith("ct_001_")
+
+
+def test_train_sampler_shards_disjointly_across_ranks():
+    """Data parallelism: rank r's batches are its share of a global single-modality batch -- disjoint slices,
+    same modality on the same step, identical epoch length on every rank, world=1 order untouched."""
+    import random
+    from smsut_amd.data_loader.inTurnLoader import InTurnTrainBatchSampler
+    samples = [list(range(0, 40)), list(range(100, 164)), list(range(200, 233))]
+    world, bs = 2, 4
+    per_rank = [list(InTurnTrainBatchSampler(samples, bs, shuffle=False, rank=r, world=world)) for r in range(world)]
+    assert len(per_rank[0]) == len(per_rank[1]) > 0
+    for b0, b1 in zip(*per_rank):
+        assert len(b0) == len(b1) == bs and not set(b0) & set(b1)
+        assert len({i // 100 for i in b0 + b1}) == 1                 # one modality per global batch
+    # the same ranks, same seed -> the same global batches (the private generator does not depend on global random state)
+    random.seed(123)
+    again = list(InTurnTrainBatchSampler(samples, bs, shuffle=False, rank=0, world=world))
+    assert again == per_rank[0]
+    # world = 1 keeps the reference's draw order from the global generator
+    random.seed(7); a = list(InTurnTrainBatchSampler(samples, bs, shuffle=True))
+    random.seed(7); b = list(InTurnTrainBatchSampler(samples, bs, shuffle=True, rank=0, world=1))
+    assert a == b

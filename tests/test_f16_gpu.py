@@ -1,0 +1,227 @@
+"""BASELINE config 5: the fp16-operand MFMA conv path (``ops.set_conv_dtype("f16")``), fp32 tensors / accumulators /
+InstanceNorm statistics / losses.  The reference has no AMP: the oracle is the fp32 path, the tolerance is
+what fp16 operands allow -- each operand carries 2^-11 relative rounding, a 3x3 conv over C channels averages 9*C such
+products -- stated per check below (DESIGN.md "fp16 path").
+
+Gradients are exercised at their REAL magnitude (1e-7 and below at 512^2): without the per-tensor power-of-two scale of
+``smsut_absmax_scale`` they are fp16 subnormals / zeros."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, l2_rel
+from oracle import recipe, smsut_oracle as O
+
+pytestmark = pytest.mark.gpu
+FWD_TOL = 4e-3        # max-norm relative, one block (two stacked 3x3 convs + IN)
+# l2-relative, gradients through a block.  Dominated not by the fp16 products but by LeakyReLU mask flips: the forward
+# activations move by ~1e-3 relative, so the ~0.1 % of pre-activations that close to zero change sign and re-route their
+# gradient (factor 100 between the two slopes) -- the same mechanism that separates the reference's own fp32 and fp64
+# gradients, at fp16 instead of fp32 rounding.
+GRAD_TOL = 4e-2
+
+
+@pytest.fixture()
+def ops():
+    import smsut_amd  # noqa: F401
+    from smsut_amd import ops as o
+    prev = o.conv_dtype()
+    yield o
+    o.set_conv_dtype(prev)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape) * scale).float()
+
+
+def hwio(ops, w):
+    out = ops.new_weight(*w.shape, device="cuda")
+    out.copy_(w)
+    return out
+
+
+def test_absmax_scale(ops):
+    from smsut_amd import _hip as H
+    for mx, n in ((3.1e-7, 100_003), (1.0, 64), (7000.0, 1 << 20), (0.0, 4096)):
+        x = rnd(n, seed=3) * 0.2
+        x = x / x.abs().max() * mx if mx else torch.zeros(n)
+        out = ops._grad_scale(x.cuda()).cpu().numpy()
+        if mx == 0.0:
+            assert tuple(out) == (1.0, 1.0)
+            continue
+        assert out[0] * out[1] == 1.0 and np.log2(out[0]) == np.round(np.log2(out[0]))       # an exact power of two
+        assert 2.0 ** 13 <= mx * out[0] <= 2.0 ** 14, (mx, out)
+
+
+def _block(ops, x, ws_, gout, mode, parts=None):
+    """Fused BasicBlock forward + backward in the given operand dtype; returns (out, grads...)."""
+    ops.set_conv_dtype(mode)
+    w1, g1, b1, w2, g2, b2, ws, gs, bs = [t.clone().requires_grad_(True) if t is not None else None for t in ws_]
+    if parts is None:
+        xd = x.clone().requires_grad_(True)
+        out = ops.basic_block(xd, w1, g1, b1, w2, g2, b2, ws, gs, bs, 0.01)
+        leaves = [xd]
+    else:
+        a, b = [p.clone().requires_grad_(True) for p in parts]
+        out = ops.basic_block_cat(ops.CatParts(a, b), w1, g1, b1, w2, g2, b2, ws, gs, bs, 0.01)
+        leaves = [a, b]
+    out.backward(gout)
+    leaves += [t for t in (w1, g1, b1, w2, g2, b2, ws, gs, bs) if t is not None]
+    return out.detach(), [t.grad.detach() for t in leaves]
+
+
+@pytest.mark.parametrize("n,h,ci,co", [(16, 32, 32, 64), (2, 16, 64, 32), (3, 24, 16, 16),          # per-tile kernels, ragged tiles
+                                       (8, 128, 16, 16), (5, 128, 16, 32), (4, 128, 64, 32), (9, 64, 32, 64),   # persistent forms
+                                       (2, 512, 16, 16)])                                         # the config-5 top level
+def test_f16_block_matches_fp32_block(ops, n, h, ci, co):
+    """Fused BasicBlock with fp16 operands vs the SAME kernels with fp32 operands (themselves pinned against torch autograd
+    in test_ops_gpu.py): output at FWD_TOL, every gradient at GRAD_TOL, with upstream gradients of magnitude 1e-7."""
+    x = rnd(n, ci, h, h, seed=1).cuda().contiguous(memory_format=torch.channels_last)
+    has_sc = ci != co
+    ws_ = [hwio(ops, rnd(co, ci, 3, 3, seed=2) / np.sqrt(9 * ci)), (1 + 0.1 * rnd(co, seed=3)).cuda(), (0.1 * rnd(co, seed=4)).cuda(),
+           hwio(ops, rnd(co, co, 3, 3, seed=5) / np.sqrt(9 * co)), (1 + 0.1 * rnd(co, seed=6)).cuda(), (0.1 * rnd(co, seed=7)).cuda(),
+           hwio(ops, rnd(co, ci, 1, 1, seed=8) / np.sqrt(ci)) if has_sc else None,
+           (1 + 0.1 * rnd(co, seed=9)).cuda() if has_sc else None, (0.1 * rnd(co, seed=10)).cuda() if has_sc else None]
+    gout = (rnd(n, co, h, h, seed=11) * 3e-7).cuda().contiguous(memory_format=torch.channels_last)
+    o32, g32 = _block(ops, x, ws_, gout, "f32")
+    o16, g16 = _block(ops, x, ws_, gout, "f16")
+    assert not torch.equal(o32, o16)                                   # the fp16 kernels really ran
+    assert rel_err(o16.cpu().numpy(), o32.cpu().numpy()) < FWD_TOL
+    for a, b in zip(g16, g32):
+        assert float(b.abs().max()) > 0
+        err = l2_rel(a.cpu().numpy(), b.cpu().numpy())
+        assert err < GRAD_TOL, (tuple(b.shape), err)
+        if b.dim() == 4 and b.shape[0] == n:
+            # the activation gradient: its BULK is fp16-accurate, the l2 figure is carried by the few flipped positions
+            d = (a - b).abs() / b.abs().max()
+            assert float(d.median()) < 2e-3, (tuple(b.shape), float(d.median()))
+
+
+@pytest.mark.parametrize("n,h,ca,co", [(8, 128, 16, 16), (4, 64, 32, 32), (2, 32, 64, 64), (2, 512, 16, 16)])
+def test_f16_block_after_virtual_cat(ops, n, h, ca, co):
+    """The decoder form: conv1 / shortcut read cat([up, skip]) in place, the block-input gradient is written into the two
+    parts (virtual-cat forward, split-output data-gradient, virtual-cat weight gradient) -- fp16 vs fp32 operands."""
+    ci = 2 * ca
+    a = rnd(n, ca, h, h, seed=1).cuda().contiguous(memory_format=torch.channels_last)
+    b = rnd(n, ca, h, h, seed=2).cuda().contiguous(memory_format=torch.channels_last)
+    ws_ = [hwio(ops, rnd(co, ci, 3, 3, seed=2) / np.sqrt(9 * ci)), (1 + 0.1 * rnd(co, seed=3)).cuda(), (0.1 * rnd(co, seed=4)).cuda(),
+           hwio(ops, rnd(co, co, 3, 3, seed=5) / np.sqrt(9 * co)), (1 + 0.1 * rnd(co, seed=6)).cuda(), (0.1 * rnd(co, seed=7)).cuda(),
+           hwio(ops, rnd(co, ci, 1, 1, seed=8) / np.sqrt(ci)), (1 + 0.1 * rnd(co, seed=9)).cuda(), (0.1 * rnd(co, seed=10)).cuda()]
+    if not ops.basic_block_cat_fusable(ops.CatParts(a, b), ws_[0], ws_[6]):
+        pytest.skip("virtual-cat kernels do not cover this shape")
+    gout = (rnd(n, co, h, h, seed=11) * 1e-6).cuda().contiguous(memory_format=torch.channels_last)
+    o32, g32 = _block(ops, None, ws_, gout, "f32", parts=(a, b))
+    o16, g16 = _block(ops, None, ws_, gout, "f16", parts=(a, b))
+    assert not torch.equal(o32, o16)
+    assert rel_err(o16.cpu().numpy(), o32.cpu().numpy()) < FWD_TOL
+    for x16, x32 in zip(g16, g32):
+        err = l2_rel(x16.cpu().numpy(), x32.cpu().numpy())
+        assert err < GRAD_TOL, (tuple(x32.shape), err)
+
+
+def test_f16_generic_conv_family_first_order_only(ops):
+    """Generic conv / dgrad / wgrad Functions (the discriminator's BottleBlock convs): fp16 operands inside
+    ``first_order_pass()``, fp32 operands outside it (the WGAN-GP x_hat pass is differentiated twice)."""
+    x = rnd(4, 32, 32, 32, seed=1).cuda().contiguous(memory_format=torch.channels_last)
+    w = hwio(ops, rnd(64, 32, 3, 3, seed=2) / np.sqrt(9 * 32))
+    gy = (rnd(4, 64, 32, 32, seed=3) * 1e-7).cuda().contiguous(memory_format=torch.channels_last)
+
+    def run(first_order):
+        xd, wd = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        if first_order:
+            with ops.first_order_pass():
+                y = ops.conv2d(xd, wd, None, 1, 1)
+        else:
+            y = ops.conv2d(xd, wd, None, 1, 1)
+        y.backward(gy)
+        return y.detach(), xd.grad, wd.grad
+    ops.set_conv_dtype("f32")
+    ref = run(True)
+    ops.set_conv_dtype("f16")
+    got = run(True)
+    keep = run(False)
+    for a, b in zip(keep, ref):
+        assert torch.equal(a, b)                                       # outside first_order_pass(): untouched fp32 kernels
+    assert not torch.equal(got[0], ref[0])
+    assert rel_err(got[0].cpu().numpy(), ref[0].cpu().numpy()) < 2e-3
+    assert l2_rel(got[1].cpu().numpy(), ref[1].cpu().numpy()) < 2e-3 and l2_rel(got[2].cpu().numpy(), ref[2].cpu().numpy()) < 2e-3
+
+
+def test_f16_unet_512_vs_fp32_oracle(ops):
+    """U-Net(1,5,16) at 512x512 (config 5's slice size), fp16 conv operands, vs the fp32 CPU oracle: logits within 2e-2 of
+    the logit range (~40 stacked convs, each 2^-11 per operand), Dice+CE loss within 5e-3.
+
+    Parameter gradients: the network is not smooth (4 MaxPools, 18 LeakyReLUs), so a forward perturbation of relative size d
+    flips a fraction ~d of the argmax / sign decisions and moves the gradient by ~sqrt(d) in l2 terms.  SURVEY.md section 9
+    measured that law on the reference itself: fp32 vs fp64 (d ~ 1e-7) -> median 1.4e-3, worst 6.5e-3.  fp16 operands are
+    d ~ 5e-4, i.e. sqrt(5000) ~ 70x that: ~0.1.  Bars: median < 0.12, worst < 0.2, and the direction is kept -- cosine
+    similarity of the full gradient vector > 0.985."""
+    from smsut_amd.network.unet import UNet
+    from smsut_amd.misc.loss import DiceAndCrossEntropyLoss
+    torch.set_num_threads(16)
+    H = 512
+    x = recipe.synth_images((2, 1, H, H), 501)
+    y = recipe.synth_labels(2, H, H, 5, 502)
+    sd = recipe.fill(recipe.unet_shapes(1, 5, 16), 500)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = O.unet_forward(leaf, x)
+    ref_loss = O.dice_ce(ref, y)
+    ref_loss.backward()
+    ops.set_conv_dtype("f16")
+    net = UNet(1, 5, 16, norm_type="instance", act_type="lrelu")
+    net.load_state_dict(sd); net.cuda().train()
+    out = net(x.cuda())
+    loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y.cuda())
+    loss.backward()
+    e = rel_err(out.detach().cpu().numpy(), ref.detach().numpy())
+    assert 1e-5 < e < 2e-2, e                                          # (> 1e-5: the fp16 kernels really ran)
+    assert abs(loss.item() - ref_loss.item()) < 5e-3 * abs(ref_loss.item())
+    errs = {k: l2_rel(p.grad.cpu().numpy(), leaf[k].grad.numpy()) for k, p in net.named_parameters()}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    assert float(np.median(list(errs.values()))) < 0.12 and worst[1] < 0.2, (float(np.median(list(errs.values()))), worst)
+    ga = torch.cat([p.grad.detach().cpu().double().reshape(-1) for _, p in net.named_parameters()])
+    gb = torch.cat([leaf[k].grad.double().reshape(-1) for k, _ in net.named_parameters()])
+    cos = float(torch.dot(ga, gb) / (ga.norm() * gb.norm()))
+    assert cos > 0.985, cos
+
+
+def test_f16_ugan_consis_iteration_512_vs_fp32_oracle(ops):
+    """One uganConsis iteration at config 5's size (512x512, 1 labeled + 1 unlabeled slice, the 7-stage discriminator of
+    ugan.py:205-215) with fp16 conv operands vs the fp32 CPU oracle, optimizers at lr 0: segmentor-side scalars at 1e-2,
+    everything else (through the tanh translator and D) at 5e-2."""
+    from smsut_amd import config as cfg
+    from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer, SCALARS
+    old = (cfg.input_size, cfg.batch_size)
+    cfg.input_size, cfg.batch_size = 512, 1
+    try:
+        ops.set_conv_dtype("f16")
+        tr = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+        g_w = recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 91)
+        d_w = recipe.fill(recipe.disc_shapes(512, 4, 16, 256), 92)
+        tr.net.load_state_dict(g_w); tr.D.load_state_dict(d_w)
+        tr.net.train(); tr.D.train()
+        tr.epoch, tr.iter = 100, 15000
+        for grp in list(tr.d_optimizer.param_groups) + list(tr.optimizer.param_groups):
+            grp["lr"] = 0.0
+        x, y, modal, mj, alpha, ids = recipe.trace_inputs(0, b=2, size=512, base=1500)
+        got = np.array(tr.train_iteration(x.cuda(), y.cuda(), modal, mj=mj, alpha=alpha.cuda(), sample_ids=[ids.cuda()]).tolist())
+        torch.set_num_threads(16)
+        gsd = {k: v.clone().requires_grad_(True) for k, v in g_w.items()}
+        dsd = {k: v.clone().requires_grad_(True) for k, v in d_w.items()}
+        logs, _ = O.ugan_consis_iteration(gsd, dsd, torch.optim.SGD(list(gsd.values()), lr=0.0),
+                                          torch.optim.Adam(list(dsd.values()), 0.0), x, y, modal, mj, alpha, [ids], it=15000,
+                                          epoch=100, nce_batch=1, base_lr=0.0)
+        ref = np.array([logs[k] for k in SCALARS])
+        rep = dict(zip(SCALARS, zip(got, ref)))
+        assert np.isfinite(got).all(), rep
+        seg = [SCALARS.index(k) for k in ("G_seg", "G_semi", "G_rec")]
+        assert np.allclose(got[seg], ref[seg], rtol=1e-2, atol=1e-4), rep
+        rest = [i for i in range(10) if i not in seg and SCALARS[i] != "D_gp"]
+        assert np.allclose(got[rest], ref[rest], rtol=5e-2, atol=2e-3), rep
+        i_gp = SCALARS.index("D_gp")                                   # the x_hat pass keeps fp32 operands; x_fake itself is f16-made
+        assert abs(got[i_gp] - ref[i_gp]) <= 5e-2 * abs(ref[i_gp]), rep
+    finally:
+        cfg.input_size, cfg.batch_size = old
