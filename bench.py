@@ -29,6 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 PMC_FILE = "r02_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
 
@@ -63,14 +64,14 @@ def pmc_traffic_per_slice():
         return None
 
 
-def measure_dominant_conv(dev, batch):
+def measure_dominant_conv(dev, batch, size=256, f16=False):
     """HIP-event timing of the dominant kernel AS THE STEP LAUNCHES IT: conv3x3 s1 p1 of the decoder-level-1 block
     (blocks.py dec layer1.conv1: cat([up, skip]) [B,16+16,256,256] -> 16 ch), i.e. the persistent resident-weight kernel
     with the InstanceNorm-statistics epilogue and the virtual-cat input (``smsut_conv2d_fwd_mfma_stats_cat`` ->
     ``conv_mfma_fwd_p<3,8,1,2,STATS,..,DUAL>``); the 3x3 @256^2 layer class holds the largest share of the step's FLOPs.
     Returns the roofline dict."""
     from smsut_amd import ops, _hip as H
-    cin, cout, h = 32, 16, 256
+    cin, cout, h = 32, 16, size
     cl = torch.channels_last
     xa = torch.randn(batch, cin // 2, h, h, device=dev).contiguous(memory_format=cl)
     xb = torch.randn(batch, cin // 2, h, h, device=dev).contiguous(memory_format=cl)
@@ -83,7 +84,8 @@ def measure_dominant_conv(dev, batch):
     st = torch.cuda.current_stream()
 
     def launch():
-        H.call("smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y, part, batch, h, h, cin, cout, st.cuda_stream)
+        H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16 else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y, part, batch, h, h,
+               cin, cout, st.cuda_stream)
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
@@ -98,13 +100,23 @@ def measure_dominant_conv(dev, batch):
     fl = conv_flops(batch, h, h, cin, cout, 3)
     achieved = fl / (ms * 1e-3) / 1e12
     byts = 4.0 * batch * h * h * (cin + cout)
-    per_slice = pmc_traffic_per_slice()
+    per_slice = pmc_traffic_per_slice() if (size == 256 and not f16) else None
+    if f16:
+        # fp16 operands: 36 FLOP/B against a ridge of 2500 / 8 ~ 310 FLOP/B -> the kernel is HBM-bound
+        gbs = byts / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel": "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,F16> via smsut_conv2d_fwd_mfma_stats_cat_f16",
+                "kernel_kind": "mfma f16 operands", "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
+                "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
+                "algorithmic_gbytes_per_launch": round(byts / 1e9, 4), "tflops": round(achieved, 2),
+                "frac_of_fp16_mfma_peak": round(achieved / FP16_MFMA_PEAK_TFLOPS, 4),
+                "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": None if per_slice is None else round(per_slice * batch),
             "traffic_unit": f"HBM bytes per launch (PMC, profiles/{PMC_FILE})",
             "kernel": "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL> via smsut_conv2d_fwd_mfma_stats_cat", "kernel_kind": "mfma",
-            "shape": f"N{batch} 256x256 (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
+            "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
             "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
@@ -228,6 +240,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=("ugan", "unet"), default="ugan")
     ap.add_argument("--per-gpu-batch", type=int, default=None)
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32",
+                    help="conv operand dtype: f16 = BASELINE config 5's fp16 MFMA conv path (fp32 tensors / accumulators / IN / losses)")
+    ap.add_argument("--size", type=int, default=256, help="slice size (config 5: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-unet-step", action="store_true", help="skip the BASELINE config-2 (U-Net step) leg")
@@ -237,8 +252,10 @@ def main():
     args = ap.parse_args()
 
     import smsut_amd  # noqa: F401
-    from smsut_amd import config as cfg, parallel
+    from smsut_amd import config as cfg, ops, parallel
     from smsut_amd.misc.synthetic import SyntheticSliceLoader
+    cfg.input_size = args.size
+    ops.set_conv_dtype(args.dtype)
 
     rank, world, local, group = parallel.init_from_env()
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -249,7 +266,7 @@ def main():
     random.seed(cfg.seed + rank)                       # target-modality draws (uganConsisTrainer.py:114)
     if args.roofline_only:
         B = args.per_gpu_batch or (16 if args.workload == "ugan" else 32)
-        print(json.dumps({"roofline": measure_dominant_conv(dev, B)}))
+        print(json.dumps({"roofline": measure_dominant_conv(dev, B, args.size, args.dtype == "f16")}))
         return
     ns = types.SimpleNamespace(fold=0, expr_name=None, write_env=False)
 
@@ -276,8 +293,8 @@ def main():
         def step_again():
             return tr.train_iteration(*batches[-1])
         workload = f"uganConsisTrainer iteration (D-step + G-step, WGAN-GP, cycle, DiceCE, consistency, PatchNCE), " \
-                   f"{B // 2} labeled + {B // 2} unlabeled 1x256x256 slices per GPU, 5 classes, 4 modalities"
-        metric = "slices/sec uganConsisTrainer step @256x256"
+                   f"{B // 2} labeled + {B // 2} unlabeled 1x{args.size}x{args.size} slices per GPU, 5 classes, 4 modalities"
+        metric = f"slices/sec uganConsisTrainer step @{args.size}x{args.size}"
     else:
         from smsut_amd.trainer.unetTrainer import UnetTrainer
         B = args.per_gpu_batch or 32
@@ -294,8 +311,8 @@ def main():
 
         def step_again():
             return tr.train_step(*batches[-1])
-        workload = f"U-Net(1,5,16) fwd + DiceCE + bwd + SGD, {B}x1x256x256 per GPU (BASELINE config 2)"
-        metric = "slices/sec U-Net train step @256x256"
+        workload = f"U-Net(1,5,16) fwd + DiceCE + bwd + SGD, {B}x1x{args.size}x{args.size} per GPU (BASELINE config 2)"
+        metric = f"slices/sec U-Net train step @{args.size}x{args.size}"
 
     log(f"{args.workload}: {args.warmup} warm-up + {args.steps} timed steps on {world} GPU(s) ...")
     for _ in range(args.warmup):
@@ -325,7 +342,8 @@ def main():
     value = B * world * args.steps / dt
     out = {"metric": metric, "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "f16 conv operands, f32 accumulate / IN / losses",
+           "data": "synthetic",
            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
                       "parallelism": f"dp{world}", "weights": "random init (reference initialisers)"},
            "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])]}
@@ -344,22 +362,25 @@ def main():
     # whole-step arithmetic rate (all ops of the step, memory-bound ones included) against the fp32 MFMA peak: algorithmic conv
     # FLOPs per slice, fwd + dgrad + wgrad counted once each (U-Net(1,5,16)@256^2 19.61 GFLOP,
     # uganConsis iteration 1.71 TFLOP per 16 slices as the REFERENCE executes it -- G(x_real) twice)
-    gflop_slice = 19.61 if args.workload == "unet" else 1710.0 / 16
+    gflop_slice = (19.61 if args.workload == "unet" else 1710.0 / 16) * (args.size / 256.0) ** 2
     tf = value / world * gflop_slice / 1e3
     out["whole_step"] = {"algorithmic_gflop_per_slice": gflop_slice, "achieved_tflops_per_gpu": round(tf, 2),
                          "frac_of_fp32_mfma_peak": round(tf / 157.3, 4), "peak_tflops": 157.3}
     if args.workload != "unet":
         out["whole_step"]["note"] = ("FLOPs of the reference iteration (3 generator forwards); this build computes G(x_real) "
                                      "once, i.e. executes ~12 % fewer")
+    if args.dtype == "f16":
+        out["whole_step"]["note_f16"] = ("fp16-operand convolutions are HBM-bound (the fp16 dense MFMA peak is 16x the fp32 one): "
+                                         "the fp32-MFMA fraction above is a common yardstick with the f32 run, not this path's roofline")
     if not args.no_roofline:
-        out["roofline"] = measure_dominant_conv(dev, B)
+        out["roofline"] = measure_dominant_conv(dev, B, args.size, args.dtype == "f16")
         if not args.no_step_profile and world == 1:      # (an eager step holds collectives: single-rank runs only)
             prof = measure_step_conv(step_again, args.workload)
             out["roofline"]["step_conv_frac"] = prof["step_conv_frac"]
             out["roofline"]["step_conv"] = prof
-    if world == 1 and args.workload == "ugan" and not args.no_unet_step:
+    if world == 1 and args.workload == "ugan" and not args.no_unet_step and args.dtype == "f32" and args.size == 256:
         out["unet_step"] = time_unet_step(dev, rank)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and args.size == 256:
         out["cpu_baseline"] = cpu_baseline_ugan() if args.workload == "ugan" else cpu_baseline_unet()
     print(json.dumps(out), flush=True)
     if world > 1:

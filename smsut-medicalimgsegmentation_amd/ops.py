@@ -646,15 +646,18 @@ class BasicBlockFn(Function):
         t3b = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
         # fp16 operands (config 5): both 3x3 convs of the block and their gradients, when every reduction is whole 16-channel
         # chunks; same tile selection / statistics layout as the fp32 forms
-        f16 = CONV_F16 and ci % 16 == 0 and co % 16 == 0
-        ctx.f16 = f16
+        # (per conv: the 8 -> 16 first block keeps conv1 in fp32 -- half of a 16-channel chunk would be padding -- but its
+        #  16 -> 16 conv2 qualifies)
+        f16a = CONV_F16 and ci % 16 == 0 and co % 16 == 0          # conv1 and its gradients
+        f16 = CONV_F16 and co % 16 == 0                            # conv2 and its gradients
+        ctx.f16 = (f16a, f16)
         y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
         if virtual:
-            H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16 else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w1, y1, p1, n, h, w,
+            H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w1, y1, p1, n, h, w,
                    ci, co, st)
         else:
-            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
+            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16a else "smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
         m1, r1 = stat(co)
         y2 = new_act(n, co, h, w, x)
         p2 = _ws(n * t3b * co * 2, x)
@@ -746,7 +749,7 @@ class BasicBlockFn(Function):
         ga1 = new_act(n, co, h, w, x)
         gy1 = new_act(n, co, h, w, x)
         a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
-        f16 = ctx.f16
+        f16a, f16 = ctx.f16                                  # fp16 operands for conv1 / conv2 and their gradients
         sc2 = _grad_scale(gy2) if f16 else None              # one absmax pass serves conv2's data- and weight-gradient
         if FUSED_BWD_STATS and H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3):
             # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
@@ -767,7 +770,7 @@ class BasicBlockFn(Function):
                    n, hw, co, slope, st)
         gw2 = new_weight(co, co, 3, 3, device=dev)
         f16w2 = f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, co, co))
-        f16w1 = f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, ci, co))
+        f16w1 = f16a and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, ci, co))
         if f16w2:
             H.call("smsut_conv2d_wgrad_f16", a1, None, 0, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x),
                    sc2, n, h, w, co, co, st)
@@ -778,7 +781,7 @@ class BasicBlockFn(Function):
             else:
                 H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, wws2, n, h, w, co, co, 3, st)
         # ---- conv1 and the shortcut
-        sc1 = _grad_scale(gy1) if f16 else None
+        sc1 = _grad_scale(gy1) if f16a else None
         gw1 = new_weight(co, ci, 3, 3, device=dev)
         if f16w1:
             wws = _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, ci, co), x)
@@ -810,7 +813,7 @@ class BasicBlockFn(Function):
                         and H.call("smsut_conv2d_mfma_split_supported", n, h, w, co, ci, ca)):
                     # shortcut gradient first, the 3x3 data-gradient accumulates on top -- both straight into (ga, gb)
                     H.call("smsut_conv1x1_fwd_split", gs_t, ws, ga, gb, ca, n, hw, co, ci, 1, st)
-                    if f16:
+                    if f16a:
                         H.call("smsut_conv2d_fwd_mfma_split_f16", gy1, w1, ga, gb, sc1, ca, n, h, w, co, ci, 3, st)
                     else:
                         H.call("smsut_conv2d_fwd_mfma_split", gy1, w1, ga, gb, ca, n, h, w, co, ci, 3, st)
@@ -820,7 +823,7 @@ class BasicBlockFn(Function):
                         H.call("smsut_conv1x1_fwd", gs_t, ws, gx, None, n, hw, co, ci, 1, st)
                     else:
                         H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gx, n, h, w, co, ci, 1, 1, st)
-                    if f16:
+                    if f16a:
                         H.call("smsut_conv2d_fwd_mfma_f16", gy1, w1, gx, sc1, n, h, w, co, ci, 3, 3, st)
                     else:
                         H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
@@ -837,7 +840,7 @@ class BasicBlockFn(Function):
                     H.call("smsut_conv2d_fwd_mfma", gs_t, ws, gx, n, h, w, co, ci, 1, 1, st)
             else:
                 gx = gs_t
-            if f16:
+            if f16a:
                 H.call("smsut_conv2d_fwd_mfma_f16", gy1, w1, gx, sc1, n, h, w, co, ci, 3, 3, st)
             else:
                 H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
