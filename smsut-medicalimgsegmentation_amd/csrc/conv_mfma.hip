@@ -638,13 +638,16 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows (the GEMM K dimension)
+#ifndef WG11_MIN_BLOCKS
+#define WG11_MIN_BLOCKS 4    // 16x16-slab weight gradient: workgroups per CU the register allocation must allow
+#endif
 #ifndef WTS_STRIDE_VALUE
 #define WTS_STRIDE_VALUE 48
 #endif
 constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
 template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB, (KS == 3 && CIT == 1 && COT == 1 && !INAFF) ? WG11_MIN_BLOCKS : 1)
 conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                 int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci,
                 const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{}) {
