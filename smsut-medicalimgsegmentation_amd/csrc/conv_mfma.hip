@@ -638,6 +638,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 
 // ------------------------------------------------------------------------------------------------ weight gradient
 constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows (the GEMM K dimension)
+#ifndef WG_RR_UNROLL
+#define WG_RR_UNROLL 2
+#endif
+#ifndef WG_KS_UNROLL
+#define WG_KS_UNROLL 4
+#endif
 #ifndef WG11_MIN_BLOCKS
 #define WG11_MIN_BLOCKS 4    // 16x16-slab weight gradient: workgroups per CU the register allocation must allow
 #endif
@@ -762,10 +768,10 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
       if (tid + i * TPB < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
     __syncthreads();
     if (t + 1 < t_end) prefetch(t + 1);
-#pragma unroll
+#pragma unroll WG_RR_UNROLL
     for (int rr = 0; rr < WTH / 4; ++rr) {
       const int r = wave * (WTH / 4) + rr;
-#pragma unroll
+#pragma unroll WG_KS_UNROLL
       for (int ks = 0; ks < TW / 4; ++ks) {
         const int px = ks * 4 + kq;                 // this lane's pixel (the MFMA k index) within the row
         float b[COT];

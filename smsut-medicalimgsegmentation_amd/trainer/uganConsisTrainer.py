@@ -39,6 +39,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._alias = None
         self._g1 = self._g2 = None
         self._side = None
+        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1") not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
@@ -221,29 +222,32 @@ class UGANConsisTrainer(UGANShp0Trainer):
         if self._probe:
             self._finite_probe("G1", [("x_fake", x_fake)])
 
-        # ------------------------------------------------------------ D-step (:129-146)
-        d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params)
-        if self._probe:
-            self._finite_probe("D", [("d_scalars", d_scal)] + [("grad " + k, p.grad) for k, p in self.D.named_parameters()])
+        # ------------------------------------------------------------ D-step (:129-146)  ||  cycle pass of the G-step
+        # The D-step (forward x3, WGAN-GP double backward, gradient all-reduce, Adam) and the cycle pass G(x_fake) of the
+        # G-step are independent: both only READ x_fake.  The D-step is ~700 small launches (its deep levels are 8x8 / 4x4
+        # planes that fill a fraction of the chip), the cycle pass is a few dozen chip-filling ones -- so the D-step runs on a
+        # side stream UNDER the cycle pass (SMSUT_D_OVERLAP=0: one after the other).  D's weights are first needed by phase G2.
         cur = torch.cuda.current_stream()
-        if self.world > 1:
-            # D's gradient all-reduce + Adam on a side stream: the cycle pass below does not touch D
+        overlap = self._d_overlap
+        if overlap:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
-                self.d_reducer.reduce()
-                self.d_optimizer.step()
-        else:
+        with torch.cuda.stream(self._side if overlap else cur):
+            d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params)
+            if self._probe:
+                self._finite_probe("D", [("d_scalars", d_scal)] + [("grad " + k, p.grad) for k, p in self.D.named_parameters()])
+            self.d_reducer.reduce()
             self.d_optimizer.step()
+        st_semi = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids), list(self._alias.values()))
+        self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
+        if overlap:
+            cur.wait_stream(self._side)
+            d_scal.record_stream(cur)            # allocated on the side stream (eager mode), read by the final cat on this one
         if self._probe:
             self._finite_probe("D.step", list(self.D.named_parameters()))
 
-        # ------------------------------------------------------------ G-step (:150-180)
-        st_semi = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids), list(self._alias.values()))
-        self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
-        if self.world > 1:
-            cur.wait_stream(self._side)
+        # ------------------------------------------------------------ G-step (:150-180), the part that needs the updated D
         for p in d_params:                                    # D frozen: its unused gradients are neither computed nor reduced
             p.requires_grad_(False)
         g_scal = self._run_phase("G2", self._g2_phase, (y_real, modal_trg, st_seg, st_semi, lam_t), g_params)

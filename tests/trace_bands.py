@@ -8,5 +8,6 @@ whole trajectory; how tightly is bounded by how far the REFERENCE's own arithmet
 band <= 4x spread + 1e-2, so the bands can neither be tighter than the reference itself nor drift arbitrarily wide."""
 # measured spread of the reference (max over 32 iterations of |fp32 - fp64| / |fp64|):
 #   G_seg 3.4e-3, G_semi 2.3e-2, G_rec 0.53, G_nce 0.18     (G_rec / G_nce pass through the translator, which D trains)
-# the HIP path against the fp32 reference trace on the same draws: 3.2e-3, 2.1e-2, 0.30, 0.31-0.36
-TRACE_BANDS = {"G_seg": 0.01, "G_semi": 0.05, "G_rec": 0.60, "G_nce": 0.45}
+# the HIP path against the fp32 reference trace on the same draws: 3.2e-3, 2.1e-2, 0.30, 0.31-0.63 (two builds whose only
+# difference is the order of a few fp32 sums land on G_nce trajectories that far apart: it is the most D-coupled of the four)
+TRACE_BANDS = {"G_seg": 0.01, "G_semi": 0.05, "G_rec": 0.60, "G_nce": 0.70}
