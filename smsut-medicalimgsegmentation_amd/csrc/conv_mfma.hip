@@ -334,26 +334,32 @@ __device__ __forceinline__ float aff1(float v, float m, float r, float g, float 
 struct BstRef { const float* y1; const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
 
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false>
+          bool F16 = false, bool K8 = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
                 BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0,
                 const float* __restrict__ x2 = nullptr, AffRef aff = AffRef{}, const float* __restrict__ gsc = nullptr) {
   // F16: fp16 operands (see the block comment above mfma16h); gsc (nullable) = {s, 1/s} for a gradient input.
+  // K8: the reduction is 8 channels wide (first block after the stem, network/blocks.py:123-127: 8 -> 16 @256^2).  A 16-wide
+  // chunk would be half padding; instead PAIRS OF TAPS share one MFMA: k-slots kq = 0, 1 carry the 8 channels of tap 2g,
+  // kq = 2, 3 those of tap 2g+1 (a lane picks its tap's halo offset and weight block) -- 5 x 4 MFMAs per 16x16 output tile
+  // instead of 9 x 4.
+  static_assert(!K8 || (NCH == 1 && !DUAL && !INAFF && !F16 && !BST), "8-channel reduction: plain / statistics / accumulate forms");
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
   static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
   static_assert(!DUAL || NCH % 2 == 0, "virtual cat input: two equal halves of whole 16-channel chunks");
   // DUAL: the input is the virtual cat([x, x2]) of two [N,H,W,Kdim/2] tensors (common.h): chunks [0, NCH/2) are staged
   // from x, the rest from x2 -- same chunk order, same arithmetic as on the materialised cat.
-  constexpr int KST = DUAL ? 8 * NCH : 16 * NCH;             // pixel stride of the tensor(s) the input is read from
+  constexpr int KST = K8 ? 8 : (DUAL ? 8 * NCH : 16 * NCH);  // pixel stride of the tensor(s) the input is read from
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
   constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
   constexpr int CO_T = 16 * NTN;
   constexpr int MR = TH / 4, NR = NTN;
-  constexpr int Kdim = 16 * NCH, K4 = Kdim / 4;
-  constexpr int UNITS = IH * IW * 4;          // float4 units of one 16-channel input chunk
+  constexpr int Kdim = K8 ? 8 : 16 * NCH, K4 = Kdim / 4;
+  constexpr int UQ = K8 ? 2 : 4;              // float4 units per pixel of one input chunk
+  constexpr int UNITS = IH * IW * UQ;         // float4 units of one input chunk
   constexpr int NI = (UNITS + TPB - 1) / TPB;
   extern __shared__ float smem[];
   float* in_s = smem;                         // [IH][IW][SPIX] + one dummy pixel (sink for the padding units)
@@ -411,7 +417,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     const int u = tid + i * TPB;
     const bool real = u < UNITS;
     const int uu = real ? u : 0;
-    const int q = uu & 3, pix = uu >> 2;
+    const int q = uu % UQ, pix = uu / UQ;
     const int iy = pix / IW, ix = pix % IW;
     u_off[i] = (iy * W + ix) * KST + 4 * q;
     u_lds[i] = real ? pix * (F16 ? SPIXH : SPIX) + 4 * q : IH * IW * (F16 ? SPIXH : SPIX);
@@ -549,6 +555,32 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     }
   };
   auto mma_chunk = [&](int c) {
+    if constexpr (K8) {
+      const int half = kq >> 1, kk = kq & 1;
+#pragma unroll
+      for (int g = 0; g < (KK + 1) / 2; ++g) {
+        constexpr int dummy = 0; (void)dummy;
+        const int tA = 2 * g, tB = (2 * g + 1 < KK) ? 2 * g + 1 : 2 * g;      // (the unpaired last tap: second half zeroed)
+        const int t = half ? tB : tA;
+        const bool live = !(half && 2 * g + 1 >= KK);
+        const int toff = ((t / KS) * IW + (t % KS)) * SPIX + 4 * kk;
+        f32x4 a[MR], b[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) a[i] = *(const f32x4*)(in_s + ((wave * MR + i) * IW + lm) * SPIX + toff);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          b[j] = *(const f32x4*)(w_s + (((size_t)(t * K4 + kk) * CO_T) + j * 16 + lm) * 4);
+          if (!live) b[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < MR; ++i)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+      }
+      return;
+    }
     if constexpr (F16) {
 #pragma unroll
       for (int tap = 0; tap < KK; ++tap) {
@@ -645,27 +677,34 @@ constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows 
 #define WG_KS_UNROLL 4
 #endif
 #ifndef WG11_MIN_BLOCKS
-#define WG11_MIN_BLOCKS 4    // 16x16-slab weight gradient: workgroups per CU the register allocation must allow
+#define WG11_MIN_BLOCKS 1    // 16x16-slab weight gradient: workgroups per CU the register allocation must allow (r02 A/B on
+                             // H256 16->16 B32: uncapped 168 VGPR / 3 waves 104 us; cap 4 with the row loop rolled (94-111 VGPR)
+                             // 103-126 us; cap 4 fully unrolled spills -- occupancy is not what limits this kernel)
 #endif
 #ifndef WTS_STRIDE_VALUE
 #define WTS_STRIDE_VALUE 48
 #endif
 constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
-template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false>
+template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false, bool C8 = false>
 __global__ void __launch_bounds__(TPB, (KS == 3 && CIT == 1 && COT == 1 && !INAFF) ? WG11_MIN_BLOCKS : 1)
 conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                 int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci,
                 const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{}) {
   // INAFF: x is the raw conv output whose lrelu(IN(.)) is the operand (see AffRef); applied when a tile is published.
   // gsc = 2 / 4 tap groups in blockIdx.y: weight-gradient of ConvTranspose2x2 (gy is the 2x larger tensor).
+  // C8: Cin == 8 (first block after the stem).  Half of the 16 MFMA rows would be padding; instead PAIRS OF TAPS share one
+  // accumulator tile: rows 0-7 = (tap 2g, ci), rows 8-15 = (tap 2g+1, ci) -- lane lm reads x at its tap's halo offset --
+  // 5 accumulator tiles and 5 MFMAs per pixel quad instead of 9.
+  static_assert(!C8 || (KS == 3 && CIT == 1 && !DUAL && !INAFF), "8-channel form: plain 3x3");
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
   constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;     // pixel stride = 16 (mod 32): 4 pixels x 16 ch conflict-free
   constexpr int SO = (CO_T % 32 == 16) ? CO_T : CO_T + 16;
-  constexpr int NACC = KK * CIT * COT;
+  constexpr int NG = C8 ? (KK + 1) / 2 : KK;   // accumulator tile groups per (ci tile, co tile): taps, or tap pairs
+  constexpr int NACC = NG * CIT * COT;
   extern __shared__ float smem[];
   float* in_s = smem;                         // [IH][IW][SI]
   float* gy_s = smem + IH * IW * SI;          // [WTH][TW][SO]
@@ -777,6 +816,18 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
         float b[COT];
 #pragma unroll
         for (int j = 0; j < COT; ++j) b[j] = gy_s[(r * TW + px) * SO + j * 16 + lm];
+        if constexpr (C8) {
+          const int hi = lm >> 3;                    // this lane's MFMA row belongs to the second tap of the pair
+#pragma unroll
+          for (int g = 0; g < NG; ++g) {
+            const int tB = (2 * g + 1 < KK) ? 2 * g + 1 : 2 * g;
+            const int t = hi ? tB : 2 * g;
+            float a = in_s[((r + t / KS) * IW + px + t % KS) * SI + (lm & 7)];
+            if (hi && 2 * g + 1 >= KK) a = 0.f;      // the unpaired last tap
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[g * COT + j] = mfma16(a, b[j], acc[g * COT + j]);
+          }
+        } else
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
           const int kh = tap / KS, kw = tap % KS;
@@ -804,6 +855,23 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
 #pragma unroll
       for (int i = 0; i < NACC; ++i) acc[i] += *(const f32x4*)(red + ((size_t)i * 64 + lane) * 4);
     }
+  }
+  if (C8) {
+    if (wave == 0) {
+      float* out = part + (size_t)split * KK * Cin * Cout;            // rows 4kq + r: tap 2g + (row >> 3), ci = row & 7
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+          const int co = co0 + j * 16 + lm;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r, tap = 2 * g + (row >> 3);
+            if (tap < KK && co < Cout) out[((size_t)tap * Cin + (row & 7)) * Cout + co] = acc[g * COT + j][r];
+          }
+        }
+    }
+    return;
   }
   if (wave == 0) {
     float* out = part + ((size_t)split * (gridDim.y / nci) + tg) * KK * Cin * Cout;
@@ -1296,7 +1364,7 @@ constexpr size_t fwd_p_lds() {
          sizeof(float);
 }
 
-template <int KS, int TH, int NTN, int NCH>
+template <int KS, int TH, int NTN, int NCH, bool K8 = false>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
                  float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
@@ -1304,9 +1372,10 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
   if constexpr (sh > 64 * 1024) return -1;
   else {
-  if (Kdim != 16 * NCH || W % TW != 0 || H % TH != 0 || Ndim % (16 * NTN) != 0 ||
+  if (Kdim != (K8 ? 8 : 16 * NCH) || W % TW != 0 || H % TH != 0 || Ndim % (16 * NTN) != 0 ||
       (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) >= (1ll << 31))
     return -1;
+  if (K8 && (f16 || bst || x2 || aff)) return -1;
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int tiles_img = tiles_x * tiles_y;
   if (y2 && (split <= 0 || split >= Ndim || split % (16 * NTN) != 0 || stats || bst)) return -1;
@@ -1333,7 +1402,11 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   // one launch site for every form; the fp16-operand twin of each form is chosen at run time (f16)
 #define P_GO(ST, AC, BS, DU, IA)                                                                                             \
   do {                                                                                                                       \
-    if (f16)                                                                                                                 \
+    if constexpr (K8) {                                                                                                      \
+      if constexpr (!BS && !DU && !IA)                                                                                       \
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, false, false, false, false, true><<<grid, TPB, sh, st>>>(                  \
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                 \
+    } else if (f16)                                                                                                          \
       conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, true><<<grid, TPB, sh, st>>>(                                     \
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, gsc);                       \
     else                                                                                                                     \
@@ -1361,7 +1434,8 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
 // one resident round.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
 inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
   static const bool use_p = [] { const char* e = getenv("SMSUT_CONV_PERSISTENT"); return !e || atoi(e) != 0; }();
-  return use_p && (Kdim == 16 || Kdim == 32 || Kdim == 64) && W % TW == 0 && H % 8 == 0 && Ndim % 16 == 0 &&
+  static const bool use_k8 = [] { const char* e = getenv("SMSUT_CONV_K8"); return !e || atoi(e) != 0; }();
+  return use_p && (Kdim == 16 || Kdim == 32 || Kdim == 64 || (Kdim == 8 && use_k8)) && W % TW == 0 && H % 8 == 0 && Ndim % 16 == 0 &&
          (int64_t)N * (H / 8) * (W / TW) * (Ndim / 16) >= 1024 && (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) < (1ll << 31);
 }
 
@@ -1374,6 +1448,7 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr) {
 #define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc
+  if (Kdim == 8) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, true>(PARGS);
 #ifndef SMSUT_P_OLD_TABLE
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
   if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(PARGS);
@@ -1573,7 +1648,7 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
 template <int KS, int CIT, int COT>
 int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int W, int Cin, int Cout,
                  const WgradPlan& p, int gsc, int ntaps, hipStream_t st, const float* x2 = nullptr, int ca = 0,
-                 const AffRef* aff = nullptr) {
+                 const AffRef* aff = nullptr, bool c8 = false) {
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
   constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;
@@ -1584,7 +1659,13 @@ int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int
   static_assert(sh <= 64 * 1024, "LDS budget");
   const int nci = (Cin + CI_T - 1) / CI_T;
   dim3 grid(p.splits, nci * ntaps, (Cout + CO_T - 1) / CO_T);
-  if (aff) {
+  if (c8) {
+    if constexpr (KS == 3 && CIT == 1) {
+      if (aff || x2 || gsc != 1 || Cin != 8) return -1;
+      conv_mfma_wgrad<KS, CIT, COT, false, false, true><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x,
+                                                                              p.tiles_y, p.tiles_per_split, gsc, nci, nullptr, 0);
+    } else return -1;
+  } else if (aff) {
     if (x2 || gsc != 1) return -1;
     conv_mfma_wgrad<KS, CIT, COT, false, true><<<grid, TPB, sh, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
                                                                      p.tiles_per_split, gsc, nci, nullptr, 0, *aff);
@@ -1803,8 +1884,10 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
     SMSUT_LAUNCH_CHECK();
     return SMSUT_OK;                                 // final values written directly: no split-slab sum
   } else {
-    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
-    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
+    static const bool use_c8 = [] { const char* e = getenv("SMSUT_CONV_K8"); return !e || atoi(e) != 0; }();
+    const bool c8 = use_c8 && Cin == 8 && !x2 && !aff;                    // tap pairs share an accumulator tile
+    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8);
+    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8);
     else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
     else if (H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
              (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {

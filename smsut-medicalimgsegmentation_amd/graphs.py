@@ -14,6 +14,7 @@ import os
 from typing import Callable, Iterable, Sequence
 
 import torch
+import torch.distributed
 
 
 def graphs_enabled(world: int, collective_free: bool = False) -> bool:
@@ -49,7 +50,10 @@ class GraphedPhase:
         torch.cuda.synchronize()
         self._clear()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # under torch.distributed the RCCL watchdog thread polls events while we capture: with the default "global" error
+        # mode any such call from ANOTHER thread can invalidate the capture; "thread_local" polices this thread only
+        mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.static_out = fn(*self.static_in)
         self.graph.replay()          # capture records without executing: run it once so static_out holds real values
 

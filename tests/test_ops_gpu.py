@@ -46,6 +46,8 @@ CONV_CASES = [
     (2, 8, 8, 6, 10, 3, 1, 1, False),
     # MFMA implicit-GEMM shapes: every tile config, ragged tiles, K chunk tails (Cin 8 / 24 / 40), N tails
     (2, 32, 32, 8, 16, 3, 1, 1, False),
+    (8, 128, 128, 8, 16, 3, 1, 1, False),       # 8-channel reduction on the persistent kernel: tap pairs share an MFMA
+    (5, 64, 128, 8, 32, 3, 1, 1, False),        # ... 8-row items, two output-channel tiles
     (1, 48, 40, 16, 16, 3, 1, 1, False),
     (2, 64, 64, 16, 32, 3, 1, 1, False),
     (1, 72, 80, 32, 64, 3, 1, 1, False),
@@ -340,7 +342,8 @@ def test_fused_in_statistics_match_standalone_pass(ops, n, h, ci, co, k):
 @pytest.mark.parametrize("n,h,ci,co", [(2, 32, 8, 16), (16, 32, 32, 64), (3, 24, 16, 16), (2, 16, 64, 32), (1, 40, 12, 20),
                                        # persistent-kernel sizes: stats epilogue, accumulate dgrad, IN-backward statistics in
                                        # the conv2 dgrad epilogue (Kdim = 16 / 32 / 64)
-                                       (8, 128, 16, 16), (5, 128, 16, 32), (4, 128, 64, 32), (9, 64, 32, 64)])
+                                       (8, 128, 16, 16), (5, 128, 16, 32), (4, 128, 64, 32), (9, 64, 32, 64),
+                                       (8, 128, 8, 16)])      # the first block after the stem: 8-channel tap-paired kernels
 def test_fused_basic_block_vs_torch(ops, n, h, ci, co):
     """The fused BasicBlock (forward + hand-written backward) against torch autograd of the reference
     composition (network/blocks.py:53-80), incl. the identity-shortcut form and ragged tiles."""
