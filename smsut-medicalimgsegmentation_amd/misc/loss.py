@@ -29,7 +29,8 @@ class DiceAndCrossEntropyLoss(nn.Module):
 
     def reduce_stats(self, flats):
         """Sum the flat statistics of any number of loss terms over the process group with ONE all-reduce (in place)."""
-        if self.world() > 1:
+        from .. import parallel
+        if self.world() > 1 or (parallel.force_dist() and self.process_group is not None and self.batch_dice):
             ops.all_reduce_dice_stats([tuple(flats)], self.process_group)
 
     def from_stats(self, x, y, flat):

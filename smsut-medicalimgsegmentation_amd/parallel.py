@@ -15,6 +15,13 @@ import torch
 import torch.distributed as dist
 
 
+def force_dist() -> bool:
+    """``SMSUT_FORCE_DIST=1``: run the collective code path even at world size 1 (a one-rank RCCL communicator) -- the
+    rehearsal of the multi-GPU path that a one-GPU box allows: communicator set-up, flat-buffer all-reduces on the side
+    stream, hipGraph capture next to the RCCL watchdog thread.  Numerically the identity."""
+    return os.environ.get("SMSUT_FORCE_DIST", "0") not in ("0", "")
+
+
 def init_from_env(backend: Optional[str] = None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
     Returns (rank, world, local_rank, group or None)."""
@@ -26,8 +33,9 @@ def init_from_env(backend: Optional[str] = None):
     forced = os.environ.get("SMSUT_FORCE_DEVICE")
     if forced is not None:
         local = int(forced)
-    if world <= 1:
+    if world <= 1 and not force_dist():
         return 0, 1, local, None
+    world = max(world, 1)
     if backend is None:
         backend = os.environ.get("SMSUT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
@@ -58,7 +66,7 @@ class GradAllReducer:
         self._flat: Optional[torch.Tensor] = None
 
     def reduce(self):
-        if self.world <= 1:
+        if self.world <= 1 and not (force_dist() and self.group is not None):
             return
         dev = self.params[0].device
         if self._flat is None or self._flat.device != dev:
@@ -92,7 +100,7 @@ class GradAllReducer:
 
 def broadcast_parameters(module: torch.nn.Module, group=None, src: int = 0):
     """Make every rank start from rank ``src``'s weights."""
-    if group is None or not dist.is_initialized() or dist.get_world_size(group) <= 1:
+    if group is None or not dist.is_initialized() or (dist.get_world_size(group) <= 1 and not force_dist()):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         flat = _flat_memory(t.data)

@@ -139,3 +139,58 @@ def test_two_rank_gloo_on_device():
                 assert abs(got[k] - logs[k]) < 1e-3 * abs(logs[k]), (k, got[k], logs[k])
             assert gerr < 2e-2, gerr
         assert res["ugan_graph"]["mode"].startswith("graph"), res["ugan_graph"]
+
+
+def _rccl_worker(q, force):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", SMSUT_FORCE_DIST="1" if force else "0")
+    os.environ.pop("SMSUT_DIST_BACKEND", None)
+    import smsut_amd  # noqa: F401
+    from smsut_amd import config as cfg
+    from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer
+    from smsut_amd.trainer.unetTrainer import UnetTrainer
+    from oracle import recipe
+    import torch.distributed as dist
+    cfg.input_size, cfg.batch_size = 64, 2
+    ut = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+    assert (ut.group is not None) == force
+    if force:
+        assert dist.get_backend() == "nccl"
+    ut.net.load_state_dict(recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 61)); ut.D.load_state_dict(recipe.fill(recipe.disc_shapes(64, 4, 16, 256), 62))
+    ut.net.train(); ut.D.train(); ut.epoch, ut.iter = 100, 15000
+    scal = []
+    for it in range(5):                                   # eager, capture, three replays -- with the all-reduces in between
+        x, y, modal, mj, alpha, ids = recipe.trace_inputs(it, b=4, size=64, base=900)
+        scal.append(ut.train_iteration(x.cuda(), y.cuda(), modal, mj=mj, alpha=alpha.cuda(), sample_ids=[ids.cuda()]).tolist())
+    cfg.n_label, cfg.base_width, cfg.batch_size = 2, 8, 4
+    tr = UnetTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+    tr.net.load_state_dict(recipe.fill(recipe.unet_shapes(1, 3, 8), 3)); tr.net.train()
+    losses = []
+    for it in range(4):
+        xg = recipe.synth_images((4, 1, 64, 64), 40 + it); yg = recipe.synth_labels(4, 64, 64, 3, 50 + it, block=8)
+        losses.append(float(tr.train_step(xg.cuda(), yg.cuda()).item()))
+    torch.cuda.synchronize()
+    q.put((scal, losses, ut.graph_report(), float(sum(p.double().sum() for p in ut.net.parameters()))))
+    if force:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_one_rank_rccl_rehearsal_is_the_identity():
+    """The collective code path over RCCL itself, as far as a one-GPU box allows (``SMSUT_FORCE_DIST=1``: a one-rank ``nccl``
+    communicator): gradient all-reduces on the side stream, the Dice-statistics all-reduce between captured phases, hipGraph
+    capture next to the RCCL watchdog thread.  Five uganConsis iterations and four U-Net steps must reproduce the plain
+    single-process run bit for bit."""
+    ctx = mp.get_context("spawn")
+    out = []
+    for force in (False, True):
+        q = ctx.Queue()
+        p = ctx.Process(target=_rccl_worker, args=(q, force))
+        p.start()
+        out.append(q.get(timeout=600))
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (s0, l0, g0, w0), (s1, l1, g1, w1) = out
+    assert s0 == s1 and l0 == l1 and w0 == w1, (s0[-1], s1[-1], l0, l1)
+    assert g1["mode"] == "graph" and g1["fallback"] is False
