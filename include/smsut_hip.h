@@ -142,6 +142,17 @@ int smsut_conv2d_wgrad_f16(const float* x, const float* x2 /*nullable*/, int ca,
 int64_t smsut_absmax_scale_ws(int64_t n);
 int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace, void* stream);
 
+/* 4x4 stride-1 pad-1 convolutions on the matrix cores: networks.NLayerDiscriminator / PatchDiscriminator (reference
+ * network/networks.py:977-1032, 64 -> 128 -> 256 -> 512 channels).  (H, W) = extents of the conv's forward input; the output
+ * is (H-1) x (W-1).  transposed = 0: x [N,H,W,Cin] -> y [N,H-1,W-1,Cout]; transposed = 1 (data-gradient): x = gy
+ * [N,H-1,W-1,Cout] -> y = gx [N,H,W,Cin].  Weights [4][4][Cin][Cout]; Cin, Cout multiples of 4. */
+int smsut_conv2d_k4_supported(int Cin, int Cout);
+int smsut_conv2d_k4_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int transposed,
+                        void* stream);
+int64_t smsut_conv2d_k4_wgrad_ws(int N, int H, int W, int Cin, int Cout);
+int smsut_conv2d_k4_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                          void* stream);
+
 /* thin 1x1 layers (Cout <= 8, Cin in {8,16,32,64}; reference: the nn.Conv2d heads at network/blocks.py:123-125 and
    network/ugan.py:70): data-gradient gx[P][Cin] = gy[P][Cout] W^T and weight-gradient gw[Cin][Cout], both streaming. */
 int smsut_conv1x1_thin_supported(int Cin, int Cout);

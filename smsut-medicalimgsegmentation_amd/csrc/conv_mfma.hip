@@ -1614,6 +1614,229 @@ plane_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __
   }
 }
 
+// ---- 4x4 stride-1 pad-1 convolutions on the matrix cores (networks.NLayerDiscriminator / PatchDiscriminator, reference
+// network/networks.py:977-1032: 64 -> 128 -> 256 -> 512 channels -- the place where north_star's "4x4 conv inner contractions"
+// live).  An even kernel has an asymmetric halo and an output one pixel smaller than its input, so these are separate kernels
+// with explicit input / output extents instead of more parameters on the "same"-conv kernels above:
+//   forward   x [N,Hi,Wi,K] -> y [N,Ho,Wo,Nd], Ho = Hi + 2*pad - 3, pad = 1
+//   dgrad     the same kernel on gy [N,Hi-1,Wi-1,Cout] with pad = 2, weights read transposed and tap-flipped -> gx [N,Hi,Wi,Cin]
+// Same tiling as conv_mfma_fwd: TH x 16 output pixels x 16*NTN channels per workgroup, 16-channel K chunks staged in LDS with
+// the halo ((TH+3) x 19 pixels, stride 24 floats), 16 taps x 4 MFMAs per chunk and accumulator tile, next chunk prefetched
+// into registers under the MFMAs.
+template <int TH, int NTN>
+__global__ void __launch_bounds__(TPB)
+conv_k4_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int Hi, int Wi, int Ho, int Wo,
+            int Kdim, int Ndim, int tiles_x, int pad, int transposed) {
+  constexpr int KS = 4, KK = 16;
+  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  constexpr int CO_T = 16 * NTN, MR = TH / 4, NR = NTN;
+  extern __shared__ float smem[];
+  float* in_s = smem;                        // [IH][IW][SPIX]
+  float* w_s = smem + IH * IW * SPIX;        // [KK][4][CO_T][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  const int n_img = blockIdx.y, co0 = blockIdx.z * CO_T;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const float* xin = x + (size_t)n_img * Hi * Wi * Kdim;
+  f32x4 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NI = (IH * IW * 4 + TPB - 1) / TPB, NW = (KK * 4 * CO_T + TPB - 1) / TPB;
+  float4 rin[NI], rw[NW];
+  int in_off[NI], w_off[NW];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int u = tid + i * TPB, q = u & 3, pix = u >> 2;
+    const int gy_ = y0 + pix / IW - pad, gx_ = x0 + pix % IW - pad;
+    in_off[i] = (u < IH * IW * 4 && gy_ >= 0 && gy_ < Hi && gx_ >= 0 && gx_ < Wi) ? (gy_ * Wi + gx_) * Kdim + 4 * q : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int u = tid + i * TPB, n = u % CO_T, k4 = (u / CO_T) & 3, tap = u / (4 * CO_T), ng = co0 + n;
+    w_off[i] = !(u < KK * 4 * CO_T && ng < Ndim) ? -1
+               : (!transposed ? (tap * Kdim + 4 * k4) * Ndim + ng : ((KK - 1 - tap) * Ndim + ng) * Kdim + 4 * k4);
+  }
+  auto prefetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in_off[i] >= 0 && c0 + 4 * ((tid + i * TPB) & 3) < Kdim) v = *(const float4*)(xin + in_off[i] + c0);
+      rin[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k4 = ((tid + i * TPB) / CO_T) & 3;
+      if (w_off[i] >= 0 && c0 + 4 * k4 < Kdim) {
+        if (!transposed) {
+          const float* p = w + w_off[i] + (size_t)c0 * Ndim;
+          v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim];
+        } else v = *(const float4*)(w + w_off[i] + c0);
+      }
+      rw[i] = v;
+    }
+  };
+  prefetch(0);
+  for (int c0 = 0; c0 < Kdim; c0 += CK) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int u = tid + i * TPB;
+      if (u < IH * IW * 4) *(float4*)(in_s + (u >> 2) * SPIX + 4 * (u & 3)) = rin[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int u = tid + i * TPB;
+      if (u < KK * 4 * CO_T) *(float4*)(w_s + (size_t)u * 4) = rw[i];
+    }
+    __syncthreads();
+    if (c0 + CK < Kdim) prefetch(c0 + CK);
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      const int kh = tap / KS, kw = tap % KS;
+      f32x4 a[MR], b[NR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) a[i] = *(const f32x4*)(in_s + ((wave * MR + i + kh) * IW + lm + kw) * SPIX + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) b[j] = *(const f32x4*)(w_s + (((tap * 4 + kq) * CO_T) + j * 16 + lm) * 4);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s4], b[j][s4], acc[i][j]);
+    }
+  }
+  float* yout = y + (size_t)n_img * Ho * Wo * Ndim;
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    const int gy_ = y0 + wave * MR + i;
+    if (gy_ >= Ho) continue;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int co = co0 + j * 16 + lm;
+      if (co >= Ndim) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gx_ = x0 + 4 * kq + r;
+        if (gx_ < Wo) yout[((size_t)gy_ * Wo + gx_) * Ndim + co] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// weight gradient of the 4x4 s1 p1 conv: gW[tap][ci][co] = sum over output pixels of x[p + tap - 1][ci] * gy[p][co].  A workgroup
+// owns a 16 x 16*COT slab for all 16 taps and walks 8x16-OUTPUT-pixel tiles of a split; waves split the tile rows, fixed-order
+// combine, per-split slabs summed by sum_splits (as conv_mfma_wgrad).
+template <int COT>
+__global__ void __launch_bounds__(TPB)
+conv_k4_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int Hi, int Wi,
+              int Ho, int Wo, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split) {
+  constexpr int KS = 4, KK = 16, PAD = 1;
+  constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
+  constexpr int CO_T = 16 * COT, SI = 16, SO = (CO_T % 32 == 16) ? CO_T : CO_T + 16;
+  constexpr int NACC = KK * COT;
+  extern __shared__ float smem[];
+  float* in_s = smem;                         // [IH][IW][SI]
+  float* gy_s = smem + IH * IW * SI;          // [WTH][TW][SO]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x, ci0 = blockIdx.y * 16, co0 = blockIdx.z * CO_T;
+  const int tiles_img = tiles_x * tiles_y, total_tiles = N * tiles_img;
+  const int t_begin = split * tiles_per_split, t_end = min(t_begin + tiles_per_split, total_tiles);
+  f32x4 acc[NACC];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NIN = (IH * IW * 4 + TPB - 1) / TPB, NGY = (WTH * TW * (CO_T / 4) + TPB - 1) / TPB;
+  float4 rin[NIN], rgy[NGY];
+  auto prefetch = [&](int t) {
+    const int n_img = t / tiles_img, rem = t % tiles_img;
+    const int y0 = (rem / tiles_x) * WTH, x0 = (rem % tiles_x) * TW;
+    const float* xin = x + (size_t)n_img * Hi * Wi * Cin;
+    const float* gin = gy + (size_t)n_img * Ho * Wo * Cout;
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int u = tid + i * TPB, q = u & 3, pix = u >> 2;
+      const int gy_ = y0 + pix / IW - PAD, gx_ = x0 + pix % IW - PAD, c = ci0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < IH * IW * 4 && c < Cin && gy_ >= 0 && gy_ < Hi && gx_ >= 0 && gx_ < Wi)
+        v = *(const float4*)(xin + ((size_t)gy_ * Wi + gx_) * Cin + c);
+      rin[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < NGY; ++i) {
+      const int u = tid + i * TPB, q = u % (CO_T / 4), pix = u / (CO_T / 4);
+      const int gy_ = y0 + pix / TW, gx_ = x0 + pix % TW, c = co0 + 4 * q;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (u < WTH * TW * (CO_T / 4) && c < Cout && gy_ < Ho && gx_ < Wo) v = *(const float4*)(gin + ((size_t)gy_ * Wo + gx_) * Cout + c);
+      rgy[i] = v;
+    }
+  };
+  if (t_begin < t_end) prefetch(t_begin);
+  for (int t = t_begin; t < t_end; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+      const int u = tid + i * TPB;
+      if (u < IH * IW * 4) *(float4*)(in_s + (u >> 2) * SI + 4 * (u & 3)) = rin[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NGY; ++i) {
+      const int u = tid + i * TPB;
+      if (u < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + (u / (CO_T / 4)) * SO + 4 * (u % (CO_T / 4))) = rgy[i];
+    }
+    __syncthreads();
+    if (t + 1 < t_end) prefetch(t + 1);
+#pragma unroll
+    for (int rr = 0; rr < WTH / 4; ++rr) {
+      const int r = wave * (WTH / 4) + rr;
+#pragma unroll
+      for (int ks = 0; ks < TW / 4; ++ks) {
+        const int px = ks * 4 + kq;
+        float b[COT];
+#pragma unroll
+        for (int j = 0; j < COT; ++j) b[j] = gy_s[(r * TW + px) * SO + j * 16 + lm];
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+          const float a = in_s[((r + tap / KS) * IW + px + tap % KS) * SI + lm];
+#pragma unroll
+          for (int j = 0; j < COT; ++j) acc[tap * COT + j] = mfma16(a, b[j], acc[tap * COT + j]);
+        }
+      }
+    }
+  }
+  float* red = smem;
+  for (int src = 1; src < 4; ++src) {
+    __syncthreads();
+    if (wave == src) {
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) *(f32x4*)(red + ((size_t)k * 64 + lane) * 4) = acc[k];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int k = 0; k < NACC; ++k) acc[k] += *(const f32x4*)(red + ((size_t)k * 64 + lane) * 4);
+    }
+  }
+  if (wave == 0) {
+    float* out = part + (size_t)split * KK * Cin * Cout;
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+      for (int j = 0; j < COT; ++j) {
+        const int co = co0 + j * 16 + lm;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ci = ci0 + 4 * kq + r;
+          if (ci < Cin && co < Cout) out[((size_t)tap * Cin + ci) * Cout + co] = acc[tap * COT + j][r];
+        }
+      }
+  }
+}
+
 struct WgradPlan { int cit, cot, splits, tiles_per_split, tiles_x, tiles_y; };
 
 WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
@@ -2042,6 +2265,74 @@ int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace,
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   k_absmax_partial<<<blocks, TPB, 0, st>>>(x, n, workspace);
   k_absmax_final<<<1, TPB, 0, st>>>(workspace, blocks, out2);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// ---- 4x4 stride-1 pad-1 convolutions (networks.NLayerDiscriminator, reference network/networks.py:977-1032) -----------------
+// (H, W) are always the extents of the conv's FORWARD INPUT; its output is (H-1) x (W-1).
+int smsut_conv2d_k4_supported(int Cin, int Cout) { return Cin >= 4 && Cin % 4 == 0 && Cout >= 4 && Cout % 4 == 0; }
+// transposed = 0: x [N,H,W,Cin] -> y [N,H-1,W-1,Cout];  transposed = 1: x = gy [N,H-1,W-1,Cout] -> y = gx [N,H,W,Cin]
+int smsut_conv2d_k4_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, int transposed,
+                        void* stream) {
+  SMSUT_REQUIRE(x && w && y && N > 0 && H > 1 && W > 1 && smsut_conv2d_k4_supported(Cin, Cout) && (transposed & ~1) == 0);
+  SMSUT_REQUIRE((int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31));
+  const int Hi = transposed ? H - 1 : H, Wi = transposed ? W - 1 : W, Ho = transposed ? H : H - 1, Wo = transposed ? W : W - 1;
+  const int Kdim = transposed ? Cout : Cin, Ndim = transposed ? Cin : Cout, pad = transposed ? 2 : 1;
+  constexpr int TH = 8;
+  const int tiles_x = (Wo + TW - 1) / TW, tiles_y = (Ho + TH - 1) / TH;
+  hipStream_t st = (hipStream_t)stream;
+  if (Ndim % 32 == 0 || Ndim > 16) {
+    constexpr size_t sh = (size_t)((TH + 3) * (TW + 3) * SPIX + 16 * CK * 32) * sizeof(float);
+    conv_k4_fwd<TH, 2><<<dim3(tiles_x * tiles_y, N, (Ndim + 31) / 32), TPB, sh, st>>>(x, w, y, Hi, Wi, Ho, Wo, Kdim, Ndim, tiles_x,
+                                                                                    pad, transposed);
+  } else {
+    constexpr size_t sh = (size_t)((TH + 3) * (TW + 3) * SPIX + 16 * CK * 16) * sizeof(float);
+    conv_k4_fwd<TH, 1><<<dim3(tiles_x * tiles_y, N, (Ndim + 15) / 16), TPB, sh, st>>>(x, w, y, Hi, Wi, Ho, Wo, Kdim, Ndim, tiles_x,
+                                                                                    pad, transposed);
+  }
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+static WgradPlan plan_wgrad_k4(int N, int H, int W, int Cin, int Cout) {
+  WgradPlan p;
+  p.cit = 1; p.cot = (Cout > 16) ? 2 : 1;
+  p.tiles_x = (W - 1 + TW - 1) / TW;
+  p.tiles_y = (H - 1 + WTH - 1) / WTH;
+  const int total = N * p.tiles_x * p.tiles_y;
+  const int slabs = ((Cin + 15) / 16) * ((Cout + 16 * p.cot - 1) / (16 * p.cot));
+  int want = (512 + slabs - 1) / slabs;
+  const int64_t wsz = (int64_t)Cin * Cout * 16;
+  int cap = (int)(((int64_t)8 << 20) / wsz);
+  if (cap < 1) cap = 1;
+  if (want > cap) want = cap;
+  if (want > total) want = total;
+  if (want < 1) want = 1;
+  p.tiles_per_split = (total + want - 1) / want;
+  p.splits = (total + p.tiles_per_split - 1) / p.tiles_per_split;
+  return p;
+}
+int64_t smsut_conv2d_k4_wgrad_ws(int N, int H, int W, int Cin, int Cout) {
+  return (int64_t)plan_wgrad_k4(N, H, W, Cin, Cout).splits * 16 * Cin * Cout;
+}
+// x [N,H,W,Cin], gy [N,H-1,W-1,Cout] -> gw [4][4][Cin][Cout]
+int smsut_conv2d_k4_wgrad(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin, int Cout,
+                          void* stream) {
+  SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 1 && W > 1 && smsut_conv2d_k4_supported(Cin, Cout));
+  SMSUT_REQUIRE((int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31));
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = plan_wgrad_k4(N, H, W, Cin, Cout);
+  constexpr int IH = WTH + 3, IW = TW + 3;
+  if (p.cot == 2) {
+    constexpr size_t stage = (size_t)(IH * IW * 16 + WTH * TW * 48) * sizeof(float), red = (size_t)32 * 64 * 4 * sizeof(float);
+    conv_k4_wgrad<2><<<dim3(p.splits, (Cin + 15) / 16, (Cout + 31) / 32), TPB, stage > red ? stage : red, st>>>(
+        x, gy, workspace, N, H, W, H - 1, W - 1, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_per_split);
+  } else {
+    constexpr size_t stage = (size_t)(IH * IW * 16 + WTH * TW * 16) * sizeof(float), red = (size_t)16 * 64 * 4 * sizeof(float);
+    conv_k4_wgrad<1><<<dim3(p.splits, (Cin + 15) / 16, (Cout + 15) / 16), TPB, stage > red ? stage : red, st>>>(
+        x, gy, workspace, N, H, W, H - 1, W - 1, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_per_split);
+  }
+  launch_sum_splits(workspace, gw, 16 * Cin * Cout, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

@@ -204,6 +204,12 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False, f16=False):
             H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, wd, ci, co, kh, 0, _s())
         if bias is not None:
             H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
+    elif (kh == 4 and kw == 4 and stride == 1 and pad == 1 and not FORCE_GENERIC_CONV
+          and H.call("smsut_conv2d_k4_supported", ci, co)):
+        # networks.NLayerDiscriminator (networks.py:977-1032): 4x4 s1 p1 on the matrix cores
+        H.call("smsut_conv2d_k4_fwd", x, w, y, n, h, wd, ci, co, 0, _s())
+        if bias is not None:
+            H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
     elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_small_supported", kh, ci, co):
         H.call("smsut_conv2d_small_fwd", x, w, bias, y, n, h, wd, ci, ho, wo, co, kh, stride, pad, _s())
     else:
@@ -228,6 +234,9 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad, f16=False):
             H.call("smsut_conv2d_fwd_mfma_f16", gy, w, gx, _grad_scale(gy), n, h, wd, co, ci, kh, 1, _s())
         else:
             H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
+    elif (kh == 4 and kw == 4 and stride == 1 and pad == 1 and not FORCE_GENERIC_CONV
+          and H.call("smsut_conv2d_k4_supported", ci, co)):
+        H.call("smsut_conv2d_k4_fwd", gy, w, gx, n, h, wd, ci, co, 1, _s())
     elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_small_supported", kh, ci, co):
         H.call("smsut_conv2d_small_dgrad", gy, w, gx, n, h, wd, ci, ho, wo, co, kh, stride, pad, _s())
     else:
@@ -254,6 +263,10 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad, f16=False):
     if kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_wgrad_mfma_supported", kh, stride, pad, ci, co):
         ws = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, wd, ci, co, kh), x)
         H.call("smsut_conv2d_wgrad_mfma", x, gy, gw, ws, n, h, wd, ci, co, kh, _s())
+    elif (kh == 4 and kw == 4 and stride == 1 and pad == 1 and not FORCE_GENERIC_CONV
+          and H.call("smsut_conv2d_k4_supported", ci, co)):
+        ws = _ws(H.call("smsut_conv2d_k4_wgrad_ws", n, h, wd, ci, co), x)
+        H.call("smsut_conv2d_k4_wgrad", x, gy, gw, ws, n, h, wd, ci, co, _s())
     elif kh == kw and not FORCE_GENERIC_CONV and H.call("smsut_conv2d_flat_wgrad_supported", kh, stride, ci, co):
         ws = _ws(H.call("smsut_conv2d_flat_wgrad_ws", n, ho, wo, ci, co, kh), x)
         H.call("smsut_conv2d_flat_wgrad", x, gy, gw, ws, n, h, wd, ci, ho, wo, co, kh, stride, pad, _s())

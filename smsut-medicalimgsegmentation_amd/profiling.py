@@ -39,6 +39,8 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_fwd_mfma_stats_cat": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_mfma_cat": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * _k2(a, 6), "mfma"),
     "smsut_conv2d_fwd_mfma_split": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
+    "smsut_conv2d_k4_fwd": (lambda a: 32.0 * a[0] * (a[1] - 1) * (a[2] - 1) * a[3] * a[4], "mfma"),
+    "smsut_conv2d_k4_wgrad": (lambda a: 32.0 * a[0] * (a[1] - 1) * (a[2] - 1) * a[3] * a[4], "mfma"),
     # fp16-operand forms (config 5)
     "smsut_conv2d_fwd_mfma_f16": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
     "smsut_conv2d_fwd_mfma_stats_f16": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),

@@ -53,6 +53,11 @@ CONV_CASES = [
     (1, 72, 80, 32, 64, 3, 1, 1, False),
     (2, 32, 32, 64, 128, 3, 1, 1, False),
     (2, 16, 16, 24, 40, 3, 1, 1, False),
+    # 4x4 stride-1 pad-1 on the matrix cores (networks.NLayerDiscriminator, networks.py:977-1032): output (H-1) x (W-1)
+    (2, 32, 32, 64, 128, 4, 1, 1, True),
+    (1, 31, 45, 16, 16, 4, 1, 1, False),
+    (3, 16, 16, 128, 256, 4, 1, 1, True),
+    (2, 9, 20, 20, 12, 4, 1, 1, False),
     (3, 8, 8, 40, 256, 3, 1, 1, False),
     (2, 4, 4, 128, 256, 3, 1, 1, False),
     (2, 20, 12, 12, 5, 3, 1, 1, False),
