@@ -86,6 +86,10 @@ class BaseTrainer(abc.ABC):
         maybe_mkdir(root, *(pjoin(root, d) for d in ("ckpt", "tb", "result", "sample")))
         logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s: %(message)s")
         self.logger = logging.getLogger("FileLogger")
+        self.logger.setLevel(logging.INFO)           # (basicConfig is a no-op when the host application configured logging first)
+        for h in list(self.logger.handlers):         # one run directory per trainer: do not keep writing into an earlier one
+            if isinstance(h, logging.FileHandler):
+                self.logger.removeHandler(h); h.close()
         self.logger.addHandler(logging.FileHandler(pjoin(root, "train.log"), mode="a", encoding="utf-8"))
         self.info(f"Create train environment in {root}.")
 

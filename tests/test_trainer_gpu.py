@@ -313,3 +313,49 @@ def test_checkpoint_resume_round_trip(small_cfg, tmp_path):
         assert all(v.is_contiguous() for v in sd.values())
     finally:
         cfg.expr_root = old_root
+
+
+def test_cli_train_then_test_entry_points(small_cfg, tmp_path):
+    """The reference's entry points (trainer/uganConsisTrainer.py:307-334: ``-p train -f 0 -nm NAME`` then ``-p test -i ID -wh
+    last``) end to end on the synthetic slice source: fit() = train_epoch + validate_epoch + Dice matrix + best / last
+    checkpoints, then load_model + test() writing the modality x organ Dice matrix."""
+    import os
+    from smsut_amd.trainer import uganConsisTrainer as T
+    cfg = small_cfg
+    old = (cfg.num_iter_per_epoch, cfg.max_epoch, cfg.expr_root)
+    cfg.input_size, cfg.batch_size = 64, 2
+    cfg.num_iter_per_epoch, cfg.max_epoch, cfg.expr_root = 4, 2, str(tmp_path)
+    try:
+        T.main(["-p", "train", "-f", "0", "-nm", "cli"])
+        root = os.path.join(str(tmp_path), "cli", "000")
+        assert sorted(os.listdir(os.path.join(root, "ckpt"))) == ["best_D.ckpt", "best_G.ckpt", "best_state.ckpt", "last_D.ckpt",
+                                                                "last_G.ckpt", "last_state.ckpt"]
+        log = open(os.path.join(root, "train.log")).read()
+        assert "[TRN] Epoch: 1/2" in log and "[TST] Epoch: 1/2" in log
+        T.main(["-p", "test", "-f", "0", "-nm", "cli", "-i", "000", "-wh", "last"])
+        mo = np.loadtxt(os.path.join(str(tmp_path), "cli", "000", "dice_matrix.csv"), delimiter=",")
+        assert mo.shape == (cfg.n_modal + 1, cfg.n_label + 1) and np.isfinite(mo).all() and (mo >= 0).all() and (mo <= 1).all()
+        # a reference nn.Module can load the weights as they are: plain OIHW tensors under the reference's keys
+        sd = torch.load(os.path.join(root, "ckpt", "last_G.ckpt"))
+        assert "tsl_encoder.pre.0.weight" in sd and tuple(sd["tsl_encoder.pre.0.weight"].shape) == (8, 5, 5, 5)
+    finally:
+        cfg.num_iter_per_epoch, cfg.max_epoch, cfg.expr_root = old
+
+
+def test_cli_unet_trainer_entry_points(small_cfg, tmp_path):
+    """``trainer/unetTrainer.py`` (BASELINE config 1's entry point): ``-p train`` then ``-p test -i 000`` on synthetic slices."""
+    import os
+    from smsut_amd.trainer import unetTrainer as T
+    cfg = small_cfg
+    old = (cfg.num_iter_per_epoch, cfg.max_epoch, cfg.expr_root)
+    cfg.input_size, cfg.batch_size = 64, 4
+    cfg.num_iter_per_epoch, cfg.max_epoch, cfg.expr_root = 4, 2, str(tmp_path)
+    try:
+        T.main(["-p", "train", "-nm", "u"])
+        root = os.path.join(str(tmp_path), "u", "000")
+        assert sorted(os.listdir(os.path.join(root, "ckpt"))) == ["best.ckpt", "best_state.ckpt", "last.ckpt", "last_state.ckpt"]
+        T.main(["-p", "test", "-nm", "u", "-i", "000", "-wh", "best"])
+        mo = np.loadtxt(os.path.join(root, "dice_matrix.csv"), delimiter=",")
+        assert mo.shape == (cfg.n_modal + 1, cfg.n_label + 1) and np.isfinite(mo).all()
+    finally:
+        cfg.num_iter_per_epoch, cfg.max_epoch, cfg.expr_root = old
