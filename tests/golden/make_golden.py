@@ -243,14 +243,15 @@ def gen_networks_zoo():
     save("networks_zoo", **rec)
 
 
-def gen_iter_small():
+def gen_iter_small(dtype=torch.float32, name="iter_small"):
     """Two uganConsis iterations (uganConsisTrainer.py:110-203) at 64x64, B = 2 labeled + 2 unlabeled,
     PatchNCELoss(2) fed B=4 (the reference's batch_size/B mismatch), iter >= 1000 so the
     consistency branch runs; all 10 scalars per iteration + post-step weight slices."""
     seed, bs, H, nm = 61, 2, 64, 4
     B = 2 * bs
-    G = load(UGANnce(1, 5, nm, 16), recipe.ugan_shapes(1, 5, nm, 16), seed)
-    D = load(Discriminator(H, nm, 16, max_width=256), recipe.disc_shapes(H, nm, 16, 256), seed + 1)
+    torch.set_default_dtype(dtype)
+    G = load(UGANnce(1, 5, nm, 16), recipe.ugan_shapes(1, 5, nm, 16), seed).to(dtype)
+    D = load(Discriminator(H, nm, 16, max_width=256), recipe.disc_shapes(H, nm, 16, 256), seed + 1).to(dtype)
     G.train(); D.train()
     crit = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)
     nce = PatchNCELoss(bs)
@@ -270,11 +271,11 @@ def gen_iter_small():
     logs_all = []
     for step in range(2):
         it = it0 + step
-        x_real = recipe.synth_images((B, 1, H, H), seed + 10 + step)
+        x_real = recipe.synth_images((B, 1, H, H), seed + 10 + step).to(dtype)
         y_real = recipe.synth_labels(bs, H, H, 5, seed + 20 + step, block=8)
         modal_org = torch.tensor([1] * bs + [3] * bs)
         mj = (step + 2) % nm
-        alpha = torch.from_numpy(np.random.RandomState(seed + 30 + step).standard_normal((B, 1, 1, 1))).float()
+        alpha = torch.from_numpy(np.random.RandomState(seed + 30 + step).standard_normal((B, 1, 1, 1))).float().to(dtype)
         ids = torch.from_numpy(np.random.RandomState(seed + 40 + step).permutation(16)[:64].astype(np.int64))
         modal_trg = torch.zeros_like(modal_org).fill_(mj)
         vec_org, vec_trg = onehot(modal_org), onehot(modal_trg)
@@ -339,7 +340,14 @@ def gen_iter_small():
     rec["post_G_tsl_pre"] = npy(gsd["tsl_encoder.pre.0.weight"])
     rec["post_D_cls"] = npy(dsd["conv_cls.weight"])
     rec["post_D_stem"] = npy(dsd["main.0.weight"])
-    save("iter_small", **rec)
+    save(name, **rec)
+    torch.set_default_dtype(torch.float32)
+
+
+def gen_iter_small_f64():
+    """The same two iterations with the reference's modules in fp64: the spread against ``iter_small`` is the reference's own
+    sensitivity to rounding, which bounds the bands of tests/test_trainer_gpu.py (tests/trace_bands.py)."""
+    gen_iter_small(dtype=torch.float64, name="iter_small_f64")
 
 
 def gen_siblings():

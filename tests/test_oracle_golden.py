@@ -246,3 +246,23 @@ def test_trace_bands_cover_reference_fp_spread(golden):
     # and the D-side really is chaotic in the reference itself (why it is not banded at all past iteration 0)
     i = names.index("G_fake")
     assert float(np.abs(a["scalars"][3:n, i] - b["scalars"][3:n, i]).max()) > 0.3
+
+
+def test_iter_small_bands_cover_reference_fp_spread(golden):
+    """The per-scalar bands of tests/test_trainer_gpu.py::test_ugan_consis_iterations_match_golden against the reference's OWN
+    fp32-vs-fp64 deviation on the same two iterations (iter_small.npz / iter_small_f64.npz, both replayed with the reference's
+    modules): a band may not be tighter than that deviation, nor looser than 4x it + 1e-2 relative + 5e-3 absolute."""
+    from trace_bands import ITER_SMALL_STEP0, ITER_SMALL_STEP1, ITER_SMALL_TSL_PRE
+    a, b = golden("iter_small"), golden("iter_small_f64")
+    names = [str(s) for s in a["scalar_names"]]
+    for i, k in enumerate(names):
+        r32, r64 = a["scalars"][0, i], b["scalars"][0, i]
+        tol = ITER_SMALL_STEP0.get(k, ITER_SMALL_STEP0["default"])
+        assert abs(r32 - r64) <= tol * abs(r64) + 1e-6 <= 4 * abs(r32 - r64) + 1e-2 * abs(r64) + 5e-3, (0, k)
+        r32, r64 = a["scalars"][1, i], b["scalars"][1, i]
+        rel, ab = ITER_SMALL_STEP1[k]
+        band = rel * abs(r64) + ab
+        assert abs(r32 - r64) <= band <= 4 * abs(r32 - r64) + 1e-2 * abs(r64) + 5e-3, (1, k, abs(r32 - r64), band)
+    for key, fx in (("post0", "post0_G_tsl_pre"), ("post1", "post_G_tsl_pre")):
+        spread = rel_err(a[fx], b[fx])
+        assert spread <= ITER_SMALL_TSL_PRE[key] <= 4 * spread + 1e-2, (key, spread)

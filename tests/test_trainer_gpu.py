@@ -8,6 +8,7 @@ import torch
 
 from conftest import rel_err, l2_rel
 from oracle import recipe
+from trace_bands import ITER_SMALL_STEP0, ITER_SMALL_STEP1, ITER_SMALL_TSL_PRE
 
 pytestmark = pytest.mark.gpu
 
@@ -45,43 +46,33 @@ def test_ugan_consis_iterations_match_golden(small_cfg, golden):
         ref = g["scalars"][step]
         report = dict(zip(SCALARS, zip(got, ref)))
         if step == 0:
-            # north_star bar: 1e-3 relative on loss values.  Two documented exceptions, both discontinuity-driven
-            #  and both reproduced by the reference arithmetic itself (fp32 vs fp64, oracle/):
-            #  * D_gp is the squared norm of a gradient that passes LeakyReLU masks; in this fixture one block-3
-            #    activation of sample 3 is -1.1e-8 on one summation order and +4.8e-7 on another (measured), which
-            #    moves that sample's gradient norm by 0.36 % -> D_gp by 0.3 %.  Bar 1e-2.
-            #  * G_fake / G_cls are evaluated through D AFTER its first Adam step (every weight moves by +-lr,
-            #    sign of the gradient), so they inherit any such flip at O(10 %).  Banded.
-            tight = [SCALARS.index(k) for k in ("D_real", "D_fake", "D_cls", "G_rec", "G_seg", "G_semi", "G_nce")]
-            assert np.allclose(got[tight], ref[tight], rtol=1e-3, atol=1e-5), (step, report)
-            i_gp = SCALARS.index("D_gp")
-            assert abs(got[i_gp] - ref[i_gp]) <= 1e-2 * abs(ref[i_gp]), (step, report)
-            band = [SCALARS.index(k) for k in ("G_fake", "G_cls")]
-            assert np.all(np.abs(got[band] - ref[band]) <= 0.25 * np.abs(ref[band]) + 0.02), (step, report)
+            # north_star bar: 1e-3 relative on every loss value (D_gp included: 5e-5 measured); G_fake at 3e-3 -- it passes
+            # through D after D's first Adam step and the reference's own fp32 / fp64 replays differ by 1.26e-3 there
+            # (tests/trace_bands.py, justified by iter_small_f64.npz in tests/test_oracle_golden.py)
+            for i, k in enumerate(SCALARS):
+                tol = ITER_SMALL_STEP0.get(k, ITER_SMALL_STEP0["default"])
+                assert abs(got[i] - ref[i]) <= tol * abs(ref[i]) + 1e-6, (step, k, report)
             # Adam's first update moves EVERY D weight by +-lr (sign of the gradient), SGD moves G by lr*grad:
-            # check the post-step weights element-wise.  Elements whose gradient is ~0 may flip sign in fp32
-            # (the reference's own fp32-vs-fp64 runs do), so demand >= 90 % exact agreement for D.
+            # check the post-step weights element-wise (a sign flip of a ~0 gradient would cost exactly 2*lr; none measured).
             sd_g, sd_d = tr.net.state_dict(), tr.D.state_dict()
             for key, fx in (("conv_cls.weight", "post0_D_cls"), ("main.0.weight", "post0_D_stem"),
                             ("main.2.bn1.weight", "post0_D_bn")):
                 diff = np.abs(sd_d[key].cpu().numpy() - g[fx])
-                assert (diff < 2e-3).mean() >= 0.90, (key, (diff < 2e-3).mean())
-                assert diff.max() < 2.1e-2, (key, diff.max())                        # a flip costs exactly 2*lr
+                assert (diff < 2e-3).mean() >= 0.99, (key, (diff < 2e-3).mean())
+                assert diff.max() < 2.1e-2, (key, diff.max())
             assert rel_err(sd_g["seg_decoder.fc.weight"].cpu().numpy(), g["post0_G_seg_fc"]) < 1e-3
-            # the translator's G-step gradient flows through the just-updated D: chaotic for the same reason
-            assert rel_err(sd_g["tsl_encoder.pre.0.weight"].cpu().numpy(), g["post0_G_tsl_pre"]) < 1e-1
+            # the translator's G-step gradient flows through the just-updated D (reference fp32 vs fp64: 4.1e-2)
+            assert rel_err(sd_g["tsl_encoder.pre.0.weight"].cpu().numpy(), g["post0_G_tsl_pre"]) < ITER_SMALL_TSL_PRE["post0"]
         else:
-            # Step 1 runs on D weights that just moved by +-1e-2 each: quantities that go through D are chaotic
-            # (the reference's own fp32 vs fp64 runs differ by 2x on D_fake / G_fake, 6 % on D_gp -- measured
-            # with oracle/, see DESIGN.md "Parity").  Segmentor-side scalars stay tight.
-            idx = [SCALARS.index(k) for k in ("G_rec", "G_seg", "G_semi", "G_nce")]
-            assert np.allclose(got[idx], ref[idx], rtol=3e-2, atol=1e-4), (step, report)
-            idc = [SCALARS.index(k) for k in ("D_real", "D_cls", "D_fake", "D_gp", "G_fake", "G_cls")]
-            assert np.all(np.abs(got[idc] - ref[idc]) <= 0.6 * np.abs(ref[idc]) + 0.1), (step, report)
+            # Step 1 runs on D weights that just moved by +-1e-2 each: per-scalar bands bounded by the reference's own
+            # fp32-vs-fp64 spread on this very iteration (tests/trace_bands.py)
+            for i, k in enumerate(SCALARS):
+                rel, ab = ITER_SMALL_STEP1[k]
+                assert abs(got[i] - ref[i]) <= rel * abs(ref[i]) + ab, (step, k, report)
     assert tr.iter == int(g["it0"]) + 2
     sd_g, sd_d = tr.net.state_dict(), tr.D.state_dict()
     assert rel_err(sd_g["seg_decoder.fc.weight"].cpu().numpy(), g["post_G_seg_fc"]) < 5e-3
-    assert rel_err(sd_g["tsl_encoder.pre.0.weight"].cpu().numpy(), g["post_G_tsl_pre"]) < 3e-1   # through the chaotic D
+    assert rel_err(sd_g["tsl_encoder.pre.0.weight"].cpu().numpy(), g["post_G_tsl_pre"]) < ITER_SMALL_TSL_PRE["post1"]   # through D
     # D must be trainable again after the G-step freeze (its grads are not touched by g_loss.backward(): the G-step
     # runs with D frozen, checked in test_first_step_gradients through the optimizer hooks)
     assert all(p.requires_grad for p in tr.D.parameters())
@@ -127,7 +118,7 @@ def test_first_step_gradients(small_cfg, golden):
     # D-step gradients vs the golden replay of the reference
     for n, ref in zip([str(n) for n in g["D0_grad_names"]], g["D0_grad_l2"]):
         gn = float(grads["D." + n].double().norm())
-        assert abs(gn - ref) <= 2e-2 * ref + 1e-7, ("D", n, gn, ref)       # GP term carries the mask flip (see above)
+        assert abs(gn - ref) <= 5e-3 * ref + 1e-7, ("D", n, gn, ref)       # (reference fp32 vs fp64: worst 5.4e-4)
     for k in ("conv_cls.weight", "main.0.weight"):
         assert l2_rel(grads["D." + k].numpy(), g["D0_grad::" + k]) < 3e-2, k
     # G-step gradients vs the oracle on identical weights (D not updated on either side)
@@ -140,10 +131,7 @@ def test_first_step_gradients(small_cfg, golden):
     from smsut_amd.trainer.uganConsisTrainer import SCALARS
     ref = np.array([logs[k] for k in SCALARS])
     gotv = np.array(got.tolist())
-    not_gp = [i for i, k in enumerate(SCALARS) if k != "D_gp"]
-    assert np.allclose(gotv[not_gp], ref[not_gp], rtol=1e-3, atol=1e-5), dict(zip(SCALARS, zip(gotv, ref)))
-    i_gp = SCALARS.index("D_gp")        # LeakyReLU-mask flip of a ~1e-8 activation, see the iteration test
-    assert abs(gotv[i_gp] - ref[i_gp]) <= 1e-2 * abs(ref[i_gp])
+    assert np.allclose(gotv, ref, rtol=1e-3, atol=1e-5), dict(zip(SCALARS, zip(gotv, ref)))      # D_gp included (5e-5 measured)
     errs = {k: l2_rel(grads["G." + k].numpy(), v.grad.numpy()) for k, v in gsd.items() if v.grad is not None}
     worst = max(errs.items(), key=lambda kv: kv[1])
     # the reference's own fp32 backward is 1.3e-3 l2-rel (worst 6.5e-3) from fp64 on the U-Net
@@ -210,10 +198,7 @@ def test_full_size_iteration_scalars_vs_oracle(small_cfg):
                                       it=15000, epoch=100, nce_batch=2)
     ref = np.array([logs[k] for k in SCALARS])
     rep = dict(zip(SCALARS, zip(got, ref)))
-    i_gp = SCALARS.index("D_gp")
-    rest = [i for i in range(len(SCALARS)) if i != i_gp]
-    assert np.allclose(got[rest], ref[rest], rtol=1e-3, atol=1e-5), rep
-    assert abs(got[i_gp] - ref[i_gp]) <= 1e-2 * abs(ref[i_gp]), rep
+    assert np.allclose(got, ref, rtol=1e-3, atol=1e-5), rep                  # all ten, D_gp included
 
 
 def test_config1_unet_two_class_train_steps_vs_oracle(small_cfg):

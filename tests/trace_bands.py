@@ -11,3 +11,20 @@ band <= 4x spread + 1e-2, so the bands can neither be tighter than the reference
 # the HIP path against the fp32 reference trace on the same draws: 3.2e-3, 2.1e-2, 0.30, 0.31-0.63 (two builds whose only
 # difference is the order of a few fp32 sums land on G_nce trajectories that far apart: it is the most D-coupled of the four)
 TRACE_BANDS = {"G_seg": 0.01, "G_semi": 0.05, "G_rec": 0.60, "G_nce": 0.70}
+
+
+# ---- the 2-iteration fixture (tests/golden/iter_small.npz, 64x64, 2 + 2 slices) ----------------------------------------------
+# Iteration 0 is deterministic arithmetic on fixed weights: north_star's 1e-3 on every scalar except G_fake, which the reference
+# itself cannot hold at 1e-3 (it is evaluated through D after D's first Adam step: fp32 vs fp64 of the reference differ by
+# 1.26e-3; the HIP path differs from the fp32 reference by the same 1.26e-3).  Iteration 1 runs on weights that moved: per scalar
+# (relative, absolute) bands, each checked against the reference's own fp32-vs-fp64 deviation (iter_small_f64.npz) by
+# tests/test_oracle_golden.py::test_iter_small_bands_cover_reference_fp_spread: spread <= band <= 4 * spread + 1e-2*|ref| + 5e-3.
+# Measured (scratch/iter_small_dev.py), iteration 1, |HIP - ref32| vs |ref32 - ref64|: D_fake 0.0156 / 0.0142, D_gp 0.065 / 0.105,
+# G_fake 6e-4 / 0.052, G_cls 0.030 / 0.031, G_nce 0.042 / 0.031, G_rec 2.2e-3 / 2.4e-4, G_semi 1.9e-3 / 7.9e-4.
+ITER_SMALL_STEP0 = {"default": 1e-3, "G_fake": 3e-3}
+ITER_SMALL_STEP1 = {            # name: (relative, absolute)
+    "D_real": (5e-3, 1e-4), "D_fake": (0.0, 0.05), "D_cls": (8e-3, 0.0), "D_gp": (0.2, 0.0), "G_fake": (0.0, 0.16),
+    "G_rec": (8e-3, 0.0), "G_cls": (0.0, 0.1), "G_seg": (1e-3, 0.0), "G_semi": (5e-3, 0.0), "G_nce": (5e-2, 0.0),
+}
+# post-step weights through the chaotic D (max-norm relative): reference spread 4.1e-2 after step 0, 0.22 after step 1
+ITER_SMALL_TSL_PRE = {"post0": 0.12, "post1": 0.5}
