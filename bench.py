@@ -321,6 +321,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    copies0 = ops.layout_copies()
     t0 = time.perf_counter()
     last = None
     for _ in range(args.steps):
@@ -349,6 +350,9 @@ def main():
            "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])]}
     log(f"timed region done: {ms:.2f} ms/step")
     out["graph"] = tr.graph_report()
+    # converting copies ops.nhwc()/hwio() had to make inside the timed region (0 = every tensor arrived in the kernels' layout;
+    # under graph replay no Python runs, so this counts the eager / capture part only -- the captured kernels are the same)
+    out["layout_copies_in_timed_region"] = ops.layout_copies() - copies0
     finite = all(v == v and abs(v) != float("inf") for v in out["last_step_scalars"])
     if not finite:
         # a throughput number of a numerically dead trajectory is not a measurement (r01's driver line ended all-NaN)

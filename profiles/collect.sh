@@ -17,4 +17,7 @@ rocprofv3 --kernel-trace --stats $common -d $out/${tag}_roof -- python3 bench.py
 tail -1 $out/${tag}_roof.log | cut -c1-400
 rocprofv3 --pmc FETCH_SIZE --kernel-trace $common -d $out/${tag}_pmc_fetch -- python3 bench.py --roofline-only > $out/${tag}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace $common -d $out/${tag}_pmc_write -- python3 bench.py --roofline-only > $out/${tag}_pmc_write.log 2>&1
+# 3. MFMA-busy of the dominant kernel (SQ block, own pass): busy cycles of the matrix pipes vs the GPU-active cycles
+rm -rf $out/${tag}_pmc_sq
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace $common -d $out/${tag}_pmc_sq -- python3 bench.py --roofline-only > $out/${tag}_pmc_sq.log 2>&1
 python3 profiles/summarize.py $tag

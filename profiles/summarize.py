@@ -100,6 +100,29 @@ dom = {"kernel": DOMINANT, "shape": live["shape"], "dispatches": len(fetch),
        "traffic_over_algorithmic": round(hbm / (live["algorithmic_gbytes_per_launch"] * 1e9), 3),
        "rocprof_avg_launch_us": round(float(roof["AverageNs"]) / 1e3, 2),
        "hip_event_avg_launch_us": round(live["avg_launch_ms"] * 1e3, 2)}
+# optional third pass: matrix-pipe busy cycles of the dominant kernel (SQ block)
+sq_note = ""
+try:
+    sq = {}
+    with open(one(f"{tag}_pmc_sq/**/*_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if DOMINANT in r["Kernel_Name"].replace("(anonymous namespace)::", ""):
+                sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    sq = {k: sum(v) / len(v) for k, v in sq.items()}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "GRBM_GUI_ACTIVE" in sq:
+        cycles = sq["GRBM_GUI_ACTIVE"] / 8.0                  # summed over the 8 XCDs
+        simds = 256 * 4
+        ideal = live["algorithmic_gflop_per_launch"] * 1e9 / 64.0     # one v_mfma_f32_16x16x4_f32 = 2048 FLOP holds its pipe 32 cycles
+        dom["sq"] = {k: round(v) for k, v in sq.items()}
+        dom["mfma_busy_frac"] = round(sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * simds), 4)
+        dom["mfma_busy_over_algorithmic"] = round(sq["SQ_VALU_MFMA_BUSY_CYCLES"] / ideal, 4)
+        dom["wave_time_split"] = {k: round(sq[k] / sq["SQ_WAVE_CYCLES"], 3) for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")
+                                  if k in sq and sq.get("SQ_WAVE_CYCLES")}
+        sq_note = (f"SQ pass: SQ_VALU_MFMA_BUSY_CYCLES {sq['SQ_VALU_MFMA_BUSY_CYCLES']:.4g} = {dom['mfma_busy_over_algorithmic']}x the algorithmic "
+                   f"FLOPs / 64 (no padded MFMAs), GRBM_GUI_ACTIVE / 8 = {cycles:.0f} cycles -> **MFMA pipes busy {dom['mfma_busy_frac'] * 100:.1f} %** "
+                   f"of the kernel's cycles; wave time: {dom['wave_time_split']}.")
+except SystemExit:
+    pass
 json.dump(dom, open(os.path.join(PROF, f"{tag}_pmc_dominant.json"), "w"), indent=1)
 md += ["## dominant kernel (roofline leg, `bench.py --roofline-only`)", "",
        f"`{DOMINANT}` at {live['shape']}: rocprofv3 average {dom['rocprof_avg_launch_us']} us over {roof['Calls']} launches; "
@@ -107,6 +130,6 @@ md += ["## dominant kernel (roofline leg, `bench.py --roofline-only`)", "",
        f"{live['frac'] * 100:.1f}% of the 157.3 TFLOP/s fp32 MFMA peak.", "",
        f"PMC: FETCH_SIZE {fetch_kb:.1f} KB (x2 gfx950 correction), WRITE_SIZE {write_kb:.1f} KB per launch -> "
        f"{hbm / 1e6:.1f} MB HBM traffic vs {dom['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic "
-       f"(x{dom['traffic_over_algorithmic']}).", ""]
+       f"(x{dom['traffic_over_algorithmic']}).", "", sq_note, ""]
 open(os.path.join(PROF, f"{tag}_summary.md"), "w").write("\n".join(md))
 print("\n".join(md[-4:]))

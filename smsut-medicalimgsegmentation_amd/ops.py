@@ -65,6 +65,26 @@ def first_order_only():
 
 
 # ------------------------------------------------------------------------------------------- layout helpers
+# Tensors produced by these ops already have the kernels' layouts, so the helpers below are no-ops on the hot path; a caller
+# that hands in another layout gets a converting COPY (a full extra pass).  That must not happen silently inside a timed
+# step: every copy is counted (``layout_copies()``; bench.py reports the count of its timed region) and
+# ``SMSUT_STRICT_LAYOUT=1`` turns it into an error.
+_LAYOUT_COPIES = 0
+_STRICT_LAYOUT = _os.environ.get("SMSUT_STRICT_LAYOUT", "0") not in ("0", "")
+
+
+def layout_copies() -> int:
+    return _LAYOUT_COPIES
+
+
+def _count_copy(what, t):
+    global _LAYOUT_COPIES
+    _LAYOUT_COPIES += 1
+    if _STRICT_LAYOUT:
+        raise RuntimeError(f"SMSUT_STRICT_LAYOUT: {what} got a tensor of shape {tuple(t.shape)} / strides {t.stride()} that needs a "
+                           "converting copy")
+
+
 def nhwc(x: torch.Tensor) -> torch.Tensor:
     """Return ``x`` (logical NCHW, fp32) with dense NHWC memory."""
     if x.dim() != 4:
@@ -76,6 +96,7 @@ def nhwc(x: torch.Tensor) -> torch.Tensor:
     st = x.stride()
     if all(x.size(d) == 1 or st[d] == want[d] for d in range(4)):
         return x
+    _count_copy("nhwc()", x)
     out = torch.empty_strided((n, c, h, w), want, dtype=x.dtype, device=x.device)
     out.copy_(x)
     return out
@@ -96,6 +117,7 @@ def hwio(w: torch.Tensor) -> torch.Tensor:
     st = w.stride()
     if all(w.size(d) == 1 or st[d] == want[d] for d in range(4)):
         return w
+    _count_copy("hwio()", w)
     out = torch.empty_strided((o, i, kh, kw), want, dtype=w.dtype, device=w.device)
     out.copy_(w)
     return out
@@ -120,6 +142,7 @@ def convT_w(w: torch.Tensor) -> torch.Tensor:
     st = w.stride()
     if all(w.size(d) == 1 or st[d] == want[d] for d in range(4)):
         return w
+    _count_copy("convT_w()", w)
     out = torch.empty_strided(tuple(w.shape), want, dtype=w.dtype, device=w.device)
     out.copy_(w)
     return out
