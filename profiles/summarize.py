@@ -106,7 +106,8 @@ try:
     sq = {}
     with open(one(f"{tag}_pmc_sq/**/*_counter_collection.csv")) as f:
         for r in csv.DictReader(f):
-            if DOMINANT in r["Kernel_Name"].replace("(anonymous namespace)::", ""):
+            # (match on the leading template arguments: the passes may come from builds that differ in trailing flags)
+            if ",".join(DOMINANT.split(",")[:8]) in r["Kernel_Name"].replace("(anonymous namespace)::", ""):
                 sq.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     sq = {k: sum(v) / len(v) for k, v in sq.items()}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "GRBM_GUI_ACTIVE" in sq:
