@@ -600,6 +600,36 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       return;
     }
     const float* wc = w_s + (size_t)(c * 4) * CO_T * 4;
+#ifdef SMSUT_FRAG_PIPELINE
+    // EXPERIMENT (r02, measured slower, off by default): fragment reads ONE TAP AHEAD of the MFMAs.  Left to itself the
+    // scheduler sinks a tap's ds_reads below the previous tap's MFMAs (ISA: rrr s_waitcnt lgkmcnt(0) MMMMMMMM rrr ...), which
+    // looks like exposed LDS latency (r02 SQ counters: matrix pipes busy 66 %, waves issue-stalled 65 %).  With the look-ahead
+    // (sched_barrier 0x77 keeps DS / MFMA order, lets ALU / VMEM cross) the waits become lgkmcnt(3) -- and the kernel gets
+    // SLOWER: two-library A/B (scratch/conv_ab.py) 16->16 @256^2 B32 statistics form 101.4 -> 106.4 us, accumulate form
+    // 99.4 -> 129.0 us (the second fragment set costs occupancy), 32-channel reductions +-1 %.  The other resident waves
+    // already cover that latency; see profiles/r02_notes.md.
+    f32x4 fa[2][MR], fb[2][NR];
+    auto ldfrag = [&](int tap, f32x4* a, f32x4* b) {
+      const int kh = tap / KS, kw = tap % KS;
+#pragma unroll
+      for (int i = 0; i < MR; ++i) a[i] = *(const f32x4*)(in_s + ((wave * MR + i + kh) * IW + lm + kw) * SPIX + 4 * kq);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) b[j] = *(const f32x4*)(wc + (((size_t)(tap * K4 + kq) * CO_T) + j * 16 + lm) * 4);
+    };
+    ldfrag(0, fa[0], fb[0]);
+#pragma unroll
+    for (int tap = 0; tap < KK; ++tap) {
+      if (tap + 1 < KK) ldfrag(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0x77);       // ALU + VMEM may cross; DS and MFMA may not
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(fa[tap & 1][i][s], fb[tap & 1][j][s], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0x77);
+    }
+#else
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
       const int kh = tap / KS, kw = tap % KS;
@@ -617,6 +647,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
           for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
     }
+#endif
   };
 
   STAMP(1);
