@@ -1,0 +1,65 @@
+"""Geometry conventions of the joint augmentation pinned against PIL -- the library the reference's transforms end in:
+``torchvision.transforms.functional.rotate`` / ``resized_crop`` on PIL images (data_loader/externalTransforms.py:45-66) are
+``Image.rotate(angle, resample, expand, center)`` and ``Image.crop(...).resize(size, resample)``.  torchvision itself is not
+installed here, so the two PIL calls it forwards to are the anchor.  Pinned: rotation direction / centre, pixel-centre
+convention of the crop + resize, bilinear for images, nearest for labels.  NOT pinned: the elastic deformation
+(``elasticdeform`` is absent) and the fact that the device path resamples once instead of three times when transforms are
+combined."""
+import numpy as np
+import pytest
+from PIL import Image
+
+from oracle import augment_oracle as A
+
+
+def _smooth_image(h, w, seed):
+    rs = np.random.RandomState(seed)
+    coarse = rs.rand(h // 16 + 2, w // 16 + 2)
+    img = np.asarray(Image.fromarray((coarse * 255).astype(np.uint8)).resize((w, h), Image.BICUBIC), dtype=np.float32)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _labels(h, w, seed):
+    rs = np.random.RandomState(seed)
+    small = rs.randint(0, 5, size=(h // 32, w // 32)).astype(np.uint8)
+    return np.repeat(np.repeat(small, 32, axis=0), 32, axis=1)
+
+
+def _affine(angle, crop, hw, out_hw):
+    import smsut_amd  # noqa: F401
+    from smsut_amd.data_loader.gpu_augment import affine_for
+    return np.array([affine_for(angle, crop, hw, out_hw)], dtype=np.float32)
+
+
+@pytest.mark.parametrize("angle", [-15.0, 7.3, 12.0])
+def test_rotation_matches_pil(angle):
+    H = W = 256
+    img8, lab8 = _smooth_image(H, W, 1), _labels(H, W, 2)
+    ref_img = np.asarray(Image.fromarray(img8).rotate(angle, Image.BILINEAR), dtype=np.float32)
+    ref_lab = np.asarray(Image.fromarray(lab8).rotate(angle, Image.NEAREST))
+    aff = _affine(angle, (0, 0, H, W), (H, W), (H, W))
+    got_img, got_lab = A.warp_joint(img8[None].astype(np.float32), lab8[None].astype(np.int64), aff, None, H, W)
+    d = np.abs(got_img[0] - ref_img)
+    inner = np.s_[8:-8, 8:-8]                     # (PIL fills what falls outside with 0 as we do; keep clear of the rim anyway)
+    assert d[inner].mean() < 1.0 and np.quantile(d[inner], 0.99) < 2.5     # (PIL rounds to uint8: 0.25 mean by itself), (d[inner].mean(), np.quantile(d[inner], 0.99))
+    assert (got_lab[0][inner] == ref_lab[inner]).mean() > 0.995
+    # the direction is pinned: the mirrored angle is far off
+    wrong, _ = A.warp_joint(img8[None].astype(np.float32), None, _affine(-angle, (0, 0, H, W), (H, W), (H, W)), None, H, W)
+    assert np.abs(wrong[0] - ref_img)[inner].mean() > 5 * d[inner].mean() + 1.0
+
+
+@pytest.mark.parametrize("crop", [(20, 37, 180, 200), (0, 0, 256, 256), (63, 5, 154, 231)])
+def test_resized_crop_matches_pil(crop):
+    """RandomResizedCrop's window (i, j, h, w) resized to the slice size: scale 0.6-1.0 of the area, so always an up-sampling
+    (plain bilinear in PIL too)."""
+    H = W = S = 256
+    i, j, h, w = crop
+    img8, lab8 = _smooth_image(H, W, 3), _labels(H, W, 4)
+    ref_img = np.asarray(Image.fromarray(img8).crop((j, i, j + w, i + h)).resize((S, S), Image.BILINEAR), dtype=np.float32)
+    ref_lab = np.asarray(Image.fromarray(lab8).crop((j, i, j + w, i + h)).resize((S, S), Image.NEAREST))
+    aff = _affine(0.0, crop, (H, W), (S, S))
+    got_img, got_lab = A.warp_joint(img8[None].astype(np.float32), lab8[None].astype(np.int64), aff, None, S, S)
+    d = np.abs(got_img[0] - ref_img)
+    inner = np.s_[2:-2, 2:-2]                     # PIL clamps at the crop's border, the joint warp reads the pixels beyond it
+    assert d[inner].mean() < 1.0 and np.quantile(d[inner], 0.99) < 2.5     # (PIL rounds to uint8: 0.25 mean by itself), (d[inner].mean(), np.quantile(d[inner], 0.99))
+    assert (got_lab[0][inner] == ref_lab[inner]).mean() > 0.995
