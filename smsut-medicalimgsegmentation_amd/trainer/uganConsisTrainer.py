@@ -39,7 +39,11 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._alias = None
         self._g1 = self._g2 = None
         self._side = None
-        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1") not in ("0", "")
+        # D-step on a side stream under the cycle pass: default on one GPU only.  Under data parallelism everything stays on
+        # ONE stream (the RCCL all-reduce is stream-ordered and asynchronous to the host anyway): the multi-stream variant
+        # could only be rehearsed with two gloo ranks SHARING one GPU, where it degenerated to seconds per iteration
+        # (profiles/r02_notes.md) -- not something to ship unmeasured for a 0.3 % gain.
+        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "0") not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
