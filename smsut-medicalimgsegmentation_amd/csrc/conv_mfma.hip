@@ -71,13 +71,16 @@ __device__ __forceinline__ h4 to_h4s(float4 v, float s) {
   return (h4){(_Float16)(v.x * s), (_Float16)(v.y * s), (_Float16)(v.z * s), (_Float16)(v.w * s)};
 }
 
-template <int KS, int TH, int WM, int WN, int NTN, bool F16 = false>
+template <int KS, int TH, int WM, int WN, int NTN, bool F16 = false, int MW = TW>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Kdim,
               int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz, float* __restrict__ stats,
               const float* __restrict__ x2 = nullptr, float* __restrict__ y2 = nullptr, int split = 0,
               const float* __restrict__ gsc = nullptr) {
   // F16: fp16 operands, converted while staging (block comment above mfma16h); gsc (nullable) = {s, 1/s} of a gradient input.
+  // MW (16, 8, 4): width of the pixel tile.  One MFMA M-tile is 16 pixels = (16 / MW) rows x MW columns, so on the
+  // discriminator's 8x8 / 4x4 planes (network/ugan.py:205-215) every MFMA row is a real pixel: with 16-wide tiles half (8x8) or
+  // three quarters (4x4) of each MFMA multiplied padding columns (r01: "dense pixel packing").  Plain conv forms only.
   // x2 (nullable, regular conv only): the input is the virtual cat([x, x2]) of two Kdim/2-channel tensors (common.h); the
   // select is per 16-channel chunk, i.e. uniform.  y2 / split (nullable): result channels >= split go to y2 (see
   // conv_mfma_fwd_p).
@@ -87,10 +90,13 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   // blockIdx.z also enumerates the 4 output taps.  ConvTranspose2x2 data-gradient: isc = 2, G = 4 input taps.
   constexpr int KK = KS * KS;
   constexpr int PAD = (KS - 1) / 2;
-  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  constexpr int IH = TH + KS - 1, IW = MW + KS - 1;
   constexpr int CO_T = 16 * NTN;
-  constexpr int MR = TH / WM, NR = NTN / WN;
-  static_assert(WM * WN == 4 && TH % WM == 0 && NTN % WN == 0, "wave grid");
+  constexpr int RPT = TW / MW;                 // rows of one 16-pixel M-tile
+  constexpr int MT = TH / RPT;                 // M-tiles per pixel tile
+  constexpr int MR = MT / WM, NR = NTN / WN;
+  static_assert(WM * WN == 4 && TH % RPT == 0 && MT % WM == 0 && MR >= 1 && NTN % WN == 0, "wave grid");
+  static_assert(MW == 16 || MW == 8 || MW == 4, "M-tile width");
   extern __shared__ float smem[];
   float* in_s = smem;                        // [IH][IW][SPIX]
   float* w_s = smem + IH * IW * SPIX;        // [KK][4][CO_T][4]
@@ -110,7 +116,9 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   [[maybe_unused]] const int stamp_wg = blockIdx.z == 0 ? (int)(blockIdx.y * gridDim.x + blockIdx.x) : -1;
   const int tapo = blockIdx.z / nz;            // output tap (transposed conv forward), else 0
   const int co0 = (blockIdx.z % nz) * CO_T;
-  const int y0 = ty * TH, x0 = tx * TW;
+  const int y0 = ty * TH, x0 = tx * MW;
+  // this lane's pixel inside an M-tile (A operand: pixel index = lm) and the pixels of its accumulator elements (4*kq + r)
+  const int a_row = lm / MW, a_col = lm % MW;
   const int Wi = W * isc;
   const int KSTR = x2 ? Kdim / 2 : Kdim;       // pixel stride of the input tensor(s)
   const float* xin = x + (size_t)n_img * H * isc * Wi * KSTR;
@@ -213,7 +221,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
         h4 a[MR], b[NR];
 #pragma unroll
         for (int i = 0; i < MR; ++i)
-          a[i] = *(const h4*)(in_h + ((wm * MR + i + kh) * IW + lm + kw) * SPIXH + 4 * kq);
+          a[i] = *(const h4*)(in_h + (((wm * MR + i) * RPT + a_row + kh) * IW + a_col + kw) * SPIXH + 4 * kq);
 #pragma unroll
         for (int j = 0; j < NR; ++j)
           b[j] = *(const h4*)(w_h + ((size_t)tap * CO_T + (wn * NR + j) * 16 + lm) * WROWH + 4 * kq);
@@ -229,7 +237,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
       f32x4 a[MR], b[NR];
 #pragma unroll
       for (int i = 0; i < MR; ++i)
-        a[i] = *(const f32x4*)(in_s + ((wm * MR + i + kh) * IW + lm + kw) * SPIX + 4 * kq);
+        a[i] = *(const f32x4*)(in_s + (((wm * MR + i) * RPT + a_row + kh) * IW + a_col + kw) * SPIX + 4 * kq);
 #pragma unroll
       for (int j = 0; j < NR; ++j)
         b[j] = *(const f32x4*)(w_s + (((tap * 4 + kq) * CO_T) + (wn * NR + j) * 16 + lm) * 4);
@@ -257,10 +265,11 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
-        const bool rok = y0 + wm * MR + i < H;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = (rok && x0 + 4 * kq + r < W) ? acc[i][j][r] : 0.f;
+          const int p = 4 * kq + r;                                     // pixel of this accumulator element inside its M-tile
+          const bool ok = y0 + (wm * MR + i) * RPT + p / MW < H && x0 + p % MW < W;
+          const float v = ok ? acc[i][j][r] : 0.f;
           s1 += v; s2 += v * v;
         }
       }
@@ -284,8 +293,6 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   const int Wo = W * osc;
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
-    const int gy_ = y0 + wm * MR + i;
-    if (gy_ >= H) continue;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int co = co0 + (wn * NR + j) * 16 + lm;
@@ -295,8 +302,9 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
       float* yout = (hi ? y2 : y) + (size_t)n_img * H * osc * Wo * os + (hi ? co - split : co);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int gx_ = x0 + 4 * kq + r;
-        if (gx_ < W) {
+        const int p = 4 * kq + r;
+        const int gy_ = y0 + (wm * MR + i) * RPT + p / MW, gx_ = x0 + p % MW;
+        if (gy_ < H && gx_ < W) {
           float* o = yout + ((size_t)(gy_ * osc + (tapo >> 1)) * Wo + gx_ * osc + (tapo & 1)) * os;
           *o = accum ? acc[i][j][r] + *o : acc[i][j][r];
         }
@@ -1354,14 +1362,15 @@ inline void launch_sum_splits(const float* part, float* out, int wsize, int spli
   else sum_splits<16><<<(wsize + 63) / 64, TPB, 0, st>>>(part, out, wsize, splits);
 }
 
-template <int KS, int TH, int WM, int WN, int NTN>
+template <int KS, int TH, int WM, int WN, int NTN, int MW = TW>
 int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr,
                const float* x2 = nullptr, float* y2 = nullptr, int split = 0, bool f16 = false, const float* gsc = nullptr) {
-  constexpr int IH = TH + KS - 1, IW = TW + KS - 1;
+  constexpr int IH = TH + KS - 1, IW = MW + KS - 1;
   constexpr size_t sh = (size_t)(IH * IW * SPIX + KS * KS * CK * 16 * NTN) * sizeof(float);
   static_assert(sh <= 64 * 1024, "LDS budget");
-  const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + TH - 1) / TH;
+  const int tiles_x = (W + MW - 1) / MW, tiles_y = (H + TH - 1) / TH;
+  if (MW != TW && (isc != 1 || osc != 1 || G != 1 || ntap_out != 1)) return -1;
   const int nz = (Ndim + 16 * NTN - 1) / (16 * NTN);
   if (tiles_out) { *tiles_out = tiles_x * tiles_y; return 0; }          // planning query only
   dim3 grid(tiles_x * tiles_y, N, nz * ntap_out);
@@ -1369,11 +1378,11 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
       (y2 && (osc != 1 || ntap_out != 1 || stats || split <= 0 || split >= Ndim || split % 16 != 0)))
     return -1;
   if (f16)
-    conv_mfma_fwd<KS, TH, WM, WN, NTN, true><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc,
-                                                                    G, nz, stats, x2, y2, split, gsc);
+    conv_mfma_fwd<KS, TH, WM, WN, NTN, true, MW><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc,
+                                                                        osc, G, nz, stats, x2, y2, split, gsc);
   else
-    conv_mfma_fwd<KS, TH, WM, WN, NTN><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc, osc, G,
-                                                              nz, stats, x2, y2, split);
+    conv_mfma_fwd<KS, TH, WM, WN, NTN, false, MW><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc,
+                                                                         osc, G, nz, stats, x2, y2, split);
   return 0;
 }
 
@@ -1517,6 +1526,13 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
   const int64_t wg8 = (int64_t)tx * ((H + 7) / 8) * N * ((nt + 1) / 2) * ntap_out;
   // planes of <= 4 rows (discriminator 4x4 level): the 4-row tile halves the rows of padding every MFMA multiplies --
   // scratch/bench_conv_small.py, 256->256: 19.4 vs 29.1 us forward, 25.1 vs 32.7 us data-gradient at B=16 (28.7 vs 48.2 at 32)
+  // 8x8 planes of the discriminator's deep levels: M-tiles of real pixels only -- four (2 rows x 8 columns) tiles per plane, 16
+  // output channels per workgroup so that B=16 still gives one workgroup per CU (SMSUT_DENSE_PLANES=0: 16-wide tiles).
+  // (4x4 planes stay on the 4-row tile: a plane is ONE M-tile, and 64-channel workgroups leave 64 of them for 256 CUs --
+  //  measured 71 us vs 19-25 us; there the limit is parallelism, not padded MFMAs.)
+  static const bool dense = [] { const char* e = getenv("SMSUT_DENSE_PLANES"); return !e || atoi(e) != 0; }();
+  if (dense && isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && !f16 && H <= 8 && W <= 8 && H > 4)
+    return launch_fwd<KS, 8, 4, 1, 1, 8>(ARGS);
   if (H <= 4 && isc == 1 && osc == 1) return launch_fwd<KS, 4, 4, 1, 1>(ARGS);
   if (nt == 1) return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
   if (wg16 >= 512) return launch_fwd<KS, 16, 4, 1, 2>(ARGS);       // >= 2 workgroups per CU with the big tile

@@ -239,10 +239,14 @@ def test_trace_bands_cover_reference_fp_spread(golden):
     names = [str(s) for s in a["scalar_names"]]
     n = min(a["scalars"].shape[0], b["scalars"].shape[0])
     assert n >= 24
-    for name, band in TRACE_BANDS.items():
+    for name, (band, n_it) in TRACE_BANDS.items():
         i = names.index(name)
-        spread = float((np.abs(a["scalars"][:n, i] - b["scalars"][:n, i]) / np.abs(b["scalars"][:n, i])).max())
+        m = min(n, n_it)
+        spread = float((np.abs(a["scalars"][:m, i] - b["scalars"][:m, i]) / np.abs(b["scalars"][:m, i])).max())
         assert spread <= band <= 4 * spread + 1e-2, (name, spread, band)
+    # ... and why the translator-side scalars are not tracked to the end: the reference itself is off by > 0.5 on G_rec there
+    i = names.index("G_rec")
+    assert float((np.abs(a["scalars"][:n, i] - b["scalars"][:n, i]) / np.abs(b["scalars"][:n, i])).max()) > 0.3
     # and the D-side really is chaotic in the reference itself (why it is not banded at all past iteration 0)
     i = names.index("G_fake")
     assert float(np.abs(a["scalars"][3:n, i] - b["scalars"][3:n, i]).max()) > 0.3

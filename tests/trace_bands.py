@@ -6,12 +6,15 @@ whole trajectory; how tightly is bounded by how far the REFERENCE's own arithmet
 (tests/golden/iter_trace.npz vs iter_trace_f64.npz: the same replay of the reference modules in fp32 and fp64).
 ``tests/test_oracle_golden.py::test_trace_bands_cover_reference_fp_spread`` asserts band >= measured spread and
 band <= 4x spread + 1e-2, so the bands can neither be tighter than the reference itself nor drift arbitrarily wide."""
-# measured spread of the reference (max over 32 iterations of |fp32 - fp64| / |fp64|):
-#   G_seg 3.4e-3, G_semi 2.3e-2, G_rec 0.53, G_nce 0.18     (G_rec / G_nce pass through the translator, which D trains)
-# the HIP path against the fp32 reference trace on the same draws: 3.2e-3, 2.1e-2, 0.30, 0.31-0.63 (two builds whose only
-# difference is the order of a few fp32 sums land on G_nce trajectories that far apart: it is the most D-coupled of the four)
-TRACE_BANDS = {"G_seg": 0.01, "G_semi": 0.05, "G_rec": 0.60, "G_nce": 0.70}
-
+# measured spread of the reference (max over the window of |fp32 - fp64| / |fp64|):
+#   all 32 iterations:  G_seg 3.4e-3, G_semi 2.3e-2, G_rec 0.53, G_nce 0.18
+#   iterations 0-5:     G_rec 5.6e-2, G_nce 2.0e-2
+# G_rec / G_nce pass through the translator, which D trains: after a handful of iterations they are as chaotic as the D-side
+# scalars (two HIP builds that differ only in the order of a few fp32 sums -- e.g. the tile shape of D's 8x8 convs -- end
+# iteration 30 with G_rec 0.41 vs 1.0: the translator saturates in some trajectories, as it does in some of bench.py's runs).
+# So they are tracked over the FIRST SIX iterations only; the segmentor-side scalars over the whole trajectory.
+# name: (relative band, number of leading iterations it applies to)
+TRACE_BANDS = {"G_seg": (0.01, 32), "G_semi": (0.05, 32), "G_rec": (0.15, 6), "G_nce": (0.08, 6)}
 
 # ---- the 2-iteration fixture (tests/golden/iter_small.npz, 64x64, 2 + 2 slices) ----------------------------------------------
 # Iteration 0 is deterministic arithmetic on fixed weights: north_star's 1e-3 on every scalar except G_fake, which the reference
