@@ -451,6 +451,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       zero[i] = (u_flag[i] & pflags) != 0;
+#ifdef SMSUT_DBG_NO_PREFETCH
+      if (c == 12345)
+#endif
       rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : u_off[i]));
     }
     if (INAFF) {                                     // every unit of a thread carries the channel quad tid & 3
@@ -526,6 +529,14 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       }
     }
     float* yb = yo + (((size_t)en * H + ety * TH) * W + etx * TW) * os + oc0;
+#ifdef SMSUT_DBG_NO_STORE            // scratch builds only (scratch/loop_ablation.py): results are dropped unless a NaN shows up
+    bool keep = false;
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) keep |= pacc[i][j][0] != pacc[i][j][0];
+    if (!keep) return;
+#endif
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -638,16 +649,25 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       __builtin_amdgcn_sched_barrier(0x77);
     }
 #else
+#ifdef SMSUT_SETPRIO
+    __builtin_amdgcn_s_setprio(SMSUT_SETPRIO);       // waves in their MFMA phase win the issue arbitration over side work
+#endif
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
+#ifdef SMSUT_DBG_NO_LDSREAD
+      const int kh = 0, kw = 0;                       // every tap reads tap 0's fragments: the compiler keeps them in registers
+      const int tapw = 0;
+#else
       const int kh = tap / KS, kw = tap % KS;
+      const int tapw = tap;
+#endif
       f32x4 a[MR], b[NR];
 #pragma unroll
       for (int i = 0; i < MR; ++i)
         a[i] = *(const f32x4*)(in_s + ((wave * MR + i + kh) * IW + lm + kw) * SPIX + 4 * kq);
 #pragma unroll
       for (int j = 0; j < NR; ++j)
-        b[j] = *(const f32x4*)(wc + (((size_t)(tap * K4 + kq) * CO_T) + j * 16 + lm) * 4);
+        b[j] = *(const f32x4*)(wc + (((size_t)(tapw * K4 + kq) * CO_T) + j * 16 + lm) * 4);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -655,6 +675,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
           for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
     }
+#ifdef SMSUT_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
   };
 
@@ -684,12 +707,18 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       }
       mma_chunk(c);
       if (item == item0 + 1 && c < 2) { STAMP(3 + 4 * c); }
+#ifndef SMSUT_DBG_NO_BARRIER
       __syncthreads();                                // in_s is free; red[par] is complete
+#endif
       if (item == item0 + 1 && c < 2) { STAMP(4 + 4 * c); }
       if (c == 0 && !FIRST) { stats_out(par); par ^= 1; }
+#ifndef SMSUT_DBG_NO_PUBLISH
       if (more) publish();
+#endif
       if (item == item0 + 1 && c < 2) { STAMP(5 + 4 * c); }
+#ifndef SMSUT_DBG_NO_BARRIER
       __syncthreads();
+#endif
       if (item == item0 + 1 && c < 2) { STAMP(6 + 4 * c); }
     }
     // item done: keep its accumulators for the next region's epilogue
@@ -1431,7 +1460,9 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       o = 1;
     occ = o;
   }
-  const int64_t slots = (int64_t)device_cus() * occ;
+  // (tuning hook: SMSUT_P_WGS_PER_CU overrides the resident-workgroup count the grid is sized for)
+  static const int occ_env = [] { const char* e = getenv("SMSUT_P_WGS_PER_CU"); return e ? atoi(e) : 0; }();
+  const int64_t slots = (int64_t)device_cus() * (occ_env > 0 ? occ_env : occ);
   const int64_t items = (int64_t)N * tiles_img;
   int ipw = (int)((items * nz + slots - 1) / slots);   // one resident round: each workgroup walks ipw consecutive items
   if (ipw < 1) ipw = 1;
