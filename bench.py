@@ -140,6 +140,9 @@ def measure_step_conv(step, label):
     out = profiling.summarize(rows, FP32_MFMA_PEAK_TFLOPS)
     out["calls"] = len(rec)
     log(f"{label}: per-shape replay of one step ({len(rec)} C-ABI calls)\n" + profiling.table(rows, 0.012))
+    if os.environ.get("SMSUT_PROFILE_DUMP"):             # full per-shape table, sorted by time above the roofline
+        with open(f"{os.environ['SMSUT_PROFILE_DUMP']}_{label}.txt", "w") as f:
+            f.write(profiling.lost_table(rows, FP32_MFMA_PEAK_TFLOPS) + "\n")
     return out
 
 

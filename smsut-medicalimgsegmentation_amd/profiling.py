@@ -160,3 +160,19 @@ def table(rows: List[Row], min_share: float = 0.007) -> str:
         out.append(f"{r.total_us / 1e3:7.3f} ms {100 * r.total_us / tot:5.1f}%  {r.calls:3d} x {r.us:7.1f} us {tf}  "
                    f"{r.name.replace('smsut_', '')} {r.args}")
     return "\n".join(out)
+
+
+def lost_table(rows: List[Row], peak_tflops: float) -> str:
+    """Every row, sorted by the time it would give back at the fp32 MFMA peak (conv rows) -- where the step's gap to the
+    roofline sits, shape by shape; non-conv rows (HBM-bound passes) are listed with their whole time."""
+    tot = sum(r.total_us for r in rows) or 1.0
+    ent = []
+    for r in rows:
+        ideal = r.flops / (peak_tflops * 1e12) * 1e6 if r.flops else 0.0
+        ent.append((r.total_us - ideal * r.calls, r))
+    out = []
+    for lost, r in sorted(ent, key=lambda e: -e[0]):
+        tf = f"{r.flops / (r.us * 1e-6) / 1e12:6.1f} TF" if r.flops else "         "
+        out.append(f"lost {lost / 1e3:7.3f} ms  total {r.total_us / 1e3:7.3f} ms {100 * r.total_us / tot:5.1f}%  {r.calls:3d} x {r.us:7.1f} us {tf}  "
+                   f"{r.name.replace('smsut_', '')} {r.args}")
+    return "\n".join(out)
