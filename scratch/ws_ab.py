@@ -16,8 +16,9 @@ def timeit(fn, reps=20):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
+ENVN = os.environ.get("AB_ENV", "SMSUT_CONV_WS")
 torch.manual_seed(0)
-cases = [(32, 256, 16, 16), (16, 256, 32, 16), (16, 256, 16, 32), (16, 128, 32, 32), (16, 128, 64, 32), (16, 64, 64, 64), (16, 64, 128, 64), (16, 32, 128, 128), (3, 64, 16, 16), (1, 32, 32, 32)]
+cases = [(32, 256, 16, 16), (16, 256, 32, 16), (16, 256, 16, 32), (16, 128, 32, 32), (16, 128, 64, 32), (16, 64, 64, 64), (16, 64, 128, 64), (3, 64, 16, 16), (2, 32, 32, 32), (5, 48, 64, 32)]
 if len(sys.argv) > 1: cases = cases[:int(sys.argv[1])]
 for (B, h, K, N) in cases:
     x = torch.randn(B, h, h, K, device='cuda'); w = torch.randn(9 * K * N, device='cuda') * 0.05
@@ -37,7 +38,7 @@ for (B, h, K, N) in cases:
     for name, f in forms.items():
         res = {}
         for mode in ("0", "1"):
-            os.environ["SMSUT_CONV_WS"] = mode
+            os.environ[ENVN] = mode
             y = torch.full((B, h, h, N), float("nan"), device='cuda'); s = torch.zeros(B * tiles * N * 2, device='cuda')
             rc = f(y, s); torch.cuda.synchronize()
             assert rc == 0, (name, mode, rc)

@@ -1433,6 +1433,7 @@ constexpr size_t fwd_p_lds() {
          sizeof(float);
 }
 
+
 template <int KS, int TH, int NTN, int NCH, bool K8 = false>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
