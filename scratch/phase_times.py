@@ -1,32 +1,56 @@
-"""Time the three phases of the ugan iteration (graph replays) + optimizer/eager parts."""
-import sys, types; sys.path.insert(0, '.')
+"""Stand-alone replay time of each captured phase of the uganConsis iteration (B = 8 + 8 @256^2)."""
+import os, sys, types
+sys.path.insert(0, '.')
 import torch, smsut_amd
 from smsut_amd import config as cfg
-from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer
 from smsut_amd.misc.synthetic import SyntheticSliceLoader
-B = 16
-cfg.batch_size = B // 2
-tr = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
-tr.net.train(); tr.D.train(); tr.iter, tr.epoch = 1000, 100
-dev = tr.device
-lb = iter(SyntheticSliceLoader(B // 2, device=dev, labeled=True)); ul = iter(SyntheticSliceLoader(B // 2, device=dev, labeled=False))
-def batch():
-    (x1, y1, m1, _), (x2, _, m2, _) = next(lb), next(ul)
-    return torch.cat([x1, x2], 0), y1, torch.cat([m1, m2], 0)
-acc = {}
-orig = tr._run_phase
-def timed(name, fn, inputs, params, collective_free=False):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(); out = orig(name, fn, inputs, params, collective_free); e1.record()
-    acc.setdefault(name, []).append((e0, e1))
-    return out
-tr._run_phase = timed
-for i in range(8):
-    x, y, m = batch()
-    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
-    t0.record(); tr.train_iteration(x, y, m); t1.record()
-    acc.setdefault('total', []).append((t0, t1))
+from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer
+dev = torch.device("cuda"); cfg.batch_size = 8
+tr = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False)); tr.net.train(); tr.D.train(); tr.iter, tr.epoch = 1000, 100
+lb = iter(SyntheticSliceLoader(8, device=dev, labeled=True, n_batches=4)); ul = iter(SyntheticSliceLoader(8, device=dev, labeled=False, n_batches=4))
+(x1, y1, m1, _), (x2, _, m2, _) = next(lb), next(ul)
+x = torch.cat([x1, x2], 0); m = torch.cat([m1, m2], 0).cuda()
+for _ in range(4): tr.train_iteration(x, y1, m)
 torch.cuda.synchronize()
-for k, v in acc.items():
-    ms = [a.elapsed_time(b) for a, b in v[3:]]
-    print(f'{k:6s} {sum(ms)/len(ms):7.2f} ms')
+def t(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+tot = 0
+for k, g in tr._graphs.items():
+    ms = t(g.graph.replay); tot += ms
+    print(f"{k[0]:6s} {ms:7.3f} ms")
+print("sum of phases", round(tot, 3))
+print("D adam ", round(t(tr.d_optimizer.step), 3), " G sgd ", round(t(tr.optimizer.step), 3))
+print("iteration", round(t(lambda: tr.train_iteration(x, y1, m)), 3))
+# ---- D and G2gen concurrently on two streams (what train_iteration does)
+gd = [g for k, g in tr._graphs.items() if k[0] == "D"][0].graph
+gg = [g for k, g in tr._graphs.items() if k[0] == "G2gen"][0].graph
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+def both():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s2.wait_stream(cur)
+    with torch.cuda.stream(s2): gd.replay()
+    with torch.cuda.stream(s1): gg.replay()
+    cur.wait_stream(s1); cur.wait_stream(s2)
+print("D alone %.3f  G2gen alone %.3f  both on two streams %.3f ms" % (t(gd.replay), t(gg.replay), t(both)))
+
+s3 = torch.cuda.Stream()
+def both0():
+    cur = torch.cuda.current_stream()
+    s1.wait_stream(cur); s3.wait_stream(cur)
+    with torch.cuda.stream(s3): gd.replay()
+    with torch.cuda.stream(s1): gg.replay()
+    cur.wait_stream(s1); cur.wait_stream(s3)
+def main_side():
+    cur = torch.cuda.current_stream()
+    s3.wait_stream(cur)
+    with torch.cuda.stream(s3): gd.replay()
+    gg.replay()
+    cur.wait_stream(s3)
+def serial2():
+    gd.replay(); gg.replay()
+print("both prio 0: %.3f   main+side: %.3f   serial same stream: %.3f ms" % (t(both0), t(main_side), t(serial2)))
