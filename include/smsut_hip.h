@@ -95,6 +95,13 @@ int smsut_conv2d_wgrad_mfma_inaff(const float* x, const float* gy, float* gw, fl
 int smsut_conv2d_mfma_cat_supported(int N, int H, int W, int Kdim, int Ndim);
 int smsut_conv2d_fwd_mfma_stats_cat(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
                                     int W, int Kdim, int Ndim, void* stream);
+/* conv1 of a BasicBlock fused with the block's 1x1 shortcut conv (reference network/blocks.py:66-80: `self.conv1(x)` and
+ * `self.shortcut(x)` read the same x): y = conv3x3(x, w), ysc = conv1x1(x, wsc) and the InstanceNorm partials of both in one
+ * pass.  xb nullable: non-null = x is the virtual cat([x, xb]) of two [N,H,W,Kdim/2] tensors.  _supported(..., cat) first. */
+int smsut_conv2d_fwd_sc_supported(int N, int H, int W, int Kdim, int Ndim, int cat);
+int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb /*nullable*/, const float* w, const float* wsc, float* y,
+                                   float* ysc, float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim,
+                                   void* stream);
 int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace,
                                 int N, int H, int W, int Cin, int Cout, int KS, void* stream);
 int smsut_conv1x1_fwd_cat(const float* xa, const float* xb, int ca, const float* w, float* y, float* stats /*nullable*/,

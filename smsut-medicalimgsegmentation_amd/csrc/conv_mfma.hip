@@ -341,13 +341,21 @@ __device__ __forceinline__ float aff1(float v, float m, float r, float g, float 
 
 struct BstRef { const float* y1; const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
 
+struct ScRef { const float* w; float* y; float* stats; };   // SC: the block's 1x1 shortcut conv, fused (see conv_mfma_fwd_p)
+
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false, bool K8 = false>
+          bool F16 = false, bool K8 = false, bool SC = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
                 BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0,
-                const float* __restrict__ x2 = nullptr, AffRef aff = AffRef{}, const float* __restrict__ gsc = nullptr) {
+                const float* __restrict__ x2 = nullptr, AffRef aff = AffRef{}, const float* __restrict__ gsc = nullptr,
+                ScRef sc = ScRef{}) {
+  // SC: conv1 of a BasicBlock AND the block's 1x1 shortcut conv in one pass (network/blocks.py:66-80: both read the block input).
+  // The 1x1 conv is the centre tap with its own weights: the A fragments of tap (1,1) feed a second accumulator set (+1/9 MFMAs),
+  // the epilogue stores the second result sc.y and its InstanceNorm partials sc.stats -- the separate 1x1 kernel and its re-read
+  // of the block input (HBM-bound, 5 FLOP/B) disappear.  Forward statistics forms (plain or virtual-cat input), fp32.
+  static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !F16 && !K8 && KS == 3), "fused shortcut: forward statistics forms");
   // F16: fp16 operands (see the block comment above mfma16h); gsc (nullable) = {s, 1/s} for a gradient input.
   // K8: the reduction is 8 channels wide (first block after the stem, network/blocks.py:123-127: 8 -> 16 @256^2).  A 16-wide
   // chunk would be half padding; instead PAIRS OF TAPS share one MFMA: k-slots kq = 0, 1 carry the 8 channels of tap 2g,
@@ -373,6 +381,8 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   float* in_s = smem;                         // [IH][IW][SPIX] + one dummy pixel (sink for the padding units)
   float* red = smem + (IH * IW + 1) * SPIX;   // [2][4][CO_T][2] + dummy
   float* w_s = red + 2 * 4 * CO_T * 2 + 8;    // [KK][K4][CO_T][4]
+  [[maybe_unused]] float* wsc_s = w_s + KK * Kdim * CO_T;             // SC: [K4][CO_T][4]
+  [[maybe_unused]] float* red_sc = wsc_s + Kdim * CO_T;               // SC: [2][4][CO_T][2] + dummy
   [[maybe_unused]] _Float16* in_h = reinterpret_cast<_Float16*>(smem);       // F16: [IH][IW][SPIXH] + dummy pixel
   [[maybe_unused]] _Float16* w_h = reinterpret_cast<_Float16*>(w_s);         // F16: [KK][NCH][CO_T][WROWH]
   [[maybe_unused]] const float gs = (F16 && gsc) ? gsc[0] : 1.f, gi = (F16 && gsc) ? gsc[1] : 1.f;
@@ -414,6 +424,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     }
     if (F16) *(h4*)(w_h + ((size_t)(tap * NCH + (k4 >> 2)) * CO_T + n) * WROWH + 4 * (k4 & 3)) = to_h4(v);
     else *(float4*)(w_s + (size_t)u * 4) = v;
+  }
+  if constexpr (SC) {
+    for (int u = tid; u < K4 * CO_T; u += TPB) {
+      const int n = u % CO_T, k4 = u / CO_T;
+      const float* p = sc.w + (size_t)(4 * k4) * Ndim + co0 + n;
+      *(float4*)(wsc_s + (size_t)u * 4) = make_float4(p[0], p[Ndim], p[2 * (size_t)Ndim], p[3 * (size_t)Ndim]);
+    }
   }
 
   // ---- per-thread staging descriptors (tile-independent): element offset relative to the tile's first halo pixel,
@@ -482,6 +499,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   };
 
   f32x4 acc[MR][NR], pacc[MR][NR];
+  [[maybe_unused]] f32x4 acs[MR][NR], pacs[MR][NR];    // SC: the shortcut's accumulators (current / previous item)
+  if constexpr (SC) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) { acs[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; pacs[i][j] = acs[i][j]; }
+  }
   [[maybe_unused]] f32x4 pold[MR][NR];                 // ACC: what the outputs hold now; BST: y1 at the output positions
   [[maybe_unused]] float nm[NR], nr[NR], ng[NR], nb[NR];   // BST: mean / rstd of (image en, channel), gamma, beta
 #pragma unroll
@@ -543,6 +567,27 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       for (int j = 0; j < NR; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) yb[o_lane + (i * W + r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
+    if constexpr (SC) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = pacs[i][j][r]; s1 += v; s2 += v * v; }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        float* rd = kq == 0 ? red_sc + par * (4 * CO_T * 2) + j * 32 + red_slot : red_sc + 2 * 4 * CO_T * 2;
+        *(float2*)rd = make_float2(s1, s2);
+      }
+      float* ys = sc.y + (((size_t)en * H + ety * TH) * W + etx * TW) * Ndim + co0;
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ys[o_lane + (i * W + r) * Ndim + j * 16] = pacs[i][j][r];
+    }
   };
   // ACC: the values the outputs of item (n_, ty_, tx_) hold now (loaded one region before they are added and stored)
   auto load_old = [&](int n_, int ty_, int tx_) {
@@ -571,6 +616,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
       for (int m = 0; m < 4; ++m) { s1 += rd[(m * CO_T + tid) * 2]; s2 += rd[(m * CO_T + tid) * 2 + 1]; }
       *(float2*)(stats + (((size_t)en * tiles_img + ety * tiles_x + etx) * Ndim + co0 + tid) * 2) = make_float2(s1, s2);
+      if constexpr (SC) {
+        const float* rs = red_sc + par * (4 * CO_T * 2);
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { t1 += rs[(m * CO_T + tid) * 2]; t2 += rs[(m * CO_T + tid) * 2 + 1]; }
+        *(float2*)(sc.stats + (((size_t)en * tiles_img + ety * tiles_x + etx) * Ndim + co0 + tid) * 2) = make_float2(t1, t2);
+      }
     }
   };
   auto mma_chunk = [&](int c) {
@@ -674,6 +726,19 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         for (int i = 0; i < MR; ++i)
 #pragma unroll
           for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+      if constexpr (SC) {
+        if (tap == KK / 2) {                             // the 1x1 shortcut: centre tap, its own weights, same A fragments
+          f32x4 bs[NR];
+#pragma unroll
+          for (int j = 0; j < NR; ++j) bs[j] = *(const f32x4*)(wsc_s + (((size_t)(c * 4 + kq) * CO_T) + j * 16 + lm) * 4);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+              for (int j = 0; j < NR; ++j) acs[i][j] = mfma16(a[i][s], bs[j][s], acs[i][j]);
+        }
+      }
     }
 #ifdef SMSUT_SETPRIO
     __builtin_amdgcn_s_setprio(0);
@@ -725,7 +790,10 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
-      for (int j = 0; j < NR; ++j) { pacc[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      for (int j = 0; j < NR; ++j) {
+        pacc[i][j] = acc[i][j]; acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SC) { pacs[i][j] = acs[i][j]; acs[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      }
     en = cn; ety = cty; etx = ctx;
     advance(cn, cty, ctx);
   };
@@ -1438,8 +1506,10 @@ template <int KS, int TH, int NTN, int NCH, bool K8 = false>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
                  float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
-                 bool f16 = false, const float* gsc = nullptr) {
+                 bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr) {
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
+  // fused 1x1 shortcut (SC): its weight block and a second statistics scratch
+  constexpr size_t sh_sc = sh + (size_t)(16 * NCH * 16 * NTN + 2 * 4 * 16 * NTN * 2 + 8) * sizeof(float);
   if constexpr (sh > 64 * 1024) return -1;
   else {
   if (Kdim != (K8 ? 8 : 16 * NCH) || W % TW != 0 || H % TH != 0 || Ndim % (16 * NTN) != 0 ||
@@ -1451,6 +1521,8 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (y2 && (split <= 0 || split >= Ndim || split % (16 * NTN) != 0 || stats || bst)) return -1;
   if (x2 && (NCH % 2 != 0 || !stats || bst || y2 || transposed)) return -1;     // virtual-cat input: forward statistics form
   if (aff && (!stats || bst || y2 || x2 || transposed)) return -1;              // input-side IN: forward statistics form
+  if (sc && (K8 || KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || f16 || !sc->w || !sc->y || !sc->stats))
+    return -1;                                                                  // fused shortcut: forward statistics forms, fp32
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = Ndim / (16 * NTN);
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
@@ -1485,7 +1557,18 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false><<<grid, TPB, sh, st>>>(                                    \
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
   } while (0)
-  if (aff) {
+  if (sc) {
+    if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
+      if (x2) {
+        if constexpr (NCH % 2 == 0)
+          conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
+              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc);
+      } else {
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+      }
+    }
+  } else if (aff) {
     P_GO(true, false, false, false, true);
   } else if (x2) {
     if constexpr (NCH % 2 == 0) P_GO(true, false, false, true, false);
@@ -1518,8 +1601,9 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
 // so that smsut_conv2d_mfma_tiles() always describes the partials the launched variant writes.
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
-                        const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr) {
-#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc
+                        const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
+                        const ScRef* sc = nullptr) {
+#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc
   if (Kdim == 8) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, true>(PARGS);
 #ifndef SMSUT_P_OLD_TABLE
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
@@ -2027,6 +2111,28 @@ int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, 
   SMSUT_REQUIRE(fwd_p_eligible(N, H, W, Kdim, Ndim));
   const AffRef a{mean, rstd, gamma, beta, slope};
   const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, nullptr, &a);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// conv1 of a BasicBlock fused with the block's 1x1 shortcut conv (network/blocks.py:66-80; both read the block input):
+//   y = conv3x3(x, w), ysc = conv1x1(x, wsc), InstanceNorm partials of both (stats / stats_sc, tiles as
+//   smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3)).  xb != null: x is the virtual cat([x, xb]) of two [N,H,W,Kdim/2] tensors.
+// w [3][3][Kdim][Ndim], wsc [Kdim][Ndim] (HWIO).  Persistent-kernel shapes with Kdim in {16, 32, 64}: _supported says which.
+int smsut_conv2d_fwd_sc_supported(int N, int H, int W, int Kdim, int Ndim, int cat) {
+  static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT"); return !e || atoi(e) != 0; }();
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  if (cat && Kdim % 32 != 0) return 0;
+  return 1;
+}
+
+int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
+                                   float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(x && w && wsc && y && ysc && stats && stats_sc && smsut_conv2d_fwd_sc_supported(N, H, W, Kdim, Ndim, xb != nullptr));
+  const ScRef sc{wsc, ysc, stats_sc};
+  const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb, nullptr,
+                              false, nullptr, &sc);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

@@ -689,7 +689,14 @@ class BasicBlockFn(Function):
         ctx.f16 = (f16a, f16)
         y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
-        if virtual:
+        # conv1 and the 1x1 shortcut read the same block input: one pass (the shortcut is conv1's centre tap with its own weights)
+        fused_sc = (has_sc and not f16a and bool(H.call("smsut_conv2d_fwd_sc_supported", n, h, w, ci, co, 1 if virtual else 0)))
+        if fused_sc:
+            s = new_act(n, co, h, w, x)
+            ps, t1 = _ws(n * t3 * co * 2, x), t3
+            H.call("smsut_conv2d_fwd_mfma_stats_sc", xa if virtual else x, xb if virtual else None, w1, ws, y1, s, p1, ps,
+                   n, h, w, ci, co, st)
+        elif virtual:
             H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w1, y1, p1, n, h, w,
                    ci, co, st)
         else:
@@ -713,7 +720,10 @@ class BasicBlockFn(Function):
             H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
         H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
-        if has_sc:
+        if fused_sc:
+            ms, rs = stat(co)
+            H.call("smsut_in_finalize_fwd", ps, t1, ms, rs, n, hw, co, IN_EPS, st)
+        elif has_sc:
             s = new_act(n, co, h, w, x)
             t1 = H.call("smsut_conv1x1_tiles", n, hw, co) if H.call("smsut_conv1x1_supported", ci, co) else 0
             if virtual:                                      # (basic_block_cat_fusable checked t1 > 0)

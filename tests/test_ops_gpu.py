@@ -559,3 +559,40 @@ def test_max_pool_skip_fused_backward(ops, n, c, h, w):
     y2, skip2 = ops.max_pool2_skip(xd2)
     (y2 * dev(gp)).sum().backward()                       # skip unused: plain pooling backward
     assert rel_err(xd2.grad.cpu().numpy(), ref_pool_only.numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("n,h,ci,co", [(32, 64, 16, 32), (8, 128, 32, 16), (4, 256, 16, 16), (16, 64, 64, 32), (8, 128, 32, 64),
+                                       (16, 64, 32, 64)])
+def test_fused_shortcut_conv(ops, n, h, ci, co):
+    """conv1 + the block's 1x1 shortcut in one pass (reference network/blocks.py:66-80): the 3x3 result and its statistics are
+    bit-identical to the plain entry point (same kernel, same order); the shortcut result matches the stand-alone 1x1 kernel
+    to fp32 rounding (different accumulation order) and its partials are the sums of what was stored; the virtual-cat form is
+    bit-identical to the materialised cat."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_conv2d_fwd_sc_supported", n, h, h, ci, co, 0) == 1
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(n, h, h, ci, generator=g).cuda()
+    w3 = (torch.randn(9 * ci * co, generator=g) / np.sqrt(9 * ci)).cuda(); w1 = (torch.randn(ci * co, generator=g) / np.sqrt(ci)).cuda()
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3)
+    hw = h * h
+    y0, y1, s1 = (torch.full((n, h, h, co), float("nan"), device="cuda") for _ in range(3))
+    p0, p1, q1 = (torch.zeros(n * tiles * co * 2, device="cuda") for _ in range(3))
+    H.call("smsut_conv2d_fwd_mfma_stats", x, w3, y0, p0, n, h, h, ci, co, 3, st)
+    H.call("smsut_conv2d_fwd_mfma_stats_sc", x, None, w3, w1, y1, s1, p1, q1, n, h, h, ci, co, st)
+    assert torch.equal(y0, y1) and torch.equal(p0, p1)
+    s0 = torch.empty(n, h, h, co, device="cuda")
+    H.call("smsut_conv1x1_fwd", x, w1, s0, None, n, hw, ci, co, 0, st)
+    ref = (x.double().reshape(-1, ci) @ w1.double().reshape(ci, co)).reshape(n, h, h, co)
+    assert (s1.double() - ref).abs().max() <= 2 * (s0.double() - ref).abs().max() + 1e-6     # as accurate as the 1x1 kernel
+    assert torch.allclose(s1, s0, rtol=1e-5, atol=1e-5)
+    q = q1.view(n, tiles, co, 2).double().sum(1)
+    assert torch.allclose(q[..., 0], s1.double().sum((1, 2)), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(q[..., 1], (s1.double() ** 2).sum((1, 2)), rtol=1e-5, atol=1e-3)
+    if ci % 32 == 0:                                                                        # virtual cat of two halves
+        assert H.call("smsut_conv2d_fwd_sc_supported", n, h, h, ci, co, 1) == 1
+        xa, xb = x[..., :ci // 2].contiguous(), x[..., ci // 2:].contiguous()
+        y2, s2 = torch.empty_like(y1), torch.empty_like(s1)
+        p2, q2 = torch.zeros_like(p1), torch.zeros_like(q1)
+        H.call("smsut_conv2d_fwd_mfma_stats_sc", xa, xb, w3, w1, y2, s2, p2, q2, n, h, h, ci, co, st)
+        assert torch.equal(y1, y2) and torch.equal(s1, s2) and torch.equal(p1, p2) and torch.equal(q1, q2)

@@ -234,9 +234,17 @@ def test_trace_bands_cover_reference_fp_spread(golden):
     """The bands of tests/test_graph_gpu.py's trajectory test against the reference's OWN sensitivity to rounding: the
     same 32 iterations replayed with the reference modules in fp32 (iter_trace) and fp64 (iter_trace_f64).  A band may
     not be tighter than that spread (no fp32 implementation could meet it) nor looser than 4x the spread + 1e-2."""
-    from trace_bands import TRACE_BANDS
+    from trace_bands import TRACE_BANDS, TRACE_STEP0
     a, b = golden("iter_trace"), golden("iter_trace_f64")
     names = [str(s) for s in a["scalar_names"]]
+    for i, k in enumerate(names):                     # iteration 0: per-scalar tolerance vs the reference's own fp32/fp64 spread
+        if k == "D_gp":
+            continue
+        spread0 = abs(a["scalars"][0, i] - b["scalars"][0, i]) / abs(b["scalars"][0, i])
+        tol = TRACE_STEP0.get(k, TRACE_STEP0["default"])
+        assert spread0 <= tol, (k, spread0, tol)
+        if k in TRACE_STEP0:
+            assert tol <= 2 * spread0, (k, spread0, tol)
     n = min(a["scalars"].shape[0], b["scalars"].shape[0])
     assert n >= 24
     for name, (band, n_it) in TRACE_BANDS.items():

@@ -15,6 +15,10 @@ band <= 4x spread + 1e-2, so the bands can neither be tighter than the reference
 # So they are tracked over the FIRST SIX iterations only; the segmentor-side scalars over the whole trajectory.
 # name: (relative band, number of leading iterations it applies to)
 TRACE_BANDS = {"G_seg": (0.01, 32), "G_semi": (0.05, 32), "G_rec": (0.15, 6), "G_nce": (0.08, 6)}
+# Iteration 0 of the trace: 1e-3 on every scalar (D_gp: 1e-2, its own line in the test) except G_fake, which is evaluated
+# through D AFTER D's first Adam step -- the reference's fp32 and fp64 replays differ by 3.2e-3 there (0.28931 vs 0.29024), so
+# no fp32 implementation can be held to 1e-3 on it (checked by test_trace_bands_cover_reference_fp_spread: spread <= band <= 2x).
+TRACE_STEP0 = {"default": 1e-3, "G_fake": 6e-3}
 
 # ---- the 2-iteration fixture (tests/golden/iter_small.npz, 64x64, 2 + 2 slices) ----------------------------------------------
 # Iteration 0 is deterministic arithmetic on fixed weights: north_star's 1e-3 on every scalar except G_fake, which the reference
