@@ -123,6 +123,9 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
   }
 }
 
+#ifndef W1_UNR
+#define W1_UNR 4     // r02 A/B (scratch/w1_ab.py): 1 -> 4 groups: 107 -> 80 us at 32x256^2 (16+16)->16, 60 -> 38 us at 8->16; 8 and 16 no better
+#endif
 // weight gradient: each wave walks groups of 4 pixels of its workgroup's pixel range with direct global loads
 template <int CIT, int COT>
 __global__ void __launch_bounds__(TPB)
@@ -148,18 +151,26 @@ conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
 #pragma unroll
   for (int i = 0; i < CIT; ++i) xs[i] = cat_src(x, x2, Cin, ca, ci0 + i * 16);
   const float* gb = gy + co0 + lm;
-// (runtime trip count)
-  for (int64_t p = pb + 4 * wave + kq; p - kq < pe; p += 16) {      // this lane's pixel (the MFMA k index)
-    const bool ok = p < pe;
-    float a[CIT], b[COT];
+  // W1_UNR pixel groups per trip: all their loads are issued before the first MFMA (the rolled one-group loop kept ONE
+  // 4-byte load per operand tile in flight per lane and ran at 3.4-3.8 TB/s; see profiles/r02_notes.md)
+  constexpr int UNR = W1_UNR;
+  for (int64_t p0 = pb + 4 * wave + kq; p0 - kq < pe; p0 += 16 * UNR) {      // this lane's pixel (the MFMA k index)
+    float a[UNR][CIT], b[UNR][COT];
 #pragma unroll
-    for (int i = 0; i < CIT; ++i) a[i] = (ok && iok[i]) ? xs[i].p[(size_t)p * xs[i].stride + ci0 + i * 16 + lm - xs[i].coff] : 0.f;
+    for (int u = 0; u < UNR; ++u) {
+      const int64_t p = p0 + 16 * u;
+      const bool ok = p < pe;
 #pragma unroll
-    for (int j = 0; j < COT; ++j) b[j] = (ok && jok[j]) ? gb[(size_t)p * Cout + j * 16] : 0.f;
+      for (int i = 0; i < CIT; ++i) a[u][i] = (ok && iok[i]) ? xs[i].p[(size_t)p * xs[i].stride + ci0 + i * 16 + lm - xs[i].coff] : 0.f;
 #pragma unroll
-    for (int i = 0; i < CIT; ++i)
+      for (int j = 0; j < COT; ++j) b[u][j] = (ok && jok[j]) ? gb[(size_t)p * Cout + j * 16] : 0.f;
+    }
 #pragma unroll
-      for (int j = 0; j < COT; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+      for (int i = 0; i < CIT; ++i)
+#pragma unroll
+        for (int j = 0; j < COT; ++j) acc[i][j] = mfma16(a[u][i], b[u][j], acc[i][j]);
   }
   for (int src = 1; src < 4; ++src) {             // fixed-order combine of the 4 waves
     __syncthreads();
