@@ -102,6 +102,12 @@ int smsut_conv2d_fwd_sc_supported(int N, int H, int W, int Kdim, int Ndim, int c
 int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb /*nullable*/, const float* w, const float* wsc, float* y,
                                    float* ysc, float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim,
                                    void* stream);
+/* ... and the data-gradient of that pair in one pass: gx = dgrad3x3(gy, w) + dgrad1x1(gs, wsc) (the backward of
+ * `out = conv1(x) ... + shortcut(x)` w.r.t. x, blocks.py:66-80).  gxb nullable: non-null = channels [0, split) of gx go to
+ * gxa, the rest to gxb (the block input was cat([up, skip])).  _supported(..., split or 0) first. */
+int smsut_conv2d_dgrad_sc_supported(int N, int H, int W, int Cout, int Cin, int split);
+int smsut_conv2d_dgrad_mfma_sc(const float* gy, const float* gs, const float* w, const float* wsc, float* gxa,
+                               float* gxb /*nullable*/, int split, int N, int H, int W, int Cout, int Cin, void* stream);
 int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace,
                                 int N, int H, int W, int Cin, int Cout, int KS, void* stream);
 int smsut_conv1x1_fwd_cat(const float* xa, const float* xb, int ca, const float* w, float* y, float* stats /*nullable*/,

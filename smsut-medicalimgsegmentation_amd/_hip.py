@@ -63,6 +63,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_fwd_mfma_stats_cat": "ppppp iiiii s",
     "smsut_conv2d_fwd_sc_supported": "iiiiii",
     "smsut_conv2d_fwd_mfma_stats_sc": "pppppppp iiiii s",
+    "smsut_conv2d_dgrad_sc_supported": "iiiiii",
+    "smsut_conv2d_dgrad_mfma_sc": "pppppp iiiiii s",
     "smsut_conv2d_wgrad_mfma_cat": "pp i ppp iiiiii s",
     # 4x4 s1 p1 (networks.NLayerDiscriminator)
     "smsut_conv2d_k4_supported": "ii",
@@ -151,7 +153,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",
-                         "smsut_conv2d_fwd_sc_supported"}
+                         "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_dgrad_sc_supported"}
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

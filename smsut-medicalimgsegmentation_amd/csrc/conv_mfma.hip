@@ -344,7 +344,7 @@ struct BstRef { const float* y1; const float* mean; const float* rstd; const flo
 struct ScRef { const float* w; float* y; float* stats; };   // SC: the block's 1x1 shortcut conv, fused (see conv_mfma_fwd_p)
 
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false, bool K8 = false, bool SC = false>
+          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
@@ -356,6 +356,10 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // the epilogue stores the second result sc.y and its InstanceNorm partials sc.stats -- the separate 1x1 kernel and its re-read
   // of the block input (HBM-bound, 5 FLOP/B) disappear.  Forward statistics forms (plain or virtual-cat input), fp32.
   static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !F16 && !K8 && KS == 3), "fused shortcut: forward statistics forms");
+  // SC2: the DATA-GRADIENT of that pair in one pass: gx = dgrad3x3(gy1, w1) + dgrad1x1(gs, ws).  The two gradients are the
+  // virtual cat [gy1, gs] along the reduction (DUAL staging, unchanged); the chunks of the second half only run the centre
+  // tap, against the 1x1 weights (sc.w) -- +1/9 MFMAs instead of a 1x1 kernel plus an accumulate pass over gx.
+  static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !F16 && !K8 && !SC && KS == 3), "fused shortcut data-gradient");
   // F16: fp16 operands (see the block comment above mfma16h); gsc (nullable) = {s, 1/s} for a gradient input.
   // K8: the reduction is 8 channels wide (first block after the stem, network/blocks.py:123-127: 8 -> 16 @256^2).  A 16-wide
   // chunk would be half padding; instead PAIRS OF TAPS share one MFMA: k-slots kq = 0, 1 carry the 8 channels of tap 2g,
@@ -416,7 +420,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     const int tap = u / (CO_T * K4);
     const int ng = co0 + n;
     float4 v;
-    if (!transposed) {
+    if constexpr (SC2) {                                 // (always the transposed form) rows of Kdim/2 = Cout reduction channels
+      constexpr int Kh = Kdim / 2;
+      if (k4 < K4 / 2) v = *(const float4*)(w + ((size_t)(KK - 1 - tap) * Ndim + ng) * Kh + 4 * k4);
+      else if (tap == KK / 2) v = *(const float4*)(sc.w + (size_t)ng * Kh + 4 * (k4 - K4 / 2));
+      else v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (!transposed) {
       const float* p = w + ((size_t)tap * Kdim + 4 * k4) * Ndim + ng;
       v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim];
     } else {
@@ -706,6 +715,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #endif
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
+      if (SC2 && c >= NCH / 2 && tap != KK / 2) continue;       // the shortcut's gradient: centre tap only
 #ifdef SMSUT_DBG_NO_LDSREAD
       const int kh = 0, kw = 0;                       // every tap reads tap 0's fragments: the compiler keeps them in registers
       const int tapw = 0;
@@ -1519,9 +1529,11 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int tiles_img = tiles_x * tiles_y;
   if (y2 && (split <= 0 || split >= Ndim || split % (16 * NTN) != 0 || stats || bst)) return -1;
-  if (x2 && (NCH % 2 != 0 || !stats || bst || y2 || transposed)) return -1;     // virtual-cat input: forward statistics form
+  if (x2 && !(sc && (transposed & 1)) && (NCH % 2 != 0 || !stats || bst || y2 || transposed)) return -1;   // virtual-cat input: forward statistics form
   if (aff && (!stats || bst || y2 || x2 || transposed)) return -1;              // input-side IN: forward statistics form
-  if (sc && (K8 || KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || f16 || !sc->w || !sc->y || !sc->stats))
+  const bool sc2 = sc && (transposed & 1);                                      // fused shortcut DATA-gradient (see SC2)
+  if (sc2 && (K8 || KS != 3 || NCH % 2 != 0 || !x2 || stats || bst || aff || (transposed & 2) || f16 || !sc->w)) return -1;
+  if (sc && !sc2 && (K8 || KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || f16 || !sc->w || !sc->y || !sc->stats))
     return -1;                                                                  // fused shortcut: forward statistics forms, fp32
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = Ndim / (16 * NTN);
@@ -1557,7 +1569,11 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false><<<grid, TPB, sh, st>>>(                                    \
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
   } while (0)
-  if (sc) {
+  if (sc2) {
+    if constexpr (!K8 && KS == 3 && NCH % 2 == 0)
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true><<<grid, TPB, sh, st>>>(
+          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
+  } else if (sc) {
     if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (x2) {
         if constexpr (NCH % 2 == 0)
@@ -1607,7 +1623,7 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
   if (Kdim == 8) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, true>(PARGS);
 #ifndef SMSUT_P_OLD_TABLE
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
-  if (Kdim == 32 && Ndim % 32 == 0) return launch_fwd_p<3, 8, 2, 2>(PARGS);
+  if (Kdim == 32 && Ndim % 32 == 0 && !(y2 && split % 32 != 0)) return launch_fwd_p<3, 8, 2, 2>(PARGS);   // (32-channel slabs must not straddle a split)
 #endif
   if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(PARGS);
   if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(PARGS);
@@ -2133,6 +2149,27 @@ int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb, const float*
   const ScRef sc{wsc, ysc, stats_sc};
   const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb, nullptr,
                               false, nullptr, &sc);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// Data-gradient of that pair: gx = dgrad3x3(gy, w) + dgrad1x1(gs, wsc) in one pass (gy, gs [N,H,W,Cout]; w, wsc the forward
+// weights [3][3][Cin][Cout], [Cin][Cout]).  gxb != null: channels [0, split) of gx go to gxa [N,H,W,split], the rest to gxb
+// (block input was cat([up, skip])).  Persistent-kernel shapes with Cout in {16, 32}: _supported says which.
+int smsut_conv2d_dgrad_sc_supported(int N, int H, int W, int Cout, int Cin, int split) {
+  static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_DGRAD"); return !e || atoi(e) != 0; }();
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Cout == 16 || Cout == 32) || !fwd_p_eligible(N, H, W, 2 * Cout, Cin)) return 0;
+  if (split && (split <= 0 || split >= Cin || split % 16 != 0 || (Cin - split) % 16 != 0)) return 0;
+  return 1;
+}
+
+int smsut_conv2d_dgrad_mfma_sc(const float* gy, const float* gs, const float* w, const float* wsc, float* gxa, float* gxb,
+                               int split, int N, int H, int W, int Cout, int Cin, void* stream) {
+  SMSUT_REQUIRE(gy && gs && w && wsc && gxa && smsut_conv2d_dgrad_sc_supported(N, H, W, Cout, Cin, gxb ? split : 0));
+  const ScRef sc{wsc, nullptr, nullptr};
+  const int rc = select_fwd_p(gy, w, gxa, N, H, W, 2 * Cout, Cin, 1, (hipStream_t)stream, nullptr, nullptr, nullptr, gxb, gxb ? split : 0,
+                              gs, nullptr, false, nullptr, &sc);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

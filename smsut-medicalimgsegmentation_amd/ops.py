@@ -855,7 +855,11 @@ class BasicBlockFn(Function):
             if ctx.needs_input_grad[11] or ctx.needs_input_grad[12]:
                 ca, cb = ctx.cat_split
                 ga, gb = new_act(n, ca, h, w, x), new_act(n, cb, h, w, x)
-                if (ctx.has_sc and ca % 16 == 0 and H.call("smsut_conv1x1_supported", co, ci)
+                if ctx.has_sc and not f16a and H.call("smsut_conv2d_dgrad_sc_supported", n, h, w, co, ci, ca):
+                    # conv1's and the shortcut's data-gradients in ONE pass (the shortcut's is the centre tap of a second
+                    # reduction half), written straight into (ga, gb): no 1x1 kernel, no accumulate pass
+                    H.call("smsut_conv2d_dgrad_mfma_sc", gy1, gs_t, w1, ws, ga, gb, ca, n, h, w, co, ci, st)
+                elif (ctx.has_sc and ca % 16 == 0 and H.call("smsut_conv1x1_supported", co, ci)
                         and H.call("smsut_conv2d_mfma_split_supported", n, h, w, co, ci, ca)):
                     # shortcut gradient first, the 3x3 data-gradient accumulates on top -- both straight into (ga, gb)
                     H.call("smsut_conv1x1_fwd_split", gs_t, ws, ga, gb, ca, n, hw, co, ci, 1, st)
@@ -878,6 +882,10 @@ class BasicBlockFn(Function):
         if ctx.needs_input_grad[0]:
             # the shortcut's gradient lands in gx first; the 3x3 data-gradient then accumulates into it in its store
             # epilogue (transposed | 2), which replaces a separate 3-pass add
+            if ctx.has_sc and not f16a and H.call("smsut_conv2d_dgrad_sc_supported", n, h, w, co, ci, 0):
+                gx = new_act(n, ci, h, w, x)
+                H.call("smsut_conv2d_dgrad_mfma_sc", gy1, gs_t, w1, ws, gx, None, 0, n, h, w, co, ci, st)
+                return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
             if ctx.has_sc:
                 gx = new_act(n, ci, h, w, x)
                 if H.call("smsut_conv1x1_supported", co, ci):

@@ -596,3 +596,36 @@ def test_fused_shortcut_conv(ops, n, h, ci, co):
         p2, q2 = torch.zeros_like(p1), torch.zeros_like(q1)
         H.call("smsut_conv2d_fwd_mfma_stats_sc", xa, xb, w3, w1, y2, s2, p2, q2, n, h, h, ci, co, st)
         assert torch.equal(y1, y2) and torch.equal(s1, s2) and torch.equal(p1, p2) and torch.equal(q1, q2)
+
+
+@pytest.mark.parametrize("n,h,co,ci,split", [(8, 128, 16, 32, 16), (8, 128, 16, 32, 0), (16, 64, 32, 64, 32), (4, 256, 16, 16, 0),
+                                            (8, 128, 32, 16, 0), (16, 64, 32, 32, 0), (6, 128, 32, 64, 32)])
+def test_fused_shortcut_data_gradient(ops, n, h, co, ci, split):
+    """gx = dgrad3x3(gy, w1) + dgrad1x1(gs, ws) in one pass (backward of conv1(x) + shortcut(x) w.r.t. x, reference
+    network/blocks.py:66-80) against the two-kernel composition it replaces (1x1 data-gradient, then the 3x3 data-gradient in its
+    accumulate form) and against fp64; split output = the same values in two tensors."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_conv2d_dgrad_sc_supported", n, h, h, co, ci, split) == 1
+    g = torch.Generator(device="cpu").manual_seed(5)
+    gy = torch.randn(n, h, h, co, generator=g).cuda(); gs = torch.randn(n, h, h, co, generator=g).cuda()
+    w3 = (torch.randn(9 * ci * co, generator=g) / np.sqrt(9 * co)).cuda(); w1 = (torch.randn(ci * co, generator=g) / np.sqrt(co)).cuda()
+    hw = h * h
+    ref = torch.empty(n, h, h, ci, device="cuda")
+    H.call("smsut_conv1x1_fwd", gs, w1, ref, None, n, hw, co, ci, 1, st)
+    H.call("smsut_conv2d_fwd_mfma", gy, w3, ref, n, h, h, co, ci, 3, 3, st)
+    if split:
+        ga = torch.full((n, h, h, split), float("nan"), device="cuda"); gb = torch.full((n, h, h, ci - split), float("nan"), device="cuda")
+        H.call("smsut_conv2d_dgrad_mfma_sc", gy, gs, w3, w1, ga, gb, split, n, h, h, co, ci, st)
+        got = torch.cat([ga, gb], 3)
+    else:
+        got = torch.full((n, h, h, ci), float("nan"), device="cuda")
+        H.call("smsut_conv2d_dgrad_mfma_sc", gy, gs, w3, w1, got, None, 0, n, h, h, co, ci, st)
+    assert torch.isfinite(got).all()
+    assert torch.allclose(got, ref, rtol=1e-5, atol=2e-5)
+    # fp64 check on a few images: conv_transpose of gy with the 3x3 weights + gs @ ws^T
+    k = min(n, 2)
+    w3d = w3.double().view(3, 3, ci, co).permute(3, 2, 0, 1).contiguous()           # [co, ci, 3, 3] = conv_transpose2d weight layout
+    d = torch.nn.functional.conv_transpose2d(gy[:k].double().permute(0, 3, 1, 2), w3d, padding=1).permute(0, 2, 3, 1)
+    d = d + gs[:k].double() @ w1.double().view(ci, co).t()
+    assert (got[:k].double() - d).abs().max() <= 2 * (ref[:k].double() - d).abs().max() + 1e-6
