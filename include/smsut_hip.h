@@ -108,6 +108,12 @@ int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb /*nullable*/,
 int smsut_conv2d_dgrad_sc_supported(int N, int H, int W, int Cout, int Cin, int split);
 int smsut_conv2d_dgrad_mfma_sc(const float* gy, const float* gs, const float* w, const float* wsc, float* gxa,
                                float* gxb /*nullable*/, int split, int N, int H, int W, int Cout, int Cin, void* stream);
+/* ... and both weight gradients in one pass: gw10 [10][Cin][Cout], rows 0..8 = conv1's 3x3 gradient (HWIO), row 9 = the 1x1
+ * shortcut's; gs = gradient of the shortcut's output.  xb nullable (virtual cat, ca channels in xa). */
+int smsut_conv2d_wgrad_sc_supported(int N, int H, int W, int Cin, int Cout);
+int64_t smsut_conv2d_wgrad_sc_ws(int N, int H, int W, int Cin, int Cout);
+int smsut_conv2d_wgrad_mfma_sc(const float* xa, const float* xb /*nullable*/, int ca, const float* gy, const float* gs,
+                               float* gw10, float* workspace, int N, int H, int W, int Cin, int Cout, void* stream);
 int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace,
                                 int N, int H, int W, int Cin, int Cout, int KS, void* stream);
 int smsut_conv1x1_fwd_cat(const float* xa, const float* xb, int ca, const float* w, float* y, float* stats /*nullable*/,

@@ -1049,14 +1049,20 @@ typedef float4 wvec;
 typedef f32x4 wvec;
 #define WZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
 #endif
-template <bool DUAL = false, bool INAFF = false>
+template <bool DUAL = false, bool INAFF = false, bool SC = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                    int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split,
-                   const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{}) {
+                   const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{},
+                   const float* __restrict__ gs = nullptr) {
+  // SC: the weight gradient of the block's 1x1 shortcut conv rides along (network/blocks.py:66-80: conv1 and the shortcut read
+  // the same x): a tenth "tap" whose A operand is the centre tap's x and whose B operand is gs (the gradient of the shortcut's
+  // output) -- every wave gets ONE more accumulator tile (ci tile wave >> 1, its co tile), stored as row KK of a (KK+1)-row slab.  gy and gs share one LDS tile [pixel][gy 32 | gs 32 | pad 16]
+  // (80-float stride: pixel groups kq, kq + 1 still land on disjoint bank halves), 75.5 KB with the x tile: two workgroups per CU.
+  static_assert(!SC || !INAFF, "fused shortcut weight gradient: plain / virtual-cat input");
   constexpr int KS = 3, KK = 9, PAD = 1, CIT = 2, COT = 2;
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
-  constexpr int CI_T = 32, CO_T = 32, SI = WTS_STRIDE, SO = WTS_STRIDE;
+  constexpr int CI_T = 32, CO_T = 32, SI = WTS_STRIDE, SO = SC ? 80 : WTS_STRIDE;
   constexpr int NSLOT = KK * CIT * COT / 4;                    // 9 accumulator tiles per wave
   extern __shared__ float smem[];
   float* in_s = smem;                         // [IH][IW][SI]
@@ -1083,6 +1089,8 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   f32x4 acc[NSLOT];
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] f32x4 acc_sc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  [[maybe_unused]] const int a_off_sc = (PAD * IW + PAD) * SI + (wave >> 1) * 16;
 
   // Staging descriptors, computed once (full tiles and full 32-channel slabs only -- the host checks H % 8 == 0,
   // W % 16 == 0, Cin % 32 == 0, Cout % 32 == 0 and 32-bit element offsets): element offset of the unit relative to the
@@ -1092,6 +1100,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   constexpr int NGY = (WTH * TW * (CO_T / 4) + TPB - 1) / TPB;
   static_assert(WTH * TW * (CO_T / 4) % TPB == 0, "gy tile units divide evenly");
   wvec rin[NIN], rgy[NGY];     // ext-vector values (HIP's float4 struct kept rgy in scratch memory)
+  [[maybe_unused]] wvec rgs[NGY];
   int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
   // x2 != null: x is the virtual cat([x, x2]) (common.h).  A thread's units all carry the same channel quad
   // (TPB % (CI_T/4) == 0; padding units keep it too), so its source tensor, pixel stride and channel offset are fixed.
@@ -1135,6 +1144,11 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     }
 #pragma unroll
     for (int i = 0; i < NGY; ++i) rgy[i] = *(const wvec*)(gb + gy_off[i]);
+    if constexpr (SC) {
+      const float* sb = gs + (((pn * H + pty * WTH) * W) + ptx * TW) * Cout + co0;
+#pragma unroll
+      for (int i = 0; i < NGY; ++i) rgs[i] = *(const wvec*)(sb + gy_off[i]);
+    }
     if (INAFF) {
       a_m = *(const float4*)(aff.mean + (size_t)pn * Cin + aq);
       a_r = *(const float4*)(aff.rstd + (size_t)pn * Cin + aq);
@@ -1160,7 +1174,10 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
       *(wvec*)(in_s + in_lds[i]) = v;
     }
 #pragma unroll
-    for (int i = 0; i < NGY; ++i) *(wvec*)(gy_s + gy_lds[i]) = rgy[i];
+    for (int i = 0; i < NGY; ++i) {
+      *(wvec*)(gy_s + gy_lds[i]) = rgy[i];
+      if constexpr (SC) *(wvec*)(gy_s + gy_lds[i] + 32) = rgs[i];
+    }
     __syncthreads();
     if (t - t_begin < 2) { STAMP(3 + 4 * (t - t_begin)); }
     if (t + 1 < t_end) prefetch();
@@ -1177,12 +1194,13 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
         const float* ap = in_s + (r * IW + px) * SI + lm;
 #pragma unroll
         for (int k = 0; k < NSLOT; ++k) acc[k] = mfma16(ap[a_off[k]], b, acc[k]);
+        if constexpr (SC) acc_sc = mfma16(ap[a_off_sc], gy_s[(r * TW + px) * SO + 32 + jt * 16 + lm], acc_sc);
       }
     }
     if (t - t_begin < 2) { STAMP(5 + 4 * (t - t_begin)); }
   }
   STAMP(10);
-  float* out = part + (size_t)split * KK * Cin * Cout + (size_t)(ci0 + 4 * kq) * Cout + co0 + jt * 16 + lm;
+  float* out = part + (size_t)split * (SC ? KK + 1 : KK) * Cin * Cout + (size_t)(ci0 + 4 * kq) * Cout + co0 + jt * 16 + lm;
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) {
     const int ti = (wave + 4 * k) >> 1;
@@ -1196,6 +1214,11 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
       o[r * Cout] = acc[k][r];
 #endif
     }
+  }
+  if constexpr (SC) {                           // slab row KK: the shortcut's [Cin][Cout] gradient, this wave's (ci tile, co tile)
+    float* o = out + (KK * Cin + (wave >> 1) * 16) * Cout;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r * Cout] = acc_sc[r];
   }
   STAMP(11);
 }
@@ -2311,9 +2334,14 @@ inline bool plane_wgrad_applies(int N, int H, int W, int Cin, int Cout) {
          (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31);
 }
 
+int smsut_conv2d_wgrad_sc_supported(int N, int H, int W, int Cin, int Cout);
+// gs != null (tap-split kernel shapes only): fused weight gradient of the block's 1x1 shortcut; gw and the slabs then have
+// KS*KS + 1 rows (row 9 = shortcut)
 static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
-                             int Cout, int KS, void* stream, const float* x2, int ca, const AffRef* aff = nullptr) {
+                             int Cout, int KS, void* stream, const float* x2, int ca, const AffRef* aff = nullptr,
+                             const float* gs = nullptr) {
   SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(!gs || (KS == 3 && !aff && smsut_conv2d_wgrad_sc_supported(N, H, W, Cin, Cout)));
   SMSUT_REQUIRE(smsut_conv2d_wgrad_mfma_supported(KS, 1, (KS - 1) / 2, Cin, Cout));
   SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0 && (Cin - ca) % 4 == 0));
   SMSUT_REQUIRE(!aff || (KS == 3 && !x2));
@@ -2338,7 +2366,21 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
              (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {
       constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE + 4) * sizeof(float);
       dim3 grid(p.splits, Cin / 32, Cout / 32);
-      if (aff)
+      if (gs) {
+        constexpr size_t sh_sc = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * 80 + 4) * sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+          (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad_ts<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_sc);
+          (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad_ts<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_sc);
+          attr = true;
+        }
+        if (x2)
+          conv_mfma_wgrad_ts<true, false, true><<<grid, TPB, sh_sc, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                                         p.tiles_per_split, x2, ca, AffRef{}, gs);
+        else
+          conv_mfma_wgrad_ts<false, false, true><<<grid, TPB, sh_sc, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
+                                                                          p.tiles_per_split, nullptr, 0, AffRef{}, gs);
+      } else if (aff)
         conv_mfma_wgrad_ts<false, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
                                                                p.tiles_per_split, nullptr, 0, *aff);
       else if (x2)
@@ -2349,7 +2391,7 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
                                                          p.tiles_per_split, nullptr, 0);
     } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
   }
-  const int wsize = KS * KS * Cin * Cout;
+  const int wsize = (KS * KS + (gs ? 1 : 0)) * Cin * Cout;
   launch_sum_splits(workspace, gw, wsize, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
@@ -2368,6 +2410,27 @@ int smsut_conv2d_wgrad_mfma_inaff(const float* x, const float* gy, float* gw, fl
   SMSUT_REQUIRE(mean && rstd && gamma && beta);
   const AffRef a{mean, rstd, gamma, beta, slope};
   return wgrad_mfma_launch(x, gy, gw, workspace, N, H, W, Cin, Cout, 3, stream, nullptr, 0, &a);
+}
+
+// conv1's 3x3 weight gradient AND the 1x1 shortcut's (network/blocks.py:66-80: both convs read x) in one pass:
+//   gw10 [10][Cin][Cout]: rows 0..8 = sum_p x[p + tap] (x) gy[p]  (as smsut_conv2d_wgrad_mfma), row 9 = sum_p x[p] (x) gs[p].
+// xb nullable: non-null = x is the virtual cat([xa, xb]), ca channels in xa.  workspace: smsut_conv2d_wgrad_sc_ws floats.
+int smsut_conv2d_wgrad_sc_supported(int N, int H, int W, int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_WGRAD"); return !e || atoi(e) != 0; }();
+  // the tap-split kernel's shapes (whole 32 x 32 channel slabs, full tiles): there the fusion wins 6-14 us per call.  On the
+  // 16-channel slabs (32->16, 16->32) the extra tile pushed the row-split kernel over 256 VGPRs and the pair ran 0-7 us SLOWER
+  // fused (scratch/wsc_ab.py) -- those keep the two-kernel form.
+  return on && N > 0 && H > 0 && W > 0 && H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
+         !plane_wgrad_applies(N, H, W, Cin, Cout) && (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31);
+}
+int64_t smsut_conv2d_wgrad_sc_ws(int N, int H, int W, int Cin, int Cout) {
+  const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
+  return (int64_t)p.splits * 10 * Cin * Cout;
+}
+int smsut_conv2d_wgrad_mfma_sc(const float* xa, const float* xb, int ca, const float* gy, const float* gs, float* gw10,
+                               float* workspace, int N, int H, int W, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(gs && smsut_conv2d_wgrad_sc_supported(N, H, W, Cin, Cout));
+  return wgrad_mfma_launch(xa, gy, gw10, workspace, N, H, W, Cin, Cout, 3, stream, xb, xb ? ca : 0, nullptr, gs);
 }
 
 // Weight gradient with x = the virtual cat([xa, xb]) (xa [N,H,W,ca], xb [N,H,W,Cin-ca], ca % 16 == 0) read in place;

@@ -828,8 +828,19 @@ class BasicBlockFn(Function):
                 H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, wws2, n, h, w, co, co, 3, st)
         # ---- conv1 and the shortcut
         sc1 = _grad_scale(gy1) if f16a else None
-        gw1 = new_weight(co, ci, 3, 3, device=dev)
-        if f16w1:
+        fused_wsc = (ctx.has_sc and not f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_supported", n, h, w, ci, co)))
+        if fused_wsc:
+            # both weight gradients in one pass over x: rows 0..8 = conv1's taps, row 9 = the 1x1 shortcut's
+            g10 = torch.empty(10 * ci * co, dtype=torch.float32, device=dev)
+            gw1 = torch.as_strided(g10, (co, ci, 3, 3), hwio_strides(co, ci, 3, 3))
+            gws = torch.as_strided(g10, (co, ci, 1, 1), hwio_strides(co, ci, 1, 1), 9 * ci * co)
+            H.call("smsut_conv2d_wgrad_mfma_sc", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
+                   g10, _ws(H.call("smsut_conv2d_wgrad_sc_ws", n, h, w, ci, co), x), n, h, w, ci, co, st)
+        else:
+            gw1 = new_weight(co, ci, 3, 3, device=dev)
+        if fused_wsc:
+            pass
+        elif f16w1:
             wws = _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, ci, co), x)
             if ctx.virtual:
                 H.call("smsut_conv2d_wgrad_f16", x, xb_part, x.shape[1], gy1, gw1, wws, sc1, n, h, w, ci, co, st)
@@ -841,8 +852,9 @@ class BasicBlockFn(Function):
                 H.call("smsut_conv2d_wgrad_mfma_cat", x, xb_part, x.shape[1], gy1, gw1, wws, n, h, w, ci, co, 3, st)
             else:
                 H.call("smsut_conv2d_wgrad_mfma", x, gy1, gw1, wws, n, h, w, ci, co, 3, st)
-        gws = None
-        if ctx.has_sc:
+        if not fused_wsc:
+            gws = None
+        if ctx.has_sc and not fused_wsc:
             gws = new_weight(co, ci, 1, 1, device=dev)
             wws1 = _ws(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), x)
             if ctx.virtual:

@@ -629,3 +629,35 @@ def test_fused_shortcut_data_gradient(ops, n, h, co, ci, split):
     d = torch.nn.functional.conv_transpose2d(gy[:k].double().permute(0, 3, 1, 2), w3d, padding=1).permute(0, 2, 3, 1)
     d = d + gs[:k].double() @ w1.double().view(ci, co).t()
     assert (got[:k].double() - d).abs().max() <= 2 * (ref[:k].double() - d).abs().max() + 1e-6
+
+
+@pytest.mark.parametrize("n,h,ci,co,cat", [(16, 64, 32, 64, 0), (16, 64, 64, 32, 1), (8, 32, 128, 64, 1), (6, 32, 64, 128, 0),
+                                          (3, 128, 64, 32, 1), (5, 16, 256, 128, 1)])
+def test_fused_shortcut_weight_gradient(ops, n, h, ci, co, cat):
+    """conv1's 3x3 weight gradient and the 1x1 shortcut's in one pass (both convs read x, reference network/blocks.py:66-80):
+    rows 0..8 of the result are bit-identical to the plain entry point (same kernel, same order), row 9 matches the
+    stand-alone 1x1 weight gradient to fp32 rounding and is as close to fp64; virtual-cat input included."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_conv2d_wgrad_sc_supported", n, h, h, ci, co) == 1
+    assert H.call("smsut_conv2d_wgrad_sc_supported", n, h, h, 16, co) == 0          # 16-channel slabs keep the two-kernel form
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(n, h, h, ci, generator=g).cuda(); gy = torch.randn(n, h, h, co, generator=g).cuda(); gs = torch.randn(n, h, h, co, generator=g).cuda()
+    hw = h * h
+    g9 = torch.empty(9 * ci * co, device="cuda"); g1 = torch.empty(ci * co, device="cuda")
+    H.call("smsut_conv2d_wgrad_mfma", x, gy, g9, torch.empty(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, h, ci, co, 3), device="cuda"),
+           n, h, h, ci, co, 3, st)
+    H.call("smsut_conv1x1_wgrad", x, gs, g1, torch.empty(H.call("smsut_conv1x1_wgrad_ws", n, hw, ci, co), device="cuda"), n, hw, ci, co, st)
+    g10 = torch.full((10 * ci * co,), float("nan"), device="cuda")
+    ws = torch.empty(H.call("smsut_conv2d_wgrad_sc_ws", n, h, h, ci, co), device="cuda")
+    if cat:
+        xa, xb = x[..., :ci // 2].contiguous(), x[..., ci // 2:].contiguous()
+        H.call("smsut_conv2d_wgrad_mfma_sc", xa, xb, ci // 2, gy, gs, g10, ws, n, h, h, ci, co, st)
+    else:
+        H.call("smsut_conv2d_wgrad_mfma_sc", x, None, 0, gy, gs, g10, ws, n, h, h, ci, co, st)
+    assert torch.isfinite(g10).all()
+    assert torch.equal(g10[:9 * ci * co], g9)
+    ref = x.double().reshape(-1, ci).t() @ gs.double().reshape(-1, co)
+    e_new = (g10[9 * ci * co:].double().view(ci, co) - ref).abs().max(); e_old = (g1.double().view(ci, co) - ref).abs().max()
+    assert e_new <= 2 * e_old + 1e-3 * ref.abs().max() * 1e-3, (float(e_new), float(e_old))
+    assert torch.allclose(g10[9 * ci * co:], g1, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
