@@ -39,6 +39,10 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_fwd_mfma_stats_cat": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_mfma_cat": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * _k2(a, 6), "mfma"),
     "smsut_conv2d_fwd_mfma_split": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
+    # conv1 + 1x1 shortcut fused (3x3 taps + the centre-tap shortcut = 10 "taps"): forward, data- and weight-gradient
+    "smsut_conv2d_fwd_mfma_stats_sc": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 10, "mfma"),
+    "smsut_conv2d_dgrad_mfma_sc": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 10, "mfma"),
+    "smsut_conv2d_wgrad_mfma_sc": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 10, "mfma"),
     "smsut_conv2d_k4_fwd": (lambda a: 32.0 * a[0] * (a[1] - 1) * (a[2] - 1) * a[3] * a[4], "mfma"),
     "smsut_conv2d_k4_wgrad": (lambda a: 32.0 * a[0] * (a[1] - 1) * (a[2] - 1) * a[3] * a[4], "mfma"),
     # fp16-operand forms (config 5)
