@@ -344,7 +344,7 @@ struct BstRef { const float* y1; const float* mean; const float* rstd; const flo
 struct ScRef { const float* w; float* y; float* stats; };   // SC: the block's 1x1 shortcut conv, fused (see conv_mfma_fwd_p)
 
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false>
+          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
@@ -360,6 +360,10 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // virtual cat [gy1, gs] along the reduction (DUAL staging, unchanged); the chunks of the second half only run the centre
   // tap, against the 1x1 weights (sc.w) -- +1/9 MFMAs instead of a 1x1 kernel plus an accumulate pass over gx.
   static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !F16 && !K8 && !SC && KS == 3), "fused shortcut data-gradient");
+  // N8: the result has 8 channels (Ndim == 8: the data-gradient of the first block after the stem, 16 -> 8 @256^2, ran on the per-tile
+  // kernel at 35 TFLOP/s).  The weight block is padded to 16 columns with zeros, lanes lm >= 8 neither load nor store.
+  static_assert(!N8 || (NTN == 1 && !STATS && !BST && !INAFF && !F16 && !K8 && !SC), "8 result channels: plain / accumulate / SC2 data-gradient forms");
+  [[maybe_unused]] const bool nok = !N8 || (threadIdx.x & 15) < 8;
   // F16: fp16 operands (see the block comment above mfma16h); gsc (nullable) = {s, 1/s} for a gradient input.
   // K8: the reduction is 8 channels wide (first block after the stem, network/blocks.py:123-127: 8 -> 16 @256^2).  A 16-wide
   // chunk would be half padding; instead PAIRS OF TAPS share one MFMA: k-slots kq = 0, 1 carry the 8 channels of tap 2g,
@@ -420,7 +424,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     const int tap = u / (CO_T * K4);
     const int ng = co0 + n;
     float4 v;
-    if constexpr (SC2) {                                 // (always the transposed form) rows of Kdim/2 = Cout reduction channels
+    if (N8 && n >= 8) {                                  // padding columns of the 8-channel result
+      v = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if constexpr (SC2) {                          // (always the transposed form) rows of Kdim/2 = Cout reduction channels
       constexpr int Kh = Kdim / 2;
       if (k4 < K4 / 2) v = *(const float4*)(w + ((size_t)(KK - 1 - tap) * Ndim + ng) * Kh + 4 * k4);
       else if (tap == KK / 2) v = *(const float4*)(sc.w + (size_t)ng * Kh + 4 * (k4 - K4 / 2));
@@ -575,7 +581,8 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
       for (int j = 0; j < NR; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) yb[o_lane + (i * W + r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
+        for (int r = 0; r < 4; ++r)
+          if (nok) yb[o_lane + (i * W + r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
     if constexpr (SC) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -615,7 +622,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pold[i][j][r] = yb[o_lane + (i * W + r) * os + j * 16];
+          for (int r = 0; r < 4; ++r) pold[i][j][r] = nok ? yb[o_lane + (i * W + r) * os + j * 16] : 0.f;
     }
   };
   auto stats_out = [&](int par) {                     // after the barrier that completes red[par]
@@ -1535,7 +1542,7 @@ constexpr size_t fwd_p_lds() {
 }
 
 
-template <int KS, int TH, int NTN, int NCH, bool K8 = false>
+template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
                  float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
@@ -1545,9 +1552,10 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   constexpr size_t sh_sc = sh + (size_t)(16 * NCH * 16 * NTN + 2 * 4 * 16 * NTN * 2 + 8) * sizeof(float);
   if constexpr (sh > 64 * 1024) return -1;
   else {
-  if (Kdim != (K8 ? 8 : 16 * NCH) || W % TW != 0 || H % TH != 0 || Ndim % (16 * NTN) != 0 ||
+  if (Kdim != (K8 ? 8 : 16 * NCH) || W % TW != 0 || H % TH != 0 || (N8 ? Ndim != 8 : Ndim % (16 * NTN) != 0) ||
       (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) >= (1ll << 31))
     return -1;
+  if (N8 && (NTN != 1 || K8 || stats || tiles_out || bst || y2 || aff || f16 || !(transposed & 1) || (x2 && !(sc && sc->w)))) return -1;
   if (K8 && (f16 || bst || x2 || aff)) return -1;
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int tiles_img = tiles_x * tiles_y;
@@ -1559,7 +1567,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (sc && !sc2 && (K8 || KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || f16 || !sc->w || !sc->y || !sc->stats))
     return -1;                                                                  // fused shortcut: forward statistics forms, fp32
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
-  const int nz = Ndim / (16 * NTN);
+  const int nz = N8 ? 1 : Ndim / (16 * NTN);
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
   if (occ == 0) {
     int o = 0;
@@ -1592,7 +1600,22 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false><<<grid, TPB, sh, st>>>(                                    \
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
   } while (0)
-  if (sc2) {
+  if constexpr (N8) {                           // 8 result channels: data-gradient forms only (checked above)
+    if constexpr (NTN == 1 && !K8 && KS == 3) {
+      if (sc2) {
+        if constexpr (NCH % 2 == 0)
+          conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, true><<<grid, TPB, sh, st>>>(
+              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, x2, affv, nullptr, *sc);
+        else return -1;
+      } else if (transposed & 2)
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, false, true, false, false, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, nullptr, affv, nullptr);
+      else
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, false, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, nullptr, affv, nullptr);
+      return 0;
+    } else return -1;
+  } else if (sc2) {
     if constexpr (!K8 && KS == 3 && NCH % 2 == 0)
       conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true><<<grid, TPB, sh, st>>>(
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
@@ -1643,6 +1666,11 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
                         const ScRef* sc = nullptr) {
 #define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc
+  if (Ndim == 8) {                                   // 8 result channels (see conv_mfma_fwd_p, N8): data-gradient forms
+    if (Kdim == 16) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, false, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, false, true>(PARGS);
+    if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2, false, true>(PARGS);
+    return -1;
+  }
   if (Kdim == 8) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, true>(PARGS);
 #ifndef SMSUT_P_OLD_TABLE
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
@@ -1653,6 +1681,13 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
   if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(PARGS);
 #undef PARGS
   return -1;
+}
+
+// 8-channel results on the persistent kernel (data-gradient of the first block after the stem).  SMSUT_CONV_N8=0/1.
+inline bool fwd_p_n8_eligible(int N, int H, int W, int Kdim, int Ndim) {
+  static const bool on = [] { const char* e = getenv("SMSUT_CONV_N8"); return !e || atoi(e) != 0; }();
+  return on && Ndim == 8 && (Kdim == 16 || Kdim == 32) && W % TW == 0 && H % 8 == 0 && (int64_t)N * (H / 8) * (W / TW) >= 1024 &&
+         (int64_t)N * H * W * Kdim < (1ll << 31);
 }
 
 template <int KS>
@@ -1673,6 +1708,10 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
       if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr, y2, split, x2, nullptr, f16,
                        gsc) == 0)
         return 0;
+    }
+    if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && (transposed & 1) && !stats && !tiles_out && !x2 && !y2 && !f16 &&
+        fwd_p_n8_eligible(N, H, W, Kdim, Ndim)) {
+      if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, nullptr, nullptr, nullptr) == 0) return 0;
     }
   }
   const int nt = (Ndim + 15) / 16;
@@ -2182,7 +2221,9 @@ int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb, const float*
 // (block input was cat([up, skip])).  Persistent-kernel shapes with Cout in {16, 32}: _supported says which.
 int smsut_conv2d_dgrad_sc_supported(int N, int H, int W, int Cout, int Cin, int split) {
   static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_DGRAD"); return !e || atoi(e) != 0; }();
-  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Cout == 16 || Cout == 32) || !fwd_p_eligible(N, H, W, 2 * Cout, Cin)) return 0;
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Cout == 16 || Cout == 32)) return 0;
+  if (Cin == 8) return !split && Cout == 16 && fwd_p_n8_eligible(N, H, W, 2 * Cout, Cin);       // first block after the stem: 8-channel result
+  if (!fwd_p_eligible(N, H, W, 2 * Cout, Cin)) return 0;
   if (split && (split <= 0 || split >= Cin || split % 16 != 0 || (Cin - split) % 16 != 0)) return 0;
   return 1;
 }

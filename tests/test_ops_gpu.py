@@ -599,7 +599,8 @@ def test_fused_shortcut_conv(ops, n, h, ci, co):
 
 
 @pytest.mark.parametrize("n,h,co,ci,split", [(8, 128, 16, 32, 16), (8, 128, 16, 32, 0), (16, 64, 32, 64, 32), (4, 256, 16, 16, 0),
-                                            (8, 128, 32, 16, 0), (16, 64, 32, 32, 0), (6, 128, 32, 64, 32)])
+                                            (8, 128, 32, 16, 0), (16, 64, 32, 32, 0), (6, 128, 32, 64, 32),
+                                            (8, 128, 16, 8, 0), (4, 256, 16, 8, 0)])          # 8-channel result (first block after the stem)
 def test_fused_shortcut_data_gradient(ops, n, h, co, ci, split):
     """gx = dgrad3x3(gy, w1) + dgrad1x1(gs, ws) in one pass (backward of conv1(x) + shortcut(x) w.r.t. x, reference
     network/blocks.py:66-80) against the two-kernel composition it replaces (1x1 data-gradient, then the 3x3 data-gradient in its
@@ -661,3 +662,26 @@ def test_fused_shortcut_weight_gradient(ops, n, h, ci, co, cat):
     e_new = (g10[9 * ci * co:].double().view(ci, co) - ref).abs().max(); e_old = (g1.double().view(ci, co) - ref).abs().max()
     assert e_new <= 2 * e_old + 1e-3 * ref.abs().max() * 1e-3, (float(e_new), float(e_old))
     assert torch.allclose(g10[9 * ci * co:], g1, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("n,h,acc", [(8, 128, 0), (8, 128, 1), (4, 256, 1), (3, 256, 0)])
+def test_data_gradient_8_channel_result(ops, n, h, acc):
+    """Data-gradient 16 -> 8 channels (first block after the stem, network/blocks.py:123-127) on the persistent kernel's
+    8-channel-result form: plain and accumulate, against fp64; nothing outside the 8 channels is touched."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    co, ci = 16, 8
+    g = torch.Generator(device="cpu").manual_seed(9)
+    gy = torch.randn(n, h, h, co, generator=g).cuda()
+    w3 = (torch.randn(9 * ci * co, generator=g) / np.sqrt(9 * co)).cuda()
+    base = torch.randn(n, h, h, ci, generator=g).cuda()
+    buf = torch.full((n * h * h * ci + 64,), 7.0, device="cuda")                 # guard words behind the tensor
+    gx = buf[:n * h * h * ci].view(n, h, h, ci)
+    gx.copy_(base)
+    H.call("smsut_conv2d_fwd_mfma", gy, w3, gx, n, h, h, co, ci, 3, 3 if acc else 1, st)
+    w3d = w3.double().view(3, 3, ci, co).permute(3, 2, 0, 1).contiguous()
+    ref = torch.nn.functional.conv_transpose2d(gy.double().permute(0, 3, 1, 2), w3d, padding=1).permute(0, 2, 3, 1)
+    if acc:
+        ref = ref + base.double()
+    assert (gx.double() - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert bool((buf[n * h * h * ci:] == 7.0).all())
