@@ -37,7 +37,11 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
                    int HW, int C, int pix_per_chunk, float slope) {
   constexpr int NS = NSums<MODE>::n;
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
-  const int CV = C / VEC;
+  // gridDim.z channel slabs (host: slab_count): small planes with many channels (discriminator / bottleneck levels) had only
+  // N * chunks workgroups, each walking ALL channels serially -- e.g. 64 workgroups for 16 x 32x32 x 128
+  const int CVA = C / VEC;                    // all channel groups
+  const int CV = CVA / gridDim.z;             // ... of this workgroup's slab (gridDim.z divides CVA)
+  const int cvb = blockIdx.z * CV;
   const int TC = CV < TPB ? CV : TPB;
   const int rows = TPB / TC;
   const int tc = threadIdx.x % TC, trow = threadIdx.x / TC;
@@ -47,8 +51,8 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
   const size_t base = (size_t)n * HW * C;
 
   for (int cv0 = 0; cv0 < CV; cv0 += TC) {   // uniform trip count: barriers inside
-    const int cv = cv0 + tc;
-    const bool cv_ok = cv < CV;
+    const int cv = cvb + cv0 + tc;
+    const bool cv_ok = cv0 + tc < CV;
     float acc[NS][VEC];
 #pragma unroll
     for (int s = 0; s < NS; ++s)
@@ -433,7 +437,9 @@ __global__ void __launch_bounds__(TPB)       // (a 128-VGPR cap spills here: 244
 restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
                     int HW, int C, int pix_per_chunk, float slope) {
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
-  const int CV = C / VEC;
+  const int CVA = C / VEC;                    // gridDim.z channel slabs, as in in_moments_partial
+  const int CV = CVA / gridDim.z;
+  const int cvb = blockIdx.z * CV;
   const int TC = CV < TPB ? CV : TPB;
   const int rows = TPB / TC;
   const int tc = threadIdx.x % TC, trow = threadIdx.x / TC;
@@ -442,8 +448,8 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
   __shared__ float sm[TPB * 4 * 3];
   const size_t base = (size_t)n * HW * C;
   for (int cv0 = 0; cv0 < CV; cv0 += TC) {
-    const int cv = cv0 + tc;
-    const bool cv_ok = cv < CV;
+    const int cv = cvb + cv0 + tc;
+    const bool cv_ok = cv0 + tc < CV;
     float acc[3][VEC];
 #pragma unroll
     for (int q = 0; q < 3; ++q)
@@ -608,6 +614,16 @@ inline int pick_chunk(int HW, int C, int N) {
   return ppc;
 }
 
+// channel slabs for the partial-sum kernels: until ~512 workgroups, slabs of >= 16 channels (64 contiguous bytes per pixel)
+inline int slab_count(int N, int chunks, int C, int vec) {
+  static const bool on = [] { const char* e = getenv("SMSUT_IN_SLABS"); return !e || atoi(e) != 0; }();
+  if (!on || vec != 4) return 1;
+  const int cv = C / 4;
+  int z = 1;
+  while ((int64_t)N * chunks * z < 512 && cv % (2 * z) == 0 && cv / (2 * z) >= 4) z *= 2;
+  return z;
+}
+
 }  // namespace
 
 extern "C" {
@@ -621,7 +637,7 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
   hipStream_t st = (hipStream_t)stream;
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);
-  dim3 g(chunks, N);
+  dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
   if (C % 4 == 0)
     in_moments_partial<0, 4><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
   else
@@ -664,7 +680,7 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta, const
   hipStream_t st = (hipStream_t)stream;
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);
-  dim3 g(chunks, N);
+  dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
   if (C % 4 == 0)
     in_moments_partial<1, 4><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
   else
@@ -694,7 +710,7 @@ int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const 
   hipStream_t st = (hipStream_t)stream;
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);
-  dim3 g(chunks, N);
+  dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
   float* cvm = scratch; float* dvm = scratch + (size_t)N * C; float* em = scratch + 2 * (size_t)N * C;
   if (C % 4 == 0)
     in_moments_partial<2, 4><<<g, TPB, 0, st>>>(v, x, gy, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
@@ -783,7 +799,7 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
   hipStream_t st = (hipStream_t)stream;
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);
-  dim3 g(chunks, N);
+  dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
   const bool remask = ms && b2 && bs;
 #define TAIL_PARTIAL(V, R) restail_bwd_partial<V, R><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope)
   if (C % 4 == 0) { if (remask) TAIL_PARTIAL(4, true); else TAIL_PARTIAL(4, false); }
