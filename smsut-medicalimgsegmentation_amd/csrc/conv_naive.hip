@@ -135,8 +135,19 @@ reduce_chunks(const float* __restrict__ part, float* __restrict__ out, int wsize
   const int e = blockIdx.x * 64 + (threadIdx.x & 63);
   const int lane_c = threadIdx.x >> 6;
   double s = 0.0;
-  if (e < wsize)
-    for (int c = lane_c; c < chunks; c += 4) s += (double)part[(size_t)c * wsize + e];
+  if (e < wsize) {
+    // eight chunk rows in flight, added in the original order (rolled, this loop was chunks / 4 dependent load latencies:
+    // a constant ~25 us under every smsut_colsum / generic weight-gradient call)
+    int c = lane_c;
+    for (; c + 28 < chunks; c += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(c + 4 * u) * wsize + e];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; c < chunks; c += 4) s += (double)part[(size_t)c * wsize + e];
+  }
   sm[threadIdx.x] = s;
   __syncthreads();
   if (lane_c == 0 && e < wsize)
@@ -156,8 +167,18 @@ colsum_partial(const float* __restrict__ x, float* __restrict__ part, int64_t ro
   for (int c0 = 0; c0 < C; c0 += TC) {
     const int c = c0 + tc;
     float acc = 0.f;
-    if (tr < nrow && c < C)
-      for (int64_t r = r0 + tr; r < r1; r += nrow) acc += x[(size_t)r * C + c];
+    if (tr < nrow && c < C) {
+      // eight rows in flight per thread, added in the original order (the rolled loop kept ONE 4-byte load in flight: 0.8 TB/s)
+      int64_t r = r0 + tr;
+      for (; r + 7 * (int64_t)nrow < r1; r += 8 * (int64_t)nrow) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(r + u * (int64_t)nrow) * C + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+      }
+      for (; r < r1; r += nrow) acc += x[(size_t)r * C + c];
+    }
     __syncthreads();
     sm[threadIdx.x] = acc;
     __syncthreads();

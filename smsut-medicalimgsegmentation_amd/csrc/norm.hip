@@ -620,7 +620,8 @@ inline int slab_count(int N, int chunks, int C, int vec) {
   if (!on || vec != 4) return 1;
   const int cv = C / 4;
   int z = 1;
-  while ((int64_t)N * chunks * z < 512 && cv % (2 * z) == 0 && cv / (2 * z) >= 4) z *= 2;
+  static const int target = [] { const char* e = getenv("SMSUT_IN_SLAB_WGS"); return e ? atoi(e) : 512; }();
+  while ((int64_t)N * chunks * z < target && cv % (2 * z) == 0 && cv / (2 * z) >= 4) z *= 2;
   return z;
 }
 
