@@ -233,6 +233,162 @@ flat_sum(const float* __restrict__ part, float* __restrict__ out, int wsize, int
   }
 }
 
+// ---- the 5x5 stems (Cin 1 or 1 + n_modal = 5 -> 8 channels, stride 1, pad 2: network/blocks.py:123, ugan.py:26) -----------------
+// The generic kernels above do one global load and two LDS reads per 8 FMAs (forward: 17-25 TFLOP/s) or one LDS gather per
+// MFMA with half the matrix padding (weight gradient: 10-18 TFLOP/s) -- 0.45 ms of the uganConsis iteration for convs whose
+// tensors stream in 10 us.  Here a workgroup owns a 16 x 64 pixel tile: the input tile with its halo is staged ONCE into LDS as
+// channel planes [ci][20][68] (zero padded), a thread computes 4 consecutive pixels x all 8 output channels, and a
+// (kernel row, input channel) pair costs two 16-byte LDS reads of inputs + ten broadcast reads of weights for 160 FMAs.
+constexpr int STY = 16, STX = 64, SKS = 5, SPD = 2, SCO = 8;
+constexpr int SIH = STY + SKS - 1, SIW = STX + SKS - 1;          // 20 x 68 haloed tile
+
+template <int CIN>
+__device__ __forceinline__ void stem_stage(const float* __restrict__ x, float* __restrict__ in_s, int n, int y0, int x0,
+                                           int H, int W) {
+  // global [y][x][ci] -> LDS planes [ci][SIH][SIW]
+  for (int u = threadIdx.x; u < SIH * SIW * CIN; u += TPB) {
+    const int ci = u % CIN, pix = u / CIN;
+    const int iy = pix / SIW, ix = pix % SIW;
+    const int gy_ = y0 + iy - SPD, gx_ = x0 + ix - SPD;
+    float v = 0.f;
+    if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W) v = x[(((size_t)n * H + gy_) * W + gx_) * CIN + ci];
+    in_s[(ci * SIH + iy) * SIW + ix] = v;
+  }
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(TPB)
+stem_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+         int N, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float in_s[CIN * SIH * SIW];
+  __shared__ __attribute__((aligned(16))) float w_s[SKS * SKS * CIN * SCO];
+  const int tiles_x = W / STX, tiles_y = H / STY;
+  const int t = blockIdx.x;
+  const int n = t / (tiles_x * tiles_y), rem = t % (tiles_x * tiles_y);
+  const int y0 = (rem / tiles_x) * STY, x0 = (rem % tiles_x) * STX;
+  for (int u = threadIdx.x; u < SKS * SKS * CIN * SCO; u += TPB) w_s[u] = w[u];
+  stem_stage<CIN>(x, in_s, n, y0, x0, H, W);
+  __syncthreads();
+  const int row = threadIdx.x >> 4, cg = threadIdx.x & 15;
+  float acc[4][SCO];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int c = 0; c < SCO; ++c) acc[p][c] = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int kh = 0; kh < SKS; ++kh)
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci) {
+      float v[8];
+      const float* ip = in_s + (ci * SIH + row + kh) * SIW + 4 * cg;
+      *(float4*)v = *(const float4*)ip; *(float4*)(v + 4) = *(const float4*)(ip + 4);
+#pragma unroll
+      for (int kw = 0; kw < SKS; ++kw) {
+        float wv[SCO];
+        const float* wp = w_s + ((kh * SKS + kw) * CIN + ci) * SCO;
+        *(float4*)wv = *(const float4*)wp; *(float4*)(wv + 4) = *(const float4*)(wp + 4);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int c = 0; c < SCO; ++c) acc[p][c] = fmaf(v[p + kw], wv[c], acc[p][c]);
+      }
+    }
+  float* yp = y + (((size_t)n * H + y0 + row) * W + x0 + 4 * cg) * SCO;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    *(float4*)(yp + p * SCO) = *(float4*)acc[p];
+    *(float4*)(yp + p * SCO + 4) = *(float4*)(acc[p] + 4);
+  }
+}
+
+// weight gradient: gw[kh][kw][ci][co] = sum over pixels of x[y + kh - 2][x + kw - 2][ci] * gy[y][x][co].  5 * CIN "pairs"
+// q = (kh, ci); TPP threads share a pair (8 for CIN = 5: 200 live threads, 32 for CIN = 1: 160) and split the tile's 256 pixel
+// quads; a thread keeps its pair's 5 kw x 8 co accumulators in registers ACROSS the tiles of its workgroup (two 16-byte input
+// reads + eight of gy per 160 FMAs) and the TPP partial sums are combined once at the end (xor tree, fixed order) into the
+// workgroup's slab.  gy tile in LDS with a 36-float quad stride (the eight quads a wave reads
+// together hit disjoint bank quartets).
+constexpr int SGQ = 36;
+template <int CIN>
+__global__ void __launch_bounds__(TPB)
+stem_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H, int W,
+           int tiles_per_wg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* in_s = smem;                                   // [CIN][SIH][SIW]
+  float* gy_s = smem + CIN * SIH * SIW;                 // [256 quads][SGQ]: 4 pixels x 8 channels + pad
+  constexpr int NACC = SKS * SCO;                       // per-thread accumulators
+  constexpr int TPP = (CIN == 1) ? 32 : 8;              // threads per pair
+  const int tiles_x = W / STX, tiles_y = H / STY, total = N * tiles_x * tiles_y;
+  const int q = threadIdx.x / TPP, sub = threadIdx.x % TPP;       // pair, share of the quads
+  const bool live = q < SKS * CIN;
+  const int kh = q / CIN, k2 = q % CIN;                           // kernel row, input channel
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+  const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, total);
+  for (int t = t0; t < t1; ++t) {
+    const int n = t / (tiles_x * tiles_y), rem = t % (tiles_x * tiles_y);
+    const int y0 = (rem / tiles_x) * STY, x0 = (rem % tiles_x) * STX;
+    __syncthreads();
+    stem_stage<CIN>(x, in_s, n, y0, x0, H, W);
+    for (int u = threadIdx.x; u < STY * (STX / 4) * 8; u += TPB) {           // float4 units: quad, pixel of the quad, half
+      const int half = u & 1, px = (u >> 1) & 3, quad = u >> 3;
+      const int row = quad >> 4, cgq = quad & 15;
+      *(float4*)(gy_s + quad * SGQ + px * SCO + 4 * half) =
+          *(const float4*)(gy + (((size_t)n * H + y0 + row) * W + x0 + 4 * cgq + px) * SCO + 4 * half);
+    }
+    __syncthreads();
+    if (live) {
+      for (int k = 0; k < 256 / TPP; ++k) {
+        const int quad = sub + TPP * k;
+        const int row = quad >> 4, cgq = quad & 15;
+        float g[4][SCO];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          *(float4*)g[p] = *(const float4*)(gy_s + quad * SGQ + p * SCO);
+          *(float4*)(g[p] + 4) = *(const float4*)(gy_s + quad * SGQ + p * SCO + 4);
+        }
+        {
+          float v[8];
+          const float* ip = in_s + (k2 * SIH + row + kh) * SIW + 4 * cgq;
+          *(float4*)v = *(const float4*)ip; *(float4*)(v + 4) = *(const float4*)(ip + 4);
+#pragma unroll
+          for (int kw = 0; kw < SKS; ++kw)
+#pragma unroll
+            for (int c = 0; c < SCO; ++c)
+              acc[kw * SCO + c] += v[kw] * g[0][c] + v[kw + 1] * g[1][c] + v[kw + 2] * g[2][c] + v[kw + 3] * g[3][c];
+        }
+      }
+    }
+  }
+  // the eight threads of a pair: xor tree over sub (lanes 8q .. 8q+7 of one wave), then thread sub == 0 writes the pair's rows
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    float a = acc[i];
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    if constexpr (TPP == 32) { a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); }
+    acc[i] = a;
+  }
+  if (live && sub == 0) {
+    float* out = part + (size_t)blockIdx.x * SKS * SKS * CIN * SCO;
+#pragma unroll
+    for (int kw = 0; kw < SKS; ++kw)
+#pragma unroll
+      for (int c = 0; c < SCO; ++c) out[((kh * SKS + kw) * CIN + k2) * SCO + c] = acc[kw * SCO + c];
+  }
+}
+
+inline bool stem_shape(const SmallGeom& g) {
+  static const bool on = [] { const char* e = getenv("SMSUT_STEM"); return !e || atoi(e) != 0; }();
+  return on && g.KS == SKS && g.stride == 1 && g.pad == SPD && g.Cout == SCO && (g.Cin == 1 || g.Cin == 5) && g.H % STY == 0 &&
+         g.W % STX == 0 && g.Ho == g.H && g.Wo == g.W;
+}
+inline int stem_wgrad_wgs(const SmallGeom& g, int max_slabs) {
+  const int total = g.N * (g.H / STY) * (g.W / STX);
+  int wgs = total < 512 ? total : 512;
+  if (wgs > max_slabs) wgs = max_slabs;
+  return wgs < 1 ? 1 : wgs;
+}
+
 inline bool geom_ok(const SmallGeom& g) {
   return g.N > 0 && g.H > 0 && g.W > 0 && g.Cin > 0 && g.Cout > 0 && g.KS > 0 && g.stride > 0 && g.pad >= 0 &&
          g.Ho == (g.H + 2 * g.pad - g.KS) / g.stride + 1 && g.Wo == (g.W + 2 * g.pad - g.KS) / g.stride + 1 && g.Ho > 0 &&
@@ -267,6 +423,13 @@ int smsut_conv2d_small_fwd(const float* x, const float* w, const float* bias, fl
   const int64_t npix = (int64_t)N * Ho * Wo;
   const int grid = ew_grid(npix) * 2;
   hipStream_t st = (hipStream_t)stream;
+  if (stem_shape(g)) {                                   // the 5x5 stems: tiled kernel (see stem_fwd)
+    const int tiles = N * (H / STY) * (W / STX);
+    if (Cin == 1) stem_fwd<1><<<tiles, TPB, 0, st>>>(x, w, bias, y, N, H, W);
+    else stem_fwd<5><<<tiles, TPB, 0, st>>>(x, w, bias, y, N, H, W);
+    SMSUT_LAUNCH_CHECK();
+    return SMSUT_OK;
+  }
   switch (Cout / 4) {
     case 1: small_fwd<1><<<grid, TPB, 0, st>>>(x, w, bias, y, g, npix); break;
     case 2: small_fwd<2><<<grid, TPB, 0, st>>>(x, w, bias, y, g, npix); break;
@@ -311,6 +474,25 @@ int smsut_conv2d_flat_wgrad(const float* x, const float* gy, float* gw, float* w
   SMSUT_REQUIRE(x && gy && gw && workspace && geom_ok(g) && smsut_conv2d_flat_wgrad_supported(KS, stride, Cin, Cout));
   const FlatPlan p = flat_plan(g);
   hipStream_t st = (hipStream_t)stream;
+  if (stem_shape(g)) {                                   // the 5x5 stems: register-tiled VALU kernel (see stem_wgrad)
+    const int wgs = stem_wgrad_wgs(g, p.splits);         // (the workspace holds p.splits slabs)
+    const int total = N * (H / STY) * (W / STX);
+    const int tpw = (total + wgs - 1) / wgs;
+    const int nwg = (total + tpw - 1) / tpw;
+    const int wsz = KS * KS * Cin * Cout;
+    if (Cin == 1) {
+      constexpr size_t sh = (size_t)(1 * SIH * SIW + STY * (STX / 4) * SGQ) * sizeof(float);
+      stem_wgrad<1><<<nwg, TPB, sh, st>>>(x, gy, workspace, N, H, W, tpw);
+    } else {
+      constexpr size_t sh = (size_t)(5 * SIH * SIW + STY * (STX / 4) * SGQ) * sizeof(float);
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute((const void*)stem_wgrad<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); attr = true; }
+      stem_wgrad<5><<<nwg, TPB, sh, st>>>(x, gy, workspace, N, H, W, tpw);
+    }
+    flat_sum<<<(wsz + FS_COLS - 1) / FS_COLS, TPB, 0, st>>>(workspace, gw, wsz, nwg);
+    SMSUT_LAUNCH_CHECK();
+    return SMSUT_OK;
+  }
   const int mt = (KS * KS * Cin + 15) / 16;
   if (mt <= 1) flat_wgrad<1><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);
   else if (mt <= 2) flat_wgrad<2><<<p.splits, TPB, 0, st>>>(x, gy, workspace, g, p.tiles_x, p.tiles_y, p.tiles_per_split);

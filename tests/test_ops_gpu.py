@@ -685,3 +685,33 @@ def test_data_gradient_8_channel_result(ops, n, h, acc):
         ref = ref + base.double()
     assert (gx.double() - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
     assert bool((buf[n * h * h * ci:] == 7.0).all())
+
+
+@pytest.mark.parametrize("n,h,w,ci", [(3, 64, 64, 1), (2, 64, 128, 5), (4, 128, 64, 5), (1, 16, 64, 1), (16, 256, 256, 5)])
+def test_stem_5x5_kernels(ops, n, h, w, ci):
+    """The 5x5 stems (network/blocks.py:123, ugan.py:26: Cin 1 / 5 -> 8, stride 1, pad 2) on the tiled kernels: forward with
+    bias and weight gradient against fp64."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    co = 8
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = torch.randn(n, h, w, ci, generator=g).cuda(); gy = torch.randn(n, h, w, co, generator=g).cuda()
+    wt = (torch.randn(5, 5, ci, co, generator=g) / np.sqrt(25 * ci)).cuda(); b = torch.randn(co, generator=g).cuda()
+    y = torch.full((n, h, w, co), float("nan"), device="cuda")
+    H.call("smsut_conv2d_small_fwd", x, wt, b, y, n, h, w, ci, h, w, co, 5, 1, 2, st)
+    k = min(n, 2)
+    wd = wt.double().permute(3, 2, 0, 1).contiguous()
+    ref = torch.nn.functional.conv2d(x[:k].double().permute(0, 3, 1, 2), wd, b.double(), padding=2).permute(0, 2, 3, 1)
+    assert torch.isfinite(y).all()
+    assert (y[:k].double() - ref).abs().max() < 1e-5 * max(1.0, float(ref.abs().max()))
+    gw = torch.full((25 * ci * co,), float("nan"), device="cuda")
+    ws = torch.empty(H.call("smsut_conv2d_flat_wgrad_ws", n, h, w, ci, co, 5), device="cuda")
+    H.call("smsut_conv2d_flat_wgrad", x, gy, gw, ws, n, h, w, ci, h, w, co, 5, 1, 2, st)
+    xp = torch.nn.functional.pad(x.double().permute(0, 3, 1, 2), (2, 2, 2, 2))
+    gref = torch.empty(5, 5, ci, co, dtype=torch.float64, device="cuda")
+    gyd = gy.double()
+    for kh in range(5):
+        for kw in range(5):
+            gref[kh, kw] = torch.einsum("nchw,nhwo->co", xp[:, :, kh:kh + h, kw:kw + w], gyd)
+    err = (gw.double().view(5, 5, ci, co) - gref).abs().max()
+    assert err < 2e-5 * float(gref.abs().max()) + 1e-3, float(err)
