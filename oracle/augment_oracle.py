@@ -1,7 +1,9 @@
 """TEST INFRASTRUCTURE ONLY (imported by tests/): numpy restatement of the joint augmentation resampling that
-``smsut_warp_joint`` implements.  Parity unpinned: the reference composes PIL / torchvision / elasticdeform
-(data_loader/externalTransforms.py:45-90), none of which is installed here, and the device path deliberately resamples
-ONCE instead of three times -- so this oracle pins the kernel to its own stated definition, not to the reference.
+``smsut_warp_joint`` implements.  The reference composes PIL / torchvision / elasticdeform
+(data_loader/externalTransforms.py:45-90).  Pinned (r02, tests/test_augment_pil_cpu.py): the rotation-only and crop-only warps of
+this oracle match PIL's ``Image.rotate`` / ``Image.crop().resize()`` -- what torchvision's ``F.rotate`` / ``F.resized_crop`` call on
+PIL images -- in direction, centre, pixel-centre convention and bilinear / nearest interpolation.  Still parity UNPINNED: the elastic
+deformation (``elasticdeform`` is not installed here) and the composition (the device path resamples ONCE instead of three times).
 
     source(yo, xo) = A * (xo, yo, 1) + bilinear(ctrl)(yo, xo);  image: bilinear, zeros outside;  labels: nearest.
 """
