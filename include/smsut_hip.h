@@ -201,6 +201,13 @@ int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N,
 int64_t smsut_convT2x2_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout);
 int smsut_convT2x2_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
                               int Cout, void* stream);
+/* The same transposed conv through the 1x1 kernels' pixel-shuffle forms (x read once per 64-column slab of the 4 * Cout tap-major
+ * columns instead of once per tap; Cout % 16 == 0): forward and weight gradient; the data gradient is already one pass. */
+int smsut_convT2x2_ps_supported(int Cin, int Cout);
+int smsut_convT2x2_fwd_ps(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, void* stream);
+int64_t smsut_convT2x2_wgrad_ps_ws(int N, int H, int W, int Cin, int Cout);
+int smsut_convT2x2_wgrad_ps(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                            int Cout, void* stream);
 
 /* bias gradient: out[c] = sum over rows of x[rows][C] */
 int64_t smsut_colsum_ws(int64_t rows, int C);

@@ -51,6 +51,10 @@ SIGNATURES: Dict[str, str] = {
     "smsut_convT2x2_dgrad_mfma": "ppp iiiii s",
     "smsut_convT2x2_wgrad_mfma_ws": "iiiii",
     "smsut_convT2x2_wgrad_mfma": "pppp iiiii s",
+    "smsut_convT2x2_ps_supported": "ii",
+    "smsut_convT2x2_fwd_ps": "ppp iiiii s",
+    "smsut_convT2x2_wgrad_ps_ws": "iiiii",
+    "smsut_convT2x2_wgrad_ps": "pppp iiiii s",
     # conv1x1.hip
     "smsut_conv1x1_supported": "ii",
     "smsut_conv1x1_tiles": "iii",
@@ -149,7 +153,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_patchnce_fwd": "pppp iii f s",
     "smsut_patchnce_bwd": "pppp iii f s",
 }
-_RET_I64 = {"smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
+_RET_I64 = {"smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws",
             "smsut_conv1x1_thin_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
@@ -157,7 +161,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",
                          "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_dgrad_sc_supported",
-                         "smsut_conv2d_wgrad_sc_supported"}
+                         "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported"}
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

@@ -23,11 +23,14 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 // MR x 16 pixels per wave step, NR x 16 output channels per workgroup.
-template <int MR, int NR, bool DUAL = false>
+// PS ("pixel shuffle"): ConvTranspose2d(k=2, s=2) as ONE 1x1 conv with Ndim = 4 * Cout result columns (tap-major), the result of
+// column (tap, co) of input pixel (h, w) stored at output pixel (2h + tap/2, 2w + tap%2) -- x is read once per 16*NR-column slab
+// instead of once per tap (network/blocks.py:41; weights [tap][Cin][Cout]; Cout % 16 == 0 so a 16-column tile is one tap; ps_w = W).
+template <int MR, int NR, bool DUAL = false, bool PS = false>
 __global__ void __launch_bounds__(TPB)
 conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, float* __restrict__ stats,
             int64_t P, int HW, int Kdim, int Ndim, int transposed, float* __restrict__ y2 = nullptr, int split = 0,
-            const float* __restrict__ x2 = nullptr, int ca = 0) {
+            const float* __restrict__ x2 = nullptr, int ca = 0, int ps_w = 0) {
   constexpr int CO_T = 16 * NR;
   extern __shared__ float w_s[];                 // [chunks][4 kq][CO_T][4]: k = 16*chunk + 4*kq + j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,7 +43,11 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
     const int ng = co0 + n;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (ng < Ndim && kg < Kdim) {
-      if (!transposed) {
+      if constexpr (PS) {
+        const int cout = Ndim >> 2, tap = ng / cout;
+        const float* p = w + ((size_t)tap * Kdim + kg) * cout + (ng - tap * cout);
+        v.x = p[0]; v.y = p[cout]; v.z = p[2 * (size_t)cout]; v.w = p[3 * (size_t)cout];
+      } else if (!transposed) {
         const float* p = w + (size_t)kg * Ndim + ng;
         v.x = p[0]; v.y = p[Ndim]; v.z = p[2 * (size_t)Ndim]; v.w = p[3 * (size_t)Ndim];
       } else {
@@ -98,6 +105,22 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
     const int os = !y2 ? Ndim : (hi ? Ndim - split : split);
     const int oc = hi ? co - split : co;
     float s1 = 0.f, s2 = 0.f;
+    if constexpr (PS) {
+      const int cout = Ndim >> 2, tap = (co0 + j * 16) / cout, cc = co - tap * cout;
+      const int W2 = 2 * ps_w;
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t p = p0 + i * 16 + 4 * kq + r;
+          if (p < P && co < Ndim) {
+            const int row = (int)p / ps_w;                         // = n * H + h   (host: P < 2^31 / (4 * cout))
+            const int wx = (int)p - row * ps_w;
+            y[((size_t)(2 * row + (tap >> 1)) * W2 + 2 * wx + (tap & 1)) * cout + cc] = acc[i][j][r];
+          }
+        }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -127,10 +150,13 @@ conv1x1_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __r
 #define W1_UNR 4     // r02 A/B (scratch/w1_ab.py): 1 -> 4 groups: 107 -> 80 us at 32x256^2 (16+16)->16, 60 -> 38 us at 8->16; 8 and 16 no better
 #endif
 // weight gradient: each wave walks groups of 4 pixels of its workgroup's pixel range with direct global loads
-template <int CIT, int COT>
+// PS: weight gradient of ConvTranspose2d(k=2, s=2): gw[tap][ci][co] = sum_p x[p][ci] * gy[2p + tap][co] as the 1x1 weight gradient
+// with Cout = 4 * cout gathered columns (the B operand of column (tap, co) is read at output pixel (2h + tap/2, 2w + tap%2));
+// x is read once per 16*COT-column slab instead of once per tap, and a slab's two taps are the two halves of the same gy lines.
+template <int CIT, int COT, bool PS = false>
 __global__ void __launch_bounds__(TPB)
 conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int64_t P, int Cin,
-              int Cout, int64_t pix_per_split, const float* __restrict__ x2 = nullptr, int ca = 0) {
+              int Cout, int64_t pix_per_split, const float* __restrict__ x2 = nullptr, int ca = 0, int ps_w = 0) {
   __shared__ float red[CIT * COT * 64 * 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, kq = lane >> 4;
@@ -151,6 +177,12 @@ conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
 #pragma unroll
   for (int i = 0; i < CIT; ++i) xs[i] = cat_src(x, x2, Cin, ca, ci0 + i * 16);
   const float* gb = gy + co0 + lm;
+  [[maybe_unused]] const int cout = Cout >> 2;             // PS: channels of the transposed conv's output
+  [[maybe_unused]] int ps_tap[COT], ps_cc[COT];
+  if constexpr (PS) {
+#pragma unroll
+    for (int j = 0; j < COT; ++j) { ps_tap[j] = (co0 + j * 16) / cout; ps_cc[j] = co0 + j * 16 - ps_tap[j] * cout + lm; }
+  }
   // W1_UNR pixel groups per trip: all their loads are issued before the first MFMA (the rolled one-group loop kept ONE
   // 4-byte load per operand tile in flight per lane and ran at 3.4-3.8 TB/s; see profiles/r02_notes.md)
   constexpr int UNR = W1_UNR;
@@ -162,8 +194,16 @@ conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
       const bool ok = p < pe;
 #pragma unroll
       for (int i = 0; i < CIT; ++i) a[u][i] = (ok && iok[i]) ? xs[i].p[(size_t)p * xs[i].stride + ci0 + i * 16 + lm - xs[i].coff] : 0.f;
+      if constexpr (PS) {
+        const int row = (int)p / ps_w;                             // = n * H + h   (host: P < 2^31 / (4 * cout))
+        const int wx = (int)p - row * ps_w;
 #pragma unroll
-      for (int j = 0; j < COT; ++j) b[u][j] = (ok && jok[j]) ? gb[(size_t)p * Cout + j * 16] : 0.f;
+        for (int j = 0; j < COT; ++j)
+          b[u][j] = (ok && jok[j]) ? gy[((size_t)(2 * row + (ps_tap[j] >> 1)) * (2 * ps_w) + 2 * wx + (ps_tap[j] & 1)) * cout + ps_cc[j]] : 0.f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < COT; ++j) b[u][j] = (ok && jok[j]) ? gb[(size_t)p * Cout + j * 16] : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < UNR; ++u)
@@ -198,7 +238,9 @@ conv1x1_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ci = ci0 + i * 16 + 4 * kq + r;
-          if (ci < Cin && co < Cout) out[(size_t)ci * Cout + co] = acc[i][j][r];
+          if constexpr (PS) {                                      // final layout [tap][ci][co]
+            if (ci < Cin && co < Cout) out[((size_t)ps_tap[j] * Cin + ci) * cout + ps_cc[j]] = acc[i][j][r];
+          } else if (ci < Cin && co < Cout) out[(size_t)ci * Cout + co] = acc[i][j][r];
         }
       }
   }
@@ -415,6 +457,61 @@ int smsut_conv1x1_fwd_split(const float* x, const float* w, float* ya, float* yb
                             int Ndim, int transposed, void* stream) {
   SMSUT_REQUIRE(yb);
   return conv1x1_fwd_launch(x, w, ya, nullptr, N, HW, Kdim, Ndim, transposed, stream, yb, split);
+}
+
+// ConvTranspose2d(k=2, s=2, bias=False) through the 1x1 kernels' pixel-shuffle forms (see conv1x1_fwd / conv1x1_wgrad, PS):
+// x [N,H,W,Cin], w [2][2][Cin][Cout], y / gy [N,2H,2W,Cout].  Cout % 16 == 0, Cin % 4 == 0.  SMSUT_CONVT_PS=0/1.
+int smsut_convT2x2_ps_supported(int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("SMSUT_CONVT_PS"); return !e || atoi(e) != 0; }();
+  // Cout == 16 only (the 128^2 -> 256^2 level): there the four taps are one 64-column slab -- 32x128^2 32->16: forward 66.4 ->
+  // 62.1 us, weight gradient 91.4 -> 53.2 us; from 32 output channels on the per-tap MFMA kernels win (64->32: 38.6 / 42.2 and
+  // 48.2 / 49.8 us; 128->64: 32.2 / 34.1 and 40.4 / 49.0) -- scratch/convt_probe.py.  The kernels take any Cout % 16 == 0.
+  return on && Cout == 16 && smsut_conv1x1_supported(Cin, 4 * Cout);
+}
+
+int smsut_convT2x2_fwd_ps(const float* x, const float* w, float* y, int N, int H, int W, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && smsut_convT2x2_ps_supported(Cin, Cout));
+  const int64_t P = (int64_t)N * H * W;
+  SMSUT_REQUIRE(P * 4 * Cout < (1ll << 31));
+  const int Nd = 4 * Cout;
+  const int mr = (P / 256 >= 512) ? 4 : 1;
+  const int nr = (Nd % 64 == 0) ? 4 : 2;                   // 64 columns per workgroup when they divide: x is read Nd / 64 times
+  const int chunks = (Cin + 15) / 16;
+  const size_t sh = (size_t)chunks * 4 * 16 * nr * 4 * sizeof(float);
+  dim3 grid((unsigned)cdiv64(P, 64 * mr), Nd / (16 * nr));
+  hipStream_t st = (hipStream_t)stream;
+#define PS_GO(M, R) conv1x1_fwd<M, R, false, true><<<grid, TPB, sh, st>>>(x, w, y, nullptr, P, H * W, Cin, Nd, 0, nullptr, 0, nullptr, 0, W)
+  if (mr == 4 && nr == 4) PS_GO(4, 4);
+  else if (mr == 4) PS_GO(4, 2);
+  else if (nr == 4) PS_GO(1, 4);
+  else PS_GO(1, 2);
+#undef PS_GO
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+int64_t smsut_convT2x2_wgrad_ps_ws(int N, int H, int W, int Cin, int Cout) {
+  const int cit = Cin > 16 ? 2 : 1;
+  return (int64_t)plan_wgrad1((int64_t)N * H * W, Cin, 4 * Cout, cit, 2).splits * Cin * 4 * Cout;
+}
+
+// gw [2][2][Cin][Cout]
+int smsut_convT2x2_wgrad_ps(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,
+                            int Cout, void* stream) {
+  SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0 && smsut_convT2x2_ps_supported(Cin, Cout));
+  const int64_t P = (int64_t)N * H * W;
+  SMSUT_REQUIRE(P * 4 * Cout < (1ll << 31));
+  const int Nd = 4 * Cout;
+  const int cit = Cin > 16 ? 2 : 1;
+  const Plan1 p = plan_wgrad1(P, Cin, Nd, cit, 2);
+  dim3 grid(p.splits, (Cin + 16 * cit - 1) / (16 * cit), Nd / 32);
+  hipStream_t st = (hipStream_t)stream;
+  if (cit == 2) conv1x1_wgrad<2, 2, true><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Nd, p.pps, nullptr, 0, W);
+  else conv1x1_wgrad<1, 2, true><<<grid, TPB, 0, st>>>(x, gy, workspace, P, Cin, Nd, p.pps, nullptr, 0, W);
+  const int wsize = Cin * Nd;
+  sum_parts<<<(wsize + 63) / 64, TPB, 0, st>>>(workspace, gw, wsize, p.splits);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
 }
 
 int64_t smsut_conv1x1_wgrad_ws(int N, int HW, int Cin, int Cout) {

@@ -439,7 +439,10 @@ class ConvT2x2Fn(Function):
             raise H.SmsutHipError(f"ConvTranspose2x2 needs channel counts that are multiples of 4, got {ci}->{co}")
         ctx.save_for_backward(x, w)
         y = new_act(n, co, 2 * h, 2 * wd, x)
-        H.call("smsut_convT2x2_fwd_mfma", x, w, y, n, h, wd, ci, co, _s())
+        if H.call("smsut_convT2x2_ps_supported", ci, co):        # one 1x1 pass over x with pixel-shuffle stores
+            H.call("smsut_convT2x2_fwd_ps", x, w, y, n, h, wd, ci, co, _s())
+        else:
+            H.call("smsut_convT2x2_fwd_mfma", x, w, y, n, h, wd, ci, co, _s())
         return y
 
     @staticmethod
@@ -455,8 +458,12 @@ class ConvT2x2Fn(Function):
             H.call("smsut_convT2x2_dgrad_mfma", gy, w, gx, n, h, wd, ci, co, _s())
         if ctx.needs_input_grad[1]:
             gw = new_convT_weight(ci, co, 2, 2, device=x.device)
-            ws = _ws(H.call("smsut_convT2x2_wgrad_mfma_ws", n, h, wd, ci, co), x)
-            H.call("smsut_convT2x2_wgrad_mfma", x, gy, gw, ws, n, h, wd, ci, co, _s())
+            if H.call("smsut_convT2x2_ps_supported", ci, co):
+                ws = _ws(H.call("smsut_convT2x2_wgrad_ps_ws", n, h, wd, ci, co), x)
+                H.call("smsut_convT2x2_wgrad_ps", x, gy, gw, ws, n, h, wd, ci, co, _s())
+            else:
+                ws = _ws(H.call("smsut_convT2x2_wgrad_mfma_ws", n, h, wd, ci, co), x)
+                H.call("smsut_convT2x2_wgrad_mfma", x, gy, gw, ws, n, h, wd, ci, co, _s())
         return gx, gw
 
 

@@ -65,6 +65,8 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_convT2x2_fwd_mfma": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
     "smsut_convT2x2_dgrad_mfma": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
     "smsut_convT2x2_wgrad_mfma": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
+    "smsut_convT2x2_fwd_ps": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
+    "smsut_convT2x2_wgrad_ps": (lambda a: 8.0 * a[0] * a[1] * a[2] * a[3] * a[4], "mfma"),
 }
 
 

@@ -715,3 +715,31 @@ def test_stem_5x5_kernels(ops, n, h, w, ci):
             gref[kh, kw] = torch.einsum("nchw,nhwo->co", xp[:, :, kh:kh + h, kw:kw + w], gyd)
     err = (gw.double().view(5, 5, ci, co) - gref).abs().max()
     assert err < 2e-5 * float(gref.abs().max()) + 1e-3, float(err)
+
+
+@pytest.mark.parametrize("n,h,w,ci,co", [(4, 32, 32, 32, 16), (2, 16, 24, 64, 16), (3, 8, 8, 256, 16), (1, 64, 64, 32, 16), (5, 12, 20, 128, 16)])
+def test_convT2x2_pixel_shuffle_forms(ops, n, h, w, ci, co):
+    """ConvTranspose2d(k=2, s=2, bias=False) (reference network/blocks.py:41) through the 1x1 kernels' pixel-shuffle forms:
+    forward and weight gradient against fp64 and against the per-tap MFMA entry points."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_convT2x2_ps_supported", ci, co) == 1
+    g = torch.Generator(device="cpu").manual_seed(13)
+    x = torch.randn(n, h, w, ci, generator=g).cuda(); wt = (torch.randn(2, 2, ci, co, generator=g) / np.sqrt(ci)).cuda()
+    gy = torch.randn(n, 2 * h, 2 * w, co, generator=g).cuda()
+    y0 = torch.empty(n, 2 * h, 2 * w, co, device="cuda"); y1 = torch.full_like(y0, float("nan"))
+    H.call("smsut_convT2x2_fwd_mfma", x, wt, y0, n, h, w, ci, co, st)
+    H.call("smsut_convT2x2_fwd_ps", x, wt, y1, n, h, w, ci, co, st)
+    ref = torch.nn.functional.conv_transpose2d(x.double().permute(0, 3, 1, 2), wt.double().permute(2, 3, 0, 1), stride=2).permute(0, 2, 3, 1)
+    assert torch.isfinite(y1).all()
+    assert (y1.double() - ref).abs().max() <= 2 * (y0.double() - ref).abs().max() + 1e-6
+    assert torch.allclose(y1, y0, rtol=1e-5, atol=1e-5)
+    g0 = torch.empty(4 * ci * co, device="cuda"); g1 = torch.full_like(g0, float("nan"))
+    H.call("smsut_convT2x2_wgrad_mfma", x, gy, g0, torch.empty(H.call("smsut_convT2x2_wgrad_mfma_ws", n, h, w, ci, co), device="cuda"),
+           n, h, w, ci, co, st)
+    H.call("smsut_convT2x2_wgrad_ps", x, gy, g1, torch.empty(H.call("smsut_convT2x2_wgrad_ps_ws", n, h, w, ci, co), device="cuda"),
+           n, h, w, ci, co, st)
+    gyd = gy.double()
+    gref = torch.stack([torch.einsum("nhwc,nhwo->co", x.double(), gyd[:, a::2, b::2]) for a in range(2) for b in range(2)]).view(2, 2, ci, co)
+    e1 = (g1.double().view(2, 2, ci, co) - gref).abs().max(); e0 = (g0.double().view(2, 2, ci, co) - gref).abs().max()
+    assert torch.isfinite(g1).all() and e1 <= 2 * e0 + 1e-6 * float(gref.abs().max()), (float(e1), float(e0))
