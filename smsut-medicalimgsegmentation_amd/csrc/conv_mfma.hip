@@ -355,7 +355,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // The 1x1 conv is the centre tap with its own weights: the A fragments of tap (1,1) feed a second accumulator set (+1/9 MFMAs),
   // the epilogue stores the second result sc.y and its InstanceNorm partials sc.stats -- the separate 1x1 kernel and its re-read
   // of the block input (HBM-bound, 5 FLOP/B) disappear.  Forward statistics forms (plain or virtual-cat input), fp32.
-  static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !F16 && !K8 && KS == 3), "fused shortcut: forward statistics forms");
+  static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !F16 && KS == 3), "fused shortcut: forward statistics forms");
   // SC2: the DATA-GRADIENT of that pair in one pass: gx = dgrad3x3(gy1, w1) + dgrad1x1(gs, ws).  The two gradients are the
   // virtual cat [gy1, gs] along the reduction (DUAL staging, unchanged); the chunks of the second half only run the centre
   // tap, against the 1x1 weights (sc.w) -- +1/9 MFMAs instead of a 1x1 kernel plus an accumulate pass over gx.
@@ -369,7 +369,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // chunk would be half padding; instead PAIRS OF TAPS share one MFMA: k-slots kq = 0, 1 carry the 8 channels of tap 2g,
   // kq = 2, 3 those of tap 2g+1 (a lane picks its tap's halo offset and weight block) -- 5 x 4 MFMAs per 16x16 output tile
   // instead of 9 x 4.
-  static_assert(!K8 || (NCH == 1 && !DUAL && !INAFF && !F16 && !BST), "8-channel reduction: plain / statistics / accumulate forms");
+  static_assert(!K8 || (NCH == 1 && !DUAL && !INAFF && !F16 && !BST), "8-channel reduction: plain / statistics / accumulate / fused-shortcut forms");
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
   static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
   static_assert(!DUAL || NCH % 2 == 0, "virtual cat input: two equal halves of whole 16-channel chunks");
@@ -665,6 +665,22 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
           for (int i = 0; i < MR; ++i)
 #pragma unroll
             for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(a[i][s], b[j][s], acc[i][j]);
+        if constexpr (SC) {
+          if (2 * g == KK / 2) {                           // this group's first half is the centre tap: the 1x1 shortcut rides on it
+            f32x4 bs[NR];                                  // (k-slots of the second half, tap 5, multiply zeros)
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+              bs[j] = *(const f32x4*)(wsc_s + (((size_t)kk * CO_T) + j * 16 + lm) * 4);
+              if (half) bs[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+              for (int i = 0; i < MR; ++i)
+#pragma unroll
+                for (int j = 0; j < NR; ++j) acs[i][j] = mfma16(a[i][s], bs[j][s], acs[i][j]);
+          }
+        }
       }
       return;
     }
@@ -1564,7 +1580,8 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (aff && (!stats || bst || y2 || x2 || transposed)) return -1;              // input-side IN: forward statistics form
   const bool sc2 = sc && (transposed & 1);                                      // fused shortcut DATA-gradient (see SC2)
   if (sc2 && (K8 || KS != 3 || NCH % 2 != 0 || !x2 || stats || bst || aff || (transposed & 2) || f16 || !sc->w)) return -1;
-  if (sc && !sc2 && (K8 || KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || f16 || !sc->w || !sc->y || !sc->stats))
+  if (sc && !sc2 && (KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || f16 || !sc->w || !sc->y || !sc->stats ||
+                     (K8 && x2)))
     return -1;                                                                  // fused shortcut: forward statistics forms, fp32
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = N8 ? 1 : Ndim / (16 * NTN);
@@ -1620,6 +1637,10 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true><<<grid, TPB, sh, st>>>(
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
   } else if (sc) {
+    if constexpr (K8 && KS == 3 && sh_sc <= 64 * 1024) {
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true><<<grid, TPB, sh_sc, st>>>(
+          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+    }
     if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (x2) {
         if constexpr (NCH % 2 == 0)
@@ -2200,7 +2221,7 @@ int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, 
 // w [3][3][Kdim][Ndim], wsc [Kdim][Ndim] (HWIO).  Persistent-kernel shapes with Kdim in {16, 32, 64}: _supported says which.
 int smsut_conv2d_fwd_sc_supported(int N, int H, int W, int Kdim, int Ndim, int cat) {
   static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT"); return !e || atoi(e) != 0; }();
-  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Kdim == 8 || Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
   if (cat && Kdim % 32 != 0) return 0;
   return 1;
 }

@@ -562,7 +562,7 @@ def test_max_pool_skip_fused_backward(ops, n, c, h, w):
 
 
 @pytest.mark.parametrize("n,h,ci,co", [(32, 64, 16, 32), (8, 128, 32, 16), (4, 256, 16, 16), (16, 64, 64, 32), (8, 128, 32, 64),
-                                       (16, 64, 32, 64)])
+                                       (16, 64, 32, 64), (8, 128, 8, 16), (4, 256, 8, 16)])       # last two: 8-channel (tap-pair) form
 def test_fused_shortcut_conv(ops, n, h, ci, co):
     """conv1 + the block's 1x1 shortcut in one pass (reference network/blocks.py:66-80): the 3x3 result and its statistics are
     bit-identical to the plain entry point (same kernel, same order); the shortcut result matches the stand-alone 1x1 kernel
