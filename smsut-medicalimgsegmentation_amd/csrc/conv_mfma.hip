@@ -855,11 +855,16 @@ constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows 
 #endif
 constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
-template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false, bool C8 = false>
+template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false, bool C8 = false, bool SC8 = false>
 __global__ void __launch_bounds__(TPB, (KS == 3 && CIT == 1 && COT == 1 && !INAFF) ? WG11_MIN_BLOCKS : 1)
 conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
                 int W, int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, int gsc, int nci,
-                const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{}) {
+                const float* __restrict__ x2 = nullptr, int ca = 0, AffRef aff = AffRef{},
+                const float* __restrict__ gs = nullptr) {
+  // SC8 (with C8): the weight gradient of the first block's 1x1 shortcut rides along (see conv_mfma_wgrad_ts, SC): one more
+  // accumulator tile = the (tap 4 | tap 5) group's x rows against gs; rows 0-7 (tap 4 = the centre) are the shortcut's gradient,
+  // written as slab row KK of a (KK+1)-row slab; rows 8-15 are discarded.
+  static_assert(!SC8 || C8, "fused shortcut weight gradient of the 8-channel form");
   // INAFF: x is the raw conv output whose lrelu(IN(.)) is the operand (see AffRef); applied when a tile is published.
   // gsc = 2 / 4 tap groups in blockIdx.y: weight-gradient of ConvTranspose2x2 (gy is the 2x larger tensor).
   // C8: Cin == 8 (first block after the stem).  Half of the 16 MFMA rows would be padding; instead PAIRS OF TAPS share one
@@ -873,10 +878,11 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;     // pixel stride = 16 (mod 32): 4 pixels x 16 ch conflict-free
   constexpr int SO = (CO_T % 32 == 16) ? CO_T : CO_T + 16;
   constexpr int NG = C8 ? (KK + 1) / 2 : KK;   // accumulator tile groups per (ci tile, co tile): taps, or tap pairs
-  constexpr int NACC = NG * CIT * COT;
+  constexpr int NACC = (NG + (SC8 ? 1 : 0)) * CIT * COT;
   extern __shared__ float smem[];
   float* in_s = smem;                         // [IH][IW][SI]
   float* gy_s = smem + IH * IW * SI;          // [WTH][TW][SO]
+  [[maybe_unused]] float* gs_s = gy_s + WTH * TW * SO;   // SC8: [WTH][TW][SO]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -897,6 +903,7 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   constexpr int NIN = (IH * IW * (CI_T / 4) + TPB - 1) / TPB;
   constexpr int NGY = (WTH * TW * (CO_T / 4) + TPB - 1) / TPB;
   float4 rin[NIN], rgy[NGY];
+  [[maybe_unused]] float4 rgs[NGY];
   // per-thread unit descriptors, computed once: (iy << 8 | ix) inside the tile, or -1; channel of the unit
   int in_yx[NIN], in_c[NIN], in_lds[NIN], gy_yx[NGY], gy_c[NGY], gy_lds[NGY];
 #pragma unroll
@@ -955,6 +962,12 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
       if (gy_yx[i] >= 0 && gy_ < H && gx_ < W)
         v = *(const float4*)(gin + ((size_t)(gy_ * gsc + (tg >> 1)) * Wg + gx_ * gsc + (tg & 1)) * Cout + gy_c[i]);
       rgy[i] = v;
+      if constexpr (SC8) {                     // (gsc == 1: same geometry as gy)
+        float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gy_yx[i] >= 0 && gy_ < H && gx_ < W)
+          u = *(const float4*)(gs + (size_t)n_img * H * W * Cout + ((size_t)gy_ * W + gx_) * Cout + gy_c[i]);
+        rgs[i] = u;
+      }
     }
   };
 
@@ -973,7 +986,10 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
       }
 #pragma unroll
     for (int i = 0; i < NGY; ++i)
-      if (tid + i * TPB < WTH * TW * (CO_T / 4)) *(float4*)(gy_s + gy_lds[i]) = rgy[i];
+      if (tid + i * TPB < WTH * TW * (CO_T / 4)) {
+        *(float4*)(gy_s + gy_lds[i]) = rgy[i];
+        if constexpr (SC8) *(float4*)(gs_s + gy_lds[i]) = rgs[i];
+      }
     __syncthreads();
     if (t + 1 < t_end) prefetch(t + 1);
 #pragma unroll WG_RR_UNROLL
@@ -995,6 +1011,13 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
             if (hi && 2 * g + 1 >= KK) a = 0.f;      // the unpaired last tap
 #pragma unroll
             for (int j = 0; j < COT; ++j) acc[g * COT + j] = mfma16(a, b[j], acc[g * COT + j]);
+            if constexpr (SC8) {
+              if (2 * g == KK / 2) {                 // rows 0-7 of this group are the centre tap
+#pragma unroll
+                for (int j = 0; j < COT; ++j)
+                  acc[NG * COT + j] = mfma16(a, gs_s[(r * TW + px) * SO + j * 16 + lm], acc[NG * COT + j]);
+              }
+            }
           }
         } else
 #pragma unroll
@@ -1027,7 +1050,18 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
   }
   if (C8) {
     if (wave == 0) {
-      float* out = part + (size_t)split * KK * Cin * Cout;            // rows 4kq + r: tap 2g + (row >> 3), ci = row & 7
+      float* out = part + (size_t)split * (SC8 ? KK + 1 : KK) * Cin * Cout;   // rows 4kq + r: tap 2g + (row >> 3), ci = row & 7
+      if constexpr (SC8) {
+#pragma unroll
+        for (int j = 0; j < COT; ++j) {
+          const int co = co0 + j * 16 + lm;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            if (row < 8 && co < Cout) out[((size_t)KK * Cin + row) * Cout + co] = acc[NG * COT + j][r];
+          }
+        }
+      }
 #pragma unroll
       for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -1689,7 +1723,7 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
 #define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc
   if (Ndim == 8) {                                   // 8 result channels (see conv_mfma_fwd_p, N8): data-gradient forms
     if (Kdim == 16) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, false, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, false, true>(PARGS);
-    if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2, false, true>(PARGS);
+    if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2, false, true>(PARGS);   // (16-row items measured no better: 8.89 vs 8.91 ms U-Net)
     return -1;
   }
   if (Kdim == 8) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, true>(PARGS);
@@ -2133,7 +2167,7 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
 template <int KS, int CIT, int COT>
 int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int W, int Cin, int Cout,
                  const WgradPlan& p, int gsc, int ntaps, hipStream_t st, const float* x2 = nullptr, int ca = 0,
-                 const AffRef* aff = nullptr, bool c8 = false) {
+                 const AffRef* aff = nullptr, bool c8 = false, const float* gs = nullptr) {
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
   constexpr int SI = (CI_T % 32 == 16) ? CI_T : CI_T + 16;
@@ -2144,6 +2178,20 @@ int launch_wgrad(const float* x, const float* gy, float* part, int N, int H, int
   static_assert(sh <= 64 * 1024, "LDS budget");
   const int nci = (Cin + CI_T - 1) / CI_T;
   dim3 grid(p.splits, nci * ntaps, (Cout + CO_T - 1) / CO_T);
+  if (gs && !c8) return -1;
+  if (c8 && gs) {                                 // fused shortcut weight gradient of the 8-channel form (SC8)
+    if constexpr (KS == 3 && CIT == 1) {
+      constexpr size_t stage_sc = (size_t)(IH * IW * SI + 2 * WTH * TW * SO) * sizeof(float);
+      constexpr size_t red_sc = (size_t)((KS * KS + 1) / 2 + 1) * CIT * COT * 64 * 4 * sizeof(float);
+      constexpr size_t sh_sc = stage_sc > red_sc ? stage_sc : red_sc;
+      static_assert(sh_sc <= 64 * 1024, "LDS budget");
+      if (aff || x2 || gsc != 1 || ntaps != 1 || Cin != 8) return -1;
+      conv_mfma_wgrad<KS, CIT, COT, false, false, true, true><<<grid, TPB, sh_sc, st>>>(x, gy, part, N, H, W, Cin, Cout, p.tiles_x,
+                                                                                    p.tiles_y, p.tiles_per_split, 1, nci, nullptr, 0,
+                                                                                    AffRef{}, gs);
+      return 0;
+    } else return -1;
+  }
   if (c8) {
     if constexpr (KS == 3 && CIT == 1) {
       if (aff || x2 || gsc != 1 || Cin != 8) return -1;
@@ -2421,8 +2469,9 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
   } else {
     static const bool use_c8 = [] { const char* e = getenv("SMSUT_CONV_K8"); return !e || atoi(e) != 0; }();
     const bool c8 = use_c8 && Cin == 8 && !x2 && !aff;                    // tap pairs share an accumulator tile
-    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8);
-    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8);
+    if (gs && !c8 && !(p.cit == 2 && p.cot == 2)) return SMSUT_EINVAL;     // (fused shortcut: 8-channel form or the tap-split kernel)
+    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8, c8 ? gs : nullptr);
+    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8, c8 ? gs : nullptr);
     else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
     else if (H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
              (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {
@@ -2482,6 +2531,8 @@ int smsut_conv2d_wgrad_sc_supported(int N, int H, int W, int Cin, int Cout) {
   // the tap-split kernel's shapes (whole 32 x 32 channel slabs, full tiles): there the fusion wins 6-14 us per call.  On the
   // 16-channel slabs (32->16, 16->32) the extra tile pushed the row-split kernel over 256 VGPRs and the pair ran 0-7 us SLOWER
   // fused (scratch/wsc_ab.py) -- those keep the two-kernel form.
+  static const bool use_c8 = [] { const char* e = getenv("SMSUT_CONV_K8"); return !e || atoi(e) != 0; }();
+  if (on && use_c8 && Cin == 8 && Cout >= 4 && Cout % 4 == 0 && Cout <= 32 && N > 0 && H > 0 && W > 0) return 1;   // 8-channel form (SC8)
   return on && N > 0 && H > 0 && W > 0 && H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
          !plane_wgrad_applies(N, H, W, Cin, Cout) && (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31);
 }

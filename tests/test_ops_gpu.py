@@ -633,7 +633,8 @@ def test_fused_shortcut_data_gradient(ops, n, h, co, ci, split):
 
 
 @pytest.mark.parametrize("n,h,ci,co,cat", [(16, 64, 32, 64, 0), (16, 64, 64, 32, 1), (8, 32, 128, 64, 1), (6, 32, 64, 128, 0),
-                                          (3, 128, 64, 32, 1), (5, 16, 256, 128, 1)])
+                                          (3, 128, 64, 32, 1), (5, 16, 256, 128, 1),
+                                          (4, 256, 8, 16, 0), (8, 128, 8, 16, 0), (2, 40, 8, 16, 0)])      # 8-channel (tap-pair) form
 def test_fused_shortcut_weight_gradient(ops, n, h, ci, co, cat):
     """conv1's 3x3 weight gradient and the 1x1 shortcut's in one pass (both convs read x, reference network/blocks.py:66-80):
     rows 0..8 of the result are bit-identical to the plain entry point (same kernel, same order), row 9 matches the

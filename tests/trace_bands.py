@@ -8,13 +8,17 @@ whole trajectory; how tightly is bounded by how far the REFERENCE's own arithmet
 band <= 4x spread + 1e-2, so the bands can neither be tighter than the reference itself nor drift arbitrarily wide."""
 # measured spread of the reference (max over the window of |fp32 - fp64| / |fp64|):
 #   all 32 iterations:  G_seg 3.4e-3, G_semi 2.3e-2, G_rec 0.53, G_nce 0.18
-#   iterations 0-5:     G_rec 5.6e-2, G_nce 2.0e-2
+#   iterations 0-5:     G_rec 5.6e-2, G_nce 2.0e-2;   iterations 0-4: G_rec 1.5e-2, G_nce 1.1e-2
 # G_rec / G_nce pass through the translator, which D trains: after a handful of iterations they are as chaotic as the D-side
 # scalars (two HIP builds that differ only in the order of a few fp32 sums -- e.g. the tile shape of D's 8x8 convs -- end
 # iteration 30 with G_rec 0.41 vs 1.0: the translator saturates in some trajectories, as it does in some of bench.py's runs).
-# So they are tracked over the FIRST SIX iterations only; the segmentor-side scalars over the whole trajectory.
+# Late r02: four HIP builds that differ ONLY in the summation order of one or two kernels (fused / unfused 1x1 shortcut of the first
+# block, scratch/trace_ab.py) deviate from the reference's G_rec by 0.013 / 0.068 / 0.307 / 0.356 at iteration 5 and 0.087 - 0.28 at
+# iteration 6, while all four stay within 0.04 over iterations 0-4 (reference's own fp32-vs-fp64 spread there: 0.015; at iteration 5:
+# 0.056, at 7: 0.16): the translator side forks around iteration 5.
+# So they are tracked over the FIRST FIVE iterations only; the segmentor-side scalars over the whole trajectory.
 # name: (relative band, number of leading iterations it applies to)
-TRACE_BANDS = {"G_seg": (0.01, 32), "G_semi": (0.05, 32), "G_rec": (0.15, 6), "G_nce": (0.08, 6)}
+TRACE_BANDS = {"G_seg": (0.01, 32), "G_semi": (0.05, 32), "G_rec": (0.06, 5), "G_nce": (0.05, 5)}
 # Iteration 0 of the trace: 1e-3 on every scalar (D_gp: 1e-2, its own line in the test) except G_fake, which is evaluated
 # through D AFTER D's first Adam step -- the reference's fp32 and fp64 replays differ by 3.2e-3 there (0.28931 vs 0.29024), so
 # no fp32 implementation can be held to 1e-3 on it (checked by test_trace_bands_cover_reference_fp_spread: spread <= band <= 2x).
