@@ -37,6 +37,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._semi_on = False
         self._graphs = {}
         self._alias = None
+        self._d_alias = None
+        self._use_d_alias = os.environ.get("SMSUT_D_ALIAS", "1") not in ("0", "")
         self._g1 = self._g2 = None
         self._side = None
         # D-step on a side stream under the cycle pass: default on one GPU only.  Under data parallelism everything stays on
@@ -109,10 +111,26 @@ class UGANConsisTrainer(UGANShp0Trainer):
         d_cls = ops.cross_entropy_rows(out_cls[:b], modal_org)
         d_fake = ops.mean_all(out_src[b:], 1.0)
         x_hat = ops.row_lerp(x_real, x_fake, alpha).requires_grad_(True)
-        out_src, _ = self.D(x_hat)                  # differentiated twice (gradient penalty): default op families
+        if self._d_alias is not None:
+            # the x_hat pass on parameter ALIASES (same storage, separate .grad): every D parameter is reached by both passes, and
+            # autograd would sum their gradients with one tiny add kernel per parameter; now one multi-tensor add (as for G)
+            out_src, _ = torch.func.functional_call(self.D, self._d_alias, (x_hat,))
+        else:
+            out_src, _ = self.D(x_hat)              # differentiated twice (gradient penalty): default op families
         d_gp = self.gradient_penalty(out_src, x_hat)
         d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
         d_loss.backward()
+        if self._d_alias is not None:
+            main, extra = [], []
+            for name, p in self.D.named_parameters():
+                a = self._d_alias[name]
+                if a.grad is not None:
+                    if p.grad is None:
+                        p.grad = a.grad
+                    else:
+                        main.append(p.grad); extra.append(a.grad)
+            if main:
+                torch._foreach_add_(main, extra)
         return torch.stack([t.detach().float() for t in (d_real, d_fake, d_cls, d_gp)])
 
     def _g2gen_phase(self, x_real, vec_to, ids):
@@ -218,8 +236,10 @@ class UGANConsisTrainer(UGANShp0Trainer):
         lam_t = self._lambda_semi_t.fill_(lambda_semi)
         if self._alias is None:
             self._alias = {k: p.detach().requires_grad_(True) for k, p in self.net.named_parameters()}
+        if self._use_d_alias and self._d_alias is None:
+            self._d_alias = {k: p.detach().requires_grad_(True) for k, p in self.D.named_parameters()}
         g_params = list(self.net.parameters())
-        d_params = list(self.D.parameters())
+        d_params = list(self.D.parameters()) + (list(self._d_alias.values()) if self._d_alias else [])
 
         # ------------------------------------------------------------ G(x_real): once, shared by both steps
         x_fake, st_seg = self._run_phase("G1", self._g1_phase, (x_real, vec_ot, ids, y_real), [])
