@@ -26,6 +26,27 @@ constexpr int TPB = 256;
 // MODE 2: sums of (v, v*xh, v*gz)    -- backward of backward
 template <int MODE> struct NSums { static constexpr int n = (MODE == 2) ? 3 : 2; };
 
+// One-chunk case (planes of <= 1024 pixels: pick_chunk): the workgroup that reduces (image n, channel c) holds the COMPLETE sums, so
+// it writes the per-(n, c) means itself -- exactly what in_moments_final<MODE> would compute from this single chunk -- and that
+// launch (4.9 us at the dependent-launch floor) is skipped.  o0 == null: not fused.
+struct FinOut { float* o0; float* o1; float* o2; float eps; };
+template <int MODE>
+__device__ __forceinline__ void fin_emit(const FinOut& f, int HW, int k, const float* tot) {   // k = n * C + c; tot[NS]
+  constexpr int NS = NSums<MODE>::n;
+  const double inv = 1.0 / (double)HW;
+  if (MODE == 0) {
+    const double m = (double)tot[0] * inv;
+    double var = (double)tot[1] * inv - m * m;
+    if (var < 0.0) var = 0.0;
+    f.o0[k] = (float)m;
+    f.o1[k] = (float)(1.0 / sqrt(var + (double)f.eps));
+  } else {
+    f.o0[k] = (float)((double)tot[0] * inv);
+    f.o1[k] = (float)((double)tot[1] * inv);
+    if (MODE == 2) f.o2[k] = (float)((double)tot[NS - 1] * inv);
+  }
+}
+
 template <int MODE, int VEC>
 __global__ void __launch_bounds__(TPB, 4)   // <= 128 VGPRs: 4 waves per SIMD (it sat at 172 = 2 waves)
 in_moments_partial(const float* __restrict__ t0,   // x | gy | v
@@ -34,8 +55,9 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
                    const float* __restrict__ gamma, const float* __restrict__ beta,   // beta == null: no activation
                    const float* __restrict__ mean, const float* __restrict__ rstd,
                    float* __restrict__ part,        // [N][chunks][C][NS]
-                   int HW, int C, int pix_per_chunk, float slope) {
+                   int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}) {
   constexpr int NS = NSums<MODE>::n;
+  const bool emit = fin.o0 != nullptr;              // (host: only with gridDim.x == 1)
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
   // gridDim.z channel slabs (host: slab_count): small planes with many channels (discriminator / bottleneck levels) had only
   // N * chunks workgroups, each walking ALL channels serially -- e.g. 64 workgroups for 16 x 32x32 x 128
@@ -136,14 +158,18 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
       __syncthreads();
       if (threadIdx.x < TC && cv_ok) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int j = 0; j < VEC; ++j) {
+          float tots[NS];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
+          for (int s = 0; s < NS; ++s) {
             float tot = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) tot += sm[((w4 * TC + tc) * NS + s) * VEC + j];
             part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * NS + s] = tot;
+            tots[s] = tot;
           }
+          if (emit) fin_emit<MODE>(fin, HW, n * C + cv * VEC + j, tots);
+        }
       }
     } else {
 #pragma unroll
@@ -153,13 +179,17 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
       __syncthreads();
       if (trow == 0 && cv_ok) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+        for (int j = 0; j < VEC; ++j) {
+          float tots[NS];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
+          for (int s = 0; s < NS; ++s) {
             float tot = 0.f;
             for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * NS + s) * VEC + j];
             part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * NS + s] = tot;
+            tots[s] = tot;
           }
+          if (emit) fin_emit<MODE>(fin, HW, n * C + cv * VEC + j, tots);
+        }
       }
     }
     __syncthreads();
@@ -435,7 +465,8 @@ restail_fwd(TailRef t, float* __restrict__ out, int HW, int C, float slope) {
 template <int VEC, bool REMASK>
 __global__ void __launch_bounds__(TPB)       // (a 128-VGPR cap spills here: 244 B scratch and +30 % time)
 restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
-                    int HW, int C, int pix_per_chunk, float slope) {
+                    int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}) {
+  const bool emit = fin.o0 != nullptr;              // one-chunk case: see fin_emit
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
   const int CVA = C / VEC;                    // gridDim.z channel slabs, as in in_moments_partial
   const int CV = CVA / gridDim.z;
@@ -522,14 +553,18 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
       __syncthreads();
       if (threadIdx.x < TC && cv_ok) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < VEC; ++j) {
+          float tots[3];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
+          for (int q = 0; q < 3; ++q) {
             float tot = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) tot += sm[((w4 * TC + tc) * 3 + q) * VEC + j];
             part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
+            tots[q] = tot;
           }
+          if (emit) fin_emit<2>(fin, HW, n * C + cv * VEC + j, tots);
+        }
       }
     } else {
 #pragma unroll
@@ -539,13 +574,17 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
       __syncthreads();
       if (trow == 0 && cv_ok) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q)
+        for (int j = 0; j < VEC; ++j) {
+          float tots[3];
 #pragma unroll
-          for (int j = 0; j < VEC; ++j) {
+          for (int q = 0; q < 3; ++q) {
             float tot = 0.f;
             for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * 3 + q) * VEC + j];
             part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
+            tots[q] = tot;
           }
+          if (emit) fin_emit<2>(fin, HW, n * C + cv * VEC + j, tots);
+        }
       }
     }
     __syncthreads();
@@ -603,11 +642,18 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
     });
 }
 
+inline bool fin_emit_on() {                         // SMSUT_IN_ONE_CHUNK=0: always launch in_moments_final (A/B switch)
+  static const bool on = [] { const char* e = getenv("SMSUT_IN_ONE_CHUNK"); return !e || atoi(e) != 0; }();
+  return on;
+}
 inline int pick_chunk(int HW, int C, int N) {
   // aim for >= ~1024 blocks overall while keeping >= 256 pixels per chunk
 #ifndef SMSUT_IN_BLOCKS
 #define SMSUT_IN_BLOCKS 1024
 #endif
+  // planes of <= 256 pixels are ONE chunk: there the partial-sum kernel finalises by itself (fin_emit) and the in_moments_final
+  // launch is skipped.  (1024-pixel planes as one chunk measured no better than four chunks + the extra launch.)
+  if (HW <= 256 && C % 4 == 0) return HW;
   int ppc = 2048;
   while (ppc > 256 && (int64_t)N * cdiv64(HW, ppc) < SMSUT_IN_BLOCKS) ppc >>= 1;
   (void)C;
@@ -639,11 +685,12 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);
   dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
+  const FinOut fin = (chunks == 1 && fin_emit_on()) ? FinOut{mean, rstd, nullptr, eps} : FinOut{};
   if (C % 4 == 0)
-    in_moments_partial<0, 4><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
+    in_moments_partial<0, 4><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope, fin);
   else
-    in_moments_partial<0, 1><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope);
-  in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, eps, mean, rstd, nullptr);
+    in_moments_partial<0, 1><<<g, TPB, 0, st>>>(x, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, HW, C, ppc, slope, fin);
+  if (!fin.o0) in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, eps, mean, rstd, nullptr);
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   if (C % 4 == 0)
@@ -682,11 +729,12 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta, const
   const int ppc = pick_chunk(HW, C, N);
   const int chunks = (int)cdiv64(HW, ppc);
   dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
+  const FinOut fin = (chunks == 1 && fin_emit_on()) ? FinOut{a_mean, b_mean, nullptr, 0.f} : FinOut{};
   if (C % 4 == 0)
-    in_moments_partial<1, 4><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
+    in_moments_partial<1, 4><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope, fin);
   else
-    in_moments_partial<1, 1><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
-  in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
+    in_moments_partial<1, 1><<<g, TPB, 0, st>>>(gy, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope, fin);
+  if (!fin.o0) in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
   float* gg = (ggamma && gbeta) ? ggamma : nullptr;       // affine gradients: computed by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
@@ -713,11 +761,12 @@ int smsut_instnorm_bwd2(const float* v, const float* ug, const float* ub, const 
   const int chunks = (int)cdiv64(HW, ppc);
   dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
   float* cvm = scratch; float* dvm = scratch + (size_t)N * C; float* em = scratch + 2 * (size_t)N * C;
+  const FinOut fin = (chunks == 1 && fin_emit_on()) ? FinOut{cvm, dvm, em, 0.f} : FinOut{};
   if (C % 4 == 0)
-    in_moments_partial<2, 4><<<g, TPB, 0, st>>>(v, x, gy, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
+    in_moments_partial<2, 4><<<g, TPB, 0, st>>>(v, x, gy, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope, fin);
   else
-    in_moments_partial<2, 1><<<g, TPB, 0, st>>>(v, x, gy, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope);
-  in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, cvm, dvm, em);
+    in_moments_partial<2, 1><<<g, TPB, 0, st>>>(v, x, gy, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope, fin);
+  if (!fin.o0) in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, cvm, dvm, em);
   in_bwd2_gamma<<<(C + 63) / 64, 64, 0, st>>>(rstd, a_mean, b_mean, cvm, dvm, em, N, C, HW, d_gamma);
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
@@ -802,11 +851,12 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
   const int chunks = (int)cdiv64(HW, ppc);
   dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
   const bool remask = ms && b2 && bs;
-#define TAIL_PARTIAL(V, R) restail_bwd_partial<V, R><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope)
+  const FinOut fin = (chunks == 1 && fin_emit_on()) ? FinOut{a_mean, b2_mean, bs_mean, 0.f} : FinOut{};
+#define TAIL_PARTIAL(V, R) restail_bwd_partial<V, R><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin)
   if (C % 4 == 0) { if (remask) TAIL_PARTIAL(4, true); else TAIL_PARTIAL(4, false); }
   else { if (remask) TAIL_PARTIAL(1, true); else TAIL_PARTIAL(1, false); }
 #undef TAIL_PARTIAL
-  in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
+  if (!fin.o0) in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
   // the affine gradients (and the copy gbs = gb2) are written by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
