@@ -66,8 +66,15 @@ class GradAllReducer:
         self._flat: Optional[torch.Tensor] = None
 
     def reduce(self):
+        """Synchronous form: pack, all-reduce, average, unpack."""
+        self.finish(self.begin())
+
+    def begin(self):
+        """Pack the gradients and START the all-reduce (``async_op=True``: RCCL runs it on its own stream behind the work
+        already queued on the current one).  Whatever the caller launches next overlaps with it; ``finish`` waits, averages and
+        unpacks.  Returns a handle (None when there is nothing to reduce)."""
         if self.world <= 1 and not (force_dist() and self.group is not None):
-            return
+            return None
         dev = self.params[0].device
         if self._flat is None or self._flat.device != dev:
             self._flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
@@ -84,7 +91,13 @@ class GradAllReducer:
             off += n
         if views:
             torch._foreach_copy_(views, srcs)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self, work):
+        if work is None:
+            return
+        work.wait()                                  # the current stream now waits for the collective
+        flat = self._flat
         flat.mul_(1.0 / self.world)
         off = 0
         dsts, chunks = [], []

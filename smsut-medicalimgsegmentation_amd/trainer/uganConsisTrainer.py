@@ -261,9 +261,17 @@ class UGANConsisTrainer(UGANShp0Trainer):
             d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params)
             if self._probe:
                 self._finite_probe("D", [("d_scalars", d_scal)] + [("grad " + k, p.grad) for k, p in self.D.named_parameters()])
-            self.d_reducer.reduce()
-            self.d_optimizer.step()
+            # D's gradient all-reduce STARTS here (asynchronous: RCCL's own stream) and is collected after the cycle pass, which
+            # needs neither D's gradients nor its updated weights -- the collective is off the critical path under data parallelism
+            d_work = self.d_reducer.begin()
+            if d_work is None or overlap:
+                self.d_reducer.finish(d_work)
+                self.d_optimizer.step()
+                d_work = None
         st_semi = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids), list(self._alias.values()))
+        if d_work is not None:
+            self.d_reducer.finish(d_work)
+            self.d_optimizer.step()
         self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
         if overlap:
             cur.wait_stream(self._side)
