@@ -39,13 +39,18 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._alias = None
         self._d_alias = None
         self._use_d_alias = os.environ.get("SMSUT_D_ALIAS", "1") not in ("0", "")
+        self._d_async = os.environ.get("SMSUT_D_ASYNC_ALLREDUCE", "0") not in ("0", "")
         self._g1 = self._g2 = None
         self._side = None
-        # D-step on a side stream under the cycle pass: default on one GPU only.  Under data parallelism everything stays on
-        # ONE stream (the RCCL all-reduce is stream-ordered and asynchronous to the host anyway): the multi-stream variant
-        # could only be rehearsed with two gloo ranks SHARING one GPU, where it degenerated to seconds per iteration
-        # (profiles/r02_notes.md) -- not something to ship unmeasured for a 0.3 % gain.
-        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "0") not in ("0", "")
+        # D-step (graph, gradient all-reduce, Adam) on a side stream under the cycle pass: default on one GPU and under RCCL.  At one
+        # rank over RCCL (SMSUT_FORCE_DIST=1) the data-parallel extras -- pack, all-reduce, unpack, and the host time of enqueueing
+        # them -- cost 0.6 ms per iteration with the side stream and 1.45 ms without (27.56 vs 28.5 ms against 26.9 / 27.06).
+        # Off under gloo: two gloo ranks SHARING one card degenerated to seconds per iteration with it (profiles/r02_notes.md).
+        nccl = False
+        if self.world > 1:
+            import torch.distributed as dist
+            nccl = dist.is_initialized() and dist.get_backend() == "nccl"
+        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if (self.world == 1 or nccl) else "0") not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
@@ -264,7 +269,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
             # D's gradient all-reduce STARTS here (asynchronous: RCCL's own stream) and is collected after the cycle pass, which
             # needs neither D's gradients nor its updated weights -- the collective is off the critical path under data parallelism
             d_work = self.d_reducer.begin()
-            if d_work is None or overlap:
+            if d_work is None or overlap or not self._d_async:
                 self.d_reducer.finish(d_work)
                 self.d_optimizer.step()
                 d_work = None
