@@ -236,6 +236,51 @@ def cpu_baseline_unet(sample_b=32, timed=2):
                       f"workload), fp32, torch CPU {cores} threads, {dt:.1f} s/step"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` with no torchrun environment: start N fresh rank processes (one per GPU, RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), relay rank 0's JSON line, exit non-zero when any
+    rank does.  The parent never initialises the GPU: ``torch.cuda.device_count()`` only counts devices on this image, and
+    no HIP call, ``torch.cuda.is_available()`` or ``smsut_amd`` import happens before the children exist -- so there is no
+    exec / fork of a GPU-initialised process anywhere (the ranks are plain ``subprocess`` children of a GPU-free parent)."""
+    import subprocess
+    n = args.gpus
+    shared = os.environ.get("SMSUT_FORCE_DEVICE") is not None      # rehearsal: every rank on one card (gloo)
+    have = torch.cuda.device_count()
+    if have < n and not shared:
+        msg = f"bench.py --gpus {n}: needs >= {n} visible devices, this box has {have}"
+        log(msg)
+        print(json.dumps({"error": msg, "n_gpus": n, "devices_visible": have}), flush=True)
+        return 2
+    env0 = dict(os.environ)
+    env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC only on this pool (RCCL needs it)
+    env0["MASTER_ADDR"] = "127.0.0.1"
+    env0["MASTER_PORT"] = str(_free_port())
+    env0["WORLD_SIZE"] = env0["LOCAL_WORLD_SIZE"] = str(n)
+    # host threads: the ranks share the box's cores (torchrun sets 1; the step is launch-bound on ONE host thread per rank)
+    env0.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=out))
+    line0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(line0.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        log(f"ranks failed (rank, rc): {bad}")
+        return next(rc for _, rc in bad) or 1
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,7 +297,14 @@ def main():
     ap.add_argument("--no-step-profile", action="store_true", help="skip the per-shape replay profile (roofline.step_conv_frac)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel leg (the command the rocprofv3 stats / PMC passes profile)")
+    ap.add_argument("--d-overlap", choices=("default", "0", "1"), default="default",
+                    help="D-step on a side stream beside the cycle pass (SMSUT_D_OVERLAP): default = on at one GPU, off under "
+                         "data parallelism; an 8-GPU run can A/B it with --d-overlap 1")
     args = ap.parse_args()
+    if args.d_overlap != "default":
+        os.environ["SMSUT_D_OVERLAP"] = args.d_overlap
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
 
     import smsut_amd  # noqa: F401
     from smsut_amd import config as cfg, ops, parallel

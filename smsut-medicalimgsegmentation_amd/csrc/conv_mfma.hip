@@ -1667,28 +1667,32 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       return 0;
     } else return -1;
   } else if (sc2) {
+    // (every `if constexpr` below ends in `else return -1`: a form this instantiation does not have must report
+    //  "nothing launched", never fall through to `return 0` with y / ysc / the statistics left unwritten)
     if constexpr (!K8 && KS == 3 && NCH % 2 == 0)
       conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true><<<grid, TPB, sh, st>>>(
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
+    else return -1;
   } else if (sc) {
     if constexpr (K8 && KS == 3 && sh_sc <= 64 * 1024) {
       conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true><<<grid, TPB, sh_sc, st>>>(
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
-    }
-    if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
+    } else if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (x2) {
         if constexpr (NCH % 2 == 0)
           conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
               x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc);
+        else return -1;
       } else {
         conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
             x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
       }
-    }
+    } else return -1;
   } else if (aff) {
     P_GO(true, false, false, false, true);
   } else if (x2) {
     if constexpr (NCH % 2 == 0) P_GO(true, false, false, true, false);
+    else return -1;
   } else if (bst) {
     if (!stats || (transposed & 2)) return -1;
     P_GO(false, false, true, false, false);
@@ -2457,11 +2461,12 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
   SMSUT_REQUIRE(!aff || (KS == 3 && !x2));
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
+  int rc = 0;                        // launch_wgrad: -1 = no kernel for this form (nothing was launched)
   if (KS == 1) {
-    if (p.cit == 1 && p.cot == 1) launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
-    else if (p.cit == 1) launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
-    else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
-    else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    if (p.cit == 1 && p.cot == 1) rc = launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else if (p.cit == 1) rc = launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else if (p.cot == 1) rc = launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
+    else rc = launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca);
   } else if (plane_wgrad_applies(N, H, W, Cin, Cout) && !aff) {
     plane_wgrad<<<dim3(Cin / 32, Cout / 32, 9), TPB, 0, st>>>(x, gy, gw, N, H, W, Cin, Cout, x2, ca);
     SMSUT_LAUNCH_CHECK();
@@ -2470,9 +2475,9 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
     static const bool use_c8 = [] { const char* e = getenv("SMSUT_CONV_K8"); return !e || atoi(e) != 0; }();
     const bool c8 = use_c8 && Cin == 8 && !x2 && !aff;                    // tap pairs share an accumulator tile
     if (gs && !c8 && !(p.cit == 2 && p.cot == 2)) return SMSUT_EINVAL;     // (fused shortcut: 8-channel form or the tap-split kernel)
-    if (p.cit == 1 && p.cot == 1) launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8, c8 ? gs : nullptr);
-    else if (p.cit == 1) launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8, c8 ? gs : nullptr);
-    else if (p.cot == 1) launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
+    if (p.cit == 1 && p.cot == 1) rc = launch_wgrad<3, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8, c8 ? gs : nullptr);
+    else if (p.cit == 1) rc = launch_wgrad<3, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff, c8, c8 ? gs : nullptr);
+    else if (p.cot == 1) rc = launch_wgrad<3, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
     else if (H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
              (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31)) {
       constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE + 4) * sizeof(float);
@@ -2500,8 +2505,9 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
       else
         conv_mfma_wgrad_ts<false><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,
                                                          p.tiles_per_split, nullptr, 0);
-    } else launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
+    } else rc = launch_wgrad<3, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 1, 1, st, x2, ca, aff);
   }
+  if (rc != 0) return SMSUT_EINVAL;
   const int wsize = (KS * KS + (gs ? 1 : 0)) * Cin * Cout;
   launch_sum_splits(workspace, gw, wsize, p.splits, st);
   SMSUT_LAUNCH_CHECK();
@@ -2745,10 +2751,12 @@ int smsut_convT2x2_wgrad_mfma(const float* x, const float* gy, float* gw, float*
   SMSUT_REQUIRE(x && gy && gw && workspace && N > 0 && H > 0 && W > 0 && smsut_convT2x2_mfma_supported(Cin, Cout));
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
-  if (p.cit == 1 && p.cot == 1) launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
-  else if (p.cit == 1) launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
-  else if (p.cot == 1) launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
-  else launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  int rc;
+  if (p.cit == 1 && p.cot == 1) rc = launch_wgrad<1, 1, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  else if (p.cit == 1) rc = launch_wgrad<1, 1, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  else if (p.cot == 1) rc = launch_wgrad<1, 2, 1>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  else rc = launch_wgrad<1, 2, 2>(x, gy, workspace, N, H, W, Cin, Cout, p, 2, 4, st);
+  if (rc != 0) return SMSUT_EINVAL;
   const int wsize = 4 * Cin * Cout;
   launch_sum_splits(workspace, gw, wsize, p.splits, st);
   SMSUT_LAUNCH_CHECK();

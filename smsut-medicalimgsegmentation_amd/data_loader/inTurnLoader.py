@@ -69,6 +69,20 @@ class InTurnTrainBatchSampler:
     def __len__(self):
         return self.n
 
+    def state_dict(self):
+        """Position in the data order (part of the resumable train state): per-modality cursors and shuffled id lists, the turn
+        queue, and the private generator (``world > 1``; at ``world == 1`` the draws come from Python's global ``random``, which
+        the trainer saves itself)."""
+        return {"samples": [list(s) for s in self.samples], "starts": list(self.starts), "queue": list(self.queue),
+                "cur_modality": self.cur_modality, "rng": None if self.rng is random else self.rng.getstate()}
+
+    def load_state_dict(self, st):
+        assert [len(s) for s in st["samples"]] == [len(s) for s in self.samples], "sampler state belongs to another dataset split"
+        self.samples = [list(s) for s in st["samples"]]
+        self.starts, self.queue, self.cur_modality = list(st["starts"]), list(st["queue"]), int(st["cur_modality"])
+        if st["rng"] is not None and self.rng is not random:
+            self.rng.setstate(st["rng"])
+
 
 class InTurnTestBatchSampler:
     """inTurnLoader.py:62-79: every slice once, modality after modality, last batch of a modality may be short."""
@@ -130,6 +144,13 @@ class InTurnLoader:
 
     def __len__(self):
         return len(self.sampler)
+
+    def state_dict(self):
+        return self.sampler.state_dict() if hasattr(self.sampler, "state_dict") else None
+
+    def load_state_dict(self, st):
+        if st is not None and hasattr(self.sampler, "load_state_dict"):
+            self.sampler.load_state_dict(st)
 
     def __iter__(self):
         for ids in self.sampler:

@@ -11,31 +11,64 @@ the optimizer steps and the poly-LR write (Python floats), so their semantics ar
 from __future__ import annotations
 
 import os
+import weakref
 from typing import Callable, Iterable, Sequence
 
 import torch
 import torch.distributed
 
 
-def graphs_enabled(world: int, collective_free: bool = False) -> bool:
+_CAPTURING = 0           # > 0 while a GraphedPhase capture is recording on this thread
+_LIVE = []               # weakrefs to the captured phases (to mark them for re-binding, see GraphedPhase)
+
+
+def graphs_enabled() -> bool:
     """Default: every phase is captured, on one GPU and under data parallelism alike -- the trainers split their steps
     at the collectives (gradient all-reduce, Dice-statistics all-reduce), which run eagerly BETWEEN replays, so no
-    RCCL call ever sits inside a captured region.  ``SMSUT_GRAPH=0`` is the explicit eager mode (``world`` and
-    ``collective_free`` are kept for callers that want a per-phase policy)."""
+    RCCL call ever sits inside a captured region (enforced: ``assert_no_capture`` in every collective call site).
+    ``SMSUT_GRAPH=0`` is the explicit eager mode."""
     v = os.environ.get("SMSUT_GRAPH")
     if v is not None:
         return v not in ("0", "", "false", "False")
     return True
 
 
+def assert_no_capture(what: str):
+    """Called by every collective of the package (gradient all-reduce, Dice-statistics all-reduce, parameter broadcast):
+    a collective issued while a phase is being captured would be baked into a hipGraph (or silently dropped on replay) --
+    a trainer that wraps such a step in ``GraphedPhase`` fails here, loudly, at its first capture."""
+    if _CAPTURING:
+        raise RuntimeError(f"{what} was issued inside a hipGraph capture: phases must be split at their collectives "
+                           f"(see trainer/uganConsisTrainer.py) or run with SMSUT_GRAPH=0")
+
+
+def invalidate_grad_bindings():
+    """An eager step (``p.grad = None`` + fresh gradient tensors) or anything else that re-points ``.grad`` outside a
+    capture calls this: the next replay of every captured phase first puts ITS gradient buffers back."""
+    for r in list(_LIVE):
+        g = r()
+        if g is None:
+            _LIVE.remove(r)
+        else:
+            g._dirty = True
+
+
 class GraphedPhase:
     """Captures ``fn(*tensors) -> tensor | tuple of tensors`` and replays it on new inputs.  A phase may end in
     ``.backward()`` (its parameters' ``.grad`` then live in the graph's pool and are rewritten by every replay) or leave
     an autograd graph behind for a LATER phase to differentiate through (the later phase's capture walks it once; on
-    replay only the recorded kernels run, in capture order, on the same addresses)."""
+    replay only the recorded kernels run, in capture order, on the same addresses).
+
+    ``grad_params`` are cleared before the capture; they and ``rebind_params`` (parameters whose ``.grad`` this phase's
+    backward fills without owning the clearing, e.g. the generator's aliases in phase G2) have the gradient tensors the
+    capture bound to them RECORDED, and a replay re-installs those whenever another capture or an eager step has re-pointed
+    ``.grad`` since (replaying an older graph wrote gradients to addresses ``p.grad`` no longer named, and the
+    all-reduce / optimizer silently consumed stale ones)."""
 
     def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor],
-                 grad_params: Iterable[torch.nn.Parameter], warmup: int = 2):
+                 grad_params: Iterable[torch.nn.Parameter], warmup: int = 2,
+                 rebind_params: Iterable[torch.nn.Parameter] = ()):
+        global _CAPTURING
         self.fn = fn
         self.params = list(grad_params)
         self.static_in = [t.detach().clone() for t in example_inputs]
@@ -53,8 +86,28 @@ class GraphedPhase:
         # under torch.distributed the RCCL watchdog thread polls events while we capture: with the default "global" error
         # mode any such call from ANOTHER thread can invalidate the capture; "thread_local" polices this thread only
         mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
-        with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            self.static_out = fn(*self.static_in)
+        _CAPTURING += 1
+        try:
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                self.static_out = fn(*self.static_in)
+        finally:
+            _CAPTURING -= 1
+        seen, self._bound = set(), []
+        for p in list(self.params) + list(rebind_params):
+            if id(p) not in seen and p.grad is not None:
+                seen.add(id(p))
+                self._bound.append((p, p.grad))
+        # this capture re-pointed the .grad of its parameters: older graphs that bound the same parameters re-install
+        # their own buffers before their next replay (and mark this one in turn)
+        self._dirty = False
+        for r in list(_LIVE):
+            g = r()
+            if g is None:
+                _LIVE.remove(r)
+            elif seen & g._ids:
+                g._dirty = True
+        self._ids = seen
+        _LIVE.append(weakref.ref(self))
         self.graph.replay()          # capture records without executing: run it once so static_out holds real values
 
     def _clear(self):
@@ -62,6 +115,14 @@ class GraphedPhase:
             p.grad = None
 
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
+        if self._dirty:
+            for p, g in self._bound:
+                p.grad = g
+            self._dirty = False
+            for r in _LIVE:                              # ... which un-binds every other graph over the same parameters
+                o = r()
+                if o is not None and o is not self and (self._ids & o._ids):
+                    o._dirty = True
         for s, i in zip(self.static_in, inputs):
             s.copy_(i, non_blocking=True)
         self.graph.replay()

@@ -22,6 +22,12 @@ class SyntheticSliceLoader:
     def __len__(self):
         return self.n_batches
 
+    def state_dict(self):
+        return {"gen": self.gen.get_state(), "i": self._i}
+
+    def load_state_dict(self, st):
+        self.gen.set_state(st["gen"]); self._i = int(st["i"])
+
     def _batch(self):
         b, s = self.bs, self.size
         img = (0.5 * torch.randn(b, 1, s, s, generator=self.gen)).clamp_(-1, 1)

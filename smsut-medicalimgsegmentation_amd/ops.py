@@ -1361,6 +1361,8 @@ def all_reduce_dice_stats(pairs, group):
     """ONE all-reduce for any number of (stats, ce_sum) pairs (16 floats each at 5 classes): packed into a flat buffer,
     summed over ``group``, unpacked in place."""
     import torch.distributed as dist
+    from . import graphs
+    graphs.assert_no_capture("all_reduce_dice_stats (Dice-statistics all-reduce)")
     flat = torch.cat([t.reshape(-1) for pair in pairs for t in pair])
     dist.all_reduce(flat, group=group)
     off = 0

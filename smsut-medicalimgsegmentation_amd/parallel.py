@@ -75,6 +75,8 @@ class GradAllReducer:
         unpacks.  Returns a handle (None when there is nothing to reduce)."""
         if self.world <= 1 and not (force_dist() and self.group is not None):
             return None
+        from . import graphs
+        graphs.assert_no_capture("GradAllReducer.begin (gradient all-reduce)")
         dev = self.params[0].device
         if self._flat is None or self._flat.device != dev:
             self._flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
@@ -119,6 +121,8 @@ def broadcast_parameters(module: torch.nn.Module, group=None, src: int = 0):
     """Make every rank start from rank ``src``'s weights."""
     if group is None or not dist.is_initialized() or (dist.get_world_size(group) <= 1 and not force_dist()):
         return
+    from . import graphs
+    graphs.assert_no_capture("broadcast_parameters")
     for t in list(module.parameters()) + list(module.buffers()):
         flat = _flat_memory(t.data)
         dist.broadcast(flat, src=src, group=group)

@@ -69,6 +69,8 @@ class BaseTrainer(abc.ABC):
                                             process_group=self.group)        # baseTrainer.py:57
         self.epoch = 0
         self.iter = 0
+        self._train_loaders = None                   # (lb, ul) while fit() runs: their position is part of the train state
+        self._resume_loader_states = None
 
     # ------------------------------------------------------------------ bookkeeping (baseTrainer.py:65-123)
     @staticmethod
@@ -109,36 +111,58 @@ class BaseTrainer(abc.ABC):
         self.info(f"Load model from {path}.")
 
     def save_model(self, prefix):
-        if self.rank != 0:
-            return
-        path = pjoin(self.expr_root, self.model_idx, "ckpt", f"{prefix}.ckpt")
-        torch.save({k: v.contiguous() for k, v in self.net.state_dict().items()}, path)
+        """Weights by rank 0; the train state is a COLLECTIVE under data parallelism (every rank contributes its RNG and loader
+        state), so all ranks call this together -- ``fit`` does."""
+        if self.rank == 0:
+            path = pjoin(self.expr_root, self.model_idx, "ckpt", f"{prefix}.ckpt")
+            torch.save({k: v.contiguous() for k, v in self.net.state_dict().items()}, path)
+            self.info(f"Save model to {path}.")
         self.save_train_state(prefix)
-        self.info(f"Save model to {path}.")
 
     # ------------------------------------------------------------------ resume (SURVEY.md 8f.4; the reference saves
     # state_dicts only -- uganShp0Trainer.py:94-107, baseTrainer.py:120-123 -- and cannot continue a run)
     _OPTIMIZERS = ("optimizer", "d_optimizer", "optimizer1", "optimizer2")
 
+    def _rank_state(self):
+        """What differs from rank to rank: the host + device RNG streams (ranks seed with ``seed + rank``: target modality,
+        interpolation weights, augmentation draws) and the train loaders' position (sampler generator, per-modality cursors,
+        shuffled id lists)."""
+        import random as _random
+        loaders = [ld.state_dict() if hasattr(ld, "state_dict") else None for ld in (self._train_loaders or ())]
+        return {"rank": self.rank,
+                "rng": {"python": _random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
+                        "cuda": torch.cuda.get_rng_state(self.device)},
+                "loaders": loaders}
+
     def save_train_state(self, prefix):
         """``{prefix}_state.ckpt`` next to the weight files: every optimizer's state (momentum / Adam moments, current LR),
-        ``iter`` / ``epoch`` (poly LR, consistency ramp-up and the ``iter >= 1000`` switch depend on them) and the host +
-        device RNG states.  Optimizer state tensors keep the parameters' HWIO strides (the fused optimizers need the
-        layouts to agree), so they are saved as they are, not ``.contiguous()``."""
-        if self.rank != 0 or self.phase != "train" or self.model_idx is None:
+        ``iter`` / ``epoch`` (poly LR, consistency ramp-up and the ``iter >= 1000`` switch depend on them) and, PER RANK, the
+        host + device RNG states and the train loaders' state (gathered to rank 0: r02 saved rank 0's streams only and a resumed
+        run had every rank drawing the same modalities / alphas / augmentations, and restarted the data order).  Optimizer state
+        tensors keep the parameters' HWIO strides (the fused optimizers need the layouts to agree), so they are saved as they
+        are, not ``.contiguous()``."""
+        if self.phase != "train":
             return None
-        import random as _random
-        state = {"iter": self.iter, "epoch": self.epoch,
+        mine = self._rank_state()
+        per_rank = [mine]
+        if self.world > 1:
+            import torch.distributed as dist
+            per_rank = [None] * self.world if self.rank == 0 else None
+            dist.gather_object(mine, per_rank, dst=0, group=self.group)
+        if self.rank != 0 or self.model_idx is None:
+            return None
+        state = {"iter": self.iter, "epoch": self.epoch, "world": self.world,
                  "optimizers": {n: getattr(self, n).state_dict() for n in self._OPTIMIZERS if hasattr(self, n)},
-                 "rng": {"python": _random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
-                         "cuda": torch.cuda.get_rng_state(self.device)}}
+                 "rng": mine["rng"], "ranks": per_rank}
         path = pjoin(self.expr_root, self.model_idx, "ckpt", f"{prefix}_state.ckpt")
         torch.save(state, path)
         return path
 
     def resume(self, model_idx, which_ckpt="last", restore_rng=True):
-        """Continue a run: weights (``load_model``), optimizer states, ``iter`` / ``epoch`` and RNG streams.  Call before the
-        first training step (captured graphs bind gradient buffers at capture time)."""
+        """Continue a run: weights (``load_model``), optimizer states, ``iter`` / ``epoch``, and THIS rank's RNG streams and
+        loader position.  Call before the first training step (captured graphs bind gradient buffers at capture time).  When the
+        world size differs from the saved one the per-rank streams cannot be mapped: the rank reseeds with
+        ``seed + rank`` mixed with ``iter`` (distinct per rank, reproducible) and the loaders start a fresh order."""
         import random as _random
         self.load_model(model_idx, which_ckpt)
         self.net.to(self.device)
@@ -147,11 +171,28 @@ class BaseTrainer(abc.ABC):
         for n, sd in state["optimizers"].items():
             getattr(self, n).load_state_dict(sd)
         self.iter, self.epoch = int(state["iter"]), int(state["epoch"])
+        ranks = state.get("ranks") or [{"rank": 0, "rng": state["rng"], "loaders": []}]
+        same_world = int(state.get("world", 1)) == self.world and len(ranks) == self.world
         if restore_rng:
-            _random.setstate(state["rng"]["python"]); np.random.set_state(state["rng"]["numpy"])
-            torch.set_rng_state(state["rng"]["torch"]); torch.cuda.set_rng_state(state["rng"]["cuda"], self.device)
+            if same_world:
+                rng = ranks[self.rank]["rng"]
+                _random.setstate(rng["python"]); np.random.set_state(rng["numpy"])
+                torch.set_rng_state(rng["torch"]); torch.cuda.set_rng_state(rng["cuda"], self.device)
+            else:
+                seed_all(cfg.seed + 1000003 * (self.iter + 1))            # (seed_all adds the rank)
+        self._resume_loader_states = ranks[self.rank]["loaders"] if same_world else None
         self.model_idx = self.model_idx or model_idx
-        self.info(f"[*] Resumed from {path}: iter {self.iter}, epoch {self.epoch}.")
+        self.info(f"[*] Resumed from {path}: iter {self.iter}, epoch {self.epoch}, rank {self.rank}/{self.world}"
+                  f"{'' if same_world else ' (world size changed: reseeded, fresh data order)'}.")
+
+    def adopt_train_loaders(self, lb, ul):
+        """Register the loaders whose position belongs to the train state; after ``resume()`` they continue the saved order."""
+        self._train_loaders = (lb, ul)
+        if self._resume_loader_states:
+            for ld, st in zip(self._train_loaders, self._resume_loader_states):
+                if st is not None and hasattr(ld, "load_state_dict"):
+                    ld.load_state_dict(st)
+            self._resume_loader_states = None
 
     # ------------------------------------------------------------------ loaders
     def get_loaders(self, loader_type):
@@ -175,6 +216,7 @@ class BaseTrainer(abc.ABC):
     # ------------------------------------------------------------------ epoch loop (baseTrainer.py:125-201)
     def fit(self, loader_type="synthetic", max_epoch=None):
         lb, ul, test = self.get_loaders(loader_type)
+        self.adopt_train_loaders(lb, ul)
         keys_min = [f"loss_{i}" for i in range(cfg.n_modal)] + ["loss"]
         keys_max = [f"dice_{i}" for i in range(cfg.n_modal)] + ["dice"]
         train_meter = Meter(keys_min, [], alpha=cfg.exp_alpha)
@@ -194,10 +236,21 @@ class BaseTrainer(abc.ABC):
             test_meter.accumulate(dices, {k: 1.0 for k in dices})
             test_meter.update_cur()
             self.info("[TST] Epoch: %d/%d, elapsed: %.2fs,%s" % (epoch, cfg.max_epoch, time.time() - tic, test_meter))
-            if self.model_idx is not None and test_meter.cur_values["dice"] >= test_meter.best_values["dice"]:
+            # save_model is collective under DP (per-rank train state): rank 0 decides, every rank follows
+            best = self._agree(self.model_idx is not None and test_meter.cur_values["dice"] >= test_meter.best_values["dice"])
+            if best:
                 self.save_model(prefix="best")
-        if self.model_idx is not None:
+        if self._agree(self.model_idx is not None):
             self.save_model(prefix="last")
+
+    def _agree(self, flag):
+        """Rank 0's decision, on every rank (validation data / run directories exist per rank or on rank 0 only)."""
+        if self.world <= 1:
+            return bool(flag)
+        import torch.distributed as dist
+        box = [bool(flag)]
+        dist.broadcast_object_list(box, src=0, group=self.group)
+        return box[0]
 
     @staticmethod
     def _collect_labels(loader):

@@ -42,15 +42,13 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._d_async = os.environ.get("SMSUT_D_ASYNC_ALLREDUCE", "0") not in ("0", "")
         self._g1 = self._g2 = None
         self._side = None
-        # D-step (graph, gradient all-reduce, Adam) on a side stream under the cycle pass: default on one GPU and under RCCL.  At one
-        # rank over RCCL (SMSUT_FORCE_DIST=1) the data-parallel extras -- pack, all-reduce, unpack, and the host time of enqueueing
-        # them -- cost 0.6 ms per iteration with the side stream and 1.45 ms without (27.56 vs 28.5 ms against 26.9 / 27.06).
-        # Off under gloo: two gloo ranks SHARING one card degenerated to seconds per iteration with it (profiles/r02_notes.md).
-        nccl = False
-        if self.world > 1:
-            import torch.distributed as dist
-            nccl = dist.is_initialized() and dist.get_backend() == "nccl"
-        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if (self.world == 1 or nccl) else "0") not in ("0", "")
+        # D-step (graph, gradient all-reduce, Adam) on a side stream under the cycle pass: default ON at one GPU (measured -0.3 %),
+        # OFF under data parallelism (world > 1, any backend) -- there everything runs on ONE stream, which is the configuration
+        # the 2-rank tests cover (gloo on one card here; nccl when >= 2 devices are visible).  The side-stream variant under RCCL
+        # has only ever run at one rank (SMSUT_FORCE_DIST=1: DP extras 0.6 ms with it, 1.45 ms without) and, with two gloo ranks
+        # sharing a card, degenerated to seconds per iteration (profiles/r02_notes.md): it stays reachable for an A/B on real
+        # multi-GPU hardware through SMSUT_D_OVERLAP=1 / ``bench.py --d-overlap 1`` but is not the default until such a run exists.
+        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "0") not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
@@ -189,11 +187,14 @@ class UGANConsisTrainer(UGANShp0Trainer):
             torch._foreach_add_(main, extra)
         return torch.stack([t.detach().float() for t in (g_fake, g_rec, g_cls, g_seg, g_semi, g_nce)])
 
-    def _run_phase(self, name, fn, inputs, params, collective_free=False):
+    def _run_phase(self, name, fn, inputs, params, rebind=()):
         """Eager call, or capture-once / replay as a hipGraph (graphs.GraphedPhase) when enabled.  The very first
-        iteration always runs eagerly (it is the warm-up the capture needs)."""
-        use_graph = graphs.graphs_enabled(self.world, collective_free) and self._eager_done
+        iteration always runs eagerly (it is the warm-up the capture needs).  ``rebind``: parameters whose ``.grad`` this
+        phase's backward fills although another phase clears them (the generator aliases in G2)."""
+        use_graph = graphs.graphs_enabled() and self._eager_done
         if not use_graph:
+            if self._graphs:
+                graphs.invalidate_grad_bindings()          # an eager step re-points .grad: captured phases rebind on replay
             for p in params:
                 p.grad = None
             return fn(*inputs)
@@ -203,7 +204,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
             # A refused capture raises (r01 swallowed it and ran eagerly forever: after a partial capture p.grad points
             # into an aborted pool and G1's autograd graph may already be consumed -- there is nothing safe to fall back
             # to, and a silent eager run is a performance cliff nobody sees).  SMSUT_GRAPH=0 is the explicit eager mode.
-            g = self._graphs[key] = graphs.GraphedPhase(fn, inputs, params, warmup=0)
+            g = self._graphs[key] = graphs.GraphedPhase(fn, inputs, params, warmup=0, rebind_params=rebind)
             return g.static_out                                          # the capture pass does not execute: replay it
         return g(*inputs)
 
@@ -287,7 +288,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # ------------------------------------------------------------ G-step (:150-180), the part that needs the updated D
         for p in d_params:                                    # D frozen: its unused gradients are neither computed nor reduced
             p.requires_grad_(False)
-        g_scal = self._run_phase("G2", self._g2_phase, (y_real, modal_trg, st_seg, st_semi, lam_t), g_params)
+        g_scal = self._run_phase("G2", self._g2_phase, (y_real, modal_trg, st_seg, st_semi, lam_t), g_params,
+                                 rebind=list(self._alias.values()))
         for p in d_params:
             p.requires_grad_(True)
         if self._probe:

@@ -42,14 +42,13 @@ class UGANShp0Trainer(BaseTrainer):
         self.info(f"[*] Load G and D from {root}.")
 
     def save_model(self, prefix):
-        if self.rank != 0:
-            return
-        root = pjoin(self.expr_root, self.model_idx, "ckpt")
-        # .contiguous(): checkpoints hold plain OIHW tensors, loadable by the reference's nn.Modules
-        torch.save({k: v.contiguous() for k, v in self.net.state_dict().items()}, pjoin(root, f"{prefix}_G.ckpt"))
-        torch.save({k: v.contiguous() for k, v in self.D.state_dict().items()}, pjoin(root, f"{prefix}_D.ckpt"))
-        self.save_train_state(prefix)
-        self.info(f"[*] Save G and D to {root}.")
+        if self.rank == 0:
+            root = pjoin(self.expr_root, self.model_idx, "ckpt")
+            # .contiguous(): checkpoints hold plain OIHW tensors, loadable by the reference's nn.Modules
+            torch.save({k: v.contiguous() for k, v in self.net.state_dict().items()}, pjoin(root, f"{prefix}_G.ckpt"))
+            torch.save({k: v.contiguous() for k, v in self.D.state_dict().items()}, pjoin(root, f"{prefix}_D.ckpt"))
+            self.info(f"[*] Save G and D to {root}.")
+        self.save_train_state(prefix)                       # collective under DP: every rank's RNG / loader state
 
     def label2onehot(self, modals, dim=cfg.n_modal):
         out = torch.zeros(modals.size(0), dim)

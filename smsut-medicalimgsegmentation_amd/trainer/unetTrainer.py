@@ -46,7 +46,7 @@ class UnetTrainer(BaseTrainer):
     def train_step(self, img, msk):
         """One iteration of unetTrainer.py:66-83 (forward, DiceCE, zero_grad, backward, step, poly LR).
         Returns the loss as a 0-dim device tensor (no host sync)."""
-        if graphs.graphs_enabled(self.world):
+        if graphs.graphs_enabled():
             key = tuple(img.shape)
             if self._graph is None or self._graph[0] != key:
                 # a refused capture raises (no silent eager fallback; SMSUT_GRAPH=0 is the explicit eager mode)
@@ -65,6 +65,8 @@ class UnetTrainer(BaseTrainer):
                 self.loss.reduce_stats([stats])
                 loss = self._graph[2](msk, stats)
         else:
+            if self._graph is not None:
+                graphs.invalidate_grad_bindings()
             self.optimizer.zero_grad(set_to_none=True)
             stats = self._fwd_phase(img, msk)
             self.loss.reduce_stats([stats])

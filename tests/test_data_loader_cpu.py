@@ -118,3 +118,33 @@ def test_train_sampler_shards_disjointly_across_ranks():
     random.seed(7); a = list(InTurnTrainBatchSampler(samples, bs, shuffle=True))
     random.seed(7); b = list(InTurnTrainBatchSampler(samples, bs, shuffle=True, rank=0, world=1))
     assert a == b
+
+
+def test_sampler_state_round_trip_continues_the_data_order():
+    """The train sampler's position is part of the resumable train state: a fresh sampler loaded with the state
+    saved after k batches yields the same batches as the uninterrupted one -- with the private generator (world > 1) and with
+    Python's global ``random`` (world == 1, whose state the trainer saves itself)."""
+    import random
+    from smsut_amd.data_loader.inTurnLoader import InTurnTrainBatchSampler
+    from smsut_amd.misc.synthetic import SyntheticSliceLoader
+    ids = [list(range(0, 23)), list(range(100, 131)), list(range(200, 219))]
+    for world in (1, 2):
+        for shuffle in (False, True):
+            random.seed(5)
+            a = InTurnTrainBatchSampler(ids, 2, shuffle=shuffle, rank=world - 1, world=world, seed=11)
+            first = list(a)                                  # one "epoch": wraps and reshuffles inside
+            st, gst = a.state_dict(), random.getstate()
+            want = list(a)
+            random.seed(99)                                  # a fresh process: different global stream, different initial shuffles
+            b = InTurnTrainBatchSampler(ids, 2, shuffle=shuffle, rank=world - 1, world=world, seed=12)
+            b.load_state_dict(st)
+            random.setstate(gst)
+            assert list(b) == want and want != first
+    la = SyntheticSliceLoader(2, size=32, device="cpu", n_batches=3)
+    for _ in la:
+        pass
+    st = la.state_dict()
+    lb = SyntheticSliceLoader(2, size=32, device="cpu", n_batches=3)
+    lb.load_state_dict(st)
+    (xa, ya, ma, na), (xb, yb, mb, nb) = la._batch(), lb._batch()
+    assert torch.equal(xa, xb) and torch.equal(ya, yb) and torch.equal(ma, mb) and na == nb

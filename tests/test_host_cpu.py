@@ -111,3 +111,36 @@ def test_schedules():
     assert abs(BaseTrainer.sigmoid_rampup(100, 200) - O.sigmoid_rampup(100, 200)) < 1e-12
     assert BaseTrainer.sigmoid_rampup(5, 0) == 1.0 and abs(BaseTrainer.sigmoid_rampup(300, 200) - 1.0) < 1e-12
     assert abs(O.poly_lr(1e-2, 15000, 30000) - 1e-2 * 0.5 ** 0.9) < 1e-15
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """``python bench.py --gpus N`` without a torchrun environment starts its own ranks; with fewer than N
+    devices visible it must say so and exit non-zero -- before any child process or GPU call."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SMSUT_FORCE_DEVICE")}
+    n = torch.cuda.device_count() + 2
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    assert f"needs >= {n} visible devices" in r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["error"].startswith("bench.py --gpus")
+
+
+def test_collectives_refuse_to_run_inside_a_capture():
+    """A collective inside a captured phase would be baked into (or dropped from) a hipGraph: every collective call site of
+    the package checks ``graphs.assert_no_capture``."""
+    import pytest
+    from smsut_amd import graphs
+    graphs.assert_no_capture("outside a capture")              # no-op
+    graphs._CAPTURING += 1
+    try:
+        with pytest.raises(RuntimeError, match="inside a hipGraph capture"):
+            graphs.assert_no_capture("all_reduce")
+        with pytest.raises(RuntimeError, match="inside a hipGraph capture"):
+            ops.all_reduce_dice_stats([(torch.zeros(3), torch.zeros(1))], None)
+    finally:
+        graphs._CAPTURING -= 1

@@ -29,10 +29,16 @@ def _l2rel(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", SMSUT_DIST_BACKEND="gloo", SMSUT_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if backend == "gloo":                         # both ranks on card 0, collectives over gloo (what a one-GPU box allows)
+        os.environ.update(LOCAL_RANK="0", SMSUT_DIST_BACKEND="gloo", SMSUT_FORCE_DEVICE="0")
+    else:                                         # the real thing: one rank per device over RCCL
+        os.environ.update(LOCAL_RANK=str(rank))
+        os.environ.pop("SMSUT_DIST_BACKEND", None)
+        os.environ.pop("SMSUT_FORCE_DEVICE", None)
     torch.set_num_threads(4)
     import smsut_amd  # noqa: F401
     from smsut_amd import config as cfg, parallel
@@ -40,7 +46,10 @@ def _worker(rank, world, port, q):
     from smsut_amd.network.unet import UNet
     from oracle import recipe, smsut_oracle as O
     r, w, local, group = parallel.init_from_env()
-    dev = torch.device("cuda", 0)
+    import torch.distributed as dist
+    assert dist.get_backend() == backend and w == world
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
     res = {}
     # ---- 1. module level: DiceCE with global statistics + averaged gradients == global batch
     shapes = recipe.unet_shapes(1, 3, 8)
@@ -105,17 +114,81 @@ def _worker(rank, world, port, q):
         ugan.append((dict(zip(SCALARS, got.tolist())), logs, max(ggrad.values())))
     res["ugan"] = ugan
     res["ugan_graph"] = ut.graph_report()
+    res["ugan_overlap_default"] = ut._d_overlap
+
+    # ---- 4. (RCCL only) the D-step on the side stream == the one-stream default, with both optimizers stepping
+    if backend == "nccl":
+        runs = []
+        for ov in ("0", "1"):
+            os.environ["SMSUT_D_OVERLAP"] = ov
+            t2 = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+            assert t2._d_overlap == (ov == "1")
+            t2.net.load_state_dict(g_w); t2.D.load_state_dict(d_w); t2.net.train(); t2.D.train()
+            t2.epoch, t2.iter = 100, 15000
+            sc = []
+            for it in range(5):                           # eager, capture, three replays; all-reduces + Adam / SGD in between
+                x4, y2, _, mj, alpha, ids = recipe.trace_inputs(it, b=4, size=64, base=900)
+                modal = torch.tensor([1, 1, 3, 3])
+                sel = [rank, 2 + rank]
+                sc.append(t2.train_iteration(x4[sel].to(dev), y2[rank:rank + 1].to(dev), modal[sel], mj=mj,
+                                             alpha=alpha[sel].to(dev), sample_ids=[ids.to(dev)]).tolist())
+            torch.cuda.synchronize()
+            runs.append((sc, [p.detach().cpu().clone() for p in t2.net.parameters()],
+                         [p.detach().cpu().clone() for p in t2.D.parameters()]))
+        os.environ.pop("SMSUT_D_OVERLAP", None)
+        (s_a, g_a, d_a), (s_b, g_b, d_b) = runs
+        res["overlap_scalars_equal"] = s_a == s_b
+        res["overlap_weights_equal"] = all(torch.equal(a, b) for a, b in zip(g_a + d_a, g_b + d_b))
+        # every rank must hold the same weights after 5 all-reduced steps
+        flat = torch.cat([p.reshape(-1) for p in g_a + d_a]).to(dev)
+        other = flat.clone()
+        dist.broadcast(other, src=0)
+        res["ranks_in_sync"] = bool(torch.equal(flat, other))
+    # ---- 5. resume under DP: every rank gets ITS OWN RNG streams and loader position back (rank 0's were
+    #         restored on every rank, and the data order restarted)
+    import random as _random
+    import tempfile
+    from smsut_amd.misc.synthetic import SyntheticSliceLoader
+    from smsut_amd.trainer.baseTrainer import seed_all
+    box = [tempfile.mkdtemp(prefix="smsut_resume_") if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    old_root, cfg.expr_root = cfg.expr_root, box[0]
+    cfg.n_label, cfg.base_width, cfg.batch_size = 2, 8, 2
+    seed_all()
+    a = UnetTrainer("train", types.SimpleNamespace(fold=0, expr_name="dp", write_env=True))
+
+    def loaders():
+        return (SyntheticSliceLoader(2, size=64, device=dev, labeled=True, rank=rank, n_batches=50),
+                SyntheticSliceLoader(2, size=64, device=dev, labeled=False, rank=rank, n_batches=50))
+
+    def draws(tr):
+        lb, ul = tr._train_loaders
+        return (_random.random(), float(np.random.rand()), float(torch.rand(1)), float(torch.rand(1, device=dev)),
+                float(lb._batch()[0].double().sum()), float(ul._batch()[0].double().sum()))
+    a.adopt_train_loaders(*loaders())
+    for _ in range(3 + rank):                                  # ranks sit at different positions of their streams
+        draws(a)
+    a.iter, a.epoch = 7, 1
+    a.save_model("last")                                       # collective: gathers every rank's state to rank 0
+    want = draws(a)
+    idx = [a.model_idx]
+    dist.broadcast_object_list(idx, src=0)
+    dist.barrier()
+    b = UnetTrainer("train", types.SimpleNamespace(fold=0, expr_name="dp", write_env=False))
+    b.resume(idx[0], "last")
+    b.adopt_train_loaders(*loaders())
+    res["resume"] = (want, draws(b), (b.iter, b.epoch))
+    cfg.expr_root = old_root
     q.put((rank, res))
-    import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_on_device():
+def _two_ranks(backend):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     out = dict(q.get(timeout=600) for _ in range(2))
@@ -139,6 +212,46 @@ def test_two_rank_gloo_on_device():
                 assert abs(got[k] - logs[k]) < 1e-3 * abs(logs[k]), (k, got[k], logs[k])
             assert gerr < 2e-2, gerr
         assert res["ugan_graph"]["mode"].startswith("graph"), res["ugan_graph"]
+        assert res["ugan_overlap_default"] is False             # one stream under data parallelism
+        want, got, pos = res["resume"]
+        assert want == got and pos == (7, 1), (rank, want, got, pos)
+    assert out[0]["resume"][0] != out[1]["resume"][0]           # ... and the ranks' streams are different ones
+    return out
+
+
+def test_two_rank_gloo_on_device():
+    _two_ranks("gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible devices (one rank per device over RCCL)")
+def test_two_rank_nccl_one_rank_per_device():
+    """The same checks with ``backend='nccl'`` (RCCL over xGMI), rank r on device r, plus: the side-stream D-step
+    (SMSUT_D_OVERLAP=1) must reproduce the one-stream default bit for bit over 5 stepping iterations, and both ranks must
+    end with identical weights.  Skipped on the pool's one-GPU boxes; runs wherever two devices are visible."""
+    out = _two_ranks("nccl")
+    for rank in (0, 1):
+        assert out[rank]["overlap_scalars_equal"] and out[rank]["overlap_weights_equal"]
+        assert out[rank]["ranks_in_sync"]
+
+
+def test_bench_self_launch_two_ranks_on_one_card():
+    """``python bench.py --gpus 2`` with no torchrun environment starts its own two rank processes (rehearsed over gloo on
+    one card: SMSUT_FORCE_DEVICE=0) and relays rank 0's JSON line; without the rehearsal knob it refuses with rc != 0 and
+    says how many devices it needs."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+           "--no-roofline", "--no-unet-step", "--per-gpu-batch", "4"]
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "needs >= 2 visible devices" in r.stderr, (r.returncode, r.stderr[-400:])
+    env.update(SMSUT_FORCE_DEVICE="0", SMSUT_DIST_BACKEND="gloo")
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert all(v == v for v in line["last_step_scalars"])
 
 
 def _rccl_worker(q, force):

@@ -201,6 +201,55 @@ def test_full_size_iteration_scalars_vs_oracle(small_cfg):
     assert np.allclose(got, ref, rtol=1e-3, atol=1e-5), rep                  # all ten, D_gp included
 
 
+def test_config4_per_gpu_shape_scalars_vs_oracle(small_cfg):
+    """BASELINE config 4's per-GPU workload: 16 labeled + 16 unlabeled 256x256 slices, ``PatchNCELoss(16)``
+    (reference uganShp0Trainer.py:59 with cfg.batch_size = 16; uganConsisTrainer.py:110-180), optimizers at lr 0.  An eager
+    iteration on one batch and a hipGraph REPLAY on another, all ten scalars at 1e-3 against the CPU oracle -- the shape every
+    rank of the 8-GPU data-parallel run executes (tile / grid heuristics differ from the 8 + 8 shape of config 3)."""
+    from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer, SCALARS
+    from oracle import smsut_oracle as O
+    cfg = small_cfg
+    cfg.input_size, cfg.batch_size = 256, 16
+    tr = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+    assert tr.criterionNCE[0].batch_size == 16
+    g_w = recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 191)
+    d_w = recipe.fill(recipe.disc_shapes(256, 4, 16, 256), 192)
+    tr.net.load_state_dict(g_w); tr.D.load_state_dict(d_w)
+    tr.net.train(); tr.D.train()
+    tr.epoch, tr.iter = 100, 15000
+    for grp in list(tr.d_optimizer.param_groups) + list(tr.optimizer.param_groups):
+        grp["lr"] = 0.0
+    tr.poly_lr = lambda: 0.0
+    B = 32
+
+    def inputs(seed):
+        x = recipe.synth_images((B, 1, 256, 256), seed)
+        y = recipe.synth_labels(16, 256, 256, 5, seed + 1)
+        modal = torch.tensor([seed % 4] * 16 + [(seed + 2) % 4] * 16)
+        alpha = torch.from_numpy(np.random.RandomState(seed + 2).standard_normal((B, 1, 1, 1))).float()
+        ids = torch.from_numpy(np.random.RandomState(seed + 3).permutation(256)[:64].astype(np.int64))
+        return x, y, modal, alpha, ids
+
+    def hip(inp, mj):
+        x, y, modal, alpha, ids = inp
+        return np.array(tr.train_iteration(x.cuda(), y.cuda(), modal, mj=mj, alpha=alpha.cuda(), sample_ids=[ids.cuda()]).tolist())
+
+    a, b = inputs(193), inputs(293)
+    got_a = hip(a, 3)                      # eager
+    hip(a, 3)                              # capture
+    got_b = hip(b, 1)                      # replay on fresh inputs
+    assert tr.graph_report()["mode"] == "graph"
+    torch.set_num_threads(16)
+    for got, (x, y, modal, alpha, ids), mj in ((got_a, a, 3), (got_b, b, 1)):
+        gsd = {k: v.clone().requires_grad_(True) for k, v in g_w.items()}
+        dsd = {k: v.clone().requires_grad_(True) for k, v in d_w.items()}
+        logs, _ = O.ugan_consis_iteration(gsd, dsd, torch.optim.SGD(list(gsd.values()), lr=0.0),
+                                          torch.optim.Adam(list(dsd.values()), 0.0), x, y, modal, mj, alpha, [ids],
+                                          it=15000, epoch=100, nce_batch=16, base_lr=0.0)
+        ref = np.array([logs[k] for k in SCALARS])
+        assert np.allclose(got, ref, rtol=1e-3, atol=1e-5), dict(zip(SCALARS, zip(got, ref)))
+
+
 def test_config1_unet_two_class_train_steps_vs_oracle(small_cfg):
     """BASELINE config 1 on the GPU path: ``UNet(1, 2, 16, 'instance', 'lrelu')`` (unetTrainer.py:42 with n_label = 1), 4 slices of
     1x256x256, SGD(0.9, wd 1e-3) + poly LR -- four train steps (warm-up + capture, then hipGraph replays) against the CPU
