@@ -31,6 +31,8 @@ import torch.distributed as dist  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32 dense peak
 FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+EXECUTED_GFLOP_PER_SLICE_UGAN = 1475.4 / 16     # conv FLOPs one uganConsis iteration of THIS build executes (census, 8 + 8 slices)
+REFERENCE_GFLOP_PER_SLICE_UGAN = 1710.0 / 16    # the reference's iteration: G(x_real) twice
 PMC_FILE = "r02_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
 
 
@@ -115,6 +117,8 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": None if per_slice is None else round(per_slice * batch),
             "traffic_unit": f"HBM bytes per launch (PMC, profiles/{PMC_FILE})",
+            "traffic_source": "PROFILED, not live: FETCH_SIZE x2 + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes "
+                              "(counters cannot be read in-process), per slice, scaled to this run's batch",
             "kernel": "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL> via smsut_conv2d_fwd_mfma_stats_cat", "kernel_kind": "mfma",
             "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
@@ -182,6 +186,52 @@ def time_unet_step(dev, rank, B=32, warmup=10, steps=30):
         return out
     finally:
         cfg.batch_size = old_bs
+
+
+def time_config5(dev, rank, B=16, warmup=10, steps=30, size=512):
+    """BASELINE config 5 on one GPU, in the same run (a driver-visible number): the uganConsis iteration at
+    512x512 with the fp16-operand MFMA conv path (fp32 tensors in HBM, fp32 accumulators / InstanceNorm statistics / losses /
+    optimizers), 8 + 8 slices, consistency branch on -- with its own roofline entry: at fp16 operands the
+    3x3 convs are HBM-bound (36 FLOP/B against a ridge of ~310), so the bound is HBM GB/s."""
+    import types as _t
+    from smsut_amd import config as cfg, ops
+    from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer
+    from smsut_amd.misc.synthetic import SyntheticSliceLoader
+    old = (cfg.input_size, cfg.batch_size, ops.conv_dtype())
+    cfg.input_size, cfg.batch_size = size, B // 2
+    ops.set_conv_dtype("f16")
+    try:
+        tr = UGANConsisTrainer("train", _t.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+        tr.net.train(); tr.D.train()
+        tr.iter, tr.epoch = 1000, 100
+        lb = iter(SyntheticSliceLoader(B // 2, size=size, device=dev, labeled=True, rank=rank))
+        ul = iter(SyntheticSliceLoader(B // 2, size=size, device=dev, labeled=False, rank=rank))
+        batches = []
+        for _ in range(warmup + steps):
+            (x1, y1, m1, _), (x2, _, m2, _) = next(lb), next(ul)
+            batches.append((torch.cat([x1, x2], 0), y1, torch.cat([m1, m2], 0)))
+        it = iter(batches)
+        for _ in range(warmup):
+            tr.train_iteration(*next(it))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(steps):
+            last = tr.train_iteration(*next(it))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        scal = [round(float(v), 5) for v in last.tolist()]
+        out = {"config": f"uganConsisTrainer iteration, {B // 2} + {B // 2} slices 1x{size}x{size}, fp16-operand MFMA conv path, fp32 "
+                         f"accumulators / IN / losses (BASELINE config 5, one GPU)", "dtype": "f16 conv operands, f32 accumulate / IN / losses",
+               "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "slices_per_s": round(B / dt, 1),
+               "last_step_scalars": scal, "finite": all(v == v and abs(v) != float("inf") for v in scal),
+               "graph": tr.graph_report(), "roofline": measure_dominant_conv(dev, B, size, True)}
+        del tr, batches
+        return out
+    finally:
+        cfg.input_size, cfg.batch_size = old[0], old[1]
+        ops.set_conv_dtype(old[2])
+        torch.cuda.empty_cache()
 
 
 def cpu_baseline_ugan(sample_b=16, timed=3):
@@ -294,6 +344,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-unet-step", action="store_true", help="skip the BASELINE config-2 (U-Net step) leg")
+    ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config-5 leg (512x512, fp16 operands)")
     ap.add_argument("--no-step-profile", action="store_true", help="skip the per-shape replay profile (roofline.step_conv_frac)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel leg (the command the rocprofv3 stats / PMC passes profile)")
@@ -418,16 +469,25 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         sys.exit(3)
-    # whole-step arithmetic rate (all ops of the step, memory-bound ones included) against the fp32 MFMA peak: algorithmic conv
-    # FLOPs per slice, fwd + dgrad + wgrad counted once each (U-Net(1,5,16)@256^2 19.61 GFLOP,
-    # uganConsis iteration 1.71 TFLOP per 16 slices as the REFERENCE executes it -- G(x_real) twice)
-    gflop_slice = (19.61 if args.workload == "unet" else 1710.0 / 16) * (args.size / 256.0) ** 2
+    # whole-step arithmetic rate (all ops of the step, memory-bound ones included) against the fp32 MFMA peak, from the conv
+    # FLOPs this build EXECUTES (fwd + dgrad + wgrad counted once each per conv): U-Net(1,5,16)@256^2 19.61 GFLOP
+    # per slice; uganConsis iteration 92.21 GFLOP per slice = 1475.4 GFLOP per 16 slices (per-shape census of one step,
+    # ``roofline.step_conv.conv_gflop``, replaces this constant below when the step profile runs).  The REFERENCE's iteration
+    # does more arithmetic for the same result -- it runs G(x_real) twice with identical weights (uganConsisTrainer.py:133,152;
+    # 1710 GFLOP per 16 slices) -- that is reported as a separate, labelled rate, not as this build's FLOPs.
+    scale = (args.size / 256.0) ** 2
+    gflop_slice = (19.61 if args.workload == "unet" else EXECUTED_GFLOP_PER_SLICE_UGAN) * scale
     tf = value / world * gflop_slice / 1e3
-    out["whole_step"] = {"algorithmic_gflop_per_slice": gflop_slice, "achieved_tflops_per_gpu": round(tf, 2),
-                         "frac_of_fp32_mfma_peak": round(tf / 157.3, 4), "peak_tflops": 157.3}
+    out["whole_step"] = {"executed_gflop_per_slice": round(gflop_slice, 3), "achieved_tflops_per_gpu": round(tf, 2),
+                         "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
+                         "flops_source": "constant (census of r02)"}
     if args.workload != "unet":
-        out["whole_step"]["note"] = ("FLOPs of the reference iteration (3 generator forwards); this build computes G(x_real) "
-                                     "once, i.e. executes ~12 % fewer")
+        ref_tf = value / world * REFERENCE_GFLOP_PER_SLICE_UGAN * scale / 1e3
+        out["whole_step"]["reference_equivalent"] = {
+            "gflop_per_slice": round(REFERENCE_GFLOP_PER_SLICE_UGAN * scale, 3), "tflops_per_gpu": round(ref_tf, 2),
+            "frac_of_fp32_mfma_peak": round(ref_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+            "note": "rate at which the REFERENCE's arithmetic (3 generator forwards per iteration) would have to run to match this "
+                    "throughput; this build computes G(x_real) once (a speed-up, not executed FLOPs)"}
     if args.dtype == "f16":
         out["whole_step"]["note_f16"] = ("fp16-operand convolutions are HBM-bound (the fp16 dense MFMA peak is 16x the fp32 one): "
                                          "the fp32-MFMA fraction above is a common yardstick with the f32 run, not this path's roofline")
@@ -437,8 +497,16 @@ def main():
             prof = measure_step_conv(step_again, args.workload)
             out["roofline"]["step_conv_frac"] = prof["step_conv_frac"]
             out["roofline"]["step_conv"] = prof
+            # executed FLOPs from this run's own census of the step
+            gfs = prof["conv_gflop"] / B
+            tf = value * gfs / 1e3
+            out["whole_step"].update(executed_gflop_per_slice=round(gfs, 3), achieved_tflops_per_gpu=round(tf, 2),
+                                     frac_of_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                     flops_source="per-shape census of one step in this run (roofline.step_conv.conv_gflop)")
     if world == 1 and args.workload == "ugan" and not args.no_unet_step and args.dtype == "f32" and args.size == 256:
         out["unet_step"] = time_unet_step(dev, rank)
+        if not args.no_config5:
+            out["config5"] = time_config5(dev, rank)
     if world == 1 and not args.no_cpu_baseline and args.size == 256:
         out["cpu_baseline"] = cpu_baseline_ugan() if args.workload == "ugan" else cpu_baseline_unet()
     print(json.dumps(out), flush=True)

@@ -21,3 +21,13 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace $common -d $out/${tag}_pmc_write -- py
 rm -rf $out/${tag}_pmc_sq
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace $common -d $out/${tag}_pmc_sq -- python3 bench.py --roofline-only > $out/${tag}_pmc_sq.log 2>&1
 python3 profiles/summarize.py $tag
+# 4. whole-step counters per layer class (profiles/step_pmc.py: eager steps between two marker dispatches; four passes each:
+#    durations without counters, FETCH_SIZE, WRITE_SIZE, SQ) -> profiles/<tag>_step_<wl>_classes.{json,md}
+for wl in unet ugan; do
+  rm -rf $out/${tag}_step_${wl}_time $out/${tag}_step_${wl}_fetch $out/${tag}_step_${wl}_write $out/${tag}_step_${wl}_sq
+  rocprofv3 --kernel-trace $common -d $out/${tag}_step_${wl}_time -- python3 profiles/step_pmc.py $wl > $out/${tag}_step_${wl}_time.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace $common -d $out/${tag}_step_${wl}_fetch -- python3 profiles/step_pmc.py $wl > $out/${tag}_step_${wl}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace $common -d $out/${tag}_step_${wl}_write -- python3 profiles/step_pmc.py $wl > $out/${tag}_step_${wl}_write.log 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace $common -d $out/${tag}_step_${wl}_sq -- python3 profiles/step_pmc.py $wl > $out/${tag}_step_${wl}_sq.log 2>&1
+  python3 profiles/summarize_step.py $tag $wl
+done

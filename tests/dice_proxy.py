@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Stand-in for "Dice on CHAOS fold-0 within 0.5 pt of the reference" (BASELINE.json north_star).
+
+CHAOS is not available here (no network, no dataset), so the claim is checked on a synthetic STRUCTURED segmentation task
+instead: the same training schedule is run twice --
+
+  * on the HIP path: ``UnetTrainer.train_step`` (hand-written kernels, hipGraph replays, SGD 0.9 / wd 1e-3, poly LR), and
+  * through the CPU oracle: ``oracle.smsut_oracle.unet_train_step`` (the restatement of reference unetTrainer.py:56-85 that the
+    golden fixtures pin to the reference's own modules),
+
+from the same initial weights on the same batches, and both trained models are then validated the way the reference does
+(baseTrainer.py:246-252 -> misc/utils.py:180-203): argmax predictions assembled into per-patient volumes, per-organ Dice per
+volume (``medpy.metric.dc`` restated), averaged per modality and overall (``get_mo_matrix``).  Assertion: |mean Dice (HIP) - mean
+Dice (oracle)| <= 0.5 pt, and per organ <= 1.5 pt.
+
+The task: 64x64 (default) single-channel slices of "patients" -- stacks of slices through 3-D ellipsoids ("organs", one label
+each, smoothly changing cross-section from slice to slice) over a textured background, rendered with a modality-dependent
+intensity map (four "modalities": different organ contrasts and an inverted one) plus Gaussian noise, in [-1, 1] like
+baseLoader.py:89.  Hard enough that an untrained net scores ~0, easy enough to reach Dice > 0.85 in a few hundred steps.
+
+    python tests/dice_proxy.py [--steps 400] [--size 64] [--out gpurun_out/dice_proxy.json]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_ORGANS = 3                         # labels 1..3 (+ background 0)
+# per modality: background level, organ levels (the fourth "modality" is contrast-inverted, as T2 vs T1)
+CONTRAST = np.array([[-0.6, 0.1, 0.5, 0.8],
+                     [-0.5, 0.6, 0.0, 0.4],
+                     [-0.4, 0.3, 0.7, -0.1],
+                     [0.5, -0.2, -0.6, 0.1]], dtype=np.float32)
+
+
+def make_patient(rng, modality, n_slices, size):
+    """One synthetic volume: labels [Z, H, W] int64 and images [Z, 1, H, W] float32 in [-1, 1]."""
+    zz, yy, xx = np.meshgrid(np.arange(n_slices), np.arange(size), np.arange(size), indexing="ij")
+    lab = np.zeros((n_slices, size, size), dtype=np.int64)
+    for organ in range(1, N_ORGANS + 1):
+        c = np.array([rng.uniform(0.3, 0.7) * n_slices, rng.uniform(0.25, 0.75) * size, rng.uniform(0.25, 0.75) * size])
+        r = np.array([rng.uniform(0.5, 0.9) * n_slices, rng.uniform(0.10, 0.22) * size, rng.uniform(0.10, 0.22) * size])
+        th = rng.uniform(0, np.pi)
+        dy, dx = yy - c[1], xx - c[2]
+        u, v = np.cos(th) * dx + np.sin(th) * dy, -np.sin(th) * dx + np.cos(th) * dy
+        inside = ((zz - c[0]) / r[0]) ** 2 + (u / r[2]) ** 2 + (v / r[1]) ** 2 <= 1.0
+        lab[inside] = organ                                   # later organs overwrite earlier ones where they overlap
+    img = CONTRAST[modality][lab]
+    # smooth background texture + noise
+    tex = rng.standard_normal((n_slices, size // 8, size // 8)).astype(np.float32)
+    tex = np.repeat(np.repeat(tex, 8, axis=1), 8, axis=2) * 0.08
+    img = img + tex + rng.standard_normal(img.shape).astype(np.float32) * 0.15
+    return np.clip(img, -1.0, 1.0).astype(np.float32)[:, None], lab
+
+
+def make_dataset(seed, n_patients, n_slices, size):
+    rng = np.random.RandomState(seed)
+    vols = []
+    for p in range(n_patients):
+        m = p % 4
+        img, lab = make_patient(rng, m, n_slices, size)
+        vols.append((m, f"{p:03d}", img, lab))
+    return vols
+
+
+def train_batches(vols, steps, batch, seed):
+    """Single-modality batches, modalities taking turns (inTurnLoader.py:37-57), slices drawn at random within the modality."""
+    rng = np.random.RandomState(seed)
+    by_mod = {m: [(v[2][z], v[3][z]) for v in vols if v[0] == m for z in range(v[2].shape[0])] for m in range(4)}
+    out = []
+    for s in range(steps):
+        pool = by_mod[s % 4]
+        idx = rng.randint(0, len(pool), batch)
+        out.append((torch.from_numpy(np.stack([pool[i][0] for i in idx])), torch.from_numpy(np.stack([pool[i][1] for i in idx]))))
+    return out
+
+
+def run(steps=400, size=64, batch=8, n_train=16, n_val=8, n_slices=8, seed=2020, log=print):
+    import smsut_amd  # noqa: F401
+    from smsut_amd import config as cfg
+    from smsut_amd.misc.utils import get_mo_matrix
+    from smsut_amd.trainer.unetTrainer import UnetTrainer
+    from smsut_amd import ops
+    from oracle import recipe, smsut_oracle as O
+    old = (cfg.input_size, cfg.batch_size, cfg.n_label, cfg.base_width)
+    cfg.input_size, cfg.batch_size, cfg.n_label, cfg.base_width = size, batch, N_ORGANS, 16
+    try:
+        train_vols = make_dataset(seed, n_train, n_slices, size)
+        val_vols = make_dataset(seed + 1, n_val, n_slices, size)
+        batches = train_batches(train_vols, steps, batch, seed + 2)
+        ncls = N_ORGANS + 1
+        sd0 = recipe.fill(recipe.unet_shapes(1, ncls, 16), seed)
+
+        # ---- HIP path
+        tr = UnetTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+        tr.net.load_state_dict(sd0); tr.net.train()
+        t0 = time.time()
+        hip_losses = []
+        for it, (x, y) in enumerate(batches):
+            loss = tr.train_step(x.cuda(), y.cuda())
+            if it % 50 == 0 or it == steps - 1:
+                hip_losses.append((it, float(loss.item())))
+        torch.cuda.synchronize()
+        t_hip = time.time() - t0
+
+        # ---- CPU oracle, same schedule
+        torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+        osd = {k: v.clone().requires_grad_(True) for k, v in sd0.items()}
+        opt = torch.optim.SGD(list(osd.values()), lr=cfg.lr, momentum=0.9, weight_decay=cfg.weight_decay)
+        t0 = time.time()
+        ora_losses = []
+        for it, (x, y) in enumerate(batches):
+            l, _ = O.unet_train_step(osd, opt, x, y, it, base_lr=cfg.lr, max_it=cfg.max_epoch * cfg.num_iter_per_epoch)
+            if it % 50 == 0 or it == steps - 1:
+                ora_losses.append((it, l))
+                log(f"[dice_proxy] oracle step {it}: loss {l:.4f} (HIP {dict(hip_losses).get(it, float('nan')):.4f}), {time.time() - t0:.0f} s")
+        t_cpu = time.time() - t0
+
+        # ---- validation as baseTrainer.validate_epoch + get_mo_matrix: per-volume, per-organ Dice
+        gt = {f"{cfg.Modality(m).name}_{pid}": lab for m, pid, _, lab in val_vols}
+        prd_hip, prd_ora = {}, {}
+        tr.net.eval()
+        with torch.no_grad():
+            for m, pid, img, lab in val_vols:
+                key = f"{cfg.Modality(m).name}_{pid}"
+                x = torch.from_numpy(img)
+                prd_hip[key] = ops.argmax_channels(tr.net(x.cuda())).cpu().numpy()
+                prd_ora[key] = O.unet_forward({k: v.detach() for k, v in osd.items()}, x).argmax(1).numpy()
+        mo_hip, mo_ora = get_mo_matrix(prd_hip, gt), get_mo_matrix(prd_ora, gt)
+        agree = float(np.mean([np.mean(prd_hip[k] == prd_ora[k]) for k in gt]))
+        res = {"task": f"synthetic ellipsoid organs, {n_train} train / {n_val} validation volumes x {n_slices} slices of {size}x{size}, "
+                       f"{N_ORGANS} organs + background, 4 modalities", "steps": steps, "batch": batch,
+               "dice_mean_hip": float(mo_hip[-1, -1]), "dice_mean_oracle": float(mo_ora[-1, -1]),
+               "delta_mean_dice_pt": float(100.0 * (mo_hip[-1, -1] - mo_ora[-1, -1])),
+               "dice_per_organ_hip": [float(v) for v in mo_hip[-1, :N_ORGANS]],
+               "dice_per_organ_oracle": [float(v) for v in mo_ora[-1, :N_ORGANS]],
+               "dice_per_modality_hip": [float(v) for v in mo_hip[:4, -1]],
+               "dice_per_modality_oracle": [float(v) for v in mo_ora[:4, -1]],
+               "prediction_agreement": agree, "loss_trace_hip": hip_losses, "loss_trace_oracle": ora_losses,
+               "train_seconds_hip": round(t_hip, 2), "train_seconds_oracle_cpu": round(t_cpu, 2), "graph": tr.graph_report()}
+        return res
+    finally:
+        cfg.input_size, cfg.batch_size, cfg.n_label, cfg.base_width = old
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dice_proxy.json"))
+    a = ap.parse_args()
+    res = run(steps=a.steps, size=a.size)
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(res, open(a.out, "w"), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if not k.startswith("loss_trace")}, indent=1))
+    ok = abs(res["delta_mean_dice_pt"]) <= 0.5
+    print("PASS" if ok else "FAIL", f"|delta mean Dice| = {abs(res['delta_mean_dice_pt']):.3f} pt")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,25 @@
+""""Dice within 0.5 pt of the reference" on a task that exists here: tests/dice_proxy.py trains the HIP
+``UnetTrainer`` and the CPU oracle on the same synthetic structured segmentation task with the same schedule and compares the
+validation Dice matrices (reference baseTrainer.py:246-252, misc/utils.py:180-203)."""
+import json
+import os
+
+import pytest
+
+import dice_proxy
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_trained_dice_matches_oracle_within_half_a_point():
+    res = dice_proxy.run(steps=300, size=64)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(res, open(os.path.join(out, "dice_proxy_test.json"), "w"), indent=1)
+    assert res["graph"]["mode"] == "graph"
+    assert res["dice_mean_oracle"] > 0.80 and res["dice_mean_hip"] > 0.80, res          # both actually learned the task
+    assert abs(res["delta_mean_dice_pt"]) <= 0.5, res                                    # north_star: within 0.5 pt
+    for a, b in zip(res["dice_per_organ_hip"], res["dice_per_organ_oracle"]):
+        assert abs(a - b) <= 0.015, res
+    assert res["prediction_agreement"] > 0.99, res
