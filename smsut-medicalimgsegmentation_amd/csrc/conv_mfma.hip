@@ -343,8 +343,14 @@ struct BstRef { const float* y1; const float* mean; const float* rstd; const flo
 
 struct ScRef { const float* w; float* y; float* stats; };   // SC: the block's 1x1 shortcut conv, fused (see conv_mfma_fwd_p)
 
+// Pixel stride (floats) of the staged input tile of the Winograd form: 20 = 5 x 16 B.  A lane of the transform reads the
+// channel quad kq of pixel (2*tc + b, 2*tr + a) of its 4x4 window; 16-byte slots (pixel * 5 + kq) mod 16 over the 16 tiles of
+// a wave take 8 distinct values twice (every ds_read_b128 address is a multiple of 16 B and the tile origins are 2 pixels
+// apart, so 2-way is the floor for this lane-to-tile map; 24 would be 4-way).
+constexpr int SPIXW = 20;
+
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false>
+          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
@@ -370,6 +376,18 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // kq = 2, 3 those of tap 2g+1 (a lane picks its tap's halo offset and weight block) -- 5 x 4 MFMAs per 16x16 output tile
   // instead of 9 x 4.
   static_assert(!K8 || (NCH == 1 && !DUAL && !INAFF && !F16 && !BST), "8-channel reduction: plain / statistics / accumulate / fused-shortcut forms");
+  // WINO: Winograd F(2x2, 3x3) (Lavin & Gray 2016) in fp32: 16 element-wise products per 2x2 output tile instead of 36 -- 2.25x
+  // fewer MFMAs for the same convolution (the matrix pipes, not HBM, bound this kernel: profiles/r03_step_*_classes.md).  A wave's
+  // 4 x 16-pixel output strip is 16 tiles = the MFMA M dimension; lane (lm = tile, kq = channel quad) reads its tile's 4x4 input
+  // window from the staged tile, transforms it IN REGISTERS (B^T d B on four channels at once) and the 16 transformed values ARE
+  // its A operands of the 16 per-position GEMMs [tiles x Kdim] . [Kdim x 16]; the resident weight block holds U = G g G^T
+  // (computed by the workgroup itself from the 3x3 weights); after the last chunk the 16 position accumulators are folded by
+  // A^T m A (element-wise over the lane's four tiles) into the SAME accumulator layout the direct form hands to its epilogue --
+  // pixel map: acc[i][j][r] = (strip row 2*(kq>>1) + (i>>1), column 8*(kq&1) + 4*(i&1) + r) -- so every fused form (statistics,
+  // accumulate, BST, virtual cat, input-side IN, split output) is shared.  Zero padding = the zeroed halo units, as before.
+  static_assert(!WINO || (KS == 3 && TH == 16 && !F16 && !K8 && !N8 && !SC && !SC2), "Winograd form: 3x3, 16-row items, fp32");
+  constexpr int SPX = WINO ? SPIXW : SPIX;            // pixel stride of the staged fp32 input tile
+  constexpr int NPOS = WINO ? 16 : KS * KS;           // weight blocks held in LDS (Winograd positions | taps)
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
   static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
   static_assert(!DUAL || NCH % 2 == 0, "virtual cat input: two equal halves of whole 16-channel chunks");
@@ -387,9 +405,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   constexpr int NI = (UNITS + TPB - 1) / TPB;
   extern __shared__ float smem[];
   float* in_s = smem;                         // [IH][IW][SPIX] + one dummy pixel (sink for the padding units)
-  float* red = smem + (IH * IW + 1) * SPIX;   // [2][4][CO_T][2] + dummy
-  float* w_s = red + 2 * 4 * CO_T * 2 + 8;    // [KK][K4][CO_T][4]
-  [[maybe_unused]] float* wsc_s = w_s + KK * Kdim * CO_T;             // SC: [K4][CO_T][4]
+  float* red = smem + (IH * IW + 1) * SPX;    // [2][4][CO_T][2] + dummy
+  float* w_s = red + 2 * 4 * CO_T * 2 + 8;    // [KK | 16 positions][K4][CO_T][4]
+  [[maybe_unused]] float* wsc_s = w_s + NPOS * Kdim * CO_T;           // SC: [K4][CO_T][4]
   [[maybe_unused]] float* red_sc = wsc_s + Kdim * CO_T;               // SC: [2][4][CO_T][2] + dummy
   [[maybe_unused]] _Float16* in_h = reinterpret_cast<_Float16*>(smem);       // F16: [IH][IW][SPIXH] + dummy pixel
   [[maybe_unused]] _Float16* w_h = reinterpret_cast<_Float16*>(w_s);         // F16: [KK][NCH][CO_T][WROWH]
@@ -418,7 +436,34 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   STAMP(0);
 
   // ---- resident weights
-  for (int u = tid; u < KK * K4 * CO_T; u += TPB) {
+  if constexpr (WINO) {
+    // U = G g G^T per (reduction channel, output channel), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; stored like the taps of
+    // the direct form with the position in the tap's place: [pos][k4][n][4]
+    for (int u = tid; u < Kdim * CO_T; u += TPB) {
+      const int n = u % CO_T, ci = u / CO_T;
+      const int ng = co0 + n;
+      float g[3][3];
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap)
+        g[tap / 3][tap % 3] = !transposed ? w[((size_t)tap * Kdim + ci) * Ndim + ng]
+                                          : w[((size_t)(8 - tap) * Ndim + ng) * Kdim + ci];
+      float t[4][3];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float uu[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) w_s[(((size_t)(a * 4 + b) * K4 + (ci >> 2)) * CO_T + n) * 4 + (ci & 3)] = uu[b];
+      }
+    }
+  }
+  for (int u = tid; u < (WINO ? 0 : KK * K4 * CO_T); u += TPB) {
     const int n = u % CO_T;
     const int k4 = (u / CO_T) % K4;
     const int tap = u / (CO_T * K4);
@@ -460,7 +505,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     const int q = uu % UQ, pix = uu / UQ;
     const int iy = pix / IW, ix = pix % IW;
     u_off[i] = (iy * W + ix) * KST + 4 * q;
-    u_lds[i] = real ? pix * (F16 ? SPIXH : SPIX) + 4 * q : IH * IW * (F16 ? SPIXH : SPIX);
+    u_lds[i] = real ? pix * (F16 ? SPIXH : SPX) + 4 * q : IH * IW * (F16 ? SPIXH : SPX);
     u_flag[i] = (iy < PAD ? 1 : 0) | (iy >= TH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
   }
   // a unit outside the image reads the tile's first interior pixel instead (always valid) and is zeroed at publish
@@ -514,6 +559,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   };
 
   f32x4 acc[MR][NR], pacc[MR][NR];
+  [[maybe_unused]] f32x4 macc[WINO ? 16 : 1][NR];      // WINO: the 16 position accumulators (tiles 4kq..4kq+3, channel lm)
+  if constexpr (WINO) {
+#pragma unroll
+    for (int p_ = 0; p_ < 16; ++p_)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) macc[p_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   [[maybe_unused]] f32x4 acs[MR][NR], pacs[MR][NR];    // SC: the shortcut's accumulators (current / previous item)
   if constexpr (SC) {
 #pragma unroll
@@ -533,8 +585,10 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     for (int j = 0; j < NR; ++j) { ng[j] = bst.gamma[co0 + j * 16 + lm]; nb[j] = bst.beta[co0 + j * 16 + lm]; }
   }
   // per-lane output offset of (row wave*MR, col 4*kq, channel lm) inside a tile; red[] slot of this lane
-  const int o_lane = ((wave * MR) * W + 4 * kq) * os + lm;
+  const int o_lane = WINO ? ((wave * MR + 2 * (kq >> 1)) * W + 8 * (kq & 1)) * os + lm : ((wave * MR) * W + 4 * kq) * os + lm;
   const int red_slot = (wave * CO_T + lm) * 2;
+  // pixel of accumulator element (i, r) relative to o_lane, in pixels: direct form row i, column r; Winograd form see above
+  auto pxo = [&](int i, int r) { return WINO ? (i >> 1) * W + 4 * (i & 1) + r : i * W + r; };
 
   // statistics + stores of the item in pacc / (en, ety, etx); straight-line, no branches
   auto epilogue = [&](int par) {
@@ -582,7 +636,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       for (int j = 0; j < NR; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (nok) yb[o_lane + (i * W + r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
+          if (nok) yb[o_lane + pxo(i, r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
     if constexpr (SC) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -622,7 +676,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pold[i][j][r] = nok ? yb[o_lane + (i * W + r) * os + j * 16] : 0.f;
+          for (int r = 0; r < 4; ++r) pold[i][j][r] = nok ? yb[o_lane + pxo(i, r) * os + j * 16] : 0.f;
     }
   };
   auto stats_out = [&](int par) {                     // after the barrier that completes red[par]
@@ -642,6 +696,61 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     }
   };
   auto mma_chunk = [&](int c) {
+    if constexpr (WINO) {
+      // window of tile (tr, tc) = (lm >> 3, lm & 7) of this wave's strip: rows wave*4 + 2*tr + a, columns 2*tc + b
+      const float* dp = in_s + (((wave * 4 + 2 * (lm >> 3)) * IW) + 2 * (lm & 7)) * SPX + 4 * kq;
+      const float* wc = w_s + ((size_t)(c * 4 + kq) * CO_T + lm) * 4;
+      f32x4 d1[4], d2[4], dx[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        dx[b] = *(const f32x4*)(dp + (0 * IW + b) * SPX);
+        d1[b] = *(const f32x4*)(dp + (1 * IW + b) * SPX);
+        d2[b] = *(const f32x4*)(dp + (2 * IW + b) * SPX);
+      }
+#pragma unroll
+      for (int xi = 0; xi < 4; ++xi) {
+        if (xi == 3) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) dx[b] = *(const f32x4*)(dp + (3 * IW + b) * SPX);
+        }
+        f32x4 t[4];                                   // row combination xi of B^T: d0-d2 | d1+d2 | d2-d1 | d1-d3
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          t[b] = xi == 0 ? dx[b] - d2[b] : xi == 1 ? d1[b] + d2[b] : xi == 2 ? d2[b] - d1[b] : d1[b] - dx[b];
+        const f32x4 v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+          const int pos = xi * 4 + nu;
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            const f32x4 b = *(const f32x4*)(wc + ((size_t)pos * K4 * CO_T + j * 16) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) macc[pos][j] = mfma16(v[nu][s], b[s], macc[pos][j]);
+          }
+        }
+      }
+      if (c == NCH - 1) {                             // last chunk of the item: A^T m A, element-wise over the lane's four tiles
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          f32x4 c0[4], c1[4];
+#pragma unroll
+          for (int nu = 0; nu < 4; ++nu) {
+            c0[nu] = macc[0 + nu][j] + macc[4 + nu][j] + macc[8 + nu][j];
+            c1[nu] = macc[4 + nu][j] - macc[8 + nu][j] - macc[12 + nu][j];
+          }
+          const f32x4 o00 = c0[0] + c0[1] + c0[2], o01 = c0[1] - c0[2] - c0[3];
+          const f32x4 o10 = c1[0] + c1[1] + c1[2], o11 = c1[1] - c1[2] - c1[3];
+          // acc[2*dy + (r >> 1)][j][2*(r & 1) + dx] = o[dy][dx][r]
+          acc[0][j] = (f32x4){o00[0], o01[0], o00[1], o01[1]};
+          acc[1][j] = (f32x4){o00[2], o01[2], o00[3], o01[3]};
+          acc[2][j] = (f32x4){o10[0], o11[0], o10[1], o11[1]};
+          acc[3][j] = (f32x4){o10[2], o11[2], o10[3], o11[3]};
+#pragma unroll
+          for (int p_ = 0; p_ < 16; ++p_) macc[p_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      return;
+    }
     if constexpr (K8) {
       const int half = kq >> 1, kk = kq & 1;
 #pragma unroll
@@ -1585,10 +1694,10 @@ inline int device_cus() {
 }
 
 // Persistent variant: LDS bytes and eligibility (see conv_mfma_fwd_p).
-template <int KS, int TH, int NTN, int NCH>
+template <int KS, int TH, int NTN, int NCH, bool WINO = false>
 constexpr size_t fwd_p_lds() {
-  return (size_t)(((TH + KS - 1) * (TW + KS - 1) + 1) * SPIX + 2 * 4 * 16 * NTN * 2 + 8 + KS * KS * 16 * NCH * 16 * NTN) *
-         sizeof(float);
+  return (size_t)(((TH + KS - 1) * (TW + KS - 1) + 1) * (WINO ? SPIXW : SPIX) + 2 * 4 * 16 * NTN * 2 + 8 +
+                  (WINO ? 16 : KS * KS) * 16 * NCH * 16 * NTN) * sizeof(float);
 }
 
 

@@ -14,11 +14,11 @@ volume (``medpy.metric.dc`` restated), averaged per modality and overall (``get_
 Dice (oracle)| <= 0.5 pt, and per organ <= 1.5 pt.
 
 The task: 64x64 (default) single-channel slices of "patients" -- stacks of slices through 3-D ellipsoids ("organs", one label
-each, smoothly changing cross-section from slice to slice) over a textured background, rendered with a modality-dependent
+each, with its own position and shape, smoothly changing cross-section from slice to slice) over a textured background, rendered with a modality-dependent
 intensity map (four "modalities": different organ contrasts and an inverted one) plus Gaussian noise, in [-1, 1] like
-baseLoader.py:89.  Hard enough that an untrained net scores ~0, easy enough to reach Dice > 0.85 in a few hundred steps.
+baseLoader.py:89.  Hard enough that an untrained net scores ~0, easy enough to reach Dice ~0.96 in 600 steps (oracle, measured).
 
-    python tests/dice_proxy.py [--steps 400] [--size 64] [--out gpurun_out/dice_proxy.json]
+    python tests/dice_proxy.py [--steps 600] [--size 64] [--out gpurun_out/dice_proxy.json]
 """
 import argparse
 import json
@@ -42,17 +42,24 @@ CONTRAST = np.array([[-0.6, 0.1, 0.5, 0.8],
                      [0.5, -0.2, -0.6, 0.1]], dtype=np.float32)
 
 
+ANCHOR = np.array([[0.30, 0.32], [0.36, 0.70], [0.70, 0.48]])      # (row, column) centres of the three organs, fraction of the size
+RADIUS = np.array([[0.16, 0.13], [0.12, 0.15], [0.14, 0.20]])      # semi-axes (row, column): every organ has its own shape
+
+
 def make_patient(rng, modality, n_slices, size):
-    """One synthetic volume: labels [Z, H, W] int64 and images [Z, 1, H, W] float32 in [-1, 1]."""
+    """One synthetic volume: labels [Z, H, W] int64 and images [Z, 1, H, W] float32 in [-1, 1].  Every organ has its own
+    anatomical position and shape (jittered per patient), so that labels can be told apart by where and how big a structure
+    is -- as in real anatomy -- while its grey level depends on the modality."""
     zz, yy, xx = np.meshgrid(np.arange(n_slices), np.arange(size), np.arange(size), indexing="ij")
     lab = np.zeros((n_slices, size, size), dtype=np.int64)
     for organ in range(1, N_ORGANS + 1):
-        c = np.array([rng.uniform(0.3, 0.7) * n_slices, rng.uniform(0.25, 0.75) * size, rng.uniform(0.25, 0.75) * size])
-        r = np.array([rng.uniform(0.5, 0.9) * n_slices, rng.uniform(0.10, 0.22) * size, rng.uniform(0.10, 0.22) * size])
-        th = rng.uniform(0, np.pi)
+        a, r = ANCHOR[organ - 1], RADIUS[organ - 1]
+        c = np.array([rng.uniform(0.35, 0.65) * n_slices, (a[0] + rng.uniform(-0.06, 0.06)) * size, (a[1] + rng.uniform(-0.06, 0.06)) * size])
+        rad = np.array([rng.uniform(0.6, 1.0) * n_slices, r[0] * rng.uniform(0.8, 1.2) * size, r[1] * rng.uniform(0.8, 1.2) * size])
+        th = rng.uniform(-0.3, 0.3)
         dy, dx = yy - c[1], xx - c[2]
         u, v = np.cos(th) * dx + np.sin(th) * dy, -np.sin(th) * dx + np.cos(th) * dy
-        inside = ((zz - c[0]) / r[0]) ** 2 + (u / r[2]) ** 2 + (v / r[1]) ** 2 <= 1.0
+        inside = ((zz - c[0]) / rad[0]) ** 2 + (u / rad[2]) ** 2 + (v / rad[1]) ** 2 <= 1.0
         lab[inside] = organ                                   # later organs overwrite earlier ones where they overlap
     img = CONTRAST[modality][lab]
     # smooth background texture + noise
@@ -84,7 +91,7 @@ def train_batches(vols, steps, batch, seed):
     return out
 
 
-def run(steps=400, size=64, batch=8, n_train=16, n_val=8, n_slices=8, seed=2020, log=print):
+def run(steps=600, size=64, batch=8, n_train=32, n_val=8, n_slices=8, seed=2020, log=print):
     import smsut_amd  # noqa: F401
     from smsut_amd import config as cfg
     from smsut_amd.misc.utils import get_mo_matrix
@@ -154,7 +161,7 @@ def run(steps=400, size=64, batch=8, n_train=16, n_val=8, n_slices=8, seed=2020,
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "dice_proxy.json"))
     a = ap.parse_args()

@@ -13,13 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_trained_dice_matches_oracle_within_half_a_point():
-    res = dice_proxy.run(steps=300, size=64)
+    res = dice_proxy.run(steps=600, size=64)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     json.dump(res, open(os.path.join(out, "dice_proxy_test.json"), "w"), indent=1)
     assert res["graph"]["mode"] == "graph"
-    assert res["dice_mean_oracle"] > 0.80 and res["dice_mean_hip"] > 0.80, res          # both actually learned the task
+    assert res["dice_mean_oracle"] > 0.90 and res["dice_mean_hip"] > 0.90, res          # both actually learned the task
     assert abs(res["delta_mean_dice_pt"]) <= 0.5, res                                    # north_star: within 0.5 pt
     for a, b in zip(res["dice_per_organ_hip"], res["dice_per_organ_oracle"]):
         assert abs(a - b) <= 0.015, res
-    assert res["prediction_agreement"] > 0.99, res
+    assert res["prediction_agreement"] > 0.98, res
