@@ -385,7 +385,11 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // A^T m A (element-wise over the lane's four tiles) into the SAME accumulator layout the direct form hands to its epilogue --
   // pixel map: acc[i][j][r] = (strip row 2*(kq>>1) + (i>>1), column 8*(kq&1) + 4*(i&1) + r) -- so every fused form (statistics,
   // accumulate, BST, virtual cat, input-side IN, split output) is shared.  Zero padding = the zeroed halo units, as before.
-  static_assert(!WINO || (KS == 3 && TH == 16 && !F16 && !K8 && !N8 && !SC && !SC2), "Winograd form: 3x3, 16-row items, fp32");
+  // Fused shortcut forms under WINO: the 1x1 conv needs the RAW pixels, which the lane holds anyway -- the four output pixels of
+  // its tile are window elements (1,1), (1,2), (2,1), (2,2) -- so it is four more MFMA sets per chunk on those (SC, forward);
+  // in the data-gradient (SC2) the chunks of the second reduction half (the shortcut's gradient) run ONLY those four sets,
+  // against the 1x1 weights, and the result is added after the output transform.
+  static_assert(!WINO || (KS == 3 && TH == 16 && !F16 && !K8 && !N8), "Winograd form: 3x3, 16-row items, fp32");
   constexpr int SPX = WINO ? SPIXW : SPIX;            // pixel stride of the staged fp32 input tile
   constexpr int NPOS = WINO ? 16 : KS * KS;           // weight blocks held in LDS (Winograd positions | taps)
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
@@ -442,11 +446,19 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     for (int u = tid; u < Kdim * CO_T; u += TPB) {
       const int n = u % CO_T, ci = u / CO_T;
       const int ng = co0 + n;
+      if constexpr (SC2) {                             // second reduction half: the 1x1 weights, parked in position 0's slots
+        constexpr int Kh = Kdim / 2;
+        if (ci >= Kh) {
+          w_s[(((size_t)(ci >> 2)) * CO_T + n) * 4 + (ci & 3)] = sc.w[(size_t)ng * Kh + (ci - Kh)];
+          continue;
+        }
+      }
+      constexpr int KROW = SC2 ? Kdim / 2 : Kdim;      // reduction channels of the 3x3 weights proper
       float g[3][3];
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap)
-        g[tap / 3][tap % 3] = !transposed ? w[((size_t)tap * Kdim + ci) * Ndim + ng]
-                                          : w[((size_t)(8 - tap) * Ndim + ng) * Kdim + ci];
+        g[tap / 3][tap % 3] = !(transposed || SC2) ? w[((size_t)tap * Kdim + ci) * Ndim + ng]
+                                                   : w[((size_t)(8 - tap) * Ndim + ng) * KROW + ci];
       float t[4][3];
 #pragma unroll
       for (int b = 0; b < 3; ++b) {
@@ -567,6 +579,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       for (int j = 0; j < NR; ++j) macc[p_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
   [[maybe_unused]] f32x4 acs[MR][NR], pacs[MR][NR];    // SC: the shortcut's accumulators (current / previous item)
+  [[maybe_unused]] f32x4 qacc[(WINO && (SC || SC2)) ? 4 : 1][NR];   // WINO + SC / SC2: 1x1 products of the tile's four pixels
+  if constexpr (WINO && (SC || SC2)) {
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) qacc[q_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   if constexpr (SC) {
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -656,7 +675,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ys[o_lane + (i * W + r) * Ndim + j * 16] = pacs[i][j][r];
+          for (int r = 0; r < 4; ++r) ys[o_lane + pxo(i, r) * Ndim + j * 16] = pacs[i][j][r];
     }
   };
   // ACC: the values the outputs of item (n_, ty_, tx_) hold now (loaded one region before they are added and stored)
@@ -701,14 +720,41 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       const float* dp = in_s + (((wave * 4 + 2 * (lm >> 3)) * IW) + 2 * (lm & 7)) * SPX + 4 * kq;
       const float* wc = w_s + ((size_t)(c * 4 + kq) * CO_T + lm) * 4;
       f32x4 d1[4], d2[4], dx[4];
+      if constexpr (SC2) {
+        if (c >= NCH / 2) {                           // the shortcut's gradient: 1x1 products of the tile's four pixels only
+          const f32x4 px[4] = {*(const f32x4*)(dp + (1 * IW + 1) * SPX), *(const f32x4*)(dp + (1 * IW + 2) * SPX),
+                               *(const f32x4*)(dp + (2 * IW + 1) * SPX), *(const f32x4*)(dp + (2 * IW + 2) * SPX)};
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            const f32x4 bw = *(const f32x4*)(wc + (size_t)(j * 16) * 4);
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_)
+#pragma unroll
+              for (int s = 0; s < 4; ++s) qacc[q_][j] = mfma16(px[q_][s], bw[s], qacc[q_][j]);
+          }
+        }
+      }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         dx[b] = *(const f32x4*)(dp + (0 * IW + b) * SPX);
         d1[b] = *(const f32x4*)(dp + (1 * IW + b) * SPX);
         d2[b] = *(const f32x4*)(dp + (2 * IW + b) * SPX);
       }
+      if constexpr (SC) {                               // forward shortcut: same four pixels, the 1x1 weights of this chunk
 #pragma unroll
-      for (int xi = 0; xi < 4; ++xi) {
+        for (int j = 0; j < NR; ++j) {
+          const f32x4 bw = *(const f32x4*)(wsc_s + (((size_t)(c * 4 + kq) * CO_T) + j * 16 + lm) * 4);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            qacc[0][j] = mfma16(d1[1][s], bw[s], qacc[0][j]);
+            qacc[1][j] = mfma16(d1[2][s], bw[s], qacc[1][j]);
+            qacc[2][j] = mfma16(d2[1][s], bw[s], qacc[2][j]);
+            qacc[3][j] = mfma16(d2[2][s], bw[s], qacc[3][j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int xi = 0; xi < ((SC2 && c >= NCH / 2) ? 0 : 4); ++xi) {
         if (xi == 3) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) dx[b] = *(const f32x4*)(dp + (3 * IW + b) * SPX);
@@ -747,6 +793,16 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
           acc[3][j] = (f32x4){o10[2], o11[2], o10[3], o11[3]};
 #pragma unroll
           for (int p_ = 0; p_ < 16; ++p_) macc[p_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if constexpr (SC || SC2) {                   // the 1x1 products in the same pixel map (qacc[2*dy + dx][j][r])
+            const f32x4 q0 = (f32x4){qacc[0][j][0], qacc[1][j][0], qacc[0][j][1], qacc[1][j][1]};
+            const f32x4 q1 = (f32x4){qacc[0][j][2], qacc[1][j][2], qacc[0][j][3], qacc[1][j][3]};
+            const f32x4 q2 = (f32x4){qacc[2][j][0], qacc[3][j][0], qacc[2][j][1], qacc[3][j][1]};
+            const f32x4 q3 = (f32x4){qacc[2][j][2], qacc[3][j][2], qacc[2][j][3], qacc[3][j][3]};
+            if constexpr (SC) { acs[0][j] = q0; acs[1][j] = q1; acs[2][j] = q2; acs[3][j] = q3; }
+            else { acc[0][j] += q0; acc[1][j] += q1; acc[2][j] += q2; acc[3][j] += q3; }
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) qacc[q_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
         }
       }
       return;
@@ -1701,12 +1757,12 @@ constexpr size_t fwd_p_lds() {
 }
 
 
-template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false>
+template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false, bool WINO = false>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
                  float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
                  bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr) {
-  constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH>();
+  constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH, WINO>();
   // fused 1x1 shortcut (SC): its weight block and a second statistics scratch
   constexpr size_t sh_sc = sh + (size_t)(16 * NCH * 16 * NTN + 2 * 4 * 16 * NTN * 2 + 8) * sizeof(float);
   if constexpr (sh > 64 * 1024) return -1;
@@ -1716,6 +1772,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     return -1;
   if (N8 && (NTN != 1 || K8 || stats || tiles_out || bst || y2 || aff || f16 || !(transposed & 1) || (x2 && !(sc && sc->w)))) return -1;
   if (K8 && (f16 || bst || x2 || aff)) return -1;
+  if (WINO && (f16 || K8 || N8)) return -1;                                    // Winograd form: fp32
   const int tiles_x = W / TW, tiles_y = H / TH;
   const int tiles_img = tiles_x * tiles_y;
   if (y2 && (split <= 0 || split >= Ndim || split % (16 * NTN) != 0 || stats || bst)) return -1;
@@ -1731,7 +1788,9 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
   if (occ == 0) {
     int o = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false>, TPB, sh) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &o, conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, false, false, false, WINO>, TPB, sh) !=
+            hipSuccess ||
         o < 1)
       o = 1;
     occ = o;
@@ -1753,6 +1812,9 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       if constexpr (!BS && !DU && !IA)                                                                                       \
         conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, false, false, false, false, true><<<grid, TPB, sh, st>>>(                  \
             x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                 \
+    } else if constexpr (WINO) {                                                                                             \
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(  \
+          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
     } else if (f16)                                                                                                          \
       conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, true><<<grid, TPB, sh, st>>>(                                     \
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, gsc);                       \
@@ -1779,7 +1841,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     // (every `if constexpr` below ends in `else return -1`: a form this instantiation does not have must report
     //  "nothing launched", never fall through to `return 0` with y / ysc / the statistics left unwritten)
     if constexpr (!K8 && KS == 3 && NCH % 2 == 0)
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true><<<grid, TPB, sh, st>>>(
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, false, WINO><<<grid, TPB, sh, st>>>(
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
     else return -1;
   } else if (sc) {
@@ -1789,11 +1851,11 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     } else if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (x2) {
         if constexpr (NCH % 2 == 0)
-          conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
+          conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true, false, false, WINO><<<grid, TPB, sh_sc, st>>>(
               x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc);
         else return -1;
       } else {
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true, false, false, WINO><<<grid, TPB, sh_sc, st>>>(
             x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
       }
     } else return -1;
@@ -1840,6 +1902,17 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
     return -1;
   }
   if (Kdim == 8) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, true>(PARGS);
+  // Winograd F(2x2,3x3) form (r03: 1.2-1.4x the direct form on these shapes, scratch/wino_probe.py): every fp32 form of the
+  // 16- and 32-channel reductions on 16-row items.  SMSUT_WINOGRAD=0 keeps the direct forms (A/B switch).  Chosen by SHAPE
+  // only, never by form, so that the forms of one shape stay bit-identical to each other (virtual cat vs materialised, fused
+  // shortcut vs plain, input-side IN vs applied).
+  static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
+  if (use_wino && H % 16 == 0 && (Kdim == 16 || Kdim == 32)) {
+    if (!f16) return Kdim == 16 ? launch_fwd_p<3, 16, 1, 1, false, false, true>(PARGS) : launch_fwd_p<3, 16, 1, 2, false, false, true>(PARGS);
+    // fp16 operands: direct form, but on the SAME 16-row items, so that smsut_conv2d_mfma_tiles() (asked without a dtype:
+    // "tile selection and statistics layout are those of the fp32 entry points", smsut_hip.h) describes both
+    if (Kdim == 32) return launch_fwd_p<3, 16, 1, 2>(PARGS);
+  }
 #ifndef SMSUT_P_OLD_TABLE
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
   if (Kdim == 32 && Ndim % 32 == 0 && !(y2 && split % 32 != 0)) return launch_fwd_p<3, 8, 2, 2>(PARGS);   // (32-channel slabs must not straddle a split)
@@ -1939,6 +2012,8 @@ int dispatch_fwd_cfg(int cfg, const float* x, const float* w, float* y, int N, i
       case 27: return launch_fwd_p<3, 16, 2, 2>(PARGS);
       case 28: return launch_fwd_p<3, 8, 1, 4>(PARGS);
       case 29: return launch_fwd_p<3, 16, 1, 4>(PARGS);
+      case 30: return launch_fwd_p<3, 16, 1, 1, false, false, true>(PARGS);      // Winograd F(2x2,3x3) forms
+      case 31: return launch_fwd_p<3, 16, 1, 2, false, false, true>(PARGS);
       default: break;
     }
 #undef PARGS
