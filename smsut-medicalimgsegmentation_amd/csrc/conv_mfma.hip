@@ -49,6 +49,11 @@ __device__ int g_stamp_base = 0;                        // first workgroup (bloc
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// (r03: the Winograd transforms written as inline-asm v_pk_add_f32 with neg modifiers halve their VALU count -- the compiler
+//  scalarises a vector fsub whose lanes feed MFMA operands one by one -- but the hazard recogniser does not see inside inline
+//  asm: the VALU-write -> MFMA-read wait states were missing and the results were wrong.  Plain vector arithmetic it is.)
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 b) { return a - b; }
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 b) { return a + b; }
 
 // ---- fp16-operand mode (BASELINE config 5: 512x512 slices, "fp16 MFMA conv path with fp32 IN / loss accumulators") ----------
 // Tensors stay fp32 in HBM; a kernel instantiated with F16 converts its operands to fp16 WHILE STAGING them into LDS and
@@ -351,7 +356,7 @@ constexpr int SPIXW = 20;
 
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
           bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false>
-__global__ void __launch_bounds__(TPB)
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WINO ? 2 : 1, WINO ? 2 : 8)))
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
                 BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0,
@@ -383,7 +388,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // its A operands of the 16 per-position GEMMs [tiles x Kdim] . [Kdim x 16]; the resident weight block holds U = G g G^T
   // (computed by the workgroup itself from the 3x3 weights); after the last chunk the 16 position accumulators are folded by
   // A^T m A (element-wise over the lane's four tiles) into the SAME accumulator layout the direct form hands to its epilogue --
-  // pixel map: acc[i][j][r] = (strip row 2*(kq>>1) + (i>>1), column 8*(kq&1) + 4*(i&1) + r) -- so every fused form (statistics,
+  // pixel map: acc[i = 2*dy + dx][j][r = tile] = (strip row 2*(kq>>1) + dy, column 8*(kq&1) + 2*r + dx) -- so every fused form (statistics,
   // accumulate, BST, virtual cat, input-side IN, split output) is shared.  Zero padding = the zeroed halo units, as before.
   // Fused shortcut forms under WINO: the 1x1 conv needs the RAW pixels, which the lane holds anyway -- the four output pixels of
   // its tile are window elements (1,1), (1,2), (2,1), (2,2) -- so it is four more MFMA sets per chunk on those (SC, forward);
@@ -607,7 +612,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   const int o_lane = WINO ? ((wave * MR + 2 * (kq >> 1)) * W + 8 * (kq & 1)) * os + lm : ((wave * MR) * W + 4 * kq) * os + lm;
   const int red_slot = (wave * CO_T + lm) * 2;
   // pixel of accumulator element (i, r) relative to o_lane, in pixels: direct form row i, column r; Winograd form see above
-  auto pxo = [&](int i, int r) { return WINO ? (i >> 1) * W + 4 * (i & 1) + r : i * W + r; };
+  auto pxo = [&](int i, int r) { return WINO ? (i >> 1) * W + 2 * r + (i & 1) : i * W + r; };
 
   // statistics + stores of the item in pacc / (en, ety, etx); straight-line, no branches
   auto epilogue = [&](int par) {
@@ -753,6 +758,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
           }
         }
       }
+      // (r03: a four-stage software pipeline of this loop -- B-fragment reads and transform arithmetic of row-combination g+1
+      //  fenced into the MFMA block of g -- measured no faster at two waves per SIMD, 76.6 vs 77.2 us at 32 x 256^2 16->16, and
+      //  cost 28 VGPRs; the other resident wave already covers the LDS latency.  profiles/r03_notes.md)
 #pragma unroll
       for (int xi = 0; xi < ((SC2 && c >= NCH / 2) ? 0 : 4); ++xi) {
         if (xi == 3) {
@@ -762,8 +770,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         f32x4 t[4];                                   // row combination xi of B^T: d0-d2 | d1+d2 | d2-d1 | d1-d3
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          t[b] = xi == 0 ? dx[b] - d2[b] : xi == 1 ? d1[b] + d2[b] : xi == 2 ? d2[b] - d1[b] : d1[b] - dx[b];
-        const f32x4 v[4] = {t[0] - t[2], t[1] + t[2], t[2] - t[1], t[1] - t[3]};
+          t[b] = xi == 0 ? sub4(dx[b], d2[b]) : xi == 1 ? add4(d1[b], d2[b]) : xi == 2 ? sub4(d2[b], d1[b]) : sub4(d1[b], dx[b]);
+#ifdef SMSUT_WDBG_NO_INXF            // scratch builds (scratch/wino_ablation.py): results wrong by construction, only the time matters
+        const f32x4 v[4] = {dx[0], d1[1], d2[2], dx[3]};
+        (void)t;
+#else
+        const f32x4 v[4] = {sub4(t[0], t[2]), add4(t[1], t[2]), sub4(t[2], t[1]), sub4(t[1], t[3])};
+#endif
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
           const int pos = xi * 4 + nu;
@@ -771,7 +784,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
           for (int j = 0; j < NR; ++j) {
             const f32x4 b = *(const f32x4*)(wc + ((size_t)pos * K4 * CO_T + j * 16) * 4);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) macc[pos][j] = mfma16(v[nu][s], b[s], macc[pos][j]);
+            for (int s = 0; s < 4; ++s)
+#ifdef SMSUT_WDBG_NO_MFMA
+              macc[pos][j][s] += v[nu][s] * b[s];
+#else
+              macc[pos][j] = mfma16(v[nu][s], b[s], macc[pos][j]);
+#endif
           }
         }
       }
@@ -781,25 +799,23 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
           f32x4 c0[4], c1[4];
 #pragma unroll
           for (int nu = 0; nu < 4; ++nu) {
-            c0[nu] = macc[0 + nu][j] + macc[4 + nu][j] + macc[8 + nu][j];
-            c1[nu] = macc[4 + nu][j] - macc[8 + nu][j] - macc[12 + nu][j];
+            c0[nu] = add4(add4(macc[0 + nu][j], macc[4 + nu][j]), macc[8 + nu][j]);
+            c1[nu] = sub4(sub4(macc[4 + nu][j], macc[8 + nu][j]), macc[12 + nu][j]);
           }
-          const f32x4 o00 = c0[0] + c0[1] + c0[2], o01 = c0[1] - c0[2] - c0[3];
-          const f32x4 o10 = c1[0] + c1[1] + c1[2], o11 = c1[1] - c1[2] - c1[3];
-          // acc[2*dy + (r >> 1)][j][2*(r & 1) + dx] = o[dy][dx][r]
-          acc[0][j] = (f32x4){o00[0], o01[0], o00[1], o01[1]};
-          acc[1][j] = (f32x4){o00[2], o01[2], o00[3], o01[3]};
-          acc[2][j] = (f32x4){o10[0], o11[0], o10[1], o11[1]};
-          acc[3][j] = (f32x4){o10[2], o11[2], o10[3], o11[3]};
+#ifdef SMSUT_WDBG_NO_OUTXF
+          const f32x4 o00 = macc[0][j], o01 = macc[5][j], o10 = macc[10][j], o11 = macc[15][j];
+          (void)c0; (void)c1;
+#else
+          const f32x4 o00 = add4(add4(c0[0], c0[1]), c0[2]), o01 = sub4(sub4(c0[1], c0[2]), c0[3]);
+          const f32x4 o10 = add4(add4(c1[0], c1[1]), c1[2]), o11 = sub4(sub4(c1[1], c1[2]), c1[3]);
+#endif
+          // acc[2*dy + dx][j][r] = o[dy][dx][r]: no repacking (the epilogue stores element by element anyway)
+          acc[0][j] = o00; acc[1][j] = o01; acc[2][j] = o10; acc[3][j] = o11;
 #pragma unroll
           for (int p_ = 0; p_ < 16; ++p_) macc[p_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           if constexpr (SC || SC2) {                   // the 1x1 products in the same pixel map (qacc[2*dy + dx][j][r])
-            const f32x4 q0 = (f32x4){qacc[0][j][0], qacc[1][j][0], qacc[0][j][1], qacc[1][j][1]};
-            const f32x4 q1 = (f32x4){qacc[0][j][2], qacc[1][j][2], qacc[0][j][3], qacc[1][j][3]};
-            const f32x4 q2 = (f32x4){qacc[2][j][0], qacc[3][j][0], qacc[2][j][1], qacc[3][j][1]};
-            const f32x4 q3 = (f32x4){qacc[2][j][2], qacc[3][j][2], qacc[2][j][3], qacc[3][j][3]};
-            if constexpr (SC) { acs[0][j] = q0; acs[1][j] = q1; acs[2][j] = q2; acs[3][j] = q3; }
-            else { acc[0][j] += q0; acc[1][j] += q1; acc[2][j] += q2; acc[3][j] += q3; }
+            if constexpr (SC) { acs[0][j] = qacc[0][j]; acs[1][j] = qacc[1][j]; acs[2][j] = qacc[2][j]; acs[3][j] = qacc[3][j]; }
+            else { acc[0][j] += qacc[0][j]; acc[1][j] += qacc[1][j]; acc[2][j] += qacc[2][j]; acc[3][j] += qacc[3][j]; }
 #pragma unroll
             for (int q_ = 0; q_ < 4; ++q_) qacc[q_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
           }
@@ -1757,6 +1773,16 @@ constexpr size_t fwd_p_lds() {
 }
 
 
+// dynamic LDS above the 64 KB default needs the per-kernel opt-in once (gfx950: 160 KB per workgroup)
+template <auto Kern>
+inline void allow_big_lds(size_t bytes) {
+  static bool done = false;
+  if (!done && bytes > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done = true;
+  }
+}
+
 template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false, bool WINO = false>
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
@@ -1765,7 +1791,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH, WINO>();
   // fused 1x1 shortcut (SC): its weight block and a second statistics scratch
   constexpr size_t sh_sc = sh + (size_t)(16 * NCH * 16 * NTN + 2 * 4 * 16 * NTN * 2 + 8) * sizeof(float);
-  if constexpr (sh > 64 * 1024) return -1;
+  if constexpr (sh > (WINO ? 160 : 64) * 1024) return -1;
   else {
   if (Kdim != (K8 ? 8 : 16 * NCH) || W % TW != 0 || H % TH != 0 || (N8 ? Ndim != 8 : Ndim % (16 * NTN) != 0) ||
       (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) >= (1ll << 31))
@@ -1788,6 +1814,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
   if (occ == 0) {
     int o = 0;
+    allow_big_lds<conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, false, false, false, WINO>>(sh);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
             &o, conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, false, false, false, WINO>, TPB, sh) !=
             hipSuccess ||
@@ -1813,6 +1840,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
         conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, false, false, false, false, true><<<grid, TPB, sh, st>>>(                  \
             x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                 \
     } else if constexpr (WINO) {                                                                                             \
+      allow_big_lds<conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false, false, false, false, false, true>>(sh);      \
       conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(  \
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
     } else if (f16)                                                                                                          \
@@ -2014,6 +2042,7 @@ int dispatch_fwd_cfg(int cfg, const float* x, const float* w, float* y, int N, i
       case 29: return launch_fwd_p<3, 16, 1, 4>(PARGS);
       case 30: return launch_fwd_p<3, 16, 1, 1, false, false, true>(PARGS);      // Winograd F(2x2,3x3) forms
       case 31: return launch_fwd_p<3, 16, 1, 2, false, false, true>(PARGS);
+      case 32: return launch_fwd_p<3, 16, 1, 4, false, false, true>(PARGS);
       default: break;
     }
 #undef PARGS
