@@ -80,7 +80,7 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
     w = ops.new_weight(cout, cin, 3, 3, device=dev)
     w.copy_(torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5)
     y = ops.new_act(batch, cout, h, h, xa)
-    tiles = H.call("smsut_conv2d_mfma_tiles", batch, h, h, cin, cout, 3)
+    tiles = H.call("smsut_conv2d_mfma_tiles", batch, h, h, cin, cout, 3, int(f16))
     part = torch.empty(batch * tiles * cout * 2, device=dev)
     assert H.call("smsut_conv2d_mfma_cat_supported", batch, h, h, cin, cout), "virtual-cat form not available for this shape"
     st = torch.cuda.current_stream()

@@ -46,11 +46,14 @@ int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim)
 int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                           int transposed, void* stream);
 /* forward conv that also emits the InstanceNorm {sum, sum^2} partials of its output (fused statistics pass):
- * stats = float[N * smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, KS) * Ndim * 2], consumed by smsut_instnorm_fwd_partials
- * (the tile shape is chosen per layer shape, so the whole shape is part of the query). */
-int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS);
-/* 1 when this shape runs the persistent resident-weight kernel (conv_mfma_fwd_p: small Cin, large image), else 0. */
-int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS);
+ * stats = float[N * smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, KS, f16) * Ndim * 2], consumed by smsut_instnorm_fwd_partials
+ * (the tile shape is chosen per layer shape AND operand dtype -- f16 = 1 for the *_f16 entry points: the fp32 forms of a shape may
+ * run a Winograd kernel on 16-row items where the fp16-operand ones keep the direct kernel's -- so both are part of the query). */
+int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS, int f16);
+/* 1 when this shape runs one of the persistent kernels that carry the fused forms (statistics / input-side IN / BST epilogues):
+ * conv_mfma_fwd_p (direct or Winograd F(2x2,3x3), resident weights, Kdim <= 64) or, fp32 only, conv_wino_l (Winograd, streamed
+ * weights, Kdim >= 64); else 0 (per-tile kernel). */
+int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS, int f16);
 /* data-gradient of conv2 inside a BasicBlock (its input was LeakyReLU(IN(y1)), blocks.py:66-72) with the InstanceNorm backward
  * folded into the epilogue: gz = g * mask(y1) is written instead of g, plus the per-tile partials {sum gz, sum gz*xhat}
  * [N][smsut_conv2d_mfma_tiles(N,H,W,Kdim,Ndim,3)][Ndim][2].  Persistent-kernel shapes only (-1 otherwise). */
@@ -137,7 +140,7 @@ int smsut_conv1x1_fwd_split(const float* x, const float* w, float* ya, float* yb
  * is staged into LDS, products accumulate in fp32 (v_mfma_f32_16x16x16_f16), statistics / epilogues / outputs are the fp32 ones.
  * gsc (nullable): device float[2] = {s, 1/s} from smsut_absmax_scale -- a per-tensor power-of-two scale for a GRADIENT input operand
  * (it would underflow fp16 otherwise); the operand is multiplied by s before the conversion, the fp32 result by 1/s.
- * Tile selection, statistics layout (smsut_conv2d_mfma_tiles) and the `transposed` flags are those of the fp32 entry points. */
+ * Statistics layout as the fp32 entry points with the tiles of smsut_conv2d_mfma_tiles(..., f16 = 1); `transposed` flags alike. */
 int smsut_conv2d_f16_supported(int KS, int Kdim, int Ndim);
 int smsut_conv2d_fwd_mfma_f16(const float* x, const float* w, float* y, const float* gsc /*nullable*/, int N, int H, int W,
                               int Kdim, int Ndim, int KS, int transposed, void* stream);

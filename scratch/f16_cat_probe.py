@@ -25,7 +25,7 @@ st = torch.cuda.current_stream().cuda_stream
 if case == "stats_cat":
     xa, xb = buf(n, h, h, ca), buf(n, h, h, ca)
     w = buf(9, ci, co); w.mul_(0.06)
-    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3)
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3, 0)
     y32, y16 = buf(n, h, h, co, fill=0), buf(n, h, h, co, fill=0)
     p32, p16 = buf(n * tiles * co * 2, fill=0), buf(n * tiles * co * 2, fill=0)
     H.call("smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y32, p32, n, h, h, ci, co, st)

@@ -17,7 +17,7 @@ for (h, c) in [(256, 16), (128, 32), (64, 64)]:
     E = lambda *s: torch.randn(*s, device='cuda')
     y1, a1, y2, gy = E(n, h, h, c), E(n, h, h, c), E(n, h, h, c), E(n, h, h, c)
     w = E(9 * c * c) * 0.05; m, r, g, b = E(n, c), E(n, c).abs() + 0.5, E(c), E(c)
-    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3)
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3, 0)
     p = torch.zeros(n * tiles * c * 2, device='cuda'); gw = E(9 * c * c)
     ws = torch.empty(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, h, c, c, 3), device='cuda')
     t = {

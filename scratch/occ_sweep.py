@@ -8,7 +8,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     for (B, h, K, N, form) in [(16, 256, 32, 16, "cat"), (32, 256, 16, 16, "stats"), (32, 128, 32, 32, "stats"), (32, 64, 64, 64, "stats")]:
         x = torch.randn(B, h, h, K, device="cuda"); w = torch.randn(9, K, N, device="cuda") * 0.05
         y = torch.empty(B, h, h, N, device="cuda")
-        tiles = H.call("smsut_conv2d_mfma_tiles", B, h, h, K, N, 3)
+        tiles = H.call("smsut_conv2d_mfma_tiles", B, h, h, K, N, 3, 0)
         part = torch.empty(B * tiles * N * 2, device="cuda")
         xa, xb = x[..., :K // 2].contiguous(), x[..., K // 2:].contiguous()
         st = torch.cuda.current_stream().cuda_stream

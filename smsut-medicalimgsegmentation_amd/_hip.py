@@ -38,8 +38,8 @@ SIGNATURES: Dict[str, str] = {
     # conv_mfma.hip
     "smsut_conv2d_mfma_supported": "iiiii",
     "smsut_conv2d_fwd_mfma": "ppp iiiiii i s",
-    "smsut_conv2d_mfma_tiles": "iiiiii",
-    "smsut_conv2d_mfma_persistent": "iiiiii",
+    "smsut_conv2d_mfma_tiles": "iiiiiii",
+    "smsut_conv2d_mfma_persistent": "iiiiiii",
     "smsut_conv2d_dgrad_mfma_bwdstats": "ppppppppp f iiiii s",
     "smsut_conv2d_fwd_mfma_stats": "pppp iiiiii s",
     "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",

@@ -23,6 +23,7 @@
 // accumulators in registers across all its tiles, and are combined once at the end through LDS in a fixed
 // order; per-split slabs are summed by a second tiny kernel (deterministic, no atomics).
 #include "common.h"
+#include "conv_wino.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
@@ -1914,6 +1915,15 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
          (int64_t)N * (H / 8) * (W / TW) * (Ndim / 16) >= 1024 && (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) < (1ll << 31);
 }
 
+// ... or the large-reduction Winograd kernel (conv_wino.hip: fp32 only, Kdim >= 64, 16x16 tiles)
+inline bool wino_l_shape(int N, int H, int W, int Kdim, int Ndim) {
+  static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
+  return use_wino && Kdim >= 64 && smsut_wino_l_eligible(N, H, W, Kdim, Ndim);
+}
+inline bool fwd_any_eligible(int N, int H, int W, int Kdim, int Ndim, bool f16) {
+  return fwd_p_eligible(N, H, W, Kdim, Ndim) || (!f16 && wino_l_shape(N, H, W, Kdim, Ndim));
+}
+
 // Variant table of the persistent kernel, from the late-r01 sweep (scratch/bench_conv.py 32: cfg 20..29 on the U-Net
 // shapes, forward and data-gradient): 16-channel reductions run ~10 % faster on 16-row items (109 vs 99 TF at 256^2
 // 16->16, 103 vs 88 at 128^2 16->32), 32-channel reductions ~8 % faster with 32 output channels per workgroup when
@@ -1924,6 +1934,14 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
                         const ScRef* sc = nullptr) {
 #define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc
+  if (!f16 && wino_l_shape(N, H, W, Kdim, Ndim)) {         // Winograd, streamed weights (conv_wino.hip): every fp32 form
+    WinoBst wb; WinoAff wa; WinoSc ws;
+    if (bst) wb = WinoBst{bst->y1, bst->mean, bst->rstd, bst->gamma, bst->beta, bst->slope};
+    if (aff) wa = WinoAff{aff->mean, aff->rstd, aff->gamma, aff->beta, aff->slope};
+    if (sc) ws = WinoSc{sc->w, sc->y, sc->stats};
+    return smsut_wino_l_launch(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, tiles_out, bst ? &wb : nullptr,
+                               aff ? &wa : nullptr, sc ? &ws : nullptr, st);
+  }
   if (Ndim == 8) {                                   // 8 result channels (see conv_mfma_fwd_p, N8): data-gradient forms
     if (Kdim == 16) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, false, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, false, true>(PARGS);
     if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2, false, true>(PARGS);   // (16-row items measured no better: 8.89 vs 8.91 ms U-Net)
@@ -1935,12 +1953,8 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
   // only, never by form, so that the forms of one shape stay bit-identical to each other (virtual cat vs materialised, fused
   // shortcut vs plain, input-side IN vs applied).
   static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
-  if (use_wino && H % 16 == 0 && (Kdim == 16 || Kdim == 32)) {
-    if (!f16) return Kdim == 16 ? launch_fwd_p<3, 16, 1, 1, false, false, true>(PARGS) : launch_fwd_p<3, 16, 1, 2, false, false, true>(PARGS);
-    // fp16 operands: direct form, but on the SAME 16-row items, so that smsut_conv2d_mfma_tiles() (asked without a dtype:
-    // "tile selection and statistics layout are those of the fp32 entry points", smsut_hip.h) describes both
-    if (Kdim == 32) return launch_fwd_p<3, 16, 1, 2>(PARGS);
-  }
+  if (use_wino && !f16 && H % 16 == 0 && (Kdim == 16 || Kdim == 32))
+    return Kdim == 16 ? launch_fwd_p<3, 16, 1, 1, false, false, true>(PARGS) : launch_fwd_p<3, 16, 1, 2, false, false, true>(PARGS);
 #ifndef SMSUT_P_OLD_TABLE
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
   if (Kdim == 32 && Ndim % 32 == 0 && !(y2 && split % 32 != 0)) return launch_fwd_p<3, 8, 2, 2>(PARGS);   // (32-channel slabs must not straddle a split)
@@ -1973,7 +1987,7 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
   if constexpr (KS == 3) {
     // small-Cin / large-image layers: persistent kernel with resident weights (see conv_mfma_fwd_p); it declines
     // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
-    if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_p_eligible(N, H, W, Kdim, Ndim)) {
+    if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_any_eligible(N, H, W, Kdim, Ndim, f16)) {
       if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr, y2, split, x2, nullptr, f16,
                        gsc) == 0)
         return 0;
@@ -2472,7 +2486,7 @@ int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, 
                                       const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
                                       int W, int Kdim, int Ndim, void* stream) {
   SMSUT_REQUIRE(x && w && y && stats && mean && rstd && gamma && beta && N > 0 && H > 0 && W > 0);
-  SMSUT_REQUIRE(fwd_p_eligible(N, H, W, Kdim, Ndim));
+  SMSUT_REQUIRE(fwd_any_eligible(N, H, W, Kdim, Ndim, false));
   const AffRef a{mean, rstd, gamma, beta, slope};
   const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, nullptr, &a);
   SMSUT_REQUIRE(rc == 0);
@@ -2486,7 +2500,9 @@ int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, 
 // w [3][3][Kdim][Ndim], wsc [Kdim][Ndim] (HWIO).  Persistent-kernel shapes with Kdim in {16, 32, 64}: _supported says which.
 int smsut_conv2d_fwd_sc_supported(int N, int H, int W, int Kdim, int Ndim, int cat) {
   static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT"); return !e || atoi(e) != 0; }();
-  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Kdim == 8 || Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  if (!on || N <= 0 || H <= 0 || W <= 0) return 0;
+  if (wino_l_shape(N, H, W, Kdim, Ndim)) return (!cat || Kdim % 32 == 0) ? 1 : 0;       // (conv_wino.hip: any reduction width)
+  if (!(Kdim == 8 || Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
   if (cat && Kdim % 32 != 0) return 0;
   return 1;
 }
@@ -2509,7 +2525,7 @@ int smsut_conv2d_dgrad_sc_supported(int N, int H, int W, int Cout, int Cin, int 
   static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_DGRAD"); return !e || atoi(e) != 0; }();
   if (!on || N <= 0 || H <= 0 || W <= 0 || !(Cout == 16 || Cout == 32)) return 0;
   if (Cin == 8) return !split && Cout == 16 && fwd_p_n8_eligible(N, H, W, 2 * Cout, Cin);       // first block after the stem: 8-channel result
-  if (!fwd_p_eligible(N, H, W, 2 * Cout, Cin)) return 0;
+  if (!fwd_any_eligible(N, H, W, 2 * Cout, Cin, false)) return 0;
   if (split && (split <= 0 || split >= Cin || split % 16 != 0 || (Cin - split) % 16 != 0)) return 0;
   return 1;
 }
@@ -2590,16 +2606,19 @@ int smsut_convT2x2_dgrad_mfma(const float* gy, const float* w, float* gx, int N,
 // Forward conv that also emits the InstanceNorm statistics partials of its output (see conv_mfma_fwd).
 // stats: float[N * smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, KS) * Ndim * 2]
 // (the kernel variant and its tile shape depend on the whole layer shape, so all of it is part of the query)
-int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS) {
+int smsut_conv2d_mfma_tiles(int N, int H, int W, int Kdim, int Ndim, int KS, int f16) {
+  // f16: the tiles of the fp16-operand entry points (r03: the fp32 forms of a shape may run a Winograd kernel on 16-row items
+  // where the fp16 ones keep the direct kernel's)
   int tiles = 0;
   if (KS == 1) dispatch_fwd<1>(nullptr, nullptr, nullptr, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
-  else dispatch_fwd<3>(nullptr, nullptr, nullptr, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles);
+  else dispatch_fwd<3>(nullptr, nullptr, nullptr, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, nullptr, nullptr, &tiles, nullptr, nullptr, 0,
+                       f16 != 0);
   return tiles;
 }
 
 // 1 when conv(k=KS) on this shape runs the persistent resident-weight kernel (conv_mfma_fwd_p), 0 for the per-tile kernel
-int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS) {
-  return KS == 3 && fwd_p_eligible(N, H, W, Kdim, Ndim) ? 1 : 0;
+int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS, int f16) {
+  return KS == 3 && fwd_any_eligible(N, H, W, Kdim, Ndim, f16 != 0) ? 1 : 0;
 }
 
 int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
@@ -2620,7 +2639,7 @@ int smsut_conv2d_dgrad_mfma_bwdstats(const float* gy, const float* w, float* gz,
                                      const float* mean, const float* rstd, const float* gamma, const float* beta,
                                      float slope, int N, int H, int W, int Kdim, int Ndim, void* stream) {
   SMSUT_REQUIRE(gy && w && gz && stats && y1 && mean && rstd && gamma && beta && N > 0 && H > 0 && W > 0);
-  SMSUT_REQUIRE(fwd_p_eligible(N, H, W, Kdim, Ndim));
+  SMSUT_REQUIRE(fwd_any_eligible(N, H, W, Kdim, Ndim, false));
   const BstRef b{y1, mean, rstd, gamma, beta, slope};
   hipStream_t st = (hipStream_t)stream;
   const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);

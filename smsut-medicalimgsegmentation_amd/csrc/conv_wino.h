@@ -1,0 +1,19 @@
+// Internal interface between conv_mfma.hip (entry points, form selection) and conv_wino.hip (the large-reduction Winograd kernel).
+#pragma once
+#include "common.h"
+
+struct WinoAff { const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
+struct WinoBst { const float* y1; const float* mean; const float* rstd; const float* gamma; const float* beta; float slope; };
+struct WinoSc { const float* w; float* y; float* stats; };
+
+// Shapes the kernel takes: 3x3 stride-1 "same", Kdim % 16 == 0 (>= 32), Ndim % 16 == 0, H % 16 == 0, W % 16 == 0.
+bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim);
+
+// One launch of conv_wino_l.  `transposed` bit 0: weights read transposed + tap-flipped (data-gradient), bit 1: the result is
+// ADDED to what y holds.  x2: the input is the virtual cat([x, x2]) of two Kdim/2-channel tensors; with sc->w and bit 0 set it is
+// the fused shortcut data-gradient instead (second half = the shortcut's gradient, 1x1 weights sc->w).  sc (forward): fused 1x1
+// shortcut conv (sc->w, result sc->y, InstanceNorm partials sc->stats).  y2 / split: split output.  tiles_out: only report the
+// statistics tiles per image.  Returns 0 when launched (or reported), -1 when the form is not covered (nothing launched).
+int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W,
+                        int Kdim, int Ndim, int transposed, float* stats, int* tiles_out, const WinoBst* bst, const WinoAff* aff,
+                        const WinoSc* sc, hipStream_t st);

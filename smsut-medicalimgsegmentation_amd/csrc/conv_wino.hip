@@ -1,0 +1,547 @@
+// Winograd F(2x2, 3x3) convolution for LARGE reductions (Kdim >= 64) on the gfx950 matrix cores, fp32.
+//
+// conv_mfma.hip's Winograd form keeps the whole transformed weight block U = G g G^T resident in LDS, which stops at 32
+// reduction channels (16 positions x Kdim x 16 output channels x 4 B).  The deep levels of the U-Net / ugan generator (64 ... 256
+// channels on 64^2 ... 16^2 planes, network/blocks.py:120-174, ugan.py:22-83) carry 60 % of the 3x3 FLOPs; this kernel takes
+// them with a different economy:
+//
+//   * an item is a 16x16-pixel output tile of one image for 16*NTN output channels; its reduction is walked in 16-channel
+//     chunks, and per chunk BOTH operands are staged: the haloed input tile (as in the resident form) and the chunk's weight
+//     block, which every thread transforms ON THE FLY -- NTN (reduction channel, output channel) pairs per thread: nine
+//     weights prefetched one chunk ahead, 28 flops, sixteen LDS words -- so no transformed-weight buffer exists in HBM and the
+//     C ABI needs no workspace;
+//   * NTN = 2 output-channel slabs per wave share one input transform (B^T d B, in registers, lane = (tile, channel quad)):
+//     128 position accumulators per lane, ONE wave per SIMD with the 512-register budget, and the latency hiding that a second
+//     wave would give is written into the instruction stream instead -- the B-fragment reads and the transform arithmetic of
+//     unit u+1 sit, fenced by sched_barriers, inside the 16-MFMA block of unit u;
+//   * an item is long (>= 4 chunks x 128 MFMAs per wave), so its results are transformed (A^T m A), folded and stored right after
+//     its last chunk -- no deferred epilogue, no second accumulator set.
+//
+// Fused forms, same contracts as conv_mfma_fwd_p (the entry points of conv_mfma.hip route here by shape):
+//   STATS   per-tile {sum, sum of squares} of the result for the following InstanceNorm
+//   ACC     result added to what y holds (second gradient path into a block input)
+//   BST     conv2's data-gradient inside a BasicBlock: result x LeakyReLU mask recomputed from y1, InstanceNorm-backward partials
+//   DUAL    input = virtual cat([x, x2]) of two Kdim/2-channel tensors
+//   INAFF   input-side InstanceNorm + LeakyReLU applied while staging (the padding stays zero)
+//   SC      fused 1x1 shortcut conv (forward): four more MFMA sets per chunk on the tile's raw pixels
+//   SC2     fused shortcut data-gradient: the second reduction half is the shortcut's gradient against the 1x1 weights
+//   y2      split output (channels [0, split) to y, the rest to y2)
+// Lane <-> pixel map of the results: acc[i = 2*dy + dx][j][r] = tile 4*kq + r of the wave's 4-row strip, pixel (dy, dx) of it:
+// strip row 2*(kq >> 1) + dy, column 8*(kq & 1) + 2*r + dx.
+#include "conv_wino.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TPB = 256;
+constexpr int TH = 16, TW = 16;           // output tile of an item
+constexpr int IH = TH + 2, IW = TW + 2;   // haloed input tile
+constexpr int SPX = 20;                   // floats between pixels of the staged input tile (see SPIXW in conv_mfma.hip)
+constexpr int UNITS = IH * IW * 4;        // float4 units of one 16-channel input chunk
+constexpr int NI = (UNITS + TPB - 1) / TPB;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float aff1(float v, float m, float r, float g, float b, float slope) {
+  return lrelu_f(in_affine(v, m, r, g, b), slope);
+}
+
+template <int NTN>
+constexpr size_t wino_l_lds(bool sc) {
+  return (size_t)((IH * IW + 1) * SPX + 4 * 16 * NTN * 2 + 8 + 16 * 16 * 16 * NTN + (sc ? 16 * 16 * NTN + 4 * 16 * NTN * 2 + 8 : 0)) * sizeof(float);
+}
+
+template <int NTN, bool STATS, bool ACC, bool BST, bool DUAL, bool INAFF, bool SC, bool SC2>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(NTN >= 2 ? 1 : 2, NTN >= 2 ? 1 : 2)))
+conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ w, float* __restrict__ y,
+            float* __restrict__ y2, int split, int N, int H, int W, int nch, int Ndim, int tiles_x, int tiles_img, int items_per_wg,
+            int transposed, float* __restrict__ stats, WinoBst bst, WinoAff aff, WinoSc sc) {
+  static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
+  static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
+  static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !SC2), "fused shortcut: forward statistics forms");
+  static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !SC), "fused shortcut data-gradient");
+  constexpr int CO_T = 16 * NTN, NR = NTN;
+  extern __shared__ float smem[];
+  float* in_s = smem;                                  // [IH][IW][SPX] + one dummy pixel (sink of the padding units)
+  float* red = smem + (IH * IW + 1) * SPX;             // [4 waves][CO_T][2] + dummy
+  float* w_s = red + 4 * CO_T * 2 + 8;                 // this chunk's U: [16 positions][4 channel quads][CO_T][4]
+  [[maybe_unused]] float* wsc_s = w_s + 16 * 16 * CO_T;   // SC: this chunk's 1x1 weights [4][CO_T][4]
+  [[maybe_unused]] float* red_sc = wsc_s + 16 * CO_T;     // SC: [4][CO_T][2] + dummy
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int co0 = blockIdx.y * CO_T;
+  const int Kd = 16 * nch;                              // reduction channels
+  const int nh = nch >> 1;                              // DUAL: chunks per half
+  const int KST = DUAL ? Kd / 2 : Kd;                   // pixel stride of the tensor(s) the input is read from
+  const bool tr = SC2 || (transposed & 1);
+  const int KROW = SC2 ? Kd / 2 : Kd;                   // row length of the transposed 3x3 weights
+  float* const yo = (y2 && co0 >= split) ? y2 : y;
+  const int os = !y2 ? Ndim : (co0 >= split ? Ndim - split : split);
+  const int oc0 = (y2 && co0 >= split) ? co0 - split : co0;
+  const int total_items = N * tiles_img;
+  // XCD k gets the k-th contiguous eighth of the items (halo rows shared between neighbouring strips hit its own L2)
+  const int wg = (gridDim.x & 7) == 0 ? (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3)) : (int)blockIdx.x;
+  const int item0 = wg * items_per_wg;
+  const int item1 = min(item0 + items_per_wg, total_items);
+  if (item0 >= item1) return;
+  const int tiles_y = tiles_img / tiles_x;
+
+  // ---- input staging descriptors (tile-independent)
+  int u_off[NI], u_lds[NI], u_flag[NI];
+  float4 rin[NI];
+  bool zero[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int u = tid + i * TPB;
+    const bool real = u < UNITS;
+    const int uu = real ? u : 0;
+    const int q = uu & 3, pix = uu >> 2;
+    const int iy = pix / IW, ix = pix % IW;
+    u_off[i] = (iy * W + ix) * KST + 4 * q;
+    u_lds[i] = real ? pix * SPX + 4 * q : IH * IW * SPX;
+    u_flag[i] = (iy < 1 ? 1 : 0) | (iy >= TH + 1 ? 2 : 0) | (ix < 1 ? 4 : 0) | (ix >= TW + 1 ? 8 : 0);
+  }
+  const int safe_off = (W + 1) * KST;                  // first interior pixel of the tile: always inside the image
+
+  // ---- weight staging: NTN (reduction channel ci, output channel n) pairs per thread.  Lanes run along the contiguous
+  //      dimension of the weight tensor: n for [tap][ci][n] (forward), ci for [tap][n][ci] (transposed)
+  int w_ci[NTN], w_n[NTN];
+  unsigned w_off[NTN];                                 // element offset of the pair inside a (tap, chunk) block of the weight tensor
+  [[maybe_unused]] unsigned w_off1[NTN];               // ... inside the 1x1 weights (SC: [ci][n]; SC2: [n][ci])
+  float wreg[NTN][9];
+  [[maybe_unused]] float wx[NTN];
+#pragma unroll
+  for (int k = 0; k < NTN; ++k) {
+    const int p = tid + k * TPB;
+    if (tr) { w_ci[k] = p & 15; w_n[k] = p >> 4; }
+    else { w_n[k] = p % CO_T; w_ci[k] = p / CO_T; }
+    w_off[k] = tr ? (unsigned)((co0 + w_n[k]) * KROW + w_ci[k]) : (unsigned)(w_ci[k] * Ndim + co0 + w_n[k]);
+    if constexpr (SC) w_off1[k] = (unsigned)(w_ci[k] * Ndim + co0 + w_n[k]);
+    if constexpr (SC2) w_off1[k] = (unsigned)((co0 + w_n[k]) * KROW + w_ci[k]);
+  }
+  // (tap, chunk) blocks: forward w + (tap * Kd + 16 c) * Ndim, transposed w + (8 - tap) * Ndim * KROW + 16 c -- uniform, so a
+  // weight load is one scalar base + the thread's 32-bit offset (no per-load 64-bit vector arithmetic)
+
+  int pn = item0 / tiles_img, pty, ptx;                // cursor of the item being prefetched
+  { const int t = item0 - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
+  int cn = pn, cty = pty, ctx = ptx;                   // ... of the item being computed
+  int pflags = 0, pc = 0;                              // borders the prefetched tile touches; chunk held in the staging registers
+  [[maybe_unused]] float4 a_m, a_r, a_g, a_b;
+
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    if (++tx_ == tiles_x) { tx_ = 0; if (++ty_ == tiles_y) { ty_ = 0; ++n_; } }
+  };
+  auto prefetch = [&](int c) {
+    pc = c;
+    if (c == 0) pflags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
+    const int cl = (DUAL && c >= nh) ? c - nh : c;
+    const int base = (((pn * H + pty * TH - 1) * W) + ptx * TW - 1) * KST + cl * 16;
+    const float* xb = ((DUAL && c >= nh) ? x2 : x) + base;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      zero[i] = (u_flag[i] & pflags) != 0;
+      rin[i] = *(const float4*)(xb + (unsigned)(zero[i] ? safe_off : u_off[i]));
+    }
+    if constexpr (INAFF) {
+      const int ch = c * 16 + 4 * (tid & 3);
+      a_m = *(const float4*)(aff.mean + (size_t)pn * Kd + ch);
+      a_r = *(const float4*)(aff.rstd + (size_t)pn * Kd + ch);
+      a_g = *(const float4*)(aff.gamma + ch);
+      a_b = *(const float4*)(aff.beta + ch);
+    }
+#pragma unroll
+    for (int k = 0; k < NTN; ++k) {
+      if (SC2 && c >= nh) {
+        wreg[k][0] = (sc.w + (c - nh) * 16)[w_off1[k]];
+      } else if (tr) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = (w + (size_t)(8 - tap) * Ndim * KROW + c * 16)[w_off[k]];
+      } else {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = (w + ((size_t)tap * Kd + c * 16) * Ndim)[w_off[k]];
+      }
+      if constexpr (SC) wx[k] = (sc.w + (size_t)(c * 16) * Ndim)[w_off1[k]];
+    }
+  };
+  auto publish = [&]() {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      float4 v = rin[i];
+      if constexpr (INAFF) {
+        v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+        v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
+      }
+      if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4*)(in_s + u_lds[i]) = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NTN; ++k) {
+      const int ci = w_ci[k], n = w_n[k];
+      float* dst = w_s + ((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3);        // + pos * 4 * CO_T * 4
+      if (SC2 && pc >= nh) {
+        dst[0] = wreg[k][0];                             // the 1x1 weights, parked in position 0's block
+      } else {
+        // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+        float t[4][3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+          const float g0 = wreg[k][b], g1 = wreg[k][3 + b], g2 = wreg[k][6 + b];
+          t[0][b] = g0; t[1][b] = 0.5f * (g0 + g1 + g2); t[2][b] = 0.5f * (g0 - g1 + g2); t[3][b] = g2;
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float uu[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+          for (int b = 0; b < 4; ++b) dst[(size_t)(a * 4 + b) * 4 * CO_T * 4] = uu[b];
+        }
+      }
+      if constexpr (SC) wsc_s[((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3)] = wx[k];
+    }
+  };
+
+  f32x4 macc[16][NR], acc[4][NR];
+  [[maybe_unused]] f32x4 qacc[(SC || SC2) ? 4 : 1][NR];
+  [[maybe_unused]] f32x4 pold[(ACC || BST) ? 4 : 1][NR];
+  [[maybe_unused]] float nm[NR], nr[NR], ng_[NR], nb[NR];
+#pragma unroll
+  for (int p_ = 0; p_ < 16; ++p_)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) macc[p_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if constexpr (SC || SC2) {
+#pragma unroll
+    for (int q_ = 0; q_ < 4; ++q_)
+#pragma unroll
+      for (int j = 0; j < NR; ++j) qacc[q_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (BST) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) { ng_[j] = bst.gamma[co0 + j * 16 + lm]; nb[j] = bst.beta[co0 + j * 16 + lm]; }
+  }
+  const unsigned o_lane = (unsigned)(((wave * 4 + 2 * (kq >> 1)) * W + 8 * (kq & 1)) * os + lm);
+  auto pxo = [&](int i, int r) { return (unsigned)((i >> 1) * W + 2 * r + (i & 1)); };
+
+  // the values the outputs of the current item hold now (ACC), or y1 at those positions (BST): loaded at the start of the
+  // item's last chunk, consumed by its epilogue
+  auto load_old = [&]() {
+    if constexpr (BST) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        nm[j] = bst.mean[(size_t)cn * Ndim + co0 + j * 16 + lm];
+        nr[j] = bst.rstd[(size_t)cn * Ndim + co0 + j * 16 + lm];
+      }
+    }
+    if constexpr (ACC || BST) {
+      const float* yb = (BST ? bst.y1 : yo) + (((size_t)cn * H + cty * TH) * W + ctx * TW) * os + oc0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pold[i][j][r] = yb[o_lane + pxo(i, r) * os + j * 16];
+    }
+  };
+  auto epilogue = [&]() {                              // item (cn, cty, ctx), results in acc (and qacc for SC)
+    if constexpr (STATS || BST) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (BST) {
+              const float yv = pold[i][j][r];
+              const float gz = acc[i][j][r] * lrelu_mask(in_affine(yv, nm[j], nr[j], ng_[j], nb[j]), bst.slope);
+              acc[i][j][r] = gz;
+              s1 += gz; s2 += gz * ((yv - nm[j]) * nr[j]);
+            } else {
+              const float v = acc[i][j][r]; s1 += v; s2 += v * v;
+            }
+          }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        float* rd = kq == 0 ? red + (wave * CO_T + j * 16 + lm) * 2 : red + 4 * CO_T * 2;
+        *(float2*)rd = make_float2(s1, s2);
+      }
+    }
+    float* yb = yo + (((size_t)cn * H + cty * TH) * W + ctx * TW) * os + oc0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yb[o_lane + pxo(i, r) * os + j * 16] = acc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
+    if constexpr (SC) {
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const float v = qacc[i][j][r]; s1 += v; s2 += v * v; }
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        float* rd = kq == 0 ? red_sc + (wave * CO_T + j * 16 + lm) * 2 : red_sc + 4 * CO_T * 2;
+        *(float2*)rd = make_float2(s1, s2);
+      }
+      float* ys = sc.y + (((size_t)cn * H + cty * TH) * W + ctx * TW) * Ndim + co0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ys[o_lane + pxo(i, r) * Ndim + j * 16] = qacc[i][j][r];
+#pragma unroll
+      for (int q_ = 0; q_ < 4; ++q_)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) qacc[q_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stats_out = [&]() {                              // after the barrier that completes red[]
+    if ((STATS || BST) && tid < CO_T) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) { s1 += red[(m * CO_T + tid) * 2]; s2 += red[(m * CO_T + tid) * 2 + 1]; }
+      *(float2*)(stats + (((size_t)cn * tiles_img + cty * tiles_x + ctx) * Ndim + co0 + tid) * 2) = make_float2(s1, s2);
+      if constexpr (SC) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { t1 += red_sc[(m * CO_T + tid) * 2]; t2 += red_sc[(m * CO_T + tid) * 2 + 1]; }
+        *(float2*)(sc.stats + (((size_t)cn * tiles_img + cty * tiles_x + ctx) * Ndim + co0 + tid) * 2) = make_float2(t1, t2);
+      }
+    }
+  };
+
+  // ---- one chunk of MFMAs: lane (lm = tile, kq = channel quad) of this wave's 4 x 16-pixel strip
+  auto mma_chunk = [&](int c, auto last_tag) {
+    constexpr bool last = decltype(last_tag)::value;
+    // window of tile (tr, tc) = (lm >> 3, lm & 7): rows wave*4 + 2*tr + a, columns 2*tc + b, channel quad kq
+    const float* dp = in_s + (((wave * 4 + 2 * (lm >> 3)) * IW) + 2 * (lm & 7)) * SPX + 4 * kq;
+    const float* wc = w_s + ((size_t)kq * CO_T + lm) * 4;              // + (pos * 4 * CO_T + j * 16) * 4
+    if constexpr (SC2) {
+      if (c >= nh) {                                     // the shortcut's gradient: 1x1 products of the tile's four pixels only
+        const f32x4 px[4] = {*(const f32x4*)(dp + (1 * IW + 1) * SPX), *(const f32x4*)(dp + (1 * IW + 2) * SPX),
+                             *(const f32x4*)(dp + (2 * IW + 1) * SPX), *(const f32x4*)(dp + (2 * IW + 2) * SPX)};
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const f32x4 bw = *(const f32x4*)(wc + (size_t)(j * 16) * 4);
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int q_ = 0; q_ < 4; ++q_) qacc[q_][j] = mfma16(px[q_][s], bw[s], qacc[q_][j]);
+        }
+        return;                                          // (SC2 has no ACC / BST operands to request)
+      }
+    }
+    f32x4 d0[4], d1[4], d2[4], d3[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      d1[b] = *(const f32x4*)(dp + (1 * IW + b) * SPX);
+      d2[b] = *(const f32x4*)(dp + (2 * IW + b) * SPX);
+    }
+    if constexpr (SC) {                                  // forward shortcut: the tile's four raw pixels x this chunk's 1x1 weights
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const f32x4 bw = *(const f32x4*)(wsc_s + (((size_t)kq * CO_T) + j * 16 + lm) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          qacc[0][j] = mfma16(d1[1][s], bw[s], qacc[0][j]);
+          qacc[1][j] = mfma16(d1[2][s], bw[s], qacc[1][j]);
+          qacc[2][j] = mfma16(d2[1][s], bw[s], qacc[2][j]);
+          qacc[3][j] = mfma16(d2[2][s], bw[s], qacc[3][j]);
+        }
+      }
+    }
+    // Software pipeline over units u = (row combination xi of B^T, output-channel slab j), xi in the order 1, 2, 0, 3 (the first
+    // two need window rows 1 and 2 only; row 0 is read during group 0, row 3 during group 1): region u holds the B-fragment reads
+    // of unit u+1, the transform arithmetic of the next xi and the 16 MFMAs of unit u.  The ACC / BST operands of the epilogue
+    // are requested once the window rows are dead (last group of the item's last chunk).
+    constexpr int XO[4] = {1, 2, 0, 3};
+    constexpr int NU = 4 * NR;
+    f32x4 bf[2][4], vv[2][4];
+    auto ld_b = [&](int u, f32x4* dst) {
+      const int xi = XO[u / NR], j = u % NR;
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) dst[nu] = *(const f32x4*)(wc + ((size_t)(xi * 4 + nu) * 4 * CO_T + j * 16) * 4);
+    };
+    auto xform = [&](int g, f32x4* v) {
+      const int xi = XO[g];
+      f32x4 t[4];                                        // row combination xi of B^T: d0-d2 | d1+d2 | d2-d1 | d1-d3
+#pragma unroll
+      for (int b = 0; b < 4; ++b) t[b] = xi == 0 ? d0[b] - d2[b] : xi == 1 ? d1[b] + d2[b] : xi == 2 ? d2[b] - d1[b] : d1[b] - d3[b];
+      v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+    };
+    ld_b(0, bf[0]);
+    xform(0, vv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int g = u / NR, j = u % NR;
+      if (u + 1 < NU) {
+        ld_b(u + 1, bf[(u + 1) & 1]);
+        if ((u + 1) % NR == 0) xform(g + 1, vv[(g + 1) & 1]);
+      }
+      if (j == NR - 1) {                                 // (after the transform above in program order: its operands are dead)
+        if (g == 0) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) d0[b] = *(const f32x4*)(dp + (0 * IW + b) * SPX);
+        } else if (g == 1) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) d3[b] = *(const f32x4*)(dp + (3 * IW + b) * SPX);
+        } else if (g == 2 && last) {
+          load_old();
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+          macc[XO[g] * 4 + nu][j] = mfma16(vv[g & 1][nu][s], bf[u & 1][nu][s], macc[XO[g] * 4 + nu][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  auto out_transform = [&]() {                          // A^T m A, element-wise over the lane's four tiles; resets the accumulators
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      f32x4 c0[4], c1[4];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        c0[nu] = macc[0 + nu][j] + macc[4 + nu][j] + macc[8 + nu][j];
+        c1[nu] = macc[4 + nu][j] - macc[8 + nu][j] - macc[12 + nu][j];
+      }
+      acc[0][j] = c0[0] + c0[1] + c0[2]; acc[1][j] = c0[1] - c0[2] - c0[3];
+      acc[2][j] = c1[0] + c1[1] + c1[2]; acc[3][j] = c1[1] - c1[2] - c1[3];
+#pragma unroll
+      for (int p_ = 0; p_ < 16; ++p_) macc[p_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if constexpr (SC2) {
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_) { acc[q_][j] += qacc[q_][j]; qacc[q_][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+      }
+    }
+  };
+
+  prefetch(0);
+  if (nch == 1) advance(pn, pty, ptx);
+  __syncthreads();
+  publish();
+  __syncthreads();
+  // one chunk = one region: next loads, this chunk's MFMAs, (last chunk of an item: transform, statistics, stores), publish.
+  // `last` is a compile-time tag: as a run-time condition the compiler predicated the whole epilogue into every chunk
+  auto region = [&](int c, bool more, auto last_tag) {
+    constexpr bool last = decltype(last_tag)::value;
+    if (more) {
+      prefetch(last ? 0 : c + 1);
+      if (c + 2 == nch || nch == 1) advance(pn, pty, ptx);        // the prefetch after the next one starts a new item
+    }
+    mma_chunk(c, last_tag);
+    if constexpr (last) { out_transform(); epilogue(); }
+    __syncthreads();                                     // in_s / w_s are free; red[] is complete
+    if constexpr (last) stats_out();
+    if (more) publish();
+    __syncthreads();
+  };
+  for (int item = item0; item < item1; ++item) {
+#pragma unroll 1
+    for (int c = 0; c + 1 < nch; ++c) region(c, true, std::false_type{});
+    region(nch - 1, item + 1 < item1, std::true_type{});
+    advance(cn, cty, ctx);
+  }
+}
+
+inline int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n > 0 ? n : 256;
+  }();
+  return cus;
+}
+
+template <auto Kern>
+inline void allow_big_lds(size_t bytes) {
+  static bool done = false;
+  if (!done && bytes > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    done = true;
+  }
+}
+
+template <int NTN>
+int launch_ntn(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W, int Kdim, int Ndim,
+               int transposed, float* stats, const WinoBst* bst, const WinoAff* aff, const WinoSc* sc, hipStream_t st) {
+  const int tiles_x = W / TW, tiles_img = tiles_x * (H / TH);
+  const int nz = Ndim / (16 * NTN);
+  const int64_t items = (int64_t)N * tiles_img;
+  const int per_cu = NTN >= 2 ? 1 : 2;                  // resident workgroups per CU (registers)
+  const int64_t slots = (int64_t)device_cus() * per_cu;
+  int ipw = (int)((items * nz + slots - 1) / slots);
+  if (ipw < 1) ipw = 1;
+  dim3 grid((unsigned)((items + ipw - 1) / ipw), nz);
+  const int nch = Kdim / 16;
+  const WinoBst bv = bst ? *bst : WinoBst{};
+  const WinoAff av = aff ? *aff : WinoAff{};
+  const WinoSc sv = sc ? *sc : WinoSc{};
+  const bool sc2 = sc && (transposed & 1), scf = sc && !sc2;
+  const size_t sh = wino_l_lds<NTN>(scf);
+#define WGO(ST, AC, BS, DU, IA, S1, S2)                                                                                    \
+  do {                                                                                                                     \
+    allow_big_lds<conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2>>(sh);                                                       \
+    conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2><<<grid, TPB, sh, st>>>(x, x2, w, y, y2, split, N, H, W, nch, Ndim, tiles_x, \
+                                                                        tiles_img, ipw, transposed, stats, bv, av, sv);    \
+  } while (0)
+  if (sc2) {
+    if (!x2 || !sc->w || stats || bst || aff || (transposed & 2) || nch % 2) return -1;
+    WGO(false, false, false, true, false, false, true);
+  } else if (scf) {
+    if (!stats || bst || aff || y2 || transposed || !sc->w || !sc->y || !sc->stats || (x2 && nch % 2)) return -1;
+    if (x2) WGO(true, false, false, true, false, true, false);
+    else WGO(true, false, false, false, false, true, false);
+  } else if (aff) {
+    if (!stats || bst || y2 || x2 || transposed) return -1;
+    WGO(true, false, false, false, true, false, false);
+  } else if (x2) {
+    if (!stats || bst || y2 || transposed || nch % 2) return -1;
+    WGO(true, false, false, true, false, false, false);
+  } else if (bst) {
+    if (!stats || y2 || (transposed & 2)) return -1;
+    WGO(false, false, true, false, false, false, false);
+  } else if (transposed & 2) {
+    if (stats) return -1;
+    WGO(false, true, false, false, false, false, false);
+  } else if (stats) {
+    if (y2) return -1;
+    WGO(true, false, false, false, false, false, false);
+  } else {
+    WGO(false, false, false, false, false, false, false);
+  }
+#undef WGO
+  return 0;
+}
+
+}  // namespace
+
+bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim) {
+  static const bool on = [] { const char* e = getenv("SMSUT_WINOGRAD_L"); return !e || atoi(e) != 0; }();
+  return on && N > 0 && H >= 16 && W >= 16 && H % TH == 0 && W % TW == 0 && Kdim >= 32 && Kdim % 16 == 0 && Ndim >= 16 && Ndim % 16 == 0 &&
+         (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) < (1ll << 31);
+}
+
+int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W,
+                        int Kdim, int Ndim, int transposed, float* stats, int* tiles_out, const WinoBst* bst, const WinoAff* aff,
+                        const WinoSc* sc, hipStream_t st) {
+  if (!smsut_wino_l_eligible(N, H, W, Kdim, Ndim)) return -1;
+  if (y2 && (split <= 0 || split >= Ndim || split % 16 != 0 || (Ndim - split) % 16 != 0 || stats || bst)) return -1;
+  if (tiles_out) { *tiles_out = (W / TW) * (H / TH); return 0; }
+  // output-channel slabs per workgroup: two (one input transform feeds 32 channels, one wave per SIMD) when the grid still
+  // fills the chip and no slab straddles a split; SMSUT_WINO_NTN forces 1 / 2 (tuning hook)
+  static const int force = [] { const char* e = getenv("SMSUT_WINO_NTN"); return e ? atoi(e) : 0; }();
+  const int64_t items = (int64_t)N * (W / TW) * (H / TH);
+  int ntn = (Ndim % 32 == 0 && !(y2 && split % 32 != 0) && items * (Ndim / 32) >= device_cus()) ? 2 : 1;
+  if (force == 1 || (force == 2 && Ndim % 32 == 0 && !(y2 && split % 32 != 0))) ntn = force;
+  if (ntn == 2) return launch_ntn<2>(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
+  return launch_ntn<1>(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
+}

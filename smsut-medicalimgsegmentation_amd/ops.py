@@ -215,7 +215,7 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False, f16=False):
         if want_stats and bias is None:
             # fused InstanceNorm statistics: the conv epilogue leaves {sum, sum^2} partials that the following
             # instnorm_act picks up from the tensor object (side channel; autograd is unaffected)
-            tiles = H.call("smsut_conv2d_mfma_tiles", n, h, wd, ci, co, kh)
+            tiles = H.call("smsut_conv2d_mfma_tiles", n, h, wd, ci, co, kh, int(f16))
             part = _ws(n * tiles * co * 2, x)
             H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", x, w, y, part, n, h, wd, ci, co,
                    kh, _s())
@@ -302,7 +302,7 @@ def _conv_wgrad_launch(x, gy, kh, kw, stride, pad, f16=False):
 def conv_fwd_kernel_name(cin, cout, k, stride, pad, n=1, h=0, w=0):
     """Which device kernel ``conv2d`` dispatches to for this layer shape: (symbol, 'mfma' | 'generic')."""
     if H.call("smsut_conv2d_mfma_supported", k, stride, pad, cin, cout):
-        if h and w and H.call("smsut_conv2d_mfma_persistent", n, h, w, cin, cout, k):
+        if h and w and H.call("smsut_conv2d_mfma_persistent", n, h, w, cin, cout, k, 0):
             return "conv_mfma_fwd_p", "mfma"
         return "conv_mfma_fwd", "mfma"
     return "conv_fwd_naive", "generic"
@@ -685,8 +685,6 @@ class BasicBlockFn(Function):
         def stat(c):
             return torch.empty(n, c, dtype=torch.float32, device=dev), torch.empty(n, c, dtype=torch.float32, device=dev)
 
-        t3 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 3)        # tile shape depends on (N, H, W, Cin, Cout)
-        t3b = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
         # fp16 operands (config 5): both 3x3 convs of the block and their gradients, when every reduction is whole 16-channel
         # chunks; same tile selection / statistics layout as the fp32 forms
         # (per conv: the 8 -> 16 first block keeps conv1 in fp32 -- half of a 16-channel chunk would be padding -- but its
@@ -694,6 +692,8 @@ class BasicBlockFn(Function):
         f16a = CONV_F16 and ci % 16 == 0 and co % 16 == 0          # conv1 and its gradients
         f16 = CONV_F16 and co % 16 == 0                            # conv2 and its gradients
         ctx.f16 = (f16a, f16)
+        t3 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 3, int(f16a))    # tile shape depends on (N, H, W, Cin, Cout, dtype)
+        t3b = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3, int(f16))
         y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
         # conv1 and the 1x1 shortcut read the same block input: one pass (the shortcut is conv1's centre tap with its own weights)
@@ -714,7 +714,7 @@ class BasicBlockFn(Function):
         # (co % 32: the tap-split weight-gradient kernel takes the transform for +4 us; on the 16-channel kernel it cost
         #  +55 us at 32x256^2, more than the apply pass it removes -- scratch/inaff_ab.py)
         inaff = (INAFF_CONV2 and not f16 and co % 32 == 0
-                 and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3)))
+                 and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, 0)))
         ctx.inaff = inaff
         if inaff:
             # conv2 (and later its weight gradient) normalise the raw conv1 output while staging their tiles: a1 is never built
@@ -740,7 +740,7 @@ class BasicBlockFn(Function):
                 ps = _ws(n * t1 * co * 2, x)
                 H.call("smsut_conv1x1_fwd", x, ws, s, ps, n, hw, ci, co, 0, st)
             else:
-                t1 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 1)
+                t1 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 1, 0)
                 ps = _ws(n * t1 * co * 2, x)
                 H.call("smsut_conv2d_fwd_mfma_stats", x, ws, s, ps, n, h, w, ci, co, 1, st)
             ms, rs = stat(co)
@@ -804,9 +804,9 @@ class BasicBlockFn(Function):
         a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
         f16a, f16 = ctx.f16                                  # fp16 operands for conv1 / conv2 and their gradients
         sc2 = _grad_scale(gy2) if f16 else None              # one absmax pass serves conv2's data- and weight-gradient
-        if FUSED_BWD_STATS and H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3):
+        if FUSED_BWD_STATS and H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, int(f16)):
             # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
-            tb = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3)
+            tb = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3, int(f16))
             pb = _ws(n * tb * co * 2, x)
             if f16:
                 H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, sc2, slope, n, h, w, co, co, st)

@@ -483,7 +483,7 @@ def test_virtual_cat_entries_bit_identical(ops, n, h, ca, co):
     H.call("smsut_conv2d_fwd_mfma", gy, w3, gfull, n, h, h, co, ci, 3, 3, st)           # accumulate forms on top
     H.call("smsut_conv2d_fwd_mfma_split", gy, w3, ga, gb, ca, n, h, h, co, ci, 3, st)
     assert torch.equal(gfull[..., :ca].contiguous(), ga) and torch.equal(gfull[..., ca:].contiguous(), gb)
-    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3)
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3, 0)
     y0, y1 = torch.empty(n, h, h, co, device="cuda"), torch.empty(n, h, h, co, device="cuda")
     p0, p1 = torch.zeros(n * tiles * co * 2, device="cuda"), torch.zeros(n * tiles * co * 2, device="cuda")
     H.call("smsut_conv2d_fwd_mfma_stats", cat, w3, y0, p0, n, h, h, ci, co, 3, st)
@@ -523,8 +523,8 @@ def test_input_side_instnorm_conv_bit_identical(ops, n, h, c):
     hw = h * h
     if os.environ.get("SMSUT_CONV_PERSISTENT", "1") == "0":
         pytest.skip("SMSUT_CONV_PERSISTENT=0 in the environment")
-    assert H.call("smsut_conv2d_mfma_persistent", n, h, h, c, c, 3) == 1
-    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3)
+    assert H.call("smsut_conv2d_mfma_persistent", n, h, h, c, c, 3, 0) == 1
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3, 0)
     E = lambda *s: torch.empty(*s, device="cuda")
     y1, a1, p1 = E(n, h, h, c), E(n, h, h, c), torch.zeros(n * tiles * c * 2, device="cuda")
     H.call("smsut_conv2d_fwd_mfma_stats", x0, w1, y1, p1, n, h, h, c, c, 3, st)
@@ -574,7 +574,7 @@ def test_fused_shortcut_conv(ops, n, h, ci, co):
     g = torch.Generator(device="cpu").manual_seed(11)
     x = torch.randn(n, h, h, ci, generator=g).cuda()
     w3 = (torch.randn(9 * ci * co, generator=g) / np.sqrt(9 * ci)).cuda(); w1 = (torch.randn(ci * co, generator=g) / np.sqrt(ci)).cuda()
-    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3)
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3, 0)
     hw = h * h
     y0, y1, s1 = (torch.full((n, h, h, co), float("nan"), device="cuda") for _ in range(3))
     p0, p1, q1 = (torch.zeros(n * tiles * co * 2, device="cuda") for _ in range(3))
