@@ -48,13 +48,17 @@ __device__ __forceinline__ float aff1(float v, float m, float r, float g, float 
   return lrelu_f(in_affine(v, m, r, g, b), slope);
 }
 
+// LDS: TWO staging buffers {input tile, U chunk, (SC) 1x1 chunk} -- chunk t+1 is published while chunk t multiplies, one
+// barrier per chunk -- plus the statistics scratch
+template <int NTN>
+constexpr int wino_l_buf_floats(bool sc) { return (IH * IW + 1) * SPX + 16 * 16 * 16 * NTN + (sc ? 16 * 16 * NTN : 0); }
 template <int NTN>
 constexpr size_t wino_l_lds(bool sc) {
-  return (size_t)((IH * IW + 1) * SPX + 4 * 16 * NTN * 2 + 8 + 16 * 16 * 16 * NTN + (sc ? 16 * 16 * NTN + 4 * 16 * NTN * 2 + 8 : 0)) * sizeof(float);
+  return (size_t)(2 * wino_l_buf_floats<NTN>(sc) + (4 * 16 * NTN * 2 + 8) * (sc ? 2 : 1)) * sizeof(float);
 }
 
 template <int NTN, bool STATS, bool ACC, bool BST, bool DUAL, bool INAFF, bool SC, bool SC2>
-__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(NTN >= 2 ? 1 : 2, NTN >= 2 ? 1 : 2)))
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ w, float* __restrict__ y,
             float* __restrict__ y2, int split, int N, int H, int W, int nch, int Ndim, int tiles_x, int tiles_img, int items_per_wg,
             int transposed, float* __restrict__ stats, WinoBst bst, WinoAff aff, WinoSc sc) {
@@ -64,11 +68,14 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !SC), "fused shortcut data-gradient");
   constexpr int CO_T = 16 * NTN, NR = NTN;
   extern __shared__ float smem[];
-  float* in_s = smem;                                  // [IH][IW][SPX] + one dummy pixel (sink of the padding units)
-  float* red = smem + (IH * IW + 1) * SPX;             // [4 waves][CO_T][2] + dummy
-  float* w_s = red + 4 * CO_T * 2 + 8;                 // this chunk's U: [16 positions][4 channel quads][CO_T][4]
-  [[maybe_unused]] float* wsc_s = w_s + 16 * 16 * CO_T;   // SC: this chunk's 1x1 weights [4][CO_T][4]
-  [[maybe_unused]] float* red_sc = wsc_s + 16 * CO_T;     // SC: [4][CO_T][2] + dummy
+  constexpr int BUF = wino_l_buf_floats<NTN>(SC);      // floats per staging buffer
+  constexpr int IN_F = (IH * IW + 1) * SPX;            // [IH][IW][SPX] + one dummy pixel (sink of the padding units)
+  constexpr int W_F = 16 * 16 * CO_T;                  // a chunk's U: [16 positions][4 channel quads][CO_T][4]
+  float* red = smem + 2 * BUF;                         // [4 waves][CO_T][2] + dummy
+  [[maybe_unused]] float* red_sc = red + 4 * CO_T * 2 + 8;
+  auto in_b = [&](int b) { return smem + b * BUF; };
+  auto w_b = [&](int b) { return smem + b * BUF + IN_F; };
+  [[maybe_unused]] auto wsc_b = [&](int b) { return smem + b * BUF + IN_F + W_F; };   // SC: a chunk's 1x1 weights [4][CO_T][4]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -126,81 +133,101 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   // (tap, chunk) blocks: forward w + (tap * Kd + 16 c) * Ndim, transposed w + (8 - tap) * Ndim * KROW + 16 c -- uniform, so a
   // weight load is one scalar base + the thread's 32-bit offset (no per-load 64-bit vector arithmetic)
 
-  int pn = item0 / tiles_img, pty, ptx;                // cursor of the item being prefetched
+  int pn = item0 / tiles_img, pty, ptx;                // item of the NEXT prefetch ...
   { const int t = item0 - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
-  int cn = pn, cty = pty, ctx = ptx;                   // ... of the item being computed
-  int pflags = 0, pc = 0;                              // borders the prefetched tile touches; chunk held in the staging registers
+  int pch = 0;                                         // ... and its chunk
+  int cn = pn, cty = pty, ctx = ptx;                   // item being computed
+  int pubc = 0;                                        // chunk whose operands the staging registers hold (to be published)
+  int pfc = 0, pfl = 0;                                // chunk being prefetched, borders its tile touches
+  const float* xb = x;                                 // its input base (tile's first halo pixel, chunk's first channel)
+  int left = (item1 - item0) * nch;                    // chunks not yet requested
   [[maybe_unused]] float4 a_m, a_r, a_g, a_b;
 
   auto advance = [&](int& n_, int& ty_, int& tx_) {
     if (++tx_ == tiles_x) { tx_ = 0; if (++ty_ == tiles_y) { ty_ = 0; ++n_; } }
   };
-  auto prefetch = [&](int c) {
-    pc = c;
-    if (c == 0) pflags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
-    const int cl = (DUAL && c >= nh) ? c - nh : c;
+  // The staging work of a region is cut into NP = NI + NTN parts (an input unit or a weight pair each) so that it can be spread
+  // over the MFMA units of the chunk that multiplies meanwhile: part p first PUBLISHES what its registers hold (operands of the
+  // next chunk, requested a whole region ago) into the other LDS buffer, then REQUESTS the chunk after that into the same
+  // registers.  Everything is unconditional straight-line code (a branch would cut the scheduling region): past the workgroup's
+  // last chunk the cursor stops and the last chunk is simply requested again.
+  auto pf_setup = [&]() {                              // uniform: where the next request reads from
+    pubc = pfc;
+    pfc = pch;
+    pfl = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
+    const int cl = (DUAL && pch >= nh) ? pch - nh : pch;
     const int base = (((pn * H + pty * TH - 1) * W) + ptx * TW - 1) * KST + cl * 16;
-    const float* xb = ((DUAL && c >= nh) ? x2 : x) + base;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      zero[i] = (u_flag[i] & pflags) != 0;
-      rin[i] = *(const float4*)(xb + (unsigned)(zero[i] ? safe_off : u_off[i]));
+    xb = ((DUAL && pch >= nh) ? x2 : x) + base;
+  };
+  auto pf_advance = [&]() {                            // after the region's requests have been issued
+    if (left > 1) {
+      --left;
+      if (++pch == nch) { pch = 0; advance(pn, pty, ptx); }
     }
+  };
+  auto pf_in = [&](int i) {
+    zero[i] = (u_flag[i] & pfl) != 0;
+    rin[i] = *(const float4*)(xb + (unsigned)(zero[i] ? safe_off : u_off[i]));
+  };
+  auto pf_aff = [&]() {
     if constexpr (INAFF) {
-      const int ch = c * 16 + 4 * (tid & 3);
+      const int ch = pfc * 16 + 4 * (tid & 3);
       a_m = *(const float4*)(aff.mean + (size_t)pn * Kd + ch);
       a_r = *(const float4*)(aff.rstd + (size_t)pn * Kd + ch);
       a_g = *(const float4*)(aff.gamma + ch);
       a_b = *(const float4*)(aff.beta + ch);
     }
-#pragma unroll
-    for (int k = 0; k < NTN; ++k) {
-      if (SC2 && c >= nh) {
-        wreg[k][0] = (sc.w + (c - nh) * 16)[w_off1[k]];
-      } else if (tr) {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = (w + (size_t)(8 - tap) * Ndim * KROW + c * 16)[w_off[k]];
-      } else {
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = (w + ((size_t)tap * Kd + c * 16) * Ndim)[w_off[k]];
-      }
-      if constexpr (SC) wx[k] = (sc.w + (size_t)(c * 16) * Ndim)[w_off1[k]];
-    }
   };
-  auto publish = [&]() {
+  auto pf_w = [&](int k) {
+    const int c = pfc;
+    if (SC2 && c >= nh) {
+      wreg[k][0] = (sc.w + (c - nh) * 16)[w_off1[k]];
+    } else {
+      // tap t's block: forward w + (t * Kd + 16 c) * Ndim, transposed w + (8 - t) * Ndim * KROW + 16 c -- selected with scalar
+      // arithmetic, not a branch (a branch here cuts the MFMA unit this part rides in out of its scheduling region)
+      const ptrdiff_t tstep = tr ? -(ptrdiff_t)Ndim * KROW : (ptrdiff_t)Kd * Ndim;
+      const float* w0 = tr ? w + (size_t)8 * Ndim * KROW + c * 16 : w + (size_t)c * 16 * Ndim;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      float4 v = rin[i];
-      if constexpr (INAFF) {
-        v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
-        v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
-      }
-      if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      *(float4*)(in_s + u_lds[i]) = v;
+      for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = (w0 + tap * tstep)[w_off[k]];
     }
-#pragma unroll
-    for (int k = 0; k < NTN; ++k) {
-      const int ci = w_ci[k], n = w_n[k];
-      float* dst = w_s + ((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3);        // + pos * 4 * CO_T * 4
-      if (SC2 && pc >= nh) {
-        dst[0] = wreg[k][0];                             // the 1x1 weights, parked in position 0's block
-      } else {
-        // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-        float t[4][3];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-          const float g0 = wreg[k][b], g1 = wreg[k][3 + b], g2 = wreg[k][6 + b];
-          t[0][b] = g0; t[1][b] = 0.5f * (g0 + g1 + g2); t[2][b] = 0.5f * (g0 - g1 + g2); t[3][b] = g2;
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-          const float uu[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
-#pragma unroll
-          for (int b = 0; b < 4; ++b) dst[(size_t)(a * 4 + b) * 4 * CO_T * 4] = uu[b];
-        }
-      }
-      if constexpr (SC) wsc_s[((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3)] = wx[k];
+    if constexpr (SC) wx[k] = (sc.w + (size_t)(c * 16) * Ndim)[w_off1[k]];
+  };
+  auto pub_in = [&](int i, int b) {
+    float4 v = rin[i];
+    if constexpr (INAFF) {
+      v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+      v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
     }
+    if (zero[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *(float4*)(in_b(b) + u_lds[i]) = v;
+  };
+  auto pub_w = [&](int k, int b) {
+    const int ci = w_ci[k], n = w_n[k];
+    float* dst = w_b(b) + ((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3);        // + pos * 4 * CO_T * 4
+    if (SC2 && pubc >= nh) {
+      dst[0] = wreg[k][0];                               // the 1x1 weights, parked in position 0's block
+    } else {
+      // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+      float t[4][3];
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        const float g0 = wreg[k][bb], g1 = wreg[k][3 + bb], g2 = wreg[k][6 + bb];
+        t[0][bb] = g0; t[1][bb] = 0.5f * (g0 + g1 + g2); t[2][bb] = 0.5f * (g0 - g1 + g2); t[3][bb] = g2;
+      }
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const float uu[4] = {t[a][0], 0.5f * (t[a][0] + t[a][1] + t[a][2]), 0.5f * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) dst[(size_t)(a * 4 + bb) * 4 * CO_T * 4] = uu[bb];
+      }
+    }
+    if constexpr (SC) wsc_b(b)[((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3)] = wx[k];
+  };
+  constexpr int NP = NI + NTN;                          // staging parts
+  // part p of the region that multiplies from buffer b: publish into b ^ 1, then request
+  auto stage_part = [&](int p_, int b) {
+    if (p_ < NI) { pub_in(p_, b ^ 1); pf_in(p_); }
+    else { pub_w(p_ - NI, b ^ 1); pf_w(p_ - NI); }
   };
 
   f32x4 macc[16][NR], acc[4][NR];
@@ -317,8 +344,11 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   };
 
   // ---- one chunk of MFMAs: lane (lm = tile, kq = channel quad) of this wave's 4 x 16-pixel strip
-  auto mma_chunk = [&](int c, auto last_tag) {
+  auto mma_chunk = [&](int c, int buf, auto last_tag) {
     constexpr bool last = decltype(last_tag)::value;
+    const float* in_s = in_b(buf);
+    const float* w_s = w_b(buf);
+    [[maybe_unused]] const float* wsc_s = wsc_b(buf);
     // window of tile (tr, tc) = (lm >> 3, lm & 7): rows wave*4 + 2*tr + a, columns 2*tc + b, channel quad kq
     const float* dp = in_s + (((wave * 4 + 2 * (lm >> 3)) * IW) + 2 * (lm & 7)) * SPX + 4 * kq;
     const float* wc = w_s + ((size_t)kq * CO_T + lm) * 4;              // + (pos * 4 * CO_T + j * 16) * 4
@@ -334,6 +364,8 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
 #pragma unroll
             for (int q_ = 0; q_ < 4; ++q_) qacc[q_][j] = mfma16(px[q_][s], bw[s], qacc[q_][j]);
         }
+#pragma unroll
+        for (int p_ = 0; p_ < NP; ++p_) stage_part(p_, buf);
         return;                                          // (SC2 has no ACC / BST operands to request)
       }
     }
@@ -381,6 +413,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int g = u / NR, j = u % NR;
+#pragma unroll
+      for (int p_ = 0; p_ < NP; ++p_)
+        if (p_ % NU == u) stage_part(p_, buf);           // this unit's share of the staging work, in the shadow of its MFMAs
       if (u + 1 < NU) {
         ld_b(u + 1, bf[(u + 1) & 1]);
         if ((u + 1) % NR == 0) xform(g + 1, vv[(g + 1) & 1]);
@@ -424,30 +459,38 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     }
   };
 
-  prefetch(0);
-  if (nch == 1) advance(pn, pty, ptx);
+  // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
+  pf_setup();
+#pragma unroll
+  for (int i = 0; i < NI; ++i) pf_in(i);
+#pragma unroll
+  for (int k = 0; k < NTN; ++k) pf_w(k);
+  pf_aff();
+  pf_advance();
+  pf_setup();                                           // (pubc = 0: what the registers hold)
+#pragma unroll
+  for (int p_ = 0; p_ < NP; ++p_) stage_part(p_, 1);    // publishes into buffer 0, requests chunk 1
+  pf_aff();
+  pf_advance();
   __syncthreads();
-  publish();
-  __syncthreads();
-  // one chunk = one region: next loads, this chunk's MFMAs, (last chunk of an item: transform, statistics, stores), publish.
-  // `last` is a compile-time tag: as a run-time condition the compiler predicated the whole epilogue into every chunk
-  auto region = [&](int c, bool more, auto last_tag) {
+  int buf = 0;
+  // one chunk = one region = one barrier: staging parts + this chunk's MFMAs (+ on an item's last chunk: transform, statistics,
+  // stores).  `last` is a compile-time tag: as a run-time condition the compiler predicated the whole epilogue into every chunk
+  auto region = [&](int c, auto last_tag) {
     constexpr bool last = decltype(last_tag)::value;
-    if (more) {
-      prefetch(last ? 0 : c + 1);
-      if (c + 2 == nch || nch == 1) advance(pn, pty, ptx);        // the prefetch after the next one starts a new item
-    }
-    mma_chunk(c, last_tag);
+    pf_setup();
+    mma_chunk(c, buf, last_tag);
+    pf_aff();
+    pf_advance();
     if constexpr (last) { out_transform(); epilogue(); }
-    __syncthreads();                                     // in_s / w_s are free; red[] is complete
+    __syncthreads();                                     // buffer buf is free, buf ^ 1 is complete; red[] is complete
     if constexpr (last) stats_out();
-    if (more) publish();
-    __syncthreads();
+    buf ^= 1;
   };
   for (int item = item0; item < item1; ++item) {
 #pragma unroll 1
-    for (int c = 0; c + 1 < nch; ++c) region(c, true, std::false_type{});
-    region(nch - 1, item + 1 < item1, std::true_type{});
+    for (int c = 0; c + 1 < nch; ++c) region(c, std::false_type{});
+    region(nch - 1, std::true_type{});
     advance(cn, cty, ctx);
   }
 }
@@ -476,7 +519,7 @@ int launch_ntn(const float* x, const float* x2, const float* w, float* y, float*
   const int tiles_x = W / TW, tiles_img = tiles_x * (H / TH);
   const int nz = Ndim / (16 * NTN);
   const int64_t items = (int64_t)N * tiles_img;
-  const int per_cu = NTN >= 2 ? 1 : 2;                  // resident workgroups per CU (registers)
+  const int per_cu = 1;                                 // resident workgroups per CU (one wave per SIMD: registers, 2 LDS buffers)
   const int64_t slots = (int64_t)device_cus() * per_cu;
   int ipw = (int)((items * nz + slots - 1) / slots);
   if (ipw < 1) ipw = 1;
