@@ -33,7 +33,7 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0
 EXECUTED_GFLOP_PER_SLICE_UGAN = 1475.4 / 16     # conv FLOPs one uganConsis iteration of THIS build executes (census, 8 + 8 slices)
 REFERENCE_GFLOP_PER_SLICE_UGAN = 1710.0 / 16    # the reference's iteration: G(x_real) twice
-PMC_FILE = "r02_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
+PMC_FILE = "r03_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
 
 
 def host_cores():
@@ -69,9 +69,10 @@ def pmc_traffic_per_slice():
 def measure_dominant_conv(dev, batch, size=256, f16=False):
     """HIP-event timing of the dominant kernel AS THE STEP LAUNCHES IT: conv3x3 s1 p1 of the decoder-level-1 block
     (blocks.py dec layer1.conv1: cat([up, skip]) [B,16+16,256,256] -> 16 ch), i.e. the persistent resident-weight kernel
-    with the InstanceNorm-statistics epilogue and the virtual-cat input (``smsut_conv2d_fwd_mfma_stats_cat`` ->
-    ``conv_mfma_fwd_p<3,8,1,2,STATS,..,DUAL>``); the 3x3 @256^2 layer class holds the largest share of the step's FLOPs.
-    Returns the roofline dict."""
+    with the InstanceNorm-statistics epilogue and the virtual-cat input (``smsut_conv2d_fwd_mfma_stats_cat``); since r03 its
+    fp32 form is Winograd F(2x2,3x3) (``conv_mfma_fwd_p<3,16,1,2,STATS,..,DUAL,..,WINO>``: 16 products per 2x2 output tile
+    instead of 36).  ``achieved`` is ALGORITHMIC FLOPs (2 N H W Cin Cout 9, SURVEY 8d) / launch time, as the contract defines it;
+    ``executed_mfma_*`` is what the matrix pipes actually did (algorithmic / 2.25).  Returns the roofline dict."""
     from smsut_amd import ops, _hip as H
     cin, cout, h = 32, 16, size
     cl = torch.channels_last
@@ -113,13 +114,20 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
                 "algorithmic_gbytes_per_launch": round(byts / 1e9, 4), "tflops": round(achieved, 2),
                 "frac_of_fp16_mfma_peak": round(achieved / FP16_MFMA_PEAK_TFLOPS, 4),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
+    wino = os.environ.get("SMSUT_WINOGRAD", "1") not in ("0", "") and size % 16 == 0
+    kname = ("conv_mfma_fwd_p<3,16,1,2,STATS,DUAL,WINO> (Winograd F(2x2,3x3))" if wino else "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL>") + \
+        " via smsut_conv2d_fwd_mfma_stats_cat"
+    executed = achieved / 2.25 if wino else achieved
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "achieved_note": "algorithmic conv FLOPs / launch time; the Winograd form executes 1/2.25 of them on the matrix pipes" if wino
+                             else "algorithmic = executed FLOPs (direct form)",
+            "executed_mfma_tflops": round(executed, 3), "executed_mfma_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
             "traffic": None if per_slice is None else round(per_slice * batch),
             "traffic_unit": f"HBM bytes per launch (PMC, profiles/{PMC_FILE})",
             "traffic_source": "PROFILED, not live: FETCH_SIZE x2 + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes "
                               "(counters cannot be read in-process), per slice, scaled to this run's batch",
-            "kernel": "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL> via smsut_conv2d_fwd_mfma_stats_cat", "kernel_kind": "mfma",
+            "kernel": kname, "kernel_kind": "mfma",
             "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),

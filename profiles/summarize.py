@@ -120,7 +120,8 @@ try:
         dom["wave_time_split"] = {k: round(sq[k] / sq["SQ_WAVE_CYCLES"], 3) for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY")
                                   if k in sq and sq.get("SQ_WAVE_CYCLES")}
         sq_note = (f"SQ pass: SQ_VALU_MFMA_BUSY_CYCLES {sq['SQ_VALU_MFMA_BUSY_CYCLES']:.4g} = {dom['mfma_busy_over_algorithmic']}x the algorithmic "
-                   f"FLOPs / 64 (no padded MFMAs), GRBM_GUI_ACTIVE / 8 = {cycles:.0f} cycles -> **MFMA pipes busy {dom['mfma_busy_frac'] * 100:.1f} %** "
+                   f"FLOPs / 64 (1.0 = direct form without padded MFMAs; 0.444 = Winograd F(2x2,3x3): 16 products per tile instead of 36), "
+                   f"GRBM_GUI_ACTIVE / 8 = {cycles:.0f} cycles -> **MFMA pipes busy {dom['mfma_busy_frac'] * 100:.1f} %** "
                    f"of the kernel's cycles; wave time: {dom['wave_time_split']}.")
 except SystemExit:
     pass

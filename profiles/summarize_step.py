@@ -28,7 +28,7 @@ SIMDS = 256 * 4
 
 # first match wins
 CLASSES = [
-    ("3x3 fwd/dgrad (MFMA)", r"conv_mfma_fwd_p<3|conv_mfma_fwd<3|conv_k4_fwd"),
+    ("3x3 fwd/dgrad (MFMA)", r"conv_mfma_fwd_p<3|conv_mfma_fwd<3|conv_k4_fwd|conv_wino_l"),
     ("3x3 wgrad (MFMA)", r"conv_mfma_wgrad<3|conv_mfma_wgrad_ts|conv_f16_wgrad|plane_wgrad|sum_splits|conv_k4_wgrad"),
     ("ConvT 2x2", r"convT|conv_mfma_fwd<1|conv_mfma_fwd_p<1|conv_mfma_wgrad<1|ps_"),
     ("1x1 convs", r"conv1x1|thin1x1|sum_parts"),

@@ -1934,7 +1934,10 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
                         const ScRef* sc = nullptr) {
 #define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc
-  if (!f16 && wino_l_shape(N, H, W, Kdim, Ndim)) {         // Winograd, streamed weights (conv_wino.hip): every fp32 form
+  // (the fused shortcut data-gradient at 64 reduction channels stays on the direct resident-weight form: 107 us vs 142 us at
+  //  16 x 128^2 (32 + 32) -> 64 -- its second-half chunks are a run-time branch inside the staging parts, r03 notes)
+  const bool sc2_64 = sc && (transposed & 1) && Kdim == 64 && fwd_p_eligible(N, H, W, Kdim, Ndim);
+  if (!f16 && !sc2_64 && wino_l_shape(N, H, W, Kdim, Ndim)) {         // Winograd, streamed weights (conv_wino.hip): every fp32 form
     WinoBst wb; WinoAff wa; WinoSc ws;
     if (bst) wb = WinoBst{bst->y1, bst->mean, bst->rstd, bst->gamma, bst->beta, bst->slope};
     if (aff) wa = WinoAff{aff->mean, aff->rstd, aff->gamma, aff->beta, aff->slope};
