@@ -2667,9 +2667,19 @@ int smsut_conv2d_wgrad_mfma_supported(int KS, int stride, int pad, int Cin, int 
 }
 
 // workspace floats: splits * KS*KS*Cin*Cout
+// (3x3: the Winograd weight-gradient kernel of conv_wino.hip may take the shape instead; the workspace covers either)
+inline bool wino_wg_shape(int N, int H, int W, int Cin, int Cout, const float* x2, int ca) {
+  static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
+  return use_wino && smsut_wino_wg_eligible(N, H, W, Cin, Cout, x2, ca);
+}
 int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int KS) {
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
-  return (int64_t)p.splits * KS * KS * Cin * Cout;
+  int64_t need = (int64_t)p.splits * KS * KS * Cin * Cout;
+  if (KS == 3 && wino_wg_shape(N, H, W, Cin, Cout, nullptr, 0)) {
+    const int64_t wn = smsut_wino_wg_ws(N, H, W, Cin, Cout);
+    if (wn > need) need = wn;
+  }
+  return need;
 }
 
 // gw [KS*KS][Cin][Cout] = sum over pixels of x (x) gy
@@ -2695,6 +2705,14 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
   SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0 && (Cin - ca) % 4 == 0));
   SMSUT_REQUIRE(!aff || (KS == 3 && !x2));
   hipStream_t st = (hipStream_t)stream;
+  if (KS == 3 && !gs && wino_wg_shape(N, H, W, Cin, Cout, x2, ca)) {     // Winograd F(3x3, 2x2): plain, virtual-cat, input-side IN
+    WinoAff wa;
+    if (aff) wa = WinoAff{aff->mean, aff->rstd, aff->gamma, aff->beta, aff->slope};
+    if (smsut_wino_wg_launch(x, x2, ca, gy, gw, workspace, N, H, W, Cin, Cout, aff ? &wa : nullptr, st) == 0) {
+      SMSUT_LAUNCH_CHECK();
+      return SMSUT_OK;
+    }
+  }
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
   int rc = 0;                        // launch_wgrad: -1 = no kernel for this form (nothing was launched)
   if (KS == 1) {

@@ -17,3 +17,11 @@ bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim);
 int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W,
                         int Kdim, int Ndim, int transposed, float* stats, int* tiles_out, const WinoBst* bst, const WinoAff* aff,
                         const WinoSc* sc, hipStream_t st);
+
+// ---- Winograd weight gradient F(3x3, 2x2): gw[3][3][Cin][Cout] = sum_p x[p + tap] (x) gy[p] through
+//      dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G  (16 products per 2x2 tile of gy instead of 36).
+// x2 / ca: x is the virtual cat([x, x2]) with ca channels in x; aff: x is lrelu(IN(.)) of the tensor passed (zero padding after).
+bool smsut_wino_wg_eligible(int N, int H, int W, int Cin, int Cout, const float* x2, int ca);
+int64_t smsut_wino_wg_ws(int N, int H, int W, int Cin, int Cout);          // workspace floats
+int smsut_wino_wg_launch(const float* x, const float* x2, int ca, const float* gy, float* gw, float* workspace, int N, int H, int W,
+                         int Cin, int Cout, const WinoAff* aff, hipStream_t st);

@@ -565,6 +565,322 @@ int launch_ntn(const float* x, const float* x2, const float* w, float* y, float*
   return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight gradient (r03)
+// Winograd F(3x3, 2x2) weight gradient.  The forward form Y = A^T [(G g G^T) (.) (B^T d B)] A is bilinear in (g, d), so
+//   dg = G^T [ sum over tiles of (A dY A^T) (.) (B^T d B) ] G :
+// 16 per-position GEMMs dU[pos][ci][co] = sum_tiles V[pos][tile][ci] Z[pos][tile][co] with the TILES as the reduction -- 16
+// products per 2x2 tile of gy instead of 36.  MFMA roles: M = input channel, N = output channel, K = tile.  Lane (lm, kq) is
+// channel lm of BOTH operands for tiles 4kq .. 4kq+3 of the wave's 4 x 16-pixel strip (k-slot kq of MFMA s = tile 4kq + s): it
+// needs ONE channel of four neighbouring windows, the transpose of the pixel-major tensors -- so the operands are staged into
+// channel-major LDS planes (a thread's float4 = four channels of a pixel becomes four ds_write_b32 into four planes; plane sizes
+// 364 / 324 floats make the writes and the b128 row reads conflict-free).  Both transforms run in registers, position by position
+// (row combination xi, then column combination nu -> four tiles' values -> 4 x CIT x COT MFMAs), so only the raw rows stay live.
+// The negations of A's last row / column are left out (Z' = |A| dY |A|^T pattern with +) and applied as signs in the final pass.
+// A workgroup owns a (16 CIT x 16 COT) slab of (ci, co) and a range of 16x16-pixel items; its 4 waves take a strip each (partial
+// sums over different tiles), are combined through LDS at the end, and the split slabs are summed, sign-fixed and folded by
+// G^T . G into gw by wino_wg_final (fixed order: deterministic).
+constexpr int WRS = 20;                      // row stride (floats) of the channel-major planes
+constexpr int PSX = IH * WRS + 4;            // x plane: 18 rows (+4: plane stride / 4 odd -> conflict-free b128 reads across channels)
+constexpr int PSG = TH * WRS + 4;            // gy plane: 16 rows
+
+template <int CIT, int COT>
+constexpr int wino_wg_buf_floats() { return 16 * CIT * PSX + 16 * COT * PSG; }
+
+template <int CIT, int COT, bool DUAL, bool INAFF>
+__global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv_wino_wg(const float* __restrict__ x, const float* __restrict__ x2, int ca, const float* __restrict__ gy, float* __restrict__ part,
+             int N, int H, int W, int Cin, int Cout, int tiles_x, int tiles_img, int items_per_split, WinoAff aff) {
+  constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
+  constexpr int XB = CI_T * PSX;
+  constexpr int BUF = wino_wg_buf_floats<CIT, COT>();
+  constexpr int NUX = IH * IW * 4 * CIT, NIX = (NUX + TPB - 1) / TPB;      // float4 units of the x tile, per thread
+  constexpr int NIG = 4 * COT;                                              // ... of the gy tile (16 x 16 x 4 COT / 256)
+  extern __shared__ float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lm = lane & 15, kq = lane >> 4;
+  const int ci0 = blockIdx.y * CI_T, co0 = blockIdx.z * CO_T;
+  const int total_items = N * tiles_img;
+  const int item0 = blockIdx.x * items_per_split;
+  const int item1 = min(item0 + items_per_split, total_items);
+  const int tiles_y = tiles_img / tiles_x;
+  // source of this slab's x channels (virtual cat: a slab never straddles the seam -- host)
+  const bool second = DUAL && ci0 >= ca;
+  const float* xs = second ? x2 : x;
+  const int xst = DUAL ? (second ? Cin - ca : ca) : Cin;          // pixel stride of that tensor
+  const int xc0 = second ? ci0 - ca : ci0;                         // first channel of the slab inside it
+
+  int ux_off[NIX], ux_lds[NIX], ux_flag[NIX];
+  float4 rx[NIX];
+  bool zx[NIX];
+#pragma unroll
+  for (int i = 0; i < NIX; ++i) {
+    const int u = tid + i * TPB;
+    const bool real = u < NUX;
+    const int uu = real ? u : 0;
+    const int q = uu % (4 * CIT), pix = uu / (4 * CIT);
+    const int iy = pix / IW, ix = pix % IW;
+    ux_off[i] = (iy * W + ix) * xst + xc0 + 4 * q;
+    ux_lds[i] = real ? (4 * q) * PSX + iy * WRS + ix : -1;
+    ux_flag[i] = (iy < 1 ? 1 : 0) | (iy >= TH + 1 ? 2 : 0) | (ix < 1 ? 4 : 0) | (ix >= TW + 1 ? 8 : 0);
+  }
+  const int safe_off = (W + 1) * xst + xc0;
+  int ug_off[NIG], ug_lds[NIG];
+  float4 rg[NIG];
+#pragma unroll
+  for (int i = 0; i < NIG; ++i) {
+    const int u = tid + i * TPB;
+    const int q = u % (4 * COT), pix = u / (4 * COT);
+    const int oy = pix / TW, ox = pix % TW;
+    ug_off[i] = (oy * W + ox) * Cout + co0 + 4 * q;
+    ug_lds[i] = XB + (4 * q) * PSG + oy * WRS + ox;
+  }
+  [[maybe_unused]] float4 a_m, a_r, a_g, a_b;
+  if constexpr (INAFF) {
+    const int ch = ci0 + 4 * (tid % (4 * CIT));
+    a_g = *(const float4*)(aff.gamma + ch);
+    a_b = *(const float4*)(aff.beta + ch);
+  }
+
+  f32x4 macc[16][CIT][COT];
+#pragma unroll
+  for (int p_ = 0; p_ < 16; ++p_)
+#pragma unroll
+    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+      for (int b = 0; b < COT; ++b) macc[p_][a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int pn = item0 / tiles_img, pty, ptx;
+  { const int t = item0 - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
+  auto advance = [&](int& n_, int& ty_, int& tx_) {
+    if (++tx_ == tiles_x) { tx_ = 0; if (++ty_ == tiles_y) { ty_ = 0; ++n_; } }
+  };
+  auto prefetch = [&]() {                               // item (pn, pty, ptx) -> registers
+    const int pfl = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
+    const float* xb = xs + (ptrdiff_t)(((pn * H + pty * TH - 1) * W) + ptx * TW - 1) * xst;   // (may point before the tensor: only
+    const float* gb = gy + (ptrdiff_t)(((pn * H + pty * TH) * W) + ptx * TW) * Cout;            //  used with in-image offsets)
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+      zx[i] = (ux_flag[i] & pfl) != 0;
+      rx[i] = *(const float4*)(xb + (unsigned)(zx[i] ? safe_off : ux_off[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < NIG; ++i) rg[i] = *(const float4*)(gb + (unsigned)ug_off[i]);
+    if constexpr (INAFF) {
+      const int ch = ci0 + 4 * (tid % (4 * CIT));
+      a_m = *(const float4*)(aff.mean + (size_t)pn * Cin + ch);
+      a_r = *(const float4*)(aff.rstd + (size_t)pn * Cin + ch);
+    }
+  };
+  auto publish = [&](int b) {                           // registers -> channel-major planes of buffer b
+    float* base = smem + b * BUF;
+#pragma unroll
+    for (int i = 0; i < NIX; ++i) {
+      float4 v = rx[i];
+      if constexpr (INAFF) {
+        v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+        v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
+      }
+      if (zx[i]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ux_lds[i] >= 0) {
+        float* d = base + ux_lds[i];
+        d[0] = v.x; d[PSX] = v.y; d[2 * PSX] = v.z; d[3 * PSX] = v.w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NIG; ++i) {
+      float* d = base + ug_lds[i];
+      d[0] = rg[i].x; d[PSG] = rg[i].y; d[2 * PSG] = rg[i].z; d[3 * PSG] = rg[i].w;
+    }
+  };
+  auto compute = [&](int b) {
+    const float* base = smem + b * BUF;
+    const int ro = (wave * 4 + 2 * (kq >> 1)) * WRS + 8 * (kq & 1);     // first row / column of the lane's four tiles
+    float xr[CIT][4][10];                               // channel lm of slab block a: window rows 0..3, columns 0..9
+#pragma unroll
+    for (int a = 0; a < CIT; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* p_ = base + (a * 16 + lm) * PSX + ro + r * WRS;
+        const f32x4 v0 = *(const f32x4*)p_, v1 = *(const f32x4*)(p_ + 4);
+        const float2 v2 = *(const float2*)(p_ + 8);
+        xr[a][r][0] = v0[0]; xr[a][r][1] = v0[1]; xr[a][r][2] = v0[2]; xr[a][r][3] = v0[3];
+        xr[a][r][4] = v1[0]; xr[a][r][5] = v1[1]; xr[a][r][6] = v1[2]; xr[a][r][7] = v1[3];
+        xr[a][r][8] = v2.x; xr[a][r][9] = v2.y;
+      }
+    float gr[COT][2][8];                                // channel lm of slab block b: the strip's rows 2tr, 2tr+1, columns 0..7
+#pragma unroll
+    for (int b_ = 0; b_ < COT; ++b_)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const float* p_ = base + XB + (b_ * 16 + lm) * PSG + ro + r * WRS;
+        const f32x4 v0 = *(const f32x4*)p_, v1 = *(const f32x4*)(p_ + 4);
+        gr[b_][r][0] = v0[0]; gr[b_][r][1] = v0[1]; gr[b_][r][2] = v0[2]; gr[b_][r][3] = v0[3];
+        gr[b_][r][4] = v1[0]; gr[b_][r][5] = v1[1]; gr[b_][r][6] = v1[2]; gr[b_][r][7] = v1[3];
+      }
+#pragma unroll
+    for (int xi = 0; xi < 4; ++xi) {
+      float tx[CIT][10], zr[COT][8];
+#pragma unroll
+      for (int a = 0; a < CIT; ++a)
+#pragma unroll
+        for (int c = 0; c < 10; ++c)
+          tx[a][c] = xi == 0 ? xr[a][0][c] - xr[a][2][c] : xi == 1 ? xr[a][1][c] + xr[a][2][c]
+                   : xi == 2 ? xr[a][2][c] - xr[a][1][c] : xr[a][1][c] - xr[a][3][c];
+#pragma unroll
+      for (int b_ = 0; b_ < COT; ++b_)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)                     // rows of |A|: g0 | g0 + g1 | g0 - g1 | g1 (sign of the last one: final pass)
+          zr[b_][c] = xi == 0 ? gr[b_][0][c] : xi == 1 ? gr[b_][0][c] + gr[b_][1][c] : xi == 2 ? gr[b_][0][c] - gr[b_][1][c] : gr[b_][1][c];
+#pragma unroll
+      for (int nu = 0; nu < 4; ++nu) {
+        f32x4 v[CIT], z[COT];
+#pragma unroll
+        for (int a = 0; a < CIT; ++a)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            v[a][s] = nu == 0 ? tx[a][2 * s] - tx[a][2 * s + 2] : nu == 1 ? tx[a][2 * s + 1] + tx[a][2 * s + 2]
+                    : nu == 2 ? tx[a][2 * s + 2] - tx[a][2 * s + 1] : tx[a][2 * s + 1] - tx[a][2 * s + 3];
+#pragma unroll
+        for (int b_ = 0; b_ < COT; ++b_)
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+            z[b_][s] = nu == 0 ? zr[b_][2 * s] : nu == 1 ? zr[b_][2 * s] + zr[b_][2 * s + 1]
+                     : nu == 2 ? zr[b_][2 * s] - zr[b_][2 * s + 1] : zr[b_][2 * s + 1];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int a = 0; a < CIT; ++a)
+#pragma unroll
+            for (int b_ = 0; b_ < COT; ++b_) macc[xi * 4 + nu][a][b_] = mfma16(v[a][s], z[b_][s], macc[xi * 4 + nu][a][b_]);
+      }
+    }
+  };
+
+  if (item0 < item1) {
+    prefetch();
+    advance(pn, pty, ptx);
+    publish(0);
+    if (item0 + 1 < item1) { prefetch(); advance(pn, pty, ptx); }
+    __syncthreads();
+    int buf = 0;
+    for (int item = item0; item < item1; ++item) {
+      if (item + 1 < item1) publish(buf ^ 1);             // (operands requested a whole item ago)
+      if (item + 2 < item1) { prefetch(); advance(pn, pty, ptx); }
+      compute(buf);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // ---- combine the four waves' partial sums (fixed order 0 + 1 + 2 + 3) and store the slab of this split
+  f32x4* xch = reinterpret_cast<f32x4*>(smem);           // [16][CIT][COT][64 lanes]
+#pragma unroll 1
+  for (int w_ = 1; w_ < 4; ++w_) {
+    __syncthreads();
+    if (wave == w_) {
+#pragma unroll
+      for (int p_ = 0; p_ < 16; ++p_)
+#pragma unroll
+        for (int a = 0; a < CIT; ++a)
+#pragma unroll
+          for (int b_ = 0; b_ < COT; ++b_) xch[((p_ * CIT + a) * COT + b_) * 64 + lane] = macc[p_][a][b_];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int p_ = 0; p_ < 16; ++p_)
+#pragma unroll
+        for (int a = 0; a < CIT; ++a)
+#pragma unroll
+          for (int b_ = 0; b_ < COT; ++b_) macc[p_][a][b_] += xch[((p_ * CIT + a) * COT + b_) * 64 + lane];
+    }
+  }
+  if (wave == 0) {                                        // D layout: lane (lm = co, kq) holds rows ci = 4 kq + r
+    float* dst = part + (size_t)blockIdx.x * 16 * Cin * Cout;
+#pragma unroll
+    for (int p_ = 0; p_ < 16; ++p_)
+#pragma unroll
+      for (int a = 0; a < CIT; ++a)
+#pragma unroll
+        for (int b_ = 0; b_ < COT; ++b_)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            dst[((size_t)p_ * Cin + ci0 + a * 16 + 4 * kq + r) * Cout + co0 + b_ * 16 + lm] = macc[p_][a][b_][r];
+  }
+}
+
+// gw[tap][ci][co] = G^T (sigma dU sigma) G summed over the splits; sigma = (1, 1, 1, -1) restores the negations left out of A
+__global__ void __launch_bounds__(TPB) wino_wg_final(const float* __restrict__ part, float* __restrict__ gw, int splits, int CC) {
+  const int idx = blockIdx.x * TPB + threadIdx.x;        // (ci, co) pair
+  if (idx >= CC) return;
+  float u[4][4];
+#pragma unroll
+  for (int p_ = 0; p_ < 16; ++p_) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[((size_t)k * 16 + p_) * CC + idx];
+    const bool neg = ((p_ >> 2) == 3) != ((p_ & 3) == 3);
+    u[p_ >> 2][p_ & 3] = neg ? -s : s;
+  }
+  // G^T = [[1, .5, .5, 0], [0, .5, -.5, 0], [0, .5, .5, 1]]
+  float t[3][4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+    t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+    t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    gw[(size_t)(a * 3 + 0) * CC + idx] = t[a][0] + 0.5f * (t[a][1] + t[a][2]);
+    gw[(size_t)(a * 3 + 1) * CC + idx] = 0.5f * (t[a][1] - t[a][2]);
+    gw[(size_t)(a * 3 + 2) * CC + idx] = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+  }
+}
+
+struct WgPlan { int cit, cot, splits, items_per_split; };
+inline WgPlan plan_wino_wg(int N, int H, int W, int Cin, int Cout) {
+  WgPlan p;
+  // slab shapes: two output-channel blocks per workgroup when there are that many (the gy side of the transform is the cheap
+  // one), else two input-channel blocks, else 16 x 16
+  p.cit = 1; p.cot = 1;
+  if (Cout % 32 == 0) p.cot = 2;
+  else if (Cin % 32 == 0) p.cit = 2;
+  const int slabs = (Cin / (16 * p.cit)) * (Cout / (16 * p.cot));
+  const int items = N * (H / TH) * (W / TW);
+  int want = (2 * device_cus() + slabs - 1) / slabs;                       // about two rounds of one workgroup per CU
+  const int64_t cap = ((int64_t)8 << 20) / ((int64_t)16 * Cin * Cout);     // split slabs the final pass re-reads: <= 8 M floats
+  if (want > cap) want = (int)(cap < 1 ? 1 : cap);
+  if (want > items) want = items;
+  if (want < 1) want = 1;
+  p.items_per_split = (items + want - 1) / want;
+  p.splits = (items + p.items_per_split - 1) / p.items_per_split;
+  return p;
+}
+
+template <int CIT, int COT>
+int launch_wino_wg(const float* x, const float* x2, int ca, const float* gy, float* ws, int N, int H, int W, int Cin, int Cout,
+                   const WgPlan& p, const WinoAff* aff, hipStream_t st) {
+  constexpr size_t sh = (size_t)2 * wino_wg_buf_floats<CIT, COT>() * sizeof(float);
+  static_assert(sh <= 160 * 1024, "LDS budget");
+  static_assert((size_t)16 * CIT * COT * 64 * 16 <= sh, "cross-wave exchange fits the staging buffers");
+  dim3 grid(p.splits, Cin / (16 * CIT), Cout / (16 * COT));
+  const int tiles_x = W / TW, tiles_img = tiles_x * (H / TH);
+  const WinoAff av = aff ? *aff : WinoAff{};
+  if (aff) {
+    if (x2) return -1;
+    allow_big_lds<conv_wino_wg<CIT, COT, false, true>>(sh);
+    conv_wino_wg<CIT, COT, false, true><<<grid, TPB, sh, st>>>(x, nullptr, 0, gy, ws, N, H, W, Cin, Cout, tiles_x, tiles_img, p.items_per_split, av);
+  } else if (x2) {
+    allow_big_lds<conv_wino_wg<CIT, COT, true, false>>(sh);
+    conv_wino_wg<CIT, COT, true, false><<<grid, TPB, sh, st>>>(x, x2, ca, gy, ws, N, H, W, Cin, Cout, tiles_x, tiles_img, p.items_per_split, av);
+  } else {
+    allow_big_lds<conv_wino_wg<CIT, COT, false, false>>(sh);
+    conv_wino_wg<CIT, COT, false, false><<<grid, TPB, sh, st>>>(x, nullptr, 0, gy, ws, N, H, W, Cin, Cout, tiles_x, tiles_img, p.items_per_split, av);
+  }
+  return 0;
+}
+
 }  // namespace
 
 bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim) {
@@ -587,4 +903,37 @@ int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* 
   if (force == 1 || (force == 2 && Ndim % 32 == 0 && !(y2 && split % 32 != 0))) ntn = force;
   if (ntn == 2) return launch_ntn<2>(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
   return launch_ntn<1>(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
+}
+
+bool smsut_wino_wg_eligible(int N, int H, int W, int Cin, int Cout, const float* x2, int ca) {
+  // OFF by default (r03): correct (2-3e-7 of fp64) but only at parity with the direct weight-gradient kernels -- per-item staging
+  // (both operands transposed into channel-major planes for 128 MFMAs per wave) costs what the 2.25x fewer MFMAs save, and the
+  // split-slab pass adds to it on the 16-channel layers (profiles/r03_notes.md).  SMSUT_WINOGRAD_WG=1 enables it.
+  static const bool on = [] { const char* e = getenv("SMSUT_WINOGRAD_WG"); return e && atoi(e) != 0; }();
+  if (!on || N <= 0 || H < 16 || W < 16 || H % TH != 0 || W % TW != 0 || Cin < 16 || Cin % 16 != 0 || Cout < 16 || Cout % 16 != 0 ||
+      (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 31))
+    return false;
+  if (x2) {
+    const WgPlan p = plan_wino_wg(N, H, W, Cin, Cout);
+    if (ca <= 0 || ca >= Cin || ca % (16 * p.cit) != 0 || (Cin - ca) % (16 * p.cit) != 0) return false;     // a slab never straddles the seam
+  }
+  return true;
+}
+
+int64_t smsut_wino_wg_ws(int N, int H, int W, int Cin, int Cout) {
+  return (int64_t)plan_wino_wg(N, H, W, Cin, Cout).splits * 16 * Cin * Cout;
+}
+
+int smsut_wino_wg_launch(const float* x, const float* x2, int ca, const float* gy, float* gw, float* workspace, int N, int H, int W,
+                         int Cin, int Cout, const WinoAff* aff, hipStream_t st) {
+  if (!smsut_wino_wg_eligible(N, H, W, Cin, Cout, x2, ca)) return -1;
+  const WgPlan p = plan_wino_wg(N, H, W, Cin, Cout);
+  int rc;
+  if (p.cot == 2) rc = launch_wino_wg<1, 2>(x, x2, ca, gy, workspace, N, H, W, Cin, Cout, p, aff, st);
+  else if (p.cit == 2) rc = launch_wino_wg<2, 1>(x, x2, ca, gy, workspace, N, H, W, Cin, Cout, p, aff, st);
+  else rc = launch_wino_wg<1, 1>(x, x2, ca, gy, workspace, N, H, W, Cin, Cout, p, aff, st);
+  if (rc != 0) return rc;
+  const int CC = Cin * Cout;
+  wino_wg_final<<<(CC + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, p.splits, CC);
+  return 0;
 }
