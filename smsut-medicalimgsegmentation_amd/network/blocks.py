@@ -71,6 +71,51 @@ class InstanceNorm2d(nn.Module):
         return ops.instnorm_act(x, self.weight, self.bias, slope)
 
 
+class BatchNorm2d(nn.Module):
+    """nn.BatchNorm2d(C) -- the reference's DEFAULT norm (``norm_type='batch'``: network/unet.py:14-15, blocks.py:19-26;
+    no trainer uses it).  Same state_dict keys (``weight``, ``bias``, ``running_mean``, ``running_var``,
+    ``num_batches_tracked``), eps 1e-5, momentum 0.1.
+
+    Train mode: batch statistics over (N, H, W) per channel ARE instance statistics of the batch viewed as ONE instance of
+    N*H*W pixels -- NHWC memory makes that a free view -- so forward, backward and double backward are the InstanceNorm kernels
+    (``ops.InstNormActFn``) with N' = 1; the running statistics are updated from the kernel's own mean / rstd (unbiased variance,
+    as torch).  Eval mode: a per-channel affine on the running statistics, run as a diagonal 1x1 conv + bias through the HIP
+    conv path (cold path: kept simple)."""
+
+    def __init__(self, channels, eps=1e-5, momentum=0.1):
+        super().__init__()
+        if abs(eps - ops.IN_EPS) > 1e-12:
+            raise NotImplementedError("BatchNorm2d: eps is fixed to 1e-5 (the kernels' InstanceNorm epsilon)")
+        self.num_features, self.eps, self.momentum = channels, eps, momentum
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, slope=None):
+        n, c, h, w = x.shape
+        if self.training:
+            xc = ops.cl(x)
+            one = xc.permute(0, 2, 3, 1).reshape(1, n * h, w, c).permute(0, 3, 1, 2)       # [1, C, N*H, W], same NHWC memory
+            y, mean, rstd = ops.InstNormActFn.apply(one, self.weight, self.bias, 0.0 if slope is None else slope, slope is not None)
+            with torch.no_grad():
+                cnt = n * h * w
+                var = (1.0 / (rstd[0] * rstd[0]) - self.eps).clamp_min_(0.0)                # biased batch variance
+                self.running_mean.lerp_(mean[0], self.momentum)
+                self.running_var.lerp_(var * (cnt / max(cnt - 1, 1)), self.momentum)
+                self.num_batches_tracked += 1
+            return y.permute(0, 2, 3, 1).reshape(n, h, w, c).permute(0, 3, 1, 2)
+        scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+        shift = self.bias - self.running_mean * scale
+        wd = ops.new_weight(c, c, 1, 1, device=x.device)
+        with torch.no_grad():
+            wd.zero_()
+        wd = wd + torch.diag(scale).view(c, c, 1, 1)                                      # (keeps the graph to weight / bias)
+        y = ops.conv2d(x, wd, shift, stride=1, pad=0)
+        return y if slope is None else ops.leaky_relu(y, slope)
+
+
 class Act(nn.Module):
     """LeakyReLU(slope) / ReLU (slope 0) marker; blocks read ``.slope`` and fuse it into the norm kernel."""
 
@@ -103,8 +148,7 @@ def get_norm(channels, norm_type):
     if norm_type == "instance":
         return InstanceNorm2d(channels)
     if norm_type == "batch":
-        raise NotImplementedError("BatchNorm is outside the MI355X hot path: every reference trainer builds its "
-                                  "networks with norm_type='instance'")
+        return BatchNorm2d(channels)
     raise NotImplementedError
 
 
@@ -149,12 +193,13 @@ class BasicBlock(nn.Module):
     def forward(self, x):
         s = self.relu.slope
         ws = self.shortcut1.weight if self.downsample else None
+        fused_ok = isinstance(self.bn1, InstanceNorm2d)        # (the fused block kernels ARE InstanceNorm; BatchNorm: op by op)
         if isinstance(x, ops.CatParts):            # cat([up, skip]) not built yet (UpSampleAndConcat)
-            if ops.basic_block_cat_fusable(x, self.conv1.weight, ws):
+            if fused_ok and ops.basic_block_cat_fusable(x, self.conv1.weight, ws):
                 return ops.basic_block_cat(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
                                            self.bn2.weight, self.bn2.bias, ws, self.shortcut2.weight, self.shortcut2.bias, s)
             x = x.tensor()
-        if ops.basic_block_fusable(x, self.conv1.weight, ws):
+        if fused_ok and ops.basic_block_fusable(x, self.conv1.weight, ws):
             sc = (ws, self.shortcut2.weight, self.shortcut2.bias) if self.downsample else (None, None, None)
             return ops.basic_block(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight,
                                    self.bn2.weight, self.bn2.bias, *sc, s)
@@ -188,7 +233,7 @@ class BottleBlock(nn.Module):
         y2 = self.conv2(y, stats=True)
         if self.downsample is not None:
             sc = self.downsample[0](idn, stats=True)
-            if ops.res_tail_fusable(y2, sc):          # first-order passes: IN2 + IN(shortcut) + add + act in one kernel
+            if isinstance(self.bn2, InstanceNorm2d) and ops.res_tail_fusable(y2, sc):          # first-order passes: IN2 + IN(shortcut) + add + act in one kernel
                 return ops.res_tail(y2, self.bn2.weight, self.bn2.bias, sc, self.downsample[1].weight,
                                     self.downsample[1].bias, s)
             idn = self.downsample[1](sc)

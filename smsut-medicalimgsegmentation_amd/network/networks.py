@@ -105,13 +105,13 @@ class Identity(nn.Module):
 
 
 def get_norm_layer(norm_type="instance"):
-    """networks.py:113-131.  'batch' is outside the MI355X hot path (no reachable module uses it)."""
+    """networks.py:113-131 ('batch' -> blocks.BatchNorm2d: affine, running statistics, as nn.BatchNorm2d)."""
     if norm_type == "instance":
         return functools.partial(InstanceNorm2dNA)
     if norm_type == "none":
         return lambda ch: Identity()
     if norm_type == "batch":
-        raise NotImplementedError("BatchNorm is outside the MI355X hot path")
+        return functools.partial(blocks.BatchNorm2d)
     raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
 
 
@@ -127,8 +127,8 @@ def _make_norm(norm_layer, ch):
         if kw.get("affine", False):
             return blocks.InstanceNorm2d(ch)
         return InstanceNorm2dNA(ch)
-    if f is nn.BatchNorm2d:
-        raise NotImplementedError("BatchNorm2d norm_layer is outside the MI355X hot path; pass get_norm_layer('instance')")
+    if f in (nn.BatchNorm2d, blocks.BatchNorm2d):        # the reference's default norm_layer (networks.py:613, :980)
+        return blocks.BatchNorm2d(ch)
     return norm_layer(ch)
 
 

@@ -607,6 +607,93 @@ def gen_validate():
     save("validate", **rec)
 
 
+def gen_augment_pil():
+    """Geometry fixtures for the device-side joint augmentation: the reference's JointRotate / JointRandomResizedCrop
+    (data_loader/externalTransforms.py:45-66) end in ``torchvision.transforms.functional.rotate`` / ``resized_crop`` on PIL images,
+    i.e. ``Image.rotate(angle, resample)`` and ``Image.crop(box).resize(size, resample)`` (torchvision is not installed here; the two
+    PIL calls it forwards to are the anchor) -- bilinear for the image, nearest for the mask.  Stored: one smooth 8-bit image and
+    one block label map, PIL's results for three angles, three crop windows and the reference's ORDER of the two (rotate, then
+    crop + resize: externalTransforms.py / baseLoader.py:15-85 compose them in that order).  JointElasticDeform (:69-90) needs
+    ``elasticdeform`` (absent): not generated."""
+    from PIL import Image
+    H = W = 128
+    rs = np.random.RandomState(5)
+    coarse = rs.rand(H // 16 + 2, W // 16 + 2)
+    img8 = np.clip(np.asarray(Image.fromarray((coarse * 255).astype(np.uint8)).resize((W, H), Image.BICUBIC), dtype=np.float32), 0, 255).astype(np.uint8)
+    lab8 = np.repeat(np.repeat(rs.randint(0, 5, size=(H // 16, W // 16)).astype(np.uint8), 16, axis=0), 16, axis=1)
+    angles = np.array([-15.0, 7.3, 12.0], dtype=np.float32)
+    crops = np.array([[10, 18, 90, 100], [0, 0, 128, 128], [31, 2, 77, 115]], dtype=np.int64)     # (i, j, h, w)
+    rec = dict(img=img8, lab=lab8, angles=angles, crops=crops)
+    pi, pl = Image.fromarray(img8), Image.fromarray(lab8)
+    for k, a in enumerate(angles):
+        rec[f"rot_img_{k}"] = np.asarray(pi.rotate(float(a), Image.BILINEAR))
+        rec[f"rot_lab_{k}"] = np.asarray(pl.rotate(float(a), Image.NEAREST))
+    for k, (i, j, h, w) in enumerate(crops):
+        rec[f"crop_img_{k}"] = np.asarray(pi.crop((j, i, j + w, i + h)).resize((W, H), Image.BILINEAR))
+        rec[f"crop_lab_{k}"] = np.asarray(pl.crop((j, i, j + w, i + h)).resize((W, H), Image.NEAREST))
+    for k in range(3):                                   # the composition, in the reference's order
+        a = float(angles[k]); i, j, h, w = (int(v) for v in crops[(k + 1) % 3])
+        rec[f"both_img_{k}"] = np.asarray(pi.rotate(a, Image.BILINEAR).crop((j, i, j + w, i + h)).resize((W, H), Image.BILINEAR))
+        rec[f"both_lab_{k}"] = np.asarray(pl.rotate(a, Image.NEAREST).crop((j, i, j + w, i + h)).resize((W, H), Image.NEAREST))
+    save("augment_pil", **rec)
+
+
+def gen_sampler():
+    """Batch order of the reference's ``InTurnTrainBatchSampler`` / ``InTurnTestBatchSampler`` (data_loader/inTurnLoader.py:15-79) for
+    seeded runs.  The module itself does not import here (its imports pull in torchvision); the two classes are pure Python over
+    ``random``, so their definitions are compiled from the reference file's AST at generation time -- nothing of the source is
+    stored, only the batches they yield."""
+    import ast
+    from typing import List                      # noqa: F401  (names the class bodies use)
+    from torch.utils.data import Sampler         # noqa: F401
+    src = open(os.path.join(REF, "data_loader", "inTurnLoader.py")).read()
+    tree = ast.parse(src)
+    keep = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in ("InTurnTrainBatchSampler", "InTurnTestBatchSampler")]
+    ns = {"List": List, "Sampler": Sampler, "random": random}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), "inTurnLoader.py", "exec"), ns)
+    sizes = [23, 31, 19, 40]
+    base = [list(range(100 * m, 100 * m + n)) for m, n in enumerate(sizes)]
+    rec = dict(sizes=np.array(sizes), batch_size=4)
+    for shuffle in (0, 1):
+        random.seed(2020 + shuffle)
+        smp = ns["InTurnTrainBatchSampler"]([list(b) for b in base], 4, bool(shuffle))
+        epochs = [list(smp) for _ in range(3)]                                   # three epochs: wraps and reshuffles inside
+        rec[f"train_shuffle{shuffle}_n"] = np.array([len(e) for e in epochs])
+        rec[f"train_shuffle{shuffle}"] = np.array([b for e in epochs for b in e], dtype=np.int64)
+        rec[f"train_shuffle{shuffle}_len"] = len(smp)
+    tst = ns["InTurnTestBatchSampler"]([list(b) for b in base], 4)
+    rec["test_flat"] = np.array([i for b in tst for i in b], dtype=np.int64)
+    rec["test_sizes"] = np.array([len(b) for b in tst], dtype=np.int64)
+    rec["test_len"] = len(tst)
+    save("sampler", **rec)
+
+
+def gen_unet_batch():
+    """The reference's DEFAULT constructor arguments: ``UNet(in_ch, out_ch, base_width)`` = norm_type='batch', act_type='relu'
+    (network/unet.py:14-15; its own smoke block :35-41 runs them).  Train-mode forward (batch statistics), DiceCE, backward; the
+    running statistics two BatchNorm layers hold afterwards; then an eval-mode forward on the updated running statistics."""
+    seed, B, H, ncls, w = 29, 3, 32, 3, 8
+    net = UNet(1, ncls, w)
+    sd = recipe.fill(recipe.unet_shapes(1, ncls, w), seed)
+    missing = net.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(("running_" in k or "num_batches" in k) for k in missing.missing_keys)
+    net.train()
+    x = recipe.synth_images((B, 1, H, H), seed + 1)
+    y = recipe.synth_labels(B, H, H, ncls, seed + 2, block=8)
+    out = net(x)
+    loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y)
+    loss.backward()
+    st = net.state_dict()
+    net.eval()
+    with torch.no_grad():
+        out_eval = net(x)
+    save("unet_batch", seed=seed, B=B, H=H, ncls=ncls, w=w, logits=npy(out), loss=loss.item(), logits_eval=npy(out_eval),
+         rm_pre=npy(st["encoder.pre_bn.running_mean"]), rv_pre=npy(st["encoder.pre_bn.running_var"]),
+         rm_l3=npy(st["encoder.layer3.bn2.running_mean"]), rv_l3=npy(st["encoder.layer3.bn2.running_var"]),
+         nbt=int(st["encoder.pre_bn.num_batches_tracked"]),
+         **grad_summary(net, ("encoder.pre_conv.weight", "decoder.fc.weight", "encoder.layer1.bn1.weight", "decoder.layer4.conv1.weight")))
+
+
 if __name__ == "__main__":
     random.seed(2020); np.random.seed(2020); torch.manual_seed(2020)
     which = sys.argv[1:] or ["unet_small", "unet_relu", "unet_256", "disc_small", "ugan_small", "losses", "iter_small", "networks_zoo", "siblings"]

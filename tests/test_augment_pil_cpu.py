@@ -63,3 +63,32 @@ def test_resized_crop_matches_pil(crop):
     inner = np.s_[2:-2, 2:-2]                     # PIL clamps at the crop's border, the joint warp reads the pixels beyond it
     assert d[inner].mean() < 1.0 and np.quantile(d[inner], 0.99) < 2.5     # (PIL rounds to uint8: 0.25 mean by itself), (d[inner].mean(), np.quantile(d[inner], 0.99))
     assert (got_lab[0][inner] == ref_lab[inner]).mean() > 0.995
+
+
+def _check(got_img, got_lab, ref_img, ref_lab, rim, mean_bar=1.0, q99_bar=2.5, lab_bar=0.995):
+    d = np.abs(got_img - ref_img.astype(np.float32))
+    inner = np.s_[rim:-rim, rim:-rim]
+    assert d[inner].mean() < mean_bar and np.quantile(d[inner], 0.99) < q99_bar, (d[inner].mean(), np.quantile(d[inner], 0.99))
+    assert (got_lab[inner] == ref_lab[inner]).mean() > lab_bar, (got_lab[inner] == ref_lab[inner]).mean()
+
+
+def test_oracle_against_committed_pil_fixtures(golden):
+    """The same conventions against tests/golden/augment_pil.npz (PIL outputs committed by make_golden.py::gen_augment_pil, so the
+    GPU box -- which has no reference and needs no PIL -- checks the KERNEL against the very same arrays,
+    tests/test_data_loader_gpu.py), plus the reference's ORDER of the two transforms: rotate, then crop + resize
+    (externalTransforms.py:45-66 composed by baseLoader.py:15-85).  The device path resamples once where PIL resamples twice, so
+    the composition's bar is wider (a second bilinear pass smooths): mean < 1.5 grey levels."""
+    g = golden("augment_pil")
+    img8, lab8 = g["img"], g["lab"]
+    H, W = img8.shape
+    x, m = img8[None].astype(np.float32), lab8[None].astype(np.int64)
+    for k, a in enumerate(g["angles"]):
+        gi, gl = A.warp_joint(x, m, _affine(float(a), (0, 0, H, W), (H, W), (H, W)), None, H, W)
+        _check(gi[0], gl[0], g[f"rot_img_{k}"], g[f"rot_lab_{k}"], 8)
+    for k, c in enumerate(g["crops"]):
+        gi, gl = A.warp_joint(x, m, _affine(0.0, tuple(int(v) for v in c), (H, W), (H, W)), None, H, W)
+        _check(gi[0], gl[0], g[f"crop_img_{k}"], g[f"crop_lab_{k}"], 2)
+    for k in range(3):
+        a, c = float(g["angles"][k]), tuple(int(v) for v in g["crops"][(k + 1) % 3])
+        gi, gl = A.warp_joint(x, m, _affine(a, c, (H, W), (H, W)), None, H, W)
+        _check(gi[0], gl[0], g[f"both_img_{k}"], g[f"both_lab_{k}"], 10, mean_bar=1.5, q99_bar=4.0, lab_bar=0.97)   # (two nearest passes vs one: +-1 px at the 16-px block edges)

@@ -148,3 +148,28 @@ def test_sampler_state_round_trip_continues_the_data_order():
     lb.load_state_dict(st)
     (xa, ya, ma, na), (xb, yb, mb, nb) = la._batch(), lb._batch()
     assert torch.equal(xa, xb) and torch.equal(ya, yb) and torch.equal(ma, mb) and na == nb
+
+
+def test_samplers_reproduce_reference_batch_order(golden):
+    """tests/golden/sampler.npz holds the batches the REFERENCE's InTurnTrainBatchSampler / InTurnTestBatchSampler
+    (data_loader/inTurnLoader.py:15-79) yield over three epochs for seeded runs (generated from the reference classes by
+    make_golden.py::gen_sampler).  At world == 1 the samplers here draw from Python's global ``random`` in the same order, so a run
+    seeded alike visits exactly the same slice ids -- shuffled queue or not, wrap-arounds and reshuffles included."""
+    import random
+    from smsut_amd.data_loader.inTurnLoader import InTurnTestBatchSampler, InTurnTrainBatchSampler
+    g = golden("sampler")
+    sizes, bs = [int(v) for v in g["sizes"]], int(g["batch_size"])
+    base = [list(range(100 * m, 100 * m + n)) for m, n in enumerate(sizes)]
+    for shuffle in (0, 1):
+        random.seed(2020 + shuffle)
+        smp = InTurnTrainBatchSampler([list(b) for b in base], bs, bool(shuffle))
+        assert len(smp) == int(g[f"train_shuffle{shuffle}_len"])
+        epochs = [list(smp) for _ in range(3)]
+        assert [len(e) for e in epochs] == [int(v) for v in g[f"train_shuffle{shuffle}_n"]]
+        got = np.array([b for e in epochs for b in e], dtype=np.int64)
+        assert np.array_equal(got, g[f"train_shuffle{shuffle}"])
+    tst = InTurnTestBatchSampler([list(b) for b in base], bs)
+    assert len(tst) == int(g["test_len"])
+    batches = list(tst)
+    assert [len(b) for b in batches] == [int(v) for v in g["test_sizes"]]
+    assert [i for b in batches for i in b] == [int(v) for v in g["test_flat"]]

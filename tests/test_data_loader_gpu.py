@@ -48,3 +48,36 @@ def test_identity_warp_is_exact_and_augmenter_shapes():
     xi, yi = aug(x, y)
     assert tuple(xi.shape) == (4, 1, 48, 48) and tuple(yi.shape) == (4, 48, 48) and yi.dtype == torch.int64
     assert float(xi.abs().max()) <= 1.0 + 1e-6 and int(yi.max()) <= 4 and int(yi.min()) >= 0
+
+
+def test_warp_joint_kernel_against_pil_fixtures(golden):
+    """``smsut_warp_joint`` ITSELF (not its numpy restatement) against PIL's rotate / crop + resize outputs committed in
+    tests/golden/augment_pil.npz -- the calls the reference's JointRotate / JointRandomResizedCrop end in
+    (data_loader/externalTransforms.py:45-66) -- and against the reference's order of the two.  Bilinear image, nearest labels;
+    PIL rounds to 8 bits, the composition resamples twice where the kernel resamples once (bars as tests/test_augment_pil_cpu.py)."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd.data_loader import gpu_augment as ga
+    g = golden("augment_pil")
+    img8, lab8 = g["img"], g["lab"]
+    H, W = img8.shape
+    x = torch.from_numpy(img8.astype(np.float32))[None, None].cuda()
+    m = torch.from_numpy(lab8.astype(np.int64))[None].cuda()
+
+    def run(angle, crop):
+        aff = torch.tensor([ga.affine_for(angle, crop, (H, W), (H, W))], dtype=torch.float32)
+        oi, om = ga.warp_joint(x, m, aff, None, H, W)
+        return oi[0, 0].cpu().numpy(), om[0].cpu().numpy()
+
+    def check(got, ref_img, ref_lab, rim, mean_bar=1.0, q99_bar=2.5, lab_bar=0.995):
+        d = np.abs(got[0] - ref_img.astype(np.float32))
+        inner = np.s_[rim:-rim, rim:-rim]
+        assert d[inner].mean() < mean_bar and np.quantile(d[inner], 0.99) < q99_bar, (d[inner].mean(), np.quantile(d[inner], 0.99))
+        assert (got[1][inner] == ref_lab[inner]).mean() > lab_bar
+
+    for k, a in enumerate(g["angles"]):
+        check(run(float(a), (0, 0, H, W)), g[f"rot_img_{k}"], g[f"rot_lab_{k}"], 8)
+    for k, c in enumerate(g["crops"]):
+        check(run(0.0, tuple(int(v) for v in c)), g[f"crop_img_{k}"], g[f"crop_lab_{k}"], 2)
+    for k in range(3):
+        a, c = float(g["angles"][k]), tuple(int(v) for v in g["crops"][(k + 1) % 3])
+        check(run(a, c), g[f"both_img_{k}"], g[f"both_lab_{k}"], 10, mean_bar=1.5, q99_bar=4.0, lab_bar=0.97)

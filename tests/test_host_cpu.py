@@ -73,10 +73,18 @@ def test_dropin_aliases():
     assert DiceAndCrossEntropyLoss(0.5, 0.5, True).batch_dice is True
 
 
-def test_unsupported_surface_raises():
+def test_default_constructor_builds_batchnorm_relu():
+    """``UNet(in_ch, out_ch, base_width)`` = norm_type='batch', act_type='relu' (reference network/unet.py:14-15): the state_dict has
+    the nn.BatchNorm2d keys of the reference's (running statistics included)."""
     import pytest
+    net = UNet(1, 5, 16)
+    sd = net.state_dict()
+    assert {"encoder.pre_bn.weight", "encoder.pre_bn.bias", "encoder.pre_bn.running_mean", "encoder.pre_bn.running_var",
+            "encoder.pre_bn.num_batches_tracked"} <= set(sd)
+    assert sum(p.numel() for p in net.parameters()) == 2031976            # same parameters as the InstanceNorm variant
+    assert net.encoder.layer1.relu.slope == 0.0
     with pytest.raises(NotImplementedError):
-        UNet(1, 5, 16)                               # default norm_type='batch' is outside the hot path
+        UNet(1, 5, 16, norm_type="group")
 
 
 def test_synthetic_loader_contract():

@@ -251,3 +251,72 @@ def test_ugannce_forward(pkg, golden):
     # random patch ids path: 16 positions at 64x64 input -> all 16 sampled once
     _, _, f2, ids2 = G(x, m)
     assert f2[0].shape == (4 * 16, 256) and sorted(ids2[0].tolist()) == list(range(16))
+
+
+def test_batchnorm2d_matches_torch(pkg):
+    """blocks.BatchNorm2d (train: the InstanceNorm kernels on the batch viewed as one instance; eval: running statistics) against
+    torch.nn.BatchNorm2d in fp64: output, input / affine gradients, running statistics, then the eval-mode output."""
+    from smsut_amd.network.blocks import BatchNorm2d
+    torch.manual_seed(3)
+    n, c, h, w = 5, 24, 12, 20
+    x = torch.randn(n, c, h, w) * 2 + 0.5
+    gy = torch.randn(n, c, h, w)
+    ref = torch.nn.BatchNorm2d(c).double()
+    with torch.no_grad():
+        ref.weight.copy_(1 + 0.1 * torch.randn(c)); ref.bias.copy_(0.1 * torch.randn(c))
+    bn = BatchNorm2d(c).cuda()
+    with torch.no_grad():
+        bn.weight.copy_(ref.weight.float()); bn.bias.copy_(ref.bias.float())
+    for slope in (None, 0.0):                                   # plain, and with the fused ReLU
+        xr = x.double().requires_grad_(True)
+        yr = ref(xr) if slope is None else torch.relu(ref(xr))
+        yr.backward(gy.double())
+        xd = x.cuda().requires_grad_(True)
+        bn.weight.grad = bn.bias.grad = None
+        yd = bn(xd, slope=slope)
+        yd.backward(gy.cuda())
+        assert rel_err(yd.detach().cpu().numpy(), yr.detach().numpy()) < 1e-5
+        assert rel_err(xd.grad.cpu().numpy(), xr.grad.numpy()) < 1e-4
+        assert rel_err(bn.weight.grad.cpu().numpy(), ref.weight.grad.numpy()) < 1e-4
+        assert rel_err(bn.bias.grad.cpu().numpy(), ref.bias.grad.numpy()) < 1e-4
+        ref.weight.grad = ref.bias.grad = None
+    assert int(bn.num_batches_tracked) == 2 == int(ref.num_batches_tracked)
+    assert rel_err(bn.running_mean.cpu().numpy(), ref.running_mean.numpy()) < 1e-5
+    assert rel_err(bn.running_var.cpu().numpy(), ref.running_var.numpy()) < 1e-5
+    assert list(bn.state_dict()) == list(ref.state_dict())
+    bn.eval(); ref.eval()
+    with torch.no_grad():
+        assert rel_err(bn(x.cuda()).cpu().numpy(), ref(x.double()).numpy()) < 1e-5
+
+
+def test_unet_default_constructor_batchnorm_relu(pkg, golden):
+    """The reference's default arguments ``UNet(in_ch, out_ch, base_width)`` = BatchNorm + ReLU (network/unet.py:14-15) against
+    tests/golden/unet_batch.npz (generated from the reference modules): train-mode logits and loss, gradient norms, the running
+    statistics after the step, and the eval-mode logits on them."""
+    from smsut_amd.network.unet import UNet
+    from smsut_amd.misc.loss import DiceAndCrossEntropyLoss
+    g = golden("unet_batch")
+    seed, B, H, ncls, w = (int(g[k]) for k in ("seed", "B", "H", "ncls", "w"))
+    net = UNet(1, ncls, w)                                      # norm_type='batch', act_type='relu'
+    missing = net.load_state_dict(recipe.fill(recipe.unet_shapes(1, ncls, w), seed), strict=False)
+    assert not missing.unexpected_keys and all(("running_" in k or "num_batches" in k) for k in missing.missing_keys)
+    net.cuda().train()
+    x = recipe.synth_images((B, 1, H, H), seed + 1).cuda()
+    y = recipe.synth_labels(B, H, H, ncls, seed + 2, block=8).cuda()
+    out = net(x)
+    assert rel_err(out.detach().cpu().numpy(), g["logits"]) < TOL
+    loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y)
+    assert abs(loss.item() - float(g["loss"])) < TOL * float(g["loss"])
+    loss.backward()
+    grads = dict(net.named_parameters())
+    for n_, ref in zip([str(n_) for n_ in g["grad_names"]], g["grad_l2"]):
+        got = float(grads[n_].grad.double().norm())
+        assert abs(got - ref) <= 2e-2 * ref + 1e-7, (n_, got, ref)
+    sd = net.state_dict()
+    assert int(sd["encoder.pre_bn.num_batches_tracked"]) == int(g["nbt"])
+    for key, name in (("rm_pre", "encoder.pre_bn.running_mean"), ("rv_pre", "encoder.pre_bn.running_var"),
+                      ("rm_l3", "encoder.layer3.bn2.running_mean"), ("rv_l3", "encoder.layer3.bn2.running_var")):
+        assert rel_err(sd[name].cpu().numpy(), g[key]) < TOL, name
+    net.eval()
+    with torch.no_grad():
+        assert rel_err(net(x).cpu().numpy(), g["logits_eval"]) < TOL
