@@ -773,27 +773,31 @@ conv_wino_wg(const float* __restrict__ x, const float* __restrict__ x2, int ca, 
       buf ^= 1;
     }
   }
-  // ---- combine the four waves' partial sums (fixed order 0 + 1 + 2 + 3) and store the slab of this split
-  f32x4* xch = reinterpret_cast<f32x4*>(smem);           // [16][CIT][COT][64 lanes]
+  // ---- combine the four waves' partial sums -- fixed order (0 + 1) + (2 + 3) -- and store the slab of this split
+  f32x4* xch = reinterpret_cast<f32x4*>(smem);           // [2][16][CIT][COT][64 lanes]
+  constexpr int XW = 16 * CIT * COT * 64;
 #pragma unroll 1
-  for (int w_ = 1; w_ < 4; ++w_) {
+  for (int round = 0; round < 2; ++round) {
+    const bool writer = round == 0 ? (wave & 1) : wave == 2;
+    const bool reader = round == 0 ? !(wave & 1) : wave == 0;
+    const int slot = round == 0 ? (wave >> 1) : 0;
     __syncthreads();
-    if (wave == w_) {
+    if (writer) {
 #pragma unroll
       for (int p_ = 0; p_ < 16; ++p_)
 #pragma unroll
         for (int a = 0; a < CIT; ++a)
 #pragma unroll
-          for (int b_ = 0; b_ < COT; ++b_) xch[((p_ * CIT + a) * COT + b_) * 64 + lane] = macc[p_][a][b_];
+          for (int b_ = 0; b_ < COT; ++b_) xch[slot * XW + ((p_ * CIT + a) * COT + b_) * 64 + lane] = macc[p_][a][b_];
     }
     __syncthreads();
-    if (wave == 0) {
+    if (reader) {
 #pragma unroll
       for (int p_ = 0; p_ < 16; ++p_)
 #pragma unroll
         for (int a = 0; a < CIT; ++a)
 #pragma unroll
-          for (int b_ = 0; b_ < COT; ++b_) macc[p_][a][b_] += xch[((p_ * CIT + a) * COT + b_) * 64 + lane];
+          for (int b_ = 0; b_ < COT; ++b_) macc[p_][a][b_] += xch[slot * XW + ((p_ * CIT + a) * COT + b_) * 64 + lane];
     }
   }
   if (wave == 0) {                                        // D layout: lane (lm = co, kq) holds rows ci = 4 kq + r
@@ -810,15 +814,32 @@ conv_wino_wg(const float* __restrict__ x, const float* __restrict__ x2, int ca, 
   }
 }
 
-// gw[tap][ci][co] = G^T (sigma dU sigma) G summed over the splits; sigma = (1, 1, 1, -1) restores the negations left out of A
-__global__ void __launch_bounds__(TPB) wino_wg_final(const float* __restrict__ part, float* __restrict__ gw, int splits, int CC) {
+// Sum of the split slabs, stage 1: group g of GRP consecutive splits -> part2[g][16 * CC] (one element per thread, eight loads in
+// flight); stage 2 (wino_wg_final) sums the <= 16 groups in fixed order, restores the signs left out of A (sigma = (1, 1, 1, -1))
+// and folds gw[tap][ci][co] = G^T (sigma dU sigma) G.  Fixed orders everywhere: deterministic.
+__global__ void __launch_bounds__(TPB) wino_wg_reduce(const float* __restrict__ part, float* __restrict__ part2, int splits, int grp,
+                                                      int64_t E) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= E) return;
+  const int k0 = blockIdx.y * grp, k1 = min(k0 + grp, splits);
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int k = k0;
+  for (; k + 8 <= k1; k += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] += part[(size_t)(k + j) * E + e];
+  }
+  for (; k < k1; ++k) s[0] += part[(size_t)k * E + e];
+  part2[(size_t)blockIdx.y * E + e] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+}
+
+__global__ void __launch_bounds__(TPB) wino_wg_final(const float* __restrict__ part, float* __restrict__ gw, int groups, int CC) {
   const int idx = blockIdx.x * TPB + threadIdx.x;        // (ci, co) pair
   if (idx >= CC) return;
   float u[4][4];
 #pragma unroll
   for (int p_ = 0; p_ < 16; ++p_) {
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += part[((size_t)k * 16 + p_) * CC + idx];
+    for (int k = 0; k < groups; ++k) s += part[((size_t)k * 16 + p_) * CC + idx];
     const bool neg = ((p_ >> 2) == 3) != ((p_ & 3) == 3);
     u[p_ >> 2][p_ & 3] = neg ? -s : s;
   }
@@ -838,6 +859,8 @@ __global__ void __launch_bounds__(TPB) wino_wg_final(const float* __restrict__ p
   }
 }
 
+constexpr int WG_GROUPS = 16;                // stage-1 groups of the split sum (when there are more splits than that)
+
 struct WgPlan { int cit, cot, splits, items_per_split; };
 inline WgPlan plan_wino_wg(int N, int H, int W, int Cin, int Cout) {
   WgPlan p;
@@ -848,7 +871,9 @@ inline WgPlan plan_wino_wg(int N, int H, int W, int Cin, int Cout) {
   else if (Cin % 32 == 0) p.cit = 2;
   const int slabs = (Cin / (16 * p.cit)) * (Cout / (16 * p.cot));
   const int items = N * (H / TH) * (W / TW);
-  int want = (2 * device_cus() + slabs - 1) / slabs;                       // about two rounds of one workgroup per CU
+  // ONE round of one workgroup per CU: a workgroup's fixed costs (first item's load latency, the cross-wave combine, the slab
+  // store: ~10 us) want as many items behind them as the grid allows
+  int want = (device_cus() + slabs - 1) / slabs;
   const int64_t cap = ((int64_t)8 << 20) / ((int64_t)16 * Cin * Cout);     // split slabs the final pass re-reads: <= 8 M floats
   if (want > cap) want = (int)(cap < 1 ? 1 : cap);
   if (want > items) want = items;
@@ -863,7 +888,7 @@ int launch_wino_wg(const float* x, const float* x2, int ca, const float* gy, flo
                    const WgPlan& p, const WinoAff* aff, hipStream_t st) {
   constexpr size_t sh = (size_t)2 * wino_wg_buf_floats<CIT, COT>() * sizeof(float);
   static_assert(sh <= 160 * 1024, "LDS budget");
-  static_assert((size_t)16 * CIT * COT * 64 * 16 <= sh, "cross-wave exchange fits the staging buffers");
+  static_assert((size_t)2 * 16 * CIT * COT * 64 * 16 <= sh, "cross-wave exchange fits the staging buffers");
   dim3 grid(p.splits, Cin / (16 * CIT), Cout / (16 * COT));
   const int tiles_x = W / TW, tiles_img = tiles_x * (H / TH);
   const WinoAff av = aff ? *aff : WinoAff{};
@@ -921,7 +946,8 @@ bool smsut_wino_wg_eligible(int N, int H, int W, int Cin, int Cout, const float*
 }
 
 int64_t smsut_wino_wg_ws(int N, int H, int W, int Cin, int Cout) {
-  return (int64_t)plan_wino_wg(N, H, W, Cin, Cout).splits * 16 * Cin * Cout;
+  const int splits = plan_wino_wg(N, H, W, Cin, Cout).splits;
+  return (int64_t)(splits + (splits > WG_GROUPS ? WG_GROUPS : 0)) * 16 * Cin * Cout;       // split slabs (+ the group sums)
 }
 
 int smsut_wino_wg_launch(const float* x, const float* x2, int ca, const float* gy, float* gw, float* workspace, int N, int H, int W,
@@ -934,6 +960,16 @@ int smsut_wino_wg_launch(const float* x, const float* x2, int ca, const float* g
   else rc = launch_wino_wg<1, 1>(x, x2, ca, gy, workspace, N, H, W, Cin, Cout, p, aff, st);
   if (rc != 0) return rc;
   const int CC = Cin * Cout;
-  wino_wg_final<<<(CC + TPB - 1) / TPB, TPB, 0, st>>>(workspace, gw, p.splits, CC);
+  const float* src = workspace;
+  int groups = p.splits;
+  if (p.splits > WG_GROUPS) {
+    const int64_t E = (int64_t)16 * CC;
+    const int grp = (p.splits + WG_GROUPS - 1) / WG_GROUPS;
+    groups = (p.splits + grp - 1) / grp;
+    float* part2 = workspace + (size_t)p.splits * E;
+    wino_wg_reduce<<<dim3((unsigned)((E + TPB - 1) / TPB), groups), TPB, 0, st>>>(workspace, part2, p.splits, grp, E);
+    src = part2;
+  }
+  wino_wg_final<<<(CC + TPB - 1) / TPB, TPB, 0, st>>>(src, gw, groups, CC);
   return 0;
 }
