@@ -33,7 +33,7 @@ for (h, ci, co) in [(32, 64, 64), (32, 64, 32), (48, 128, 64), (16, 256, 128), (
     e2 = float((gx.double() - refd).abs().max() / refd.abs().max())
     print(f"{tag} check H{h} {ci}->{co}: fwd {e1:.2e} dgrad {e2:.2e}", flush=True)
 
-for (h, ci, co) in [(64, 64, 64), (128, 64, 32), (64, 128, 64), (32, 128, 128), (32, 64, 128), (32, 256, 128), (16, 256, 256), (16, 128, 256)]:
+for (h, ci, co) in [(128, 32, 32), (128, 32, 64), (64, 32, 64), (256, 32, 16), (64, 64, 64), (128, 64, 32), (64, 128, 64), (32, 128, 128), (32, 64, 128), (32, 256, 128), (16, 256, 256), (16, 128, 256)]:
     x = torch.randn(B, ci, h, h, device='cuda').contiguous(memory_format=torch.channels_last)
     w = ops.new_weight(co, ci, 3, 3, device='cuda'); w.copy_(torch.randn(co, ci, 3, 3, device='cuda') * 0.05)
     y = torch.empty(B, co, h, h, device='cuda').contiguous(memory_format=torch.channels_last)

@@ -1918,7 +1918,8 @@ inline bool fwd_p_eligible(int N, int H, int W, int Kdim, int Ndim) {
 // ... or the large-reduction Winograd kernel (conv_wino.hip: fp32 only, Kdim >= 64, 16x16 tiles)
 inline bool wino_l_shape(int N, int H, int W, int Kdim, int Ndim) {
   static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
-  return use_wino && Kdim >= 64 && smsut_wino_l_eligible(N, H, W, Kdim, Ndim);
+  static const int min_k = [] { const char* e = getenv("SMSUT_WINO_L_MIN_K"); return e ? atoi(e) : 64; }();   // (tuning hook)
+  return use_wino && Kdim >= min_k && smsut_wino_l_eligible(N, H, W, Kdim, Ndim);
 }
 inline bool fwd_any_eligible(int N, int H, int W, int Kdim, int Ndim, bool f16) {
   return fwd_p_eligible(N, H, W, Kdim, Ndim) || (!f16 && wino_l_shape(N, H, W, Kdim, Ndim));
