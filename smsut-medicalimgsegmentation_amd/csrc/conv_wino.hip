@@ -131,7 +131,11 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     if constexpr (SC2) w_off1[k] = (unsigned)((co0 + w_n[k]) * KROW + w_ci[k]);
   }
   // (tap, chunk) blocks: forward w + (tap * Kd + 16 c) * Ndim, transposed w + (8 - tap) * Ndim * KROW + 16 c -- uniform, so a
-  // weight load is one scalar base + the thread's 32-bit offset (no per-load 64-bit vector arithmetic)
+  // weight load is one scalar base + the thread's 32-bit offset (no per-load 64-bit vector arithmetic); the selects between the
+  // two layouts are hoisted out of the chunk loop (inside it they became branches that cut the MFMA units apart)
+  const ptrdiff_t w_tstep = tr ? -(ptrdiff_t)Ndim * KROW : (ptrdiff_t)Kd * Ndim;       // tap -> tap + 1
+  const ptrdiff_t w_cstep = tr ? 16 : (ptrdiff_t)16 * Ndim;                            // chunk -> chunk + 1
+  const float* const w_tap0 = tr ? w + (size_t)8 * Ndim * KROW : w;                    // tap 0, chunk 0
 
   int pn = item0 / tiles_img, pty, ptx;                // item of the NEXT prefetch ...
   { const int t = item0 - pn * tiles_img; pty = t / tiles_x; ptx = t - pty * tiles_x; }
@@ -185,10 +189,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     } else {
       // tap t's block: forward w + (t * Kd + 16 c) * Ndim, transposed w + (8 - t) * Ndim * KROW + 16 c -- selected with scalar
       // arithmetic, not a branch (a branch here cuts the MFMA unit this part rides in out of its scheduling region)
-      const ptrdiff_t tstep = tr ? -(ptrdiff_t)Ndim * KROW : (ptrdiff_t)Kd * Ndim;
-      const float* w0 = tr ? w + (size_t)8 * Ndim * KROW + c * 16 : w + (size_t)c * 16 * Ndim;
+      const float* w0 = w_tap0 + (ptrdiff_t)c * w_cstep;
 #pragma unroll
-      for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = (w0 + tap * tstep)[w_off[k]];
+      for (int tap = 0; tap < 9; ++tap) wreg[k][tap] = (w0 + tap * w_tstep)[w_off[k]];
     }
     if constexpr (SC) wx[k] = (sc.w + (size_t)(c * 16) * Ndim)[w_off1[k]];
   };
@@ -226,6 +229,20 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   constexpr int NP = NI + NTN;                          // staging parts
   // part p of the region that multiplies from buffer b: publish into b ^ 1, then request
   auto stage_part = [&](int p_, int b) {
+#ifdef SMSUT_WLDBG_NO_STAGE_IN
+    if (p_ < NI) return;
+#endif
+#ifdef SMSUT_WLDBG_NO_STAGE_W
+    if (p_ >= NI) return;
+#endif
+#ifdef SMSUT_WLDBG_NO_PF
+    if (p_ < NI) { pub_in(p_, b ^ 1); } else { pub_w(p_ - NI, b ^ 1); }
+    return;
+#endif
+#ifdef SMSUT_WLDBG_NO_PUB
+    if (p_ < NI) { pf_in(p_); } else { pf_w(p_ - NI); }
+    return;
+#endif
     if (p_ < NI) { pub_in(p_, b ^ 1); pf_in(p_); }
     else { pub_w(p_ - NI, b ^ 1); pf_w(p_ - NI); }
   };
@@ -402,6 +419,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     };
     auto xform = [&](int g, f32x4* v) {
       const int xi = XO[g];
+#ifdef SMSUT_WLDBG_NO_XFORM
+      v[0] = d1[0]; v[1] = d1[1]; v[2] = d2[2]; v[3] = d2[3]; (void)xi; return;
+#endif
       f32x4 t[4];                                        // row combination xi of B^T: d0-d2 | d1+d2 | d2-d1 | d1-d3
 #pragma unroll
       for (int b = 0; b < 4; ++b) t[b] = xi == 0 ? d0[b] - d2[b] : xi == 1 ? d1[b] + d2[b] : xi == 2 ? d2[b] - d1[b] : d1[b] - d3[b];
@@ -415,7 +435,11 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       const int g = u / NR, j = u % NR;
 #pragma unroll
       for (int p_ = 0; p_ < NP; ++p_)
+#ifdef SMSUT_WLDBG_NO_STAGE          // scratch builds (scratch/wino_l_ablation.py): results wrong by construction, only the time matters
+        if (p_ % NU == u && c < 0) stage_part(p_, buf);
+#else
         if (p_ % NU == u) stage_part(p_, buf);           // this unit's share of the staging work, in the shadow of its MFMAs
+#endif
       if (u + 1 < NU) {
         ld_b(u + 1, bf[(u + 1) & 1]);
         if ((u + 1) % NR == 0) xform(g + 1, vv[(g + 1) & 1]);
@@ -435,7 +459,22 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu)
+#ifdef SMSUT_WLDBG_NO_MFMA
+          macc[XO[g] * 4 + nu][j][s] += vv[g & 1][nu][s] * bf[u & 1][nu][s];
+#else
           macc[XO[g] * 4 + nu][j] = mfma16(vv[g & 1][nu][s], bf[u & 1][nu][s], macc[XO[g] * 4 + nu][j]);
+#endif
+      // interleave: after every MFMA up to six VALU, two LDS and two global-memory instructions of this region (left alone the
+      // scheduler emitted the 16 MFMAs back to back and the staging arithmetic after them: one wave per SIMD, nothing hidden)
+#ifndef SMSUT_WLDBG_NO_IGROUP
+#pragma unroll
+      for (int m_ = 0; m_ < 16; ++m_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+      }
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -483,7 +522,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     pf_aff();
     pf_advance();
     if constexpr (last) { out_transform(); epilogue(); }
+#ifndef SMSUT_WLDBG_NO_BARRIER
     __syncthreads();                                     // buffer buf is free, buf ^ 1 is complete; red[] is complete
+#endif
     if constexpr (last) stats_out();
     buf ^= 1;
   };
