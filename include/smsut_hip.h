@@ -65,6 +65,27 @@ int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float*
 /* tuning hook: same as smsut_conv2d_fwd_mfma with a forced tile configuration (returns -1 for an unknown cfg) */
 int smsut_conv2d_fwd_mfma_cfg(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                               int transposed, int cfg, void* stream);
+/* Prepared Winograd weights (optional; replaces nothing in the reference -- it is the cuDNN-internal filter transform of the
+ * nn.Conv2d sites above made explicit, network/blocks.py:10-16): the large-reduction Winograd kernel (Kdim >= 64) transforms its
+ * weights U = G g G^T per workgroup and chunk unless the caller hands it a prepared image.
+ *   smsut_wino_image_floats(Kdim, Ndim)  floats of one image (16 * Kdim * Ndim; 0 when the shape has none);
+ *   smsut_wino_prepare                  writes the images of `count` weight tensors in ONE launch.  w[i]: a 3x3 weight tensor in
+ *                                       this library's layout [3][3][Cin][Cout]; transposed[i] = 0: image of the forward conv
+ *                                       (Kdim[i] = Cin, Ndim[i] = Cout), 1: of its data-gradient (Kdim[i] = Cout, Ndim[i] = Cin);
+ *                                       u[i]: device float[smsut_wino_image_floats(Kdim[i], Ndim[i])].  The five arrays are HOST arrays;
+ *   smsut_wino_bind(w, transposed, u, Kdim, Ndim)  from now on a conv call with these weights (same pointer, same form, same
+ *                                       dimensions) copies u instead of transforming w; u = NULL unbinds.  The CALLER keeps u in
+ *                                       step with w: re-prepare (or unbind) after every change of w;
+ *   smsut_wino_unbind_all()             forgets every binding.
+ * Results are bit-identical with and without a binding (same arithmetic, done once instead of per workgroup). */
+int64_t smsut_wino_image_floats(int Kdim, int Ndim);
+int smsut_wino_prepare(const float* const* w, float* const* u, const int* Kdim, const int* Ndim, const int* transposed, int count,
+                       void* stream);
+int smsut_wino_bind(const float* w, int transposed, const float* u, int Kdim, int Ndim);
+/* smsut_wino_bind for `count` tensors at once (host arrays as in smsut_wino_prepare); u = NULL (or u[i] = NULL) unbinds */
+int smsut_wino_bind_many(const float* const* w, const float* const* u, const int* Kdim, const int* Ndim, const int* transposed,
+                         int count);
+int smsut_wino_unbind_all(void);
 int smsut_conv2d_wgrad_mfma_supported(int KS, int stride, int pad, int Cin, int Cout);
 int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int KS);
 int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,

@@ -43,6 +43,11 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_dgrad_mfma_bwdstats": "ppppppppp f iiiii s",
     "smsut_conv2d_fwd_mfma_stats": "pppp iiiiii s",
     "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",
+    "smsut_wino_image_floats": "ii",
+    "smsut_wino_prepare": "ppppp i s",
+    "smsut_wino_bind": "p i p ii",
+    "smsut_wino_bind_many": "ppppp i",
+    "smsut_wino_unbind_all": "",
     "smsut_conv2d_wgrad_mfma_supported": "iiiii",
     "smsut_conv2d_wgrad_mfma_ws": "iiiiii",
     "smsut_conv2d_wgrad_mfma": "pppp iiiiii s",
@@ -153,7 +158,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_patchnce_fwd": "pppp iii f s",
     "smsut_patchnce_bwd": "pppp iii f s",
 }
-_RET_I64 = {"smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
+_RET_I64 = {"smsut_wino_image_floats", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws",
             "smsut_conv1x1_thin_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",

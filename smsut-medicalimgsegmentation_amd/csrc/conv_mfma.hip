@@ -2383,7 +2383,9 @@ WgradPlan plan_wgrad(int N, int H, int W, int Cin, int Cout) {
   // PMC (r01, 64->64 @64^2): with 1024 two-tile workgroups the kernel averaged < 1 resident wave per SIMD -- the
   // per-workgroup fixed cost (descriptor setup, first-tile latency, cross-wave combine, slab store) dominated.  The
   // 144..186-VGPR variants fit 2 workgroups per CU, so ONE resident round of 512 workgroups with more tiles each.
-  const int target = (p.cit == 1 && p.cot == 1) ? 768 : 512;
+  static const int t11 = [] { const char* e = getenv("SMSUT_WGRAD_TARGET11"); return e ? atoi(e) : 768; }();   // (tuning hooks)
+  static const int t22 = [] { const char* e = getenv("SMSUT_WGRAD_TARGET"); return e ? atoi(e) : 512; }();
+  const int target = (p.cit == 1 && p.cot == 1) ? t11 : t22;
   int want = (target + slabs - 1) / slabs;
   // ... but keep the per-split slabs that sum_splits has to re-read bounded (default 32 MB = 8M floats; an 8 MB cap
   // left the 64->64 layers with 208 workgroups for 256 CUs: PMC showed < 1 resident wave per SIMD).

@@ -29,8 +29,11 @@
 // Lane <-> pixel map of the results: acc[i = 2*dy + dx][j][r] = tile 4*kq + r of the wave's 4-row strip, pixel (dy, dx) of it:
 // strip row 2*(kq >> 1) + dy, column 8*(kq & 1) + 2*r + dx.
 #include "conv_wino.h"
+#include <stdint.h>
 #include <stdlib.h>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 namespace {
 
@@ -41,7 +44,44 @@ constexpr int TH = 16, TW = 16;           // output tile of an item
 constexpr int IH = TH + 2, IW = TW + 2;   // haloed input tile
 constexpr int SPX = 20;                   // floats between pixels of the staged input tile (see SPIXW in conv_mfma.hip)
 constexpr int UNITS = IH * IW * 4;        // float4 units of one 16-channel input chunk
-constexpr int NI = (UNITS + TPB - 1) / TPB;
+constexpr int NI_R = (UNITS + TPB - 1) / TPB;
+// LDS-DMA staging of the input tile (every form but INAFF, whose values pass through the ALU): `global_load_lds_dwordx4` writes
+// wave-uniform base + lane * 16 B, so the tile image is cut into 16-byte SLOTS in LDS order -- five per pixel (four channel quads
+// + the pad quad of the 20-float pixel stride) -- and lane l of wave-instruction q fills slot 64 q + l from its own source
+// address: the pixel's channels, or a 16-byte block of zeros (padding pixels, pad quads, the slots past the tile)
+constexpr int GSLOTS = IH * IW * 5;
+constexpr int NI_G = (GSLOTS + TPB - 1) / TPB;
+#ifndef SMSUT_WINO_GLDS
+#define SMSUT_WINO_GLDS 1
+#endif
+__device__ __attribute__((aligned(16))) const float wino_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+typedef __attribute__((address_space(3))) void* lds_vp;
+// The copies are issued from inline assembly: with the builtin (__builtin_amdgcn_global_load_lds) hipcc books the DMA as a second
+// kind of pending LDS event and from the first one on turns EVERY `s_waitcnt lgkmcnt(n)` of the region into lgkmcnt(0) -- each
+// fragment read then waits for the reads issued after it as well, six exposed LDS latencies per chunk with one wave per SIMD.
+// The hardware counts an LDS-DMA on vmcnt only, so the partial waits are right; what the compiler no longer sees is waited for
+// by hand (glds_wait before the barrier that publishes the buffer).  M0 = LDS byte address of the wave's 1 KiB piece, written
+// in the statement that uses it and not restored: nothing else in these kernels reads M0 (hipcc only touches it for its own
+// LDS-DMA builtin, indirect register moves, GWS and message instructions -- checked in the ISA of every instantiation by
+// tests/test_cabi_cpu.py::test_wino_kernels_leave_m0_to_the_dma_statements).
+__device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_byte_addr) : "memory");
+}
+// ... with a uniform 64-bit base and a 32-bit byte offset per lane (no vector address arithmetic)
+__device__ __forceinline__ void glds16_so(const float* base, unsigned byte_off, unsigned lds_byte_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(byte_off), "s"(lds_byte_addr), "s"(base) : "memory");
+}
+#ifdef SMSUT_WL_STAMPS               // scratch builds: wave 0 of workgroup (0, 0) sums the cycles of the phases of its regions into y[0..7]
+#define WL_STAMP(t)                                                                         \
+  do {                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory");            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+#else
+#define WL_STAMP(t) do { } while (0)
+#endif
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float aff1(float v, float m, float r, float g, float b, float slope) {
@@ -50,26 +90,31 @@ __device__ __forceinline__ float aff1(float v, float m, float r, float g, float 
 
 // LDS: TWO staging buffers {input tile, U chunk, (SC) 1x1 chunk} -- chunk t+1 is published while chunk t multiplies, one
 // barrier per chunk -- plus the statistics scratch
+constexpr int wino_l_in_floats(bool gli) { return gli ? NI_G * TPB * 4 : (IH * IW + 1) * SPX; }
 template <int NTN>
-constexpr int wino_l_buf_floats(bool sc) { return (IH * IW + 1) * SPX + 16 * 16 * 16 * NTN + (sc ? 16 * 16 * NTN : 0); }
+constexpr int wino_l_buf_floats(bool sc, bool gli) { return wino_l_in_floats(gli) + 16 * 16 * 16 * NTN + (sc ? 16 * 16 * NTN : 0); }
 template <int NTN>
-constexpr size_t wino_l_lds(bool sc) {
-  return (size_t)(2 * wino_l_buf_floats<NTN>(sc) + (4 * 16 * NTN * 2 + 8) * (sc ? 2 : 1)) * sizeof(float);
+constexpr size_t wino_l_lds(bool sc, bool gli) {
+  return (size_t)(2 * wino_l_buf_floats<NTN>(sc, gli) + (4 * 16 * NTN * 2 + 8) * (sc ? 2 : 1)) * sizeof(float);
 }
 
-template <int NTN, bool STATS, bool ACC, bool BST, bool DUAL, bool INAFF, bool SC, bool SC2>
+template <int NTN, bool STATS, bool ACC, bool BST, bool DUAL, bool INAFF, bool SC, bool SC2, bool PRE>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1)))
-conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ w, float* __restrict__ y,
+conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ w, const float* __restrict__ wu,
+            float* __restrict__ y,
             float* __restrict__ y2, int split, int N, int H, int W, int nch, int Ndim, int tiles_x, int tiles_img, int items_per_wg,
             int transposed, float* __restrict__ stats, WinoBst bst, WinoAff aff, WinoSc sc) {
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
   static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
   static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !SC2), "fused shortcut: forward statistics forms");
   static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !SC), "fused shortcut data-gradient");
+  static_assert(!(PRE && SC2), "prepared weights: not for the fused shortcut data-gradient (two weight tensors in one reduction)");
   constexpr int CO_T = 16 * NTN, NR = NTN;
+  constexpr bool GLI = !INAFF && SMSUT_WINO_GLDS != 0; // input tile by LDS-DMA
+  constexpr int NI = GLI ? NI_G : NI_R;
   extern __shared__ float smem[];
-  constexpr int BUF = wino_l_buf_floats<NTN>(SC);      // floats per staging buffer
-  constexpr int IN_F = (IH * IW + 1) * SPX;            // [IH][IW][SPX] + one dummy pixel (sink of the padding units)
+  constexpr int BUF = wino_l_buf_floats<NTN>(SC, GLI); // floats per staging buffer
+  constexpr int IN_F = wino_l_in_floats(GLI);          // [IH][IW][SPX] + one dummy pixel (sink of the padding units) | whole DMA slots
   constexpr int W_F = 16 * 16 * CO_T;                  // a chunk's U: [16 positions][4 channel quads][CO_T][4]
   float* red = smem + 2 * BUF;                         // [4 waves][CO_T][2] + dummy
   [[maybe_unused]] float* red_sc = red + 4 * CO_T * 2 + 8;
@@ -77,6 +122,10 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   auto w_b = [&](int b) { return smem + b * BUF + IN_F; };
   [[maybe_unused]] auto wsc_b = [&](int b) { return smem + b * BUF + IN_F + W_F; };   // SC: a chunk's 1x1 weights [4][CO_T][4]
 
+#ifdef SMSUT_WL_STAMPS
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0, ts_begin, acc_t[6] = {0, 0, 0, 0, 0, 0};
+  WL_STAMP(ts_begin);
+#endif
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, kq = lane >> 4;
@@ -98,29 +147,48 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   const int tiles_y = tiles_img / tiles_x;
 
   // ---- input staging descriptors (tile-independent)
-  int u_off[NI], u_lds[NI], u_flag[NI];
-  float4 rin[NI];
-  bool zero[NI];
+  int u_off[NI], u_flag[NI];
+  [[maybe_unused]] int u_lds[NI];
+  [[maybe_unused]] float4 rin[GLI ? 1 : NI];
+  [[maybe_unused]] bool zero[NI];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int u = tid + i * TPB;
-    const bool real = u < UNITS;
+    const bool real = GLI ? (u < GSLOTS && u % 5 < 4) : u < UNITS;
     const int uu = real ? u : 0;
-    const int q = uu & 3, pix = uu >> 2;
+    const int q = GLI ? uu % 5 : uu & 3, pix = GLI ? uu / 5 : uu >> 2;
     const int iy = pix / IW, ix = pix % IW;
     u_off[i] = (iy * W + ix) * KST + 4 * q;
     u_lds[i] = real ? pix * SPX + 4 * q : IH * IW * SPX;
-    u_flag[i] = (iy < 1 ? 1 : 0) | (iy >= TH + 1 ? 2 : 0) | (ix < 1 ? 4 : 0) | (ix >= TW + 1 ? 8 : 0);
+    u_flag[i] = (iy < 1 ? 1 : 0) | (iy >= TH + 1 ? 2 : 0) | (ix < 1 ? 4 : 0) | (ix >= TW + 1 ? 8 : 0) | (real ? 0 : 16);
   }
-  const int safe_off = (W + 1) * KST;                  // first interior pixel of the tile: always inside the image
+  [[maybe_unused]] const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // LDS byte address of this wave's 1 KiB piece 0 of staging buffer 0 (uniform; pieces and buffers are constant steps from it)
+  [[maybe_unused]] const unsigned la0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_vp)smem) + (unsigned)wave_u * 1024u;
+  [[maybe_unused]] const float* xb1 = x;               // GLI: source base / border flags of the chunk one region ahead
+  [[maybe_unused]] int fl1 = 0;
+  [[maybe_unused]] const int safe_off = (W + 1) * KST;                  // first interior pixel of the tile: always inside the image
 
   // ---- weight staging: NTN (reduction channel ci, output channel n) pairs per thread.  Lanes run along the contiguous
   //      dimension of the weight tensor: n for [tap][ci][n] (forward), ci for [tap][n][ci] (transposed)
   int w_ci[NTN], w_n[NTN];
-  unsigned w_off[NTN];                                 // element offset of the pair inside a (tap, chunk) block of the weight tensor
+  [[maybe_unused]] unsigned w_off[NTN];                // element offset of the pair inside a (tap, chunk) block of the weight tensor
   [[maybe_unused]] unsigned w_off1[NTN];               // ... inside the 1x1 weights (SC: [ci][n]; SC2: [n][ci])
-  float wreg[NTN][9];
+  [[maybe_unused]] float wreg[PRE ? 1 : NTN][9];
   [[maybe_unused]] float wx[NTN];
+  // PRE: the chunk's transformed weights are copied by LDS-DMA from the image smsut_wino_prepare wrote,
+  // [chunk][16-channel slab][position][channel quad][16][4]: 16-byte slot i * 256 + tid of the LDS block [pos][quad][CO_T][4]
+  constexpr int NWG = PRE ? 4 * NTN : 0;               // DMA parts per thread and chunk
+  constexpr int NWR = (!PRE || SC) ? NTN : 0;          // register parts (on-the-fly transform and / or the 1x1 shortcut weights)
+  [[maybe_unused]] unsigned w_goff[PRE ? NWG : 1];
+  [[maybe_unused]] const float* wu1 = wu;
+  if constexpr (PRE) {
+#pragma unroll
+    for (int i = 0; i < NWG; ++i) {
+      const int idx = i * TPB + tid, n = idx % CO_T, pk = idx / CO_T;
+      w_goff[i] = (unsigned)((n >> 4) * 4096 + (pk * 16 + (n & 15)) * 4) * 4u;           // bytes
+    }
+  }
 #pragma unroll
   for (int k = 0; k < NTN; ++k) {
     const int p = tid + k * TPB;
@@ -156,7 +224,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   // registers.  Everything is unconditional straight-line code (a branch would cut the scheduling region): past the workgroup's
   // last chunk the cursor stops and the last chunk is simply requested again.
   auto pf_setup = [&]() {                              // uniform: where the next request reads from
+    xb1 = xb; fl1 = pfl;
     pubc = pfc;
+    if constexpr (PRE) wu1 = wu + ((size_t)pubc * (Ndim >> 4) + (co0 >> 4)) * 4096;
     pfc = pch;
     pfl = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
     const int cl = (DUAL && pch >= nh) ? pch - nh : pch;
@@ -170,8 +240,19 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     }
   };
   auto pf_in = [&](int i) {
-    zero[i] = (u_flag[i] & pfl) != 0;
-    rin[i] = *(const float4*)(xb + (unsigned)(zero[i] ? safe_off : u_off[i]));
+    if constexpr (!GLI) {
+      zero[i] = (u_flag[i] & pfl) != 0;
+      rin[i] = *(const float4*)(xb + (unsigned)(zero[i] ? safe_off : u_off[i]));
+    }
+  };
+  // GLI: the operands of the NEXT chunk (the one the registers of the other path would be publishing now) go straight from
+  // global memory into LDS buffer b; the barrier that ends the region waits for them (hipcc drains vmcnt before it)
+  auto gl_in = [&](int i, int b) {
+    if constexpr (GLI) {
+      const bool z = (u_flag[i] & (fl1 | 16)) != 0;
+      const float* src = z ? (const float*)wino_zero16 : xb1 + u_off[i];
+      glds16(src, la0 + (unsigned)(b * BUF + i * TPB * 4) * 4u);
+    }
   };
   auto pf_aff = [&]() {
     if constexpr (INAFF) {
@@ -182,9 +263,15 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       a_b = *(const float4*)(aff.beta + ch);
     }
   };
+  auto gl_w = [&](int i, int b) {
+    if constexpr (PRE) {
+      glds16_so(wu1, w_goff[i], la0 + (unsigned)(b * BUF + IN_F + i * TPB * 4) * 4u);
+    }
+  };
   auto pf_w = [&](int k) {
     const int c = pfc;
-    if (SC2 && c >= nh) {
+    if constexpr (PRE) {
+    } else if (SC2 && c >= nh) {
       wreg[k][0] = (sc.w + (c - nh) * 16)[w_off1[k]];
     } else {
       // tap t's block: forward w + (t * Kd + 16 c) * Ndim, transposed w + (8 - t) * Ndim * KROW + 16 c -- selected with scalar
@@ -196,7 +283,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     if constexpr (SC) wx[k] = (sc.w + (size_t)(c * 16) * Ndim)[w_off1[k]];
   };
   auto pub_in = [&](int i, int b) {
-    float4 v = rin[i];
+    float4 v = rin[GLI ? 0 : i];
     if constexpr (INAFF) {
       v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
       v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
@@ -207,7 +294,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   auto pub_w = [&](int k, int b) {
     const int ci = w_ci[k], n = w_n[k];
     float* dst = w_b(b) + ((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3);        // + pos * 4 * CO_T * 4
-    if (SC2 && pubc >= nh) {
+    if constexpr (PRE) {
+      (void)dst;
+    } else if (SC2 && pubc >= nh) {
       dst[0] = wreg[k][0];                               // the 1x1 weights, parked in position 0's block
     } else {
       // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -226,7 +315,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     }
     if constexpr (SC) wsc_b(b)[((size_t)(ci >> 2) * CO_T + n) * 4 + (ci & 3)] = wx[k];
   };
-  constexpr int NP = NI + NTN;                          // staging parts
+  constexpr int NP = NI + NWG + NWR;                    // staging parts
   // part p of the region that multiplies from buffer b: publish into b ^ 1, then request
   auto stage_part = [&](int p_, int b) {
 #ifdef SMSUT_WLDBG_NO_STAGE_IN
@@ -236,15 +325,19 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     if (p_ >= NI) return;
 #endif
 #ifdef SMSUT_WLDBG_NO_PF
-    if (p_ < NI) { pub_in(p_, b ^ 1); } else { pub_w(p_ - NI, b ^ 1); }
+    if (p_ < NI) { if constexpr (!GLI) pub_in(p_, b ^ 1); } else if (p_ >= NI + NWG) { pub_w(p_ - NI - NWG, b ^ 1); }
     return;
 #endif
 #ifdef SMSUT_WLDBG_NO_PUB
-    if (p_ < NI) { pf_in(p_); } else { pf_w(p_ - NI); }
+    if (p_ < NI) { pf_in(p_); } else if (p_ >= NI + NWG) { pf_w(p_ - NI - NWG); }
     return;
 #endif
-    if (p_ < NI) { pub_in(p_, b ^ 1); pf_in(p_); }
-    else { pub_w(p_ - NI, b ^ 1); pf_w(p_ - NI); }
+    if (p_ < NI) {
+      if constexpr (GLI) gl_in(p_, b ^ 1);
+      else { pub_in(p_, b ^ 1); pf_in(p_); }
+    } else if (p_ < NI + NWG) {
+      gl_w(p_ - NI, b ^ 1);
+    } else { pub_w(p_ - NI - NWG, b ^ 1); pf_w(p_ - NI - NWG); }
   };
 
   f32x4 macc[16][NR], acc[4][NR];
@@ -387,6 +480,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       }
     }
     f32x4 d0[4], d1[4], d2[4], d3[4];
+#ifdef SMSUT_WLDBG_NO_LDA
+    if (c >= 0) dp = smem + 2 * BUF;                     // (every window read hits the same few words: no LDS bandwidth)
+#endif
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       d1[b] = *(const f32x4*)(dp + (1 * IW + b) * SPX);
@@ -411,9 +507,38 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     // are requested once the window rows are dead (last group of the item's last chunk).
     constexpr int XO[4] = {1, 2, 0, 3};
     constexpr int NU = 4 * NR;
+    // which unit carries staging part p: the LDS-DMA pieces all go out in the first units of the chunk (SMSUT_WINO_DMA_UNITS,
+    // default half of them) -- they have to have LANDED at the barrier that ends the chunk, and an input piece that misses L2
+    // takes a good part of a chunk to arrive; the register parts (publish what was requested a chunk ago, request the next) are
+    // spread over all units as before
+#ifndef SMSUT_WL_IG_VALU
+#define SMSUT_WL_IG_VALU 6
+#endif
+#ifndef SMSUT_WL_IG_DS
+#define SMSUT_WL_IG_DS 2
+#endif
+#ifndef SMSUT_WINO_DMA_UNITS
+#define SMSUT_WINO_DMA_UNITS (NU / 2)
+#endif
+    constexpr int NDMA = (GLI ? NI : 0) + NWG;           // DMA parts: [0, NI) when GLI, [NI, NI + NWG)
+    auto part_unit = [&](int p_) {
+      const bool dma = (GLI && p_ < NI) || (p_ >= NI && p_ < NI + NWG);
+      if (dma) {
+        const int k = (GLI || p_ < NI) ? p_ : p_ - NI;   // index among the DMA parts, inputs first
+        return (k * (SMSUT_WINO_DMA_UNITS)) / NDMA;
+      }
+      return p_ % NU;
+    };
     f32x4 bf[2][4], vv[2][4];
     auto ld_b = [&](int u, f32x4* dst) {
       const int xi = XO[u / NR], j = u % NR;
+#ifdef SMSUT_WLDBG_NO_LDB
+      if (c >= 0) {
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) dst[nu] = (f32x4){(float)xi, (float)j, (float)nu, 1.f};
+        return;
+      }
+#endif
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) dst[nu] = *(const f32x4*)(wc + ((size_t)(xi * 4 + nu) * 4 * CO_T + j * 16) * 4);
     };
@@ -430,15 +555,16 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     ld_b(0, bf[0]);
     xform(0, vv[0]);
     __builtin_amdgcn_sched_barrier(0);
+    WL_STAMP(ts1);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int g = u / NR, j = u % NR;
 #pragma unroll
       for (int p_ = 0; p_ < NP; ++p_)
 #ifdef SMSUT_WLDBG_NO_STAGE          // scratch builds (scratch/wino_l_ablation.py): results wrong by construction, only the time matters
-        if (p_ % NU == u && c < 0) stage_part(p_, buf);
+        if (part_unit(p_) == u && c < 0) stage_part(p_, buf);
 #else
-        if (p_ % NU == u) stage_part(p_, buf);           // this unit's share of the staging work, in the shadow of its MFMAs
+        if (part_unit(p_) == u) stage_part(p_, buf);     // this unit's share of the staging work, in the shadow of its MFMAs
 #endif
       if (u + 1 < NU) {
         ld_b(u + 1, bf[(u + 1) & 1]);
@@ -464,14 +590,15 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
 #else
           macc[XO[g] * 4 + nu][j] = mfma16(vv[g & 1][nu][s], bf[u & 1][nu][s], macc[XO[g] * 4 + nu][j]);
 #endif
-      // interleave: after every MFMA up to six VALU, two LDS and two global-memory instructions of this region (left alone the
-      // scheduler emitted the 16 MFMAs back to back and the staging arithmetic after them: one wave per SIMD, nothing hidden)
-#ifndef SMSUT_WLDBG_NO_IGROUP
+      // SMSUT_WL_IGROUP: force an interleave -- after every MFMA up to six VALU, two LDS and two global-memory instructions of
+      // this region.  Off: with the staging done by LDS-DMA the region has ~2 other instructions per MFMA and the scheduler's
+      // own order measures 1-2 us (of 50) faster than any forced one (6/2, 4/1, 3/1, 2/1 tried: profiles/r03_notes.md)
+#ifdef SMSUT_WL_IGROUP
 #pragma unroll
       for (int m_ = 0; m_ < 16; ++m_) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
-        __builtin_amdgcn_sched_group_barrier(0x080, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, SMSUT_WL_IG_VALU, 0);
+        __builtin_amdgcn_sched_group_barrier(0x080, SMSUT_WL_IG_DS, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
       }
 #endif
@@ -503,7 +630,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
 #pragma unroll
   for (int i = 0; i < NI; ++i) pf_in(i);
 #pragma unroll
-  for (int k = 0; k < NTN; ++k) pf_w(k);
+  for (int k = 0; k < NWR; ++k) pf_w(k);
   pf_aff();
   pf_advance();
   pf_setup();                                           // (pubc = 0: what the registers hold)
@@ -511,21 +638,31 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   for (int p_ = 0; p_ < NP; ++p_) stage_part(p_, 1);    // publishes into buffer 0, requests chunk 1
   pf_aff();
   pf_advance();
+  if constexpr (GLI || PRE) glds_wait();
   __syncthreads();
   int buf = 0;
   // one chunk = one region = one barrier: staging parts + this chunk's MFMAs (+ on an item's last chunk: transform, statistics,
   // stores).  `last` is a compile-time tag: as a run-time condition the compiler predicated the whole epilogue into every chunk
   auto region = [&](int c, auto last_tag) {
     constexpr bool last = decltype(last_tag)::value;
+    WL_STAMP(ts0);
     pf_setup();
     mma_chunk(c, buf, last_tag);
     pf_aff();
     pf_advance();
+    WL_STAMP(ts2);
     if constexpr (last) { out_transform(); epilogue(); }
+    WL_STAMP(ts3);
+    if constexpr (GLI || PRE) glds_wait();               // this wave's LDS-DMA pieces of the next chunk have landed
+    WL_STAMP(ts4);
 #ifndef SMSUT_WLDBG_NO_BARRIER
     __syncthreads();                                     // buffer buf is free, buf ^ 1 is complete; red[] is complete
 #endif
     if constexpr (last) stats_out();
+    WL_STAMP(ts5);
+#ifdef SMSUT_WL_STAMPS
+    acc_t[0] += ts1 - ts0; acc_t[1] += ts2 - ts1; acc_t[2] += ts3 - ts2; acc_t[3] += ts4 - ts3; acc_t[4] += ts5 - ts4; acc_t[5] += 1;
+#endif
     buf ^= 1;
   };
   for (int item = item0; item < item1; ++item) {
@@ -534,6 +671,74 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     region(nch - 1, std::true_type{});
     advance(cn, cty, ctx);
   }
+#ifdef SMSUT_WL_STAMPS
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+    for (int i = 0; i < 6; ++i) y[i] = (float)acc_t[i];
+    y[6] = (float)(ts5 - ts_begin);
+  }
+#endif
+}
+
+// ---- prepared weights: U = G g G^T of whole weight tensors, written once per weight version in the image order the kernel's
+//      LDS-DMA copies (several tensors per launch: the table travels in the kernel arguments, so a captured launch is
+//      self-contained)
+constexpr int PREP_MAX = 32;
+struct PrepEntry { const float* w; float* u; int kd, nd, tr, blk0; };
+struct PrepTable { PrepEntry e[PREP_MAX]; int n; };
+
+__global__ void __launch_bounds__(TPB) wino_u_prepare(PrepTable t) {
+  int ei = 0;
+  for (int i = 1; i < t.n; ++i)
+    if ((int)blockIdx.x >= t.e[i].blk0) ei = i;
+  const PrepEntry e = t.e[ei];
+  const int lt = ((int)blockIdx.x - e.blk0) * TPB + (int)threadIdx.x;       // (chunk c, slab j, channel quad kq, channel n16)
+  if (lt >= e.kd * (e.nd >> 2)) return;
+  const int n16 = lt & 15, kq = (lt >> 4) & 3, cj = lt >> 6;
+  const int nj = e.nd >> 4, c = cj / nj, j = cj - c * nj;
+  const int n = j * 16 + n16, ci0 = c * 16 + kq * 4;
+  float g[4][9];
+  if (e.tr) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const float4 v = *(const float4*)(e.w + ((size_t)(8 - tap) * e.nd + n) * e.kd + ci0);
+      g[0][tap] = v.x; g[1][tap] = v.y; g[2][tap] = v.z; g[3][tap] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) g[q][tap] = e.w[((size_t)tap * e.kd + ci0 + q) * e.nd + n];
+  }
+  float uu[4][16];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                          // the arithmetic of conv_wino_l's on-the-fly form, in its order
+    float tt[4][3];
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) {
+      const float g0 = g[q][bb], g1 = g[q][3 + bb], g2 = g[q][6 + bb];
+      tt[0][bb] = g0; tt[1][bb] = 0.5f * (g0 + g1 + g2); tt[2][bb] = 0.5f * (g0 - g1 + g2); tt[3][bb] = g2;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      uu[q][a * 4 + 0] = tt[a][0];
+      uu[q][a * 4 + 1] = 0.5f * (tt[a][0] + tt[a][1] + tt[a][2]);
+      uu[q][a * 4 + 2] = 0.5f * (tt[a][0] - tt[a][1] + tt[a][2]);
+      uu[q][a * 4 + 3] = tt[a][2];
+    }
+  }
+  float4* out = (float4*)e.u + ((size_t)cj * 64 + kq) * 16 + n16;           // + pos * 4 * 16
+#pragma unroll
+  for (int pos = 0; pos < 16; ++pos) out[(size_t)pos * 64] = make_float4(uu[0][pos], uu[1][pos], uu[2][pos], uu[3][pos]);
+}
+
+struct BoundU { const float* u; int kd, nd; };
+std::mutex g_bind_mu;
+std::unordered_map<uintptr_t, BoundU> g_bound;           // key: weight address * 2 + transposed
+inline const float* bound_image(const float* w, int tr, int kd, int nd) {
+  std::lock_guard<std::mutex> lk(g_bind_mu);
+  if (g_bound.empty()) return nullptr;
+  auto it = g_bound.find((uintptr_t)w * 2 + (uintptr_t)(tr & 1));
+  return (it != g_bound.end() && it->second.kd == kd && it->second.nd == nd) ? it->second.u : nullptr;
 }
 
 inline int device_cus() {
@@ -555,8 +760,8 @@ inline void allow_big_lds(size_t bytes) {
 }
 
 template <int NTN>
-int launch_ntn(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W, int Kdim, int Ndim,
-               int transposed, float* stats, const WinoBst* bst, const WinoAff* aff, const WinoSc* sc, hipStream_t st) {
+int launch_ntn(const float* x, const float* x2, const float* w, const float* wu, float* y, float* y2, int split, int N, int H, int W,
+               int Kdim, int Ndim, int transposed, float* stats, const WinoBst* bst, const WinoAff* aff, const WinoSc* sc, hipStream_t st) {
   const int tiles_x = W / TW, tiles_img = tiles_x * (H / TH);
   const int nz = Ndim / (16 * NTN);
   const int64_t items = (int64_t)N * tiles_img;
@@ -570,12 +775,20 @@ int launch_ntn(const float* x, const float* x2, const float* w, float* y, float*
   const WinoAff av = aff ? *aff : WinoAff{};
   const WinoSc sv = sc ? *sc : WinoSc{};
   const bool sc2 = sc && (transposed & 1), scf = sc && !sc2;
-  const size_t sh = wino_l_lds<NTN>(scf);
+  const size_t sh = wino_l_lds<NTN>(scf, !aff && SMSUT_WINO_GLDS != 0);
+#define WGO1(ST, AC, BS, DU, IA, S1, S2, PR)                                                                              \
+  do {                                                                                                                     \
+    allow_big_lds<conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2, PR>>(sh);                                                   \
+    conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2, PR><<<grid, TPB, sh, st>>>(x, x2, w, wu, y, y2, split, N, H, W, nch, Ndim, \
+                                                                            tiles_x, tiles_img, ipw, transposed, stats, bv, \
+                                                                            av, sv);                                       \
+  } while (0)
 #define WGO(ST, AC, BS, DU, IA, S1, S2)                                                                                    \
   do {                                                                                                                     \
-    allow_big_lds<conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2>>(sh);                                                       \
-    conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2><<<grid, TPB, sh, st>>>(x, x2, w, y, y2, split, N, H, W, nch, Ndim, tiles_x, \
-                                                                        tiles_img, ipw, transposed, stats, bv, av, sv);    \
+    if constexpr (!(S2)) {                                                                                                 \
+      if (wu) { WGO1(ST, AC, BS, DU, IA, S1, S2, true); break; }                                                           \
+    }                                                                                                                      \
+    WGO1(ST, AC, BS, DU, IA, S1, S2, false);                                                                               \
   } while (0)
   if (sc2) {
     if (!x2 || !sc->w || stats || bst || aff || (transposed & 2) || nch % 2) return -1;
@@ -603,6 +816,7 @@ int launch_ntn(const float* x, const float* x2, const float* w, float* y, float*
     WGO(false, false, false, false, false, false, false);
   }
 #undef WGO
+#undef WGO1
   return 0;
 }
 
@@ -967,9 +1181,66 @@ int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* 
   const int64_t items = (int64_t)N * (W / TW) * (H / TH);
   int ntn = (Ndim % 32 == 0 && !(y2 && split % 32 != 0) && items * (Ndim / 32) >= device_cus()) ? 2 : 1;
   if (force == 1 || (force == 2 && Ndim % 32 == 0 && !(y2 && split % 32 != 0))) ntn = force;
-  if (ntn == 2) return launch_ntn<2>(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
-  return launch_ntn<1>(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
+  // prepared weights (smsut_wino_prepare + smsut_wino_bind by the caller): copied by LDS-DMA instead of transformed per chunk
+  const bool sc2 = sc && (transposed & 1);
+  const float* wu = sc2 ? nullptr : bound_image(w, transposed & 1, Kdim, Ndim);
+  if (ntn == 2) return launch_ntn<2>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
+  return launch_ntn<1>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
 }
+
+extern "C" {
+
+int64_t smsut_wino_image_floats(int Kdim, int Ndim) {
+  return (Kdim >= 16 && Kdim % 16 == 0 && Ndim >= 16 && Ndim % 16 == 0) ? (int64_t)16 * Kdim * Ndim : 0;
+}
+
+int smsut_wino_prepare(const float* const* w, float* const* u, const int* Kdim, const int* Ndim, const int* transposed, int count,
+                       void* stream) {
+  if (count < 0 || (count > 0 && (!w || !u || !Kdim || !Ndim || !transposed))) return -1;
+  for (int i = 0; i < count; ++i)
+    if (!w[i] || !u[i] || smsut_wino_image_floats(Kdim[i], Ndim[i]) == 0) return -1;
+  for (int i0 = 0; i0 < count; i0 += PREP_MAX) {
+    PrepTable t;
+    t.n = count - i0 < PREP_MAX ? count - i0 : PREP_MAX;
+    int blk = 0;
+    for (int i = 0; i < t.n; ++i) {
+      t.e[i] = PrepEntry{w[i0 + i], u[i0 + i], Kdim[i0 + i], Ndim[i0 + i], transposed[i0 + i] & 1, blk};
+      blk += (Kdim[i0 + i] * (Ndim[i0 + i] / 4) + TPB - 1) / TPB;
+    }
+    wino_u_prepare<<<blk, TPB, 0, (hipStream_t)stream>>>(t);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+int smsut_wino_bind(const float* w, int transposed, const float* u, int Kdim, int Ndim) {
+  if (!w) return -1;
+  std::lock_guard<std::mutex> lk(g_bind_mu);
+  const uintptr_t key = (uintptr_t)w * 2 + (uintptr_t)(transposed & 1);
+  if (!u) g_bound.erase(key);
+  else g_bound[key] = BoundU{u, Kdim, Ndim};
+  return 0;
+}
+
+int smsut_wino_bind_many(const float* const* w, const float* const* u, const int* Kdim, const int* Ndim, const int* transposed,
+                         int count) {
+  if (count < 0 || (count > 0 && (!w || !transposed || (u && (!Kdim || !Ndim))))) return -1;
+  std::lock_guard<std::mutex> lk(g_bind_mu);
+  for (int i = 0; i < count; ++i) {
+    if (!w[i]) return -1;
+    const uintptr_t key = (uintptr_t)w[i] * 2 + (uintptr_t)(transposed[i] & 1);
+    if (!u || !u[i]) g_bound.erase(key);
+    else g_bound[key] = BoundU{u[i], Kdim[i], Ndim[i]};
+  }
+  return 0;
+}
+
+int smsut_wino_unbind_all(void) {
+  std::lock_guard<std::mutex> lk(g_bind_mu);
+  g_bound.clear();
+  return 0;
+}
+
+}  // extern "C"
 
 bool smsut_wino_wg_eligible(int N, int H, int W, int Cin, int Cout, const float* x2, int ca) {
   // OFF by default (r03): correct (2-3e-7 of fp64) but only at parity with the direct weight-gradient kernels -- per-item staging

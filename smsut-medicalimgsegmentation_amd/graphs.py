@@ -33,6 +33,12 @@ def graphs_enabled() -> bool:
     return True
 
 
+def capturing() -> bool:
+    """True while launches are being recorded into a hipGraph instead of executed (a GraphedPhase capture, or anyone else's
+    capture on the current stream)."""
+    return _CAPTURING > 0 or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing())
+
+
 def assert_no_capture(what: str):
     """Called by every collective of the package (gradient all-reduce, Dice-statistics all-reduce, parameter broadcast):
     a collective issued while a phase is being captured would be baked into a hipGraph (or silently dropped on replay) --

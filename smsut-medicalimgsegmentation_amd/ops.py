@@ -174,6 +174,114 @@ def conv_dtype() -> str:
     return "f16" if CONV_F16 else "f32"
 
 
+# ------------------------------------------------------------------------------------------- prepared Winograd weights
+# The large-reduction Winograd kernel (csrc/conv_wino.hip, reductions >= 64 channels) transforms its weights U = G g G^T per
+# workgroup and chunk -- about a tenth of its time -- unless a prepared image of the weight tensor is BOUND (smsut_wino_prepare /
+# smsut_wino_bind_many): then it copies the image by LDS-DMA.  An image is only right while the weights it was made from are
+# unchanged, so images are made on entry of a scope in which the caller guarantees exactly that (a trainer's forward / backward
+# phase: weights change in optimizer.step(), between phases) and their bindings are dropped when it closes; a module called
+# outside such a scope runs the on-the-fly form.  Results are bit-identical either way.  ``SMSUT_WINO_PREPARED=0`` turns the scopes into no-ops.
+WINO_PREPARED = _os.environ.get("SMSUT_WINO_PREPARED", "1") not in ("0", "")
+_WINO_MIN_K = 64
+
+
+class _WinoForm:
+    """Images of ONE form (0: forward, 1: data-gradient) of a module's eligible 3x3 weights + the host-side argument arrays."""
+
+    def __init__(self, ent):
+        import ctypes
+        self.weights = [e[0] for e in ent]
+        self.n = n = len(ent)
+        if n == 0:
+            return
+        sizes = [16 * e[2] * e[3] for e in ent]
+        self.images = torch.empty(sum(sizes), dtype=torch.float32, device=ent[0][0].device)
+        PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+        offs = [0]
+        for z in sizes[:-1]:
+            offs.append(offs[-1] + z)
+        base = self.images.data_ptr()
+        self._keep = (PA(*[w.data_ptr() for w in self.weights]), PA(*[base + 4 * o for o in offs]), IA(*[e[2] for e in ent]),
+                      IA(*[e[3] for e in ent]), IA(*[e[1] for e in ent]))
+        self._addr = tuple(ctypes.addressof(a) for a in self._keep)
+
+    def enter(self):
+        if self.n == 0:
+            return
+        # ALWAYS re-made on entry (one launch for all tensors of the form): a weight's ``_version`` is no witness of its
+        # contents -- the fused optimizers (torch.optim.SGD / Adam(fused=True), what the trainers use) update in place without
+        # moving it, and so does anything that writes through ``.data``
+        H.call("smsut_wino_prepare", *self._addr, self.n, _s())
+        H.call("smsut_wino_bind_many", *self._addr, self.n)
+
+    def exit(self):
+        if self.n:
+            a = self._addr
+            H.call("smsut_wino_bind_many", a[0], None, a[2], a[3], a[4], self.n)
+
+
+class _WinoSet:
+    def __init__(self, module: torch.nn.Module):
+        ent = ([], [])                                       # per form: (weight, transposed, Kdim, Ndim)
+        seen = set()
+        for m in module.modules():
+            w = getattr(m, "weight", None)
+            if not isinstance(w, torch.Tensor) or w.dim() != 4 or not w.is_cuda or w.dtype != torch.float32:
+                continue
+            co, ci, kh, kw = w.shape
+            if (kh, kw) != (3, 3) or getattr(m, "stride", 1) != 1 or getattr(m, "padding", 1) != 1 or w.data_ptr() in seen:
+                continue
+            if w.stride() != hwio_strides(co, ci, 3, 3) or ci % 16 or co % 16:
+                continue
+            seen.add(w.data_ptr())
+            if ci >= _WINO_MIN_K:
+                ent[0].append((w, 0, ci, co))
+            if co >= _WINO_MIN_K:
+                ent[1].append((w, 1, co, ci))
+        self.ptrs = self._layout(module)
+        self.forms = (_WinoForm(ent[0]), _WinoForm(ent[1]))
+
+    @staticmethod
+    def _layout(module):
+        return tuple(p.data_ptr() for p in module.parameters() if p.dim() == 4)
+
+    def stale_layout(self, module):
+        """parameters re-created or moved since the images were laid out (``.to(device)``, a re-built layer)"""
+        return self._layout(module) != self.ptrs
+
+    def __deepcopy__(self, memo):                            # copy.deepcopy(module) (EMA teachers): the copy lays out its own
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
+
+@contextlib.contextmanager
+def wino_prepared(*modules: torch.nn.Module, forms: str = "fb"):
+    """Scope in which the 3x3 weights of ``modules`` do not change.  ``forms``: "f" (the forward convolutions run inside), "b"
+    (their data-gradients), "fb".  On entry the Winograd images of those forms are made from the weights as they are NOW (one
+    launch per module and form -- inside a hipGraph capture it becomes part of the captured phase, which therefore never
+    depends on what another phase left behind) and bound for the convolutions inside; unbound on exit."""
+    active = []
+    if WINO_PREPARED and not CONV_F16:
+        for m in modules:
+            ws = m.__dict__.get("_smsut_wino_set")
+            if ws is None or ws.stale_layout(m):
+                ws = _WinoSet(m)
+                m.__dict__["_smsut_wino_set"] = ws
+            if "f" in forms:
+                active.append(ws.forms[0])
+            if "b" in forms:
+                active.append(ws.forms[1])
+    for f in active:
+        f.enter()
+    try:
+        yield
+    finally:
+        for f in active:
+            f.exit()
+
+
 def _grad_scale(t: torch.Tensor) -> torch.Tensor:
     """Device float[2] = {s, 1/s}: power-of-two scale that brings max|t| into [2^13, 2^14] -- gradient tensors sit far below
     fp16's normal range (|gy| ~ 1e-7 at 512^2); the f16 kernels multiply by s before converting and by 1/s after."""

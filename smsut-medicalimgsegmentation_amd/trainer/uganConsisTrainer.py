@@ -101,12 +101,17 @@ class UGANConsisTrainer(UGANShp0Trainer):
     #   G2   D(x_fake) through the UPDATED frozen D, both DiceCE values from the global statistics, g_loss.backward()
     def _g1_phase(self, x_real, vec_ot, ids, y_real):
         """G(x_real -> x_fake) with the autograd graph retained for the G-step; returns (x_fake detached, seg statistics)."""
-        y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
+        with ops.wino_prepared(self.net, forms="f"):        # (scopes: the weights move in the optimizer steps only)
+            y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
         self._g1 = (y_fake, x_fake, feat_x)
         return x_fake.detach(), self.loss.stats(y_fake[:y_real.size(0)], y_real)
 
     def _d_phase(self, x_real, x_fake, modal_org, alpha):
         """D-step forward + backward (:129-144).  Returns [D_real, D_fake, D_cls, D_gp]."""
+        with ops.wino_prepared(self.D):
+            return self._d_phase_body(x_real, x_fake, modal_org, alpha)
+
+    def _d_phase_body(self, x_real, x_fake, modal_org, alpha):
         b = x_real.size(0)
         with ops.first_order_pass():
             out_src, out_cls = self.D(torch.cat([x_real, x_fake], 0))
@@ -142,8 +147,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
         multi-tensor add instead of one add kernel per parameter), L1, PatchNCE, the pseudo labels and the consistency
         term's Dice statistics.  Leaves its autograd graph for phase G2; returns the (local) statistics."""
         y_fake, x_fake, feat_x = self._g1
-        y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
-                                                             {"sample_ids": [ids]})
+        with ops.wino_prepared(self.net, forms="f"):
+            y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
+                                                                 {"sample_ids": [ids]})
         g_rec = ops.l1_mean(x_real, x_rec)
         g_nce = self.nce_loss(feat_x, feat_f)
         if self._semi_on:
@@ -159,6 +165,10 @@ class UGANConsisTrainer(UGANShp0Trainer):
         ``lambda_semi`` is a 0-dim device tensor (it changes every epoch and must not be baked into a captured graph);
         ``st_*`` are the Dice statistics, already summed over the ranks.
         Returns [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]."""
+        with ops.wino_prepared(self.net, forms="b"), ops.wino_prepared(self.D):
+            return self._g2_phase_body(y_real, modal_trg, st_seg, st_semi, lambda_semi)
+
+    def _g2_phase_body(self, y_real, modal_trg, st_seg, st_semi, lambda_semi):
         bs = y_real.size(0)
         y_fake, x_fake, _ = self._g1
         y_rec, pseudo, g_rec, g_nce = self._g2

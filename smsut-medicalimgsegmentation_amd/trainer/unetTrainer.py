@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from .. import config as cfg
-from .. import graphs, parallel
+from .. import graphs, ops, parallel
 from ..network.unet import UNet
 from .baseTrainer import seed_all, BaseTrainer, make_sgd
 
@@ -28,14 +28,16 @@ class UnetTrainer(BaseTrainer):
     # all-reduce runs eagerly between the two replays (a no-op on one GPU).
     def _fwd_phase(self, img, msk):
         """forward + Dice/CE statistics; leaves the autograd graph for the second phase."""
-        out = self.net(img)
+        with ops.wino_prepared(self.net, forms="f"):        # the weights move in optimizer.step() only
+            out = self.net(img)
         self._out = out
         return self.loss.stats(out, msk)
 
     def _bwd_phase(self, msk, stats):
         """loss from the (global) statistics + backward."""
         loss = self.loss.from_stats(self._out, msk, stats)
-        loss.backward()
+        with ops.wino_prepared(self.net, forms="b"):
+            loss.backward()
         self._out = None
         return loss.detach()
 

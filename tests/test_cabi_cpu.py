@@ -26,7 +26,7 @@ def header_decls():
     for m in re.finditer(r"\b(int|int64_t)\s+(smsut_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
         ret, name, args = m.group(1), m.group(2), m.group(3)
         kinds = []
-        for a in [a.strip() for a in args.split(",") if a.strip()]:
+        for a in [a.strip() for a in args.split(",") if a.strip() and a.strip() != "void"]:
             if "*" in a:
                 kinds.append("p")
             elif a.startswith("int64_t"):
@@ -90,3 +90,22 @@ def test_product_path_fails_loudly_without_gpu_or_library(monkeypatch):
     monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libsmsut_hip.so")
     with pytest.raises(_hip.SmsutHipError):
         _hip.load()
+
+
+def test_wino_kernels_leave_m0_to_the_dma_statements(tmp_path):
+    """csrc/conv_wino.hip issues its LDS-DMA copies from inline assembly that writes M0 and does not restore it (the compiler
+    reserves M0; see the comment at glds16).  That is only sound while nothing else in those kernels touches M0: every mention of
+    m0 in the generated ISA must be the `s_mov_b32 m0, sN` of such a statement, followed by its s_nop and global_load_lds."""
+    import subprocess
+    out = tmp_path / "conv_wino.s"
+    subprocess.check_call([ge.HIPCC, *ge.FLAGS, "-I", os.path.join(ge.ROOT, "include"), "--cuda-device-only", "-S",
+                           os.path.join(ge.CSRC, "conv_wino.hip"), "-o", str(out)])
+    lines = [ln.split(";")[0].strip() for ln in open(out)]
+    lines = [ln for ln in lines if ln and not ln.startswith(".")]
+    uses = [i for i, ln in enumerate(lines) if re.search(r"\bm0\b", ln)]
+    assert len(uses) > 100                                     # the DMA statements exist (15 per chunk loop and instantiation)
+    for i in uses:
+        assert re.fullmatch(r"s_mov_b32 m0, s\d+", lines[i]), lines[i]
+        assert lines[i + 1].startswith("s_nop") and lines[i + 2].startswith("global_load_lds_dwordx4"), lines[i:i + 3]
+    n_dma = sum(ln.startswith("global_load_lds_dwordx4") for ln in lines)
+    assert n_dma == len(uses)

@@ -31,16 +31,44 @@ def _dgrad64(gy, w):          # gradient of conv w.r.t. its input
     return F.conv_transpose2d(gy.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
 
 
+class _Prepared:
+    """smsut_wino_prepare + smsut_wino_bind_many for one weight tensor, both forms (the images are kept alive by the object)."""
+
+    def __init__(self, H, w, ci, co):
+        import ctypes
+        forms = [(0, ci, co), (1, co, ci)]
+        self.u = [torch.full((max(H.call("smsut_wino_image_floats", k, m), 1),), float("nan"), device="cuda") for _, k, m in forms]
+        PA, IA = ctypes.c_void_p * 2, ctypes.c_int * 2
+        self.arr = (PA(w.data_ptr(), w.data_ptr()), PA(*[u.data_ptr() for u in self.u]), IA(ci, co), IA(co, ci), IA(0, 1))
+        addr = [ctypes.addressof(a) for a in self.arr]
+        H.call("smsut_wino_prepare", *addr, 2, H.stream_ptr())
+        H.call("smsut_wino_bind_many", *addr, 2)
+        self.H = H
+
+    def close(self):
+        self.H.call("smsut_wino_unbind_all")
+
+
+@pytest.fixture(params=[False, True], ids=["on-the-fly", "prepared"])
+def prepared(request):
+    """every form test runs twice: weights transformed inside the kernel, and copied from a bound prepared image"""
+    yield request.param
+    import smsut_amd  # noqa: F401
+    from smsut_amd import _hip as H
+    H.call("smsut_wino_unbind_all")
+
+
 def _rel(a, b):
     return float((a.double() - b).abs().max() / b.abs().max())
 
 
 @pytest.mark.parametrize("n,h,ci,co", SHAPES)
-def test_forward_datagrad_accumulate_statistics(n, h, ci, co):
+def test_forward_datagrad_accumulate_statistics(n, h, ci, co, prepared):
     import smsut_amd  # noqa: F401
     from smsut_amd import _hip as H
     st = H.stream_ptr()
     g, x, w = _mk(n, h, ci, co, 3)
+    keep = _Prepared(H, w, ci, co) if prepared else None  # noqa: F841
     ref = _conv64(x, w)
     y = torch.full((n, h, h, co), float("nan"), device="cuda")
     H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, h, ci, co, 3, 0, st)
@@ -64,13 +92,14 @@ def test_forward_datagrad_accumulate_statistics(n, h, ci, co):
 
 
 @pytest.mark.parametrize("n,h,c", [(3, 32, 32), (3, 32, 64), (2, 16, 128), (2, 16, 256), (5, 32, 96)])
-def test_input_side_instnorm_and_bst_forms(n, h, c):
+def test_input_side_instnorm_and_bst_forms(n, h, c, prepared):
     """conv2 of a BasicBlock on the raw conv1 output (InstanceNorm + LeakyReLU while staging; zero padding applies AFTER the
     affine) and its data-gradient with the LeakyReLU mask / InstanceNorm-backward partials in the epilogue (blocks.py:66-72)."""
     import smsut_amd  # noqa: F401
     from smsut_amd import _hip as H
     st = H.stream_ptr()
     g, y1, w = _mk(n, h, c, c, 5)
+    keep = _Prepared(H, w, c, c) if prepared else None  # noqa: F841
     if not H.call("smsut_conv2d_mfma_persistent", n, h, h, c, c, 3, 0):
         pytest.skip("shape not on a fused-form kernel")
     slope, eps = 0.01, 1e-5
@@ -104,13 +133,14 @@ def test_input_side_instnorm_and_bst_forms(n, h, c):
 
 
 @pytest.mark.parametrize("n,h,ci,co", [(3, 32, 64, 32), (2, 32, 128, 64), (2, 16, 256, 128), (3, 32, 32, 16)])
-def test_virtual_cat_split_and_fused_shortcut_forms(n, h, ci, co):
+def test_virtual_cat_split_and_fused_shortcut_forms(n, h, ci, co, prepared):
     """Decoder conv1 on cat([up, skip]) read in place, the split-output data-gradient, and conv1 + 1x1 shortcut fused
     (blocks.py:37-50, 66-80) against fp64."""
     import smsut_amd  # noqa: F401
     from smsut_amd import _hip as H
     st = H.stream_ptr()
     g, x, w = _mk(n, h, ci, co, 9)
+    keep = _Prepared(H, w, ci, co) if prepared else None  # noqa: F841
     ca = ci // 2
     xa, xb = x[..., :ca].contiguous(), x[..., ca:].contiguous()
     ref = _conv64(x, w)
@@ -140,3 +170,80 @@ def test_virtual_cat_split_and_fused_shortcut_forms(n, h, ci, co):
         got = torch.full((n, h, h, ci), float("nan"), device="cuda")
         H.call("smsut_conv2d_dgrad_mfma_sc", gy, gs, w, w1, got, None, 0, n, h, h, co, ci, st)
         assert _rel(got, refd + gs.double() @ w1.double().t()) < 2e-6
+
+
+@pytest.mark.parametrize("n,h,ci,co", [(3, 32, 64, 64), (2, 16, 256, 128), (5, 16, 96, 32), (2, 32, 128, 48)])
+def test_prepared_weights_are_bit_identical_and_scoped(n, h, ci, co):
+    """A bound prepared image gives the bits of the on-the-fly transform (same arithmetic, done once); a binding of other
+    dimensions or after smsut_wino_bind(..., NULL) is not used; stale images are the caller's business -- shown here on purpose:
+    the kernel really reads the image."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    g, x, w = _mk(n, h, ci, co, 21)
+    gy = torch.randn(n, h, h, co, generator=g).cuda()
+    H.call("smsut_wino_unbind_all")
+
+    def run():
+        y, gx = torch.full((n, h, h, co), float("nan"), device="cuda"), torch.full((n, h, h, ci), float("nan"), device="cuda")
+        H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, h, ci, co, 3, 0, st)
+        H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, h, co, ci, 3, 1, st)
+        return y, gx
+    y0, g0 = run()
+    keep = _Prepared(H, w, ci, co)
+    y1, g1 = run()
+    assert torch.equal(y0, y1) and torch.equal(g0, g1)
+    keep.u[0].mul_(2.0)                                    # the forward image no longer matches the weights ...
+    y2, g2 = run()
+    assert torch.equal(y2, 2.0 * y0) and torch.equal(g2, g0)   # ... and it is the image that is read (x2 is exact in fp32)
+    H.call("smsut_wino_bind", w, 0, None, 0, 0)            # unbind the forward form: back to the weights
+    y3, g3 = run()
+    assert torch.equal(y3, y0) and torch.equal(g3, g0)
+    H.call("smsut_wino_bind", w, 0, keep.u[1], co, ci)     # an image of other dimensions under this key is ignored
+    if ci != co:
+        y4, _ = run()
+        assert torch.equal(y4, y0)
+    keep.close()
+
+
+def test_prepared_scope_in_a_training_step_is_bit_identical():
+    """ops.wino_prepared (what the trainers wrap their phases in): the same forward + backward with and without the scope."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd import ops
+    from smsut_amd.network.blocks import BasicBlock
+    torch.manual_seed(5)
+    blk = BasicBlock(64, 128, norm="instance", act="lrelu").cuda()
+    x = ops.nhwc(torch.randn(3, 64, 32, 32, device="cuda"))
+    outs = []
+    for scoped in (False, True, True):
+        for p in blk.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        if scoped:
+            with ops.wino_prepared(blk):
+                y = blk(xi)
+                y.square().mean().backward()
+        else:
+            y = blk(xi)
+            y.square().mean().backward()
+        outs.append([y.detach().clone(), xi.grad.clone()] + [p.grad.clone() for p in blk.parameters()])
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(outs[0], outs[2]):
+        assert torch.equal(a, b)
+    # weights updated the way the trainers do it (fused optimizer: in place, ``_version`` does not move): the next scope must
+    # see the new weights
+    opt = torch.optim.SGD(blk.parameters(), lr=0.5, fused=True)
+    opt.step()
+    res = []
+    for scoped in (True, False):
+        xi = x.clone()
+        with torch.no_grad():
+            if scoped:
+                with ops.wino_prepared(blk, forms="f"):
+                    res.append(blk(xi).clone())
+            else:
+                res.append(blk(xi).clone())
+    assert torch.equal(res[0], res[1]) and not torch.equal(res[0], outs[0][0])
+    ws = blk.__dict__["_smsut_wino_set"]
+    assert ws.forms[0].n >= 1 and ws.forms[1].n >= 1
