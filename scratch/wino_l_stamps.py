@@ -14,7 +14,8 @@ for (B, h, K, N) in [(32, 64, 64, 64), (32, 32, 128, 128), (32, 16, 256, 256)]:
     for rep in range(3):
         l.smsut_conv2d_fwd_mfma(P(x), P(w), P(y), B, h, h, K, N, 3, 0, st)
     torch.cuda.synchronize()
-    v = y.flatten()[:7].tolist()
+    v = y.flatten()[:11].tolist()
     n = max(v[5], 1)
     print(f"B{B} H{h} {K}->{N}: regions {int(v[5])}, per region: start->first MFMA {v[0]/n:.0f}, MFMA units {v[1]/n:.0f} (ideal {128*32}), "
-          f"epilogue {v[2]/n:.0f}, dma wait {v[3]/n:.0f}, barrier {v[4]/n:.0f} | whole kernel {v[6]:.0f} ticks (s_memtime: 100 MHz?)", flush=True)
+          f"epilogue {v[2]/n:.0f}, dma wait {v[3]/n:.0f}, barrier {v[4]/n:.0f} | whole kernel {v[6]:.0f} cycles; prologue: setup {v[7]:.0f}, issue {v[8]:.0f}, "
+          f"dma wait {v[9]:.0f}, barrier {v[10]:.0f}", flush=True)

@@ -34,7 +34,11 @@ def prepare(ws, forms):
     return us, kd, nd
 
 
-for (h, ci, co) in [(64, 64, 64), (32, 128, 128), (32, 64, 128), (32, 256, 128), (16, 256, 256), (16, 128, 256), (64, 128, 64)]:
+import os
+SH = [(64, 64, 64), (32, 128, 128), (32, 64, 128), (32, 256, 128), (16, 256, 256), (16, 128, 256), (64, 128, 64)]
+if os.environ.get("PROBE_K32"):
+    SH = [(128, 32, 32), (128, 32, 64), (64, 32, 64), (256, 32, 16), (256, 32, 32)]
+for (h, ci, co) in SH:
     x = torch.randn(B, ci, h, h, device='cuda').contiguous(memory_format=torch.channels_last)
     gy = torch.randn(B, co, h, h, device='cuda').contiguous(memory_format=torch.channels_last)
     w = ops.new_weight(co, ci, 3, 3, device='cuda'); w.copy_(torch.randn(co, ci, 3, 3, device='cuda') * 0.05)

@@ -625,6 +625,10 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     }
   };
 
+#ifdef SMSUT_WL_STAMPS
+  unsigned long long tp0, tp1, tp2, tp3;
+  WL_STAMP(tp0);
+#endif
   // prologue: chunk 0 -> buffer 0, chunk 1 -> registers
   pf_setup();
 #pragma unroll
@@ -638,8 +642,17 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   for (int p_ = 0; p_ < NP; ++p_) stage_part(p_, 1);    // publishes into buffer 0, requests chunk 1
   pf_aff();
   pf_advance();
+#ifdef SMSUT_WL_STAMPS
+  WL_STAMP(tp1);
+#endif
   if constexpr (GLI || PRE) glds_wait();
+#ifdef SMSUT_WL_STAMPS
+  WL_STAMP(tp2);
+#endif
   __syncthreads();
+#ifdef SMSUT_WL_STAMPS
+  WL_STAMP(tp3);
+#endif
   int buf = 0;
   // one chunk = one region = one barrier: staging parts + this chunk's MFMAs (+ on an item's last chunk: transform, statistics,
   // stores).  `last` is a compile-time tag: as a run-time condition the compiler predicated the whole epilogue into every chunk
@@ -675,6 +688,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     for (int i = 0; i < 6; ++i) y[i] = (float)acc_t[i];
     y[6] = (float)(ts5 - ts_begin);
+    y[7] = (float)(tp0 - ts_begin); y[8] = (float)(tp1 - tp0); y[9] = (float)(tp2 - tp1); y[10] = (float)(tp3 - tp2);
   }
 #endif
 }

@@ -104,6 +104,9 @@ def record_step(step: Callable[[], object]):
     return rec
 
 
+_HOST_ONLY = {"smsut_wino_bind_many", "smsut_wino_bind", "smsut_wino_unbind_all"}      # registry calls: no device work
+
+
 def replay(rec, reps: int = 8) -> List[Row]:
     """Replay each distinct (entry point, non-pointer arguments) ``reps`` times between HIP events."""
     lib = H.load()
@@ -114,11 +117,18 @@ def replay(rec, reps: int = 8) -> List[Row]:
         groups.setdefault(key, []).append(conv)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st = torch.cuda.current_stream()
+    # every prepared-weight binding the recorded step made (ops.wino_prepared scopes) is in force during the replay, so that the
+    # convolutions run the form they ran in the step (timing only: the images may be one optimizer step old); dropped at the end
+    for name, conv in rec:
+        if name == "smsut_wino_bind_many" and conv[1]:
+            getattr(lib, name)(*conv)
     rows = []
     for (name, shp), calls in groups.items():
         conv = list(calls[0])
-        conv[-1] = st.cuda_stream                        # the recorded stream may have been a capture stream
         fn = getattr(lib, name)
+        if name in _HOST_ONLY:
+            continue
+        conv[-1] = st.cuda_stream                        # the recorded stream may have been a capture stream
         for _ in range(2):
             fn(*conv)
         torch.cuda.synchronize()
@@ -128,6 +138,7 @@ def replay(rec, reps: int = 8) -> List[Row]:
         e1.record(st)
         torch.cuda.synchronize()
         rows.append(Row(name, shp, len(calls), e0.elapsed_time(e1) / reps * 1e3, conv_flops_of(name, calls[0])))
+    lib.smsut_wino_unbind_all()
     return rows
 
 
