@@ -83,6 +83,16 @@ __device__ __forceinline__ void glds16_so(const float* base, unsigned byte_off, 
 #endif
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// compile-time loop: f(integral_constant<int, I>) for I in [I, N) -- the unit index of conv_wino_l's chunk loop must be a constant in
+// EVERY instantiation (as a `#pragma unroll` loop the larger bodies were left rolled, and the accumulators went to scratch memory)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float aff1(float v, float m, float r, float g, float b, float slope) {
   return lrelu_f(in_affine(v, m, r, g, b), slope);
@@ -438,7 +448,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
         for (int j = 0; j < NR; ++j) qacc[q_][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
   };
-  auto stats_out = [&]() {                              // after the barrier that completes red[]
+  auto stats_out = [&](int cn, int cty, int ctx) {      // item (cn, cty, ctx), after the barrier that completes red[]
     if ((STATS || BST) && tid < CO_T) {
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -453,9 +463,18 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     }
   };
 
-  // ---- one chunk of MFMAs: lane (lm = tile, kq = channel quad) of this wave's 4 x 16-pixel strip
-  auto mma_chunk = [&](int c, int buf, auto last_tag) {
+  // ---- one chunk of MFMAs: lane (lm = tile, kq = channel quad) of this wave's 4 x 16-pixel strip.
+  // ROT (every form but SC2): the chunk is ROTATED around its barrier -- PH 2 (body): units 0 .. NU-2, everything that reads this
+  // chunk's LDS buffer; then the barrier; PH 1 (head) of the NEXT chunk: its first window rows and B fragments, requested from the
+  // other buffer; PH 3 (tail): the last unit of THIS chunk, whose operands are all in registers -- its 16 MFMAs run while the
+  // head's reads are in flight (unrotated, 500 cycles per chunk went by between the barrier and the first MFMA: notes).  PH 0: whole
+  // chunk between two barriers (SC2, whose second-half chunks have no units).
+  f32x4 d0[4], d1[4], d2[4], d3[4];                      // window rows of the chunk (live across the barrier under ROT)
+  f32x4 bf[2][4], vv[2][4];                              // B fragments / transformed inputs of the current and the next unit
+  auto mma_chunk = [&](int c, int buf, auto last_tag, auto phase_tag) __attribute__((always_inline)) {
     constexpr bool last = decltype(last_tag)::value;
+    constexpr int PH = decltype(phase_tag)::value;
+    static_assert(PH == 0 || !SC2, "rotated chunks: not for the fused shortcut data-gradient");
     const float* in_s = in_b(buf);
     const float* w_s = w_b(buf);
     [[maybe_unused]] const float* wsc_s = wsc_b(buf);
@@ -479,16 +498,17 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
         return;                                          // (SC2 has no ACC / BST operands to request)
       }
     }
-    f32x4 d0[4], d1[4], d2[4], d3[4];
 #ifdef SMSUT_WLDBG_NO_LDA
     if (c >= 0) dp = smem + 2 * BUF;                     // (every window read hits the same few words: no LDS bandwidth)
 #endif
+    if constexpr (PH == 0 || PH == 1) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      d1[b] = *(const f32x4*)(dp + (1 * IW + b) * SPX);
-      d2[b] = *(const f32x4*)(dp + (2 * IW + b) * SPX);
+      for (int b = 0; b < 4; ++b) {
+        d1[b] = *(const f32x4*)(dp + (1 * IW + b) * SPX);
+        d2[b] = *(const f32x4*)(dp + (2 * IW + b) * SPX);
+      }
     }
-    if constexpr (SC) {                                  // forward shortcut: the tile's four raw pixels x this chunk's 1x1 weights
+    if constexpr (SC && (PH == 0 || PH == 2)) {          // forward shortcut: the tile's four raw pixels x this chunk's 1x1 weights
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
         const f32x4 bw = *(const f32x4*)(wsc_s + (((size_t)kq * CO_T) + j * 16 + lm) * 4);
@@ -527,50 +547,56 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
         const int k = (GLI || p_ < NI) ? p_ : p_ - NI;   // index among the DMA parts, inputs first
         return (k * (SMSUT_WINO_DMA_UNITS)) / NDMA;
       }
-      return p_ % NU;
+      return p_ % (PH == 0 ? NU : NU - 1);               // (rotated: the last unit runs after the barrier that publishes them)
     };
-    f32x4 bf[2][4], vv[2][4];
-    auto ld_b = [&](int u, f32x4* dst) {
+    // (sel: which half of bf / vv -- indexed here, not passed as a pointer: with the arrays at kernel scope a pointer
+    //  parameter kept them in scratch memory in several instantiations)
+    auto ld_b = [&](int u, int sel) __attribute__((always_inline)) {
       const int xi = XO[u / NR], j = u % NR;
 #ifdef SMSUT_WLDBG_NO_LDB
       if (c >= 0) {
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) dst[nu] = (f32x4){(float)xi, (float)j, (float)nu, 1.f};
+        for (int nu = 0; nu < 4; ++nu) bf[sel][nu] = (f32x4){(float)xi, (float)j, (float)nu, 1.f};
         return;
       }
 #endif
 #pragma unroll
-      for (int nu = 0; nu < 4; ++nu) dst[nu] = *(const f32x4*)(wc + ((size_t)(xi * 4 + nu) * 4 * CO_T + j * 16) * 4);
+      for (int nu = 0; nu < 4; ++nu) bf[sel][nu] = *(const f32x4*)(wc + ((size_t)(xi * 4 + nu) * 4 * CO_T + j * 16) * 4);
     };
-    auto xform = [&](int g, f32x4* v) {
+    auto xform = [&](int g, int sel) __attribute__((always_inline)) {
       const int xi = XO[g];
 #ifdef SMSUT_WLDBG_NO_XFORM
-      v[0] = d1[0]; v[1] = d1[1]; v[2] = d2[2]; v[3] = d2[3]; (void)xi; return;
+      vv[sel][0] = d1[0]; vv[sel][1] = d1[1]; vv[sel][2] = d2[2]; vv[sel][3] = d2[3]; (void)xi; return;
 #endif
       f32x4 t[4];                                        // row combination xi of B^T: d0-d2 | d1+d2 | d2-d1 | d1-d3
 #pragma unroll
       for (int b = 0; b < 4; ++b) t[b] = xi == 0 ? d0[b] - d2[b] : xi == 1 ? d1[b] + d2[b] : xi == 2 ? d2[b] - d1[b] : d1[b] - d3[b];
-      v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+      vv[sel][0] = t[0] - t[2]; vv[sel][1] = t[1] + t[2]; vv[sel][2] = t[2] - t[1]; vv[sel][3] = t[1] - t[3];
     };
-    ld_b(0, bf[0]);
-    xform(0, vv[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    WL_STAMP(ts1);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int g = u / NR, j = u % NR;
+    if constexpr (PH == 0 || PH == 1) ld_b(0, 0);
+    if constexpr (PH == 1) return;
+    if constexpr (PH == 0 || PH == 2) {
+      xform(0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WL_STAMP(ts1);
+    }
+    static_for<0, NU>([&](auto u_tag) __attribute__((always_inline)) {
+      constexpr int u = decltype(u_tag)::value;
+      constexpr int g = u / NR, j = u % NR;
+      if constexpr ((PH == 2 && u == NU - 1) || (PH == 3 && u != NU - 1)) return;
 #pragma unroll
       for (int p_ = 0; p_ < NP; ++p_)
+        if (PH != 3)
 #ifdef SMSUT_WLDBG_NO_STAGE          // scratch builds (scratch/wino_l_ablation.py): results wrong by construction, only the time matters
         if (part_unit(p_) == u && c < 0) stage_part(p_, buf);
 #else
         if (part_unit(p_) == u) stage_part(p_, buf);     // this unit's share of the staging work, in the shadow of its MFMAs
 #endif
-      if (u + 1 < NU) {
-        ld_b(u + 1, bf[(u + 1) & 1]);
-        if ((u + 1) % NR == 0) xform(g + 1, vv[(g + 1) & 1]);
+      if (PH != 3 && u + 1 < NU) {
+        ld_b(u + 1, (u + 1) & 1);
+        if ((u + 1) % NR == 0) xform(g + 1, (g + 1) & 1);
       }
-      if (j == NR - 1) {                                 // (after the transform above in program order: its operands are dead)
+      if (PH != 3 && j == NR - 1) {                      // (after the transform above in program order: its operands are dead)
         if (g == 0) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) d0[b] = *(const f32x4*)(dp + (0 * IW + b) * SPX);
@@ -603,7 +629,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
   };
   auto out_transform = [&]() {                          // A^T m A, element-wise over the lane's four tiles; resets the accumulators
 #pragma unroll
@@ -656,22 +682,46 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   int buf = 0;
   // one chunk = one region = one barrier: staging parts + this chunk's MFMAs (+ on an item's last chunk: transform, statistics,
   // stores).  `last` is a compile-time tag: as a run-time condition the compiler predicated the whole epilogue into every chunk
-  auto region = [&](int c, auto last_tag) {
+  constexpr bool ROT = !SC2;
+  using ph_whole = std::integral_constant<int, 0>;
+  using ph_head = std::integral_constant<int, 1>;
+  using ph_body = std::integral_constant<int, 2>;
+  using ph_tail = std::integral_constant<int, 3>;
+  [[maybe_unused]] int sn = cn, sty = cty, stx = ctx;    // ROT: the item whose statistics the next barrier completes
+  [[maybe_unused]] bool st_pending = false;
+  if constexpr (ROT) mma_chunk(0, 0, std::false_type{}, ph_head{});       // first rows / fragments of chunk 0
+  auto region = [&](int c, auto last_tag, auto first_tag) __attribute__((always_inline)) {
     constexpr bool last = decltype(last_tag)::value;
+    constexpr bool first = decltype(first_tag)::value;
     WL_STAMP(ts0);
     pf_setup();
-    mma_chunk(c, buf, last_tag);
+    if constexpr (ROT) mma_chunk(c, buf, last_tag, ph_body{});
+    else mma_chunk(c, buf, last_tag, ph_whole{});
     pf_aff();
     pf_advance();
     WL_STAMP(ts2);
-    if constexpr (last) { out_transform(); epilogue(); }
+    if constexpr (!ROT && last) { out_transform(); epilogue(); }
     WL_STAMP(ts3);
     if constexpr (GLI || PRE) glds_wait();               // this wave's LDS-DMA pieces of the next chunk have landed
     WL_STAMP(ts4);
 #ifndef SMSUT_WLDBG_NO_BARRIER
     __syncthreads();                                     // buffer buf is free, buf ^ 1 is complete; red[] is complete
 #endif
-    if constexpr (last) stats_out();
+    if constexpr (!ROT) {
+      if constexpr (last) stats_out(cn, cty, ctx);
+    } else {
+      // the previous item's epilogue ran in the tail of its last region, after that region's barrier: this one completes it
+      if constexpr (first) {
+        if (st_pending) stats_out(sn, sty, stx);
+      }
+      mma_chunk(c, buf ^ 1, last_tag, ph_head{});        // next chunk's first reads ...
+      mma_chunk(c, buf, last_tag, ph_tail{});            // ... under this chunk's last unit
+      if constexpr (last) {
+        out_transform();
+        epilogue();
+        sn = cn; sty = cty; stx = ctx; st_pending = true;
+      }
+    }
     WL_STAMP(ts5);
 #ifdef SMSUT_WL_STAMPS
     acc_t[0] += ts1 - ts0; acc_t[1] += ts2 - ts1; acc_t[2] += ts3 - ts2; acc_t[3] += ts4 - ts3; acc_t[4] += ts5 - ts4; acc_t[5] += 1;
@@ -679,10 +729,15 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     buf ^= 1;
   };
   for (int item = item0; item < item1; ++item) {
+    region(0, std::false_type{}, std::true_type{});      // (nch >= 2: the first chunk of an item is never its last)
 #pragma unroll 1
-    for (int c = 0; c + 1 < nch; ++c) region(c, std::false_type{});
-    region(nch - 1, std::true_type{});
+    for (int c = 1; c + 1 < nch; ++c) region(c, std::false_type{}, std::false_type{});
+    region(nch - 1, std::true_type{}, std::false_type{});
     advance(cn, cty, ctx);
+  }
+  if constexpr (ROT && (STATS || BST)) {
+    __syncthreads();
+    stats_out(sn, sty, stx);
   }
 #ifdef SMSUT_WL_STAMPS
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
