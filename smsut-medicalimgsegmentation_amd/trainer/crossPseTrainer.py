@@ -34,18 +34,19 @@ class crossPseTrainer(BaseTrainer):
         """One iteration of :84-146; ``img`` = [labeled | unlabeled].  Returns [seg1, seg2, semi1, semi2] (device)."""
         bs = msk.size(0)
         lambda_semi = self.lambda_semi * self.sigmoid_rampup(self.epoch, cfg.max_epoch)        # :82
-        out1 = self.net(img)
-        s1 = self.loss(out1[:bs], msk)
-        out2 = self.net2(img)
-        s2 = self.loss(out2[:bs], msk)
-        pred1 = ops.argmax_channels(out1[bs:])                                                 # :122-125 (detached)
-        pred2 = ops.argmax_channels(out2[bs:])
-        semi1 = self.loss(out1[bs:], pred2)
-        semi2 = self.loss(out2[bs:], pred1)
-        total = s1 + s2 + lambda_semi * semi1 + lambda_semi * semi2
-        self.optimizer1.zero_grad(set_to_none=True)
-        self.optimizer2.zero_grad(set_to_none=True)
-        total.backward()
+        with ops.wino_prepared(self.net, self.net2):        # (the weights move in the optimizer steps only)
+            out1 = self.net(img)
+            s1 = self.loss(out1[:bs], msk)
+            out2 = self.net2(img)
+            s2 = self.loss(out2[:bs], msk)
+            pred1 = ops.argmax_channels(out1[bs:])                                                 # :122-125 (detached)
+            pred2 = ops.argmax_channels(out2[bs:])
+            semi1 = self.loss(out1[bs:], pred2)
+            semi2 = self.loss(out2[bs:], pred1)
+            total = s1 + s2 + lambda_semi * semi1 + lambda_semi * semi2
+            self.optimizer1.zero_grad(set_to_none=True)
+            self.optimizer2.zero_grad(set_to_none=True)
+            total.backward()
         self.reducer1.reduce(); self.reducer2.reduce()
         self.optimizer1.step(); self.optimizer2.step()
         lr_ = self.poly_lr()

@@ -51,17 +51,18 @@ class meanTeacherTrainer(BaseTrainer):
         if noise is None:
             noise = torch.clamp(torch.randn_like(ul_img) * 0.01, -0.02, 0.02)                  # :104
         lambda_semi = self.lambda_semi * self.sigmoid_rampup(self.epoch, self.epoch_rampup)
-        out = self.net(img)
-        with torch.no_grad():
-            ema_out = self.ema(ul_img + noise)
-        seg = self.loss(out[:bs], msk)
-        if self.iter < self.semi_start_iter:
-            semi = torch.zeros((), device=self.device)
-        else:
-            semi = ops.softmax_mse(out[bs:], ema_out)                                         # :129-131
-        total = seg + lambda_semi * semi
-        self.optimizer.zero_grad(set_to_none=True)
-        total.backward()
+        with ops.wino_prepared(self.net, self.ema):         # (student: optimizer step; teacher: EMA update -- both after)
+            out = self.net(img)
+            with torch.no_grad():
+                ema_out = self.ema(ul_img + noise)
+            seg = self.loss(out[:bs], msk)
+            if self.iter < self.semi_start_iter:
+                semi = torch.zeros((), device=self.device)
+            else:
+                semi = ops.softmax_mse(out[bs:], ema_out)                                         # :129-131
+            total = seg + lambda_semi * semi
+            self.optimizer.zero_grad(set_to_none=True)
+            total.backward()
         self.reducer.reduce()
         self.optimizer.step()
         self.update_ema_variable()

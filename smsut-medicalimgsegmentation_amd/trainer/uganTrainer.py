@@ -54,37 +54,40 @@ class UGANTrainer(UGANShp0Trainer):
         d_params = list(self.D.parameters())
 
         # G(x_real) once: the D-step uses it detached, the G-step continues from its graph (weights unchanged between)
-        y_fake, x_fake = self.net(x_real, vec_ot)
+        with ops.wino_prepared(self.net, forms="f"):
+            y_fake, x_fake = self.net(x_real, vec_ot)
 
         # ---- D-step (:155-174)
-        with ops.first_order_pass():
-            out_src, out_cls = self.D(torch.cat([x_real, x_fake.detach()], 0))
-        d_real = ops.mean_all(out_src[:b], -1.0)
-        d_cls = ops.cross_entropy_rows(out_cls[:b], modal_org)
-        d_fake = ops.mean_all(out_src[b:], 1.0)
-        x_hat = ops.row_lerp(x_real, x_fake.detach(), alpha).requires_grad_(True)
-        out_src, _ = self.D(x_hat)                  # differentiated twice (gradient penalty): default op families
-        d_gp = self.gradient_penalty(out_src, x_hat)
-        d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
-        self.d_optimizer.zero_grad(set_to_none=True)
-        d_loss.backward()
+        with ops.wino_prepared(self.D):
+            with ops.first_order_pass():
+                out_src, out_cls = self.D(torch.cat([x_real, x_fake.detach()], 0))
+            d_real = ops.mean_all(out_src[:b], -1.0)
+            d_cls = ops.cross_entropy_rows(out_cls[:b], modal_org)
+            d_fake = ops.mean_all(out_src[b:], 1.0)
+            x_hat = ops.row_lerp(x_real, x_fake.detach(), alpha).requires_grad_(True)
+            out_src, _ = self.D(x_hat)                  # differentiated twice (gradient penalty): default op families
+            d_gp = self.gradient_penalty(out_src, x_hat)
+            d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
+            self.d_optimizer.zero_grad(set_to_none=True)
+            d_loss.backward()
         self.d_reducer.reduce()
         self.d_optimizer.step()
 
         # ---- G-step (:178-198), D frozen
         for p in d_params:
             p.requires_grad_(False)
-        with ops.first_order_pass():
-            out_src, out_cls = self.D(x_fake)
-        g_fake = ops.mean_all(out_src, -1.0)
-        g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
-        g_seg = self.loss(y_fake, y_real)
-        y_rec, x_rec = self.net(x_fake, vec_to)
-        g_rec = ops.l1_mean(x_real, x_rec)
-        g_shp = self.loss(y_rec, y_real)
-        g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg + lambda_shp * g_shp
-        self.optimizer.zero_grad(set_to_none=True)
-        g_loss.backward()
+        with ops.wino_prepared(self.net), ops.wino_prepared(self.D):
+            with ops.first_order_pass():
+                out_src, out_cls = self.D(x_fake)
+            g_fake = ops.mean_all(out_src, -1.0)
+            g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
+            g_seg = self.loss(y_fake, y_real)
+            y_rec, x_rec = self.net(x_fake, vec_to)
+            g_rec = ops.l1_mean(x_real, x_rec)
+            g_shp = self.loss(y_rec, y_real)
+            g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg + lambda_shp * g_shp
+            self.optimizer.zero_grad(set_to_none=True)
+            g_loss.backward()
         for p in d_params:
             p.requires_grad_(True)
         self.g_reducer.reduce()
