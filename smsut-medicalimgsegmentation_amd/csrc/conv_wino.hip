@@ -545,7 +545,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       const bool dma = (GLI && p_ < NI) || (p_ >= NI && p_ < NI + NWG);
       if (dma) {
         const int k = (GLI || p_ < NI) ? p_ : p_ - NI;   // index among the DMA parts, inputs first
-        return (k * (SMSUT_WINO_DMA_UNITS)) / NDMA;
+        return (k * (SMSUT_WINO_DMA_UNITS)) / (NDMA > 0 ? NDMA : 1);
       }
       return p_ % (PH == 0 ? NU : NU - 1);               // (rotated: the last unit runs after the barrier that publishes them)
     };
