@@ -49,6 +49,14 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # sharing a card, degenerated to seconds per iteration (profiles/r02_notes.md): it stays reachable for an A/B on real
         # multi-GPU hardware through SMSUT_D_OVERLAP=1 / ``bench.py --d-overlap 1`` but is not the default until such a run exists.
         self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "0") not in ("0", "")
+        # Inside the D-step the twice-differentiated x_hat pass and the batched real | fake pass are independent until d_loss sums
+        # them, and both are chains of small launches (8x8 / 4x4 planes: a fraction of the chip each): the x_hat pass runs on a
+        # FORK stream, forward and -- autograd replays a node on its forward's stream -- both of its backward sweeps.  No
+        # collective is involved (the phase is collective-free), so this holds under data parallelism, where the phase-level
+        # overlap above is off.  SMSUT_D_FORK=0: one chain after the other.
+        self._d_fork = os.environ.get("SMSUT_D_FORK", "1") not in ("0", "")
+        self._fork = None
+        self._g2_fork = os.environ.get("SMSUT_G2_FORK", "1") not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
@@ -113,19 +121,36 @@ class UGANConsisTrainer(UGANShp0Trainer):
 
     def _d_phase_body(self, x_real, x_fake, modal_org, alpha):
         b = x_real.size(0)
+
+        def xhat_pass():
+            x_hat = ops.row_lerp(x_real, x_fake, alpha).requires_grad_(True)
+            if self._d_alias is not None:
+                # the x_hat pass on parameter ALIASES (same storage, separate .grad): every D parameter is reached by both passes,
+                # and autograd would sum their gradients with one tiny add kernel per parameter; now one multi-tensor add (as for G)
+                out_hat, _ = torch.func.functional_call(self.D, self._d_alias, (x_hat,))
+            else:
+                out_hat, _ = self.D(x_hat)          # differentiated twice (gradient penalty): default op families
+            return self.gradient_penalty(out_hat, x_hat)
+
+        if self._d_fork and self._d_alias is not None:
+            cur = torch.cuda.current_stream()
+            if self._fork is None:
+                self._fork = torch.cuda.Stream()
+            self._fork.wait_stream(cur)              # (inside a capture this brings the fork stream into it)
+            with torch.cuda.stream(self._fork):
+                gp = xhat_pass()
+
+            def join():
+                cur.wait_stream(self._fork)
+                return gp
+        else:
+            join = xhat_pass
         with ops.first_order_pass():
             out_src, out_cls = self.D(torch.cat([x_real, x_fake], 0))
         d_real = ops.mean_all(out_src[:b], -1.0)
         d_cls = ops.cross_entropy_rows(out_cls[:b], modal_org)
         d_fake = ops.mean_all(out_src[b:], 1.0)
-        x_hat = ops.row_lerp(x_real, x_fake, alpha).requires_grad_(True)
-        if self._d_alias is not None:
-            # the x_hat pass on parameter ALIASES (same storage, separate .grad): every D parameter is reached by both passes, and
-            # autograd would sum their gradients with one tiny add kernel per parameter; now one multi-tensor add (as for G)
-            out_src, _ = torch.func.functional_call(self.D, self._d_alias, (x_hat,))
-        else:
-            out_src, _ = self.D(x_hat)              # differentiated twice (gradient penalty): default op families
-        d_gp = self.gradient_penalty(out_src, x_hat)
+        d_gp = join()
         d_loss = d_real + d_fake + self.lambda_cls * d_cls + self.lambda_gp * d_gp
         d_loss.backward()
         if self._d_alias is not None:
@@ -172,15 +197,31 @@ class UGANConsisTrainer(UGANShp0Trainer):
         bs = y_real.size(0)
         y_fake, x_fake, _ = self._g1
         y_rec, pseudo, g_rec, g_nce = self._g2
-        with ops.first_order_pass():
-            out_src, out_cls = self.D(x_fake)
-        g_fake = ops.mean_all(out_src, -1.0)
-        g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
+        def d_pass():
+            with ops.first_order_pass():
+                out_src, out_cls = self.D(x_fake)
+            return ops.mean_all(out_src, -1.0), ops.cross_entropy_rows(out_cls, modal_trg)
+
+        fork = self._d_fork and self._g2_fork
+        if fork:
+            # D(x_fake) on the fork stream: its backward -- ~200 small launches through the frozen D, the first nodes autograd
+            # runs (they were recorded last) -- then goes out on that stream too, beside the segmentation branch's backward
+            # (independent of D) instead of in front of it
+            cur = torch.cuda.current_stream()
+            if self._fork is None:
+                self._fork = torch.cuda.Stream()
+            self._fork.wait_stream(cur)
+            with torch.cuda.stream(self._fork):
+                g_fake, g_cls = d_pass()
+        else:
+            g_fake, g_cls = d_pass()
         g_seg = self.loss.from_stats(y_fake[:bs], y_real, st_seg)
         if self._semi_on:
             g_semi = self.loss.from_stats(y_rec, pseudo, st_semi)
         else:
             g_semi = torch.zeros((), device=self.device)
+        if fork:
+            cur.wait_stream(self._fork)
         g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg \
             + lambda_semi * g_semi + 1.0 * g_nce
         g_loss.backward()
