@@ -54,3 +54,37 @@ def main_side():
 def serial2():
     gd.replay(); gg.replay()
 print("both prio 0: %.3f   main+side: %.3f   serial same stream: %.3f ms" % (t(both0), t(main_side), t(serial2)))
+
+# ---- the whole iteration issued from a pool stream instead of the default stream (does the D || G2gen overlap work there?)
+sm = torch.cuda.Stream()
+def it_on_pool():
+    sm.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(sm):
+        tr.train_iteration(x, y1, m)
+    torch.cuda.current_stream().wait_stream(sm)
+print("iteration on the default stream %.3f   on a pool stream %.3f ms" % (t(lambda: tr.train_iteration(x, y1, m)), t(it_on_pool)))
+
+# ---- the four phases back to back: all on the current stream | D on a side stream, JOINED before the next phase (no overlap)
+gs = {k[0]: g.graph for k, g in tr._graphs.items()}
+sd = torch.cuda.Stream()
+def all_main():
+    gs["G1"].replay(); gs["D"].replay(); gs["G2gen"].replay(); gs["G2"].replay()
+def d_side_joined():
+    cur = torch.cuda.current_stream()
+    gs["G1"].replay()
+    sd.wait_stream(cur)
+    with torch.cuda.stream(sd): gs["D"].replay()
+    cur.wait_stream(sd)
+    gs["G2gen"].replay(); gs["G2"].replay()
+def d_g2_side_joined():
+    cur = torch.cuda.current_stream()
+    gs["G1"].replay()
+    sd.wait_stream(cur)
+    with torch.cuda.stream(sd): gs["D"].replay()
+    cur.wait_stream(sd)
+    gs["G2gen"].replay()
+    sd.wait_stream(cur)
+    with torch.cuda.stream(sd): gs["G2"].replay()
+    cur.wait_stream(sd)
+print("four phases: all on the current stream %.3f | D on a side stream, joined %.3f | D and G2 on a side stream, joined %.3f ms"
+      % (t(all_main), t(d_side_joined), t(d_g2_side_joined)))
