@@ -88,3 +88,16 @@ def d_g2_side_joined():
     cur.wait_stream(sd)
 print("four phases: all on the current stream %.3f | D on a side stream, joined %.3f | D and G2 on a side stream, joined %.3f ms"
       % (t(all_main), t(d_side_joined), t(d_g2_side_joined)))
+
+# ---- HOST time of the replays (is the iteration launch-bound?)
+import time
+torch.cuda.synchronize()
+for k, g in tr._graphs.items():
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(5): g.graph.replay()
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print(f"{k[0]:6s} host time of a replay call {1e3 * (t1 - t0) / 5:7.3f} ms   (5 replays drained after {1e3 * (t2 - t0):7.2f} ms)")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): tr.train_iteration(x, y1, m)
+t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"train_iteration: host {1e3 * (t1 - t0) / 5:.3f} ms per call, wall {1e3 * (t2 - t0) / 5:.3f} ms per iteration")

@@ -51,12 +51,14 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "0") not in ("0", "")
         # Inside the D-step the twice-differentiated x_hat pass and the batched real | fake pass are independent until d_loss sums
         # them, and both are chains of small launches (8x8 / 4x4 planes: a fraction of the chip each): the x_hat pass runs on a
-        # FORK stream, forward and -- autograd replays a node on its forward's stream -- both of its backward sweeps.  No
-        # collective is involved (the phase is collective-free), so this holds under data parallelism, where the phase-level
-        # overlap above is off.  SMSUT_D_FORK=0: one chain after the other.
-        self._d_fork = os.environ.get("SMSUT_D_FORK", "1") not in ("0", "")
+        # FORK stream, forward and -- autograd replays a node on its forward's stream -- both of its backward sweeps.  Default: on
+        # at one GPU (24.6 -> 23.5 ms per iteration together with the G-step fork below), OFF under data parallelism: with every
+        # phase on one stream, as there, the forks measure neutral (24.46-24.52 ms with, 24.47-24.53 without), and a default that
+        # gains nothing should not put multi-stream graphs beside RCCL untested.  SMSUT_D_FORK / SMSUT_G2_FORK = 0 / 1 override.
+        fork_default = "1" if self.world == 1 else "0"
+        self._d_fork = os.environ.get("SMSUT_D_FORK", fork_default) not in ("0", "")
         self._fork = None
-        self._g2_fork = os.environ.get("SMSUT_G2_FORK", "1") not in ("0", "")
+        self._g2_fork = os.environ.get("SMSUT_G2_FORK", fork_default) not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
