@@ -92,12 +92,22 @@ class GraphedPhase:
         # under torch.distributed the RCCL watchdog thread polls events while we capture: with the default "global" error
         # mode any such call from ANOTHER thread can invalidate the capture; "thread_local" polices this thread only
         mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
+        # The cyclic garbage collector must not run while a capture records: it may finalise an OLDER trainer's graphs / streams /
+        # events (trainer <-> GraphedPhase.fn is a reference cycle, so only the collector frees them), and destroying a graph
+        # exec while another stream captures aborts the process (seen once in the full test suite, inside this constructor).
+        # torch.cuda.graph() collects once on entry; from there to the end of the capture the collector stays off.
+        import gc
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
         _CAPTURING += 1
         try:
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.static_out = fn(*self.static_in)
         finally:
             _CAPTURING -= 1
+            if gc_was_on:
+                gc.enable()
         seen, self._bound = set(), []
         for p in list(self.params) + list(rebind_params):
             if id(p) not in seen and p.grad is not None:

@@ -59,6 +59,18 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._d_fork = os.environ.get("SMSUT_D_FORK", fork_default) not in ("0", "")
         self._fork = None
         self._g2_fork = os.environ.get("SMSUT_G2_FORK", fork_default) not in ("0", "")
+        # The G-step's backward in THREE pieces (SMSUT_G_SPLIT, default on), so that only what needs the updated D waits for it:
+        #   G2a  backward of the D-independent terms (cycle L1, PatchNCE, both DiceCE values) -- the whole cycle pass and the
+        #        segmentation branch of G(x_real), ~70 % of the generator's backward -- stopping at two cut points of G(x_real)'s
+        #        graph: x_fake and the bottleneck features t_e5 (the cycle pass and netF read DETACHED copies of them);
+        #   G2d  D(x_fake) through the updated D, forward and data-gradient: d(g_fake + lambda_cls g_cls) / d x_fake;
+        #   G2c  the translation branch of G(x_real) from the summed cut-point gradients.
+        # Same sums as one g_loss.backward() (autograd adds the same contributions at x_fake / t_e5; only the order in which a
+        # shared parameter's gradient is accumulated differs, 1e-7).  On one GPU the D-step, Adam and G2d run on the side stream
+        # beside G2gen + G2a: the D-step's ~700 small launches hide under 12 ms of chip-filling kernels instead of 2.8.
+        # Default: with the side stream (one GPU: 23.3 -> 21.9 ms per iteration); without it (data parallelism) the three
+        # pieces run back to back and measure 0.5 % SLOWER than one backward (24.51 vs 24.38 ms): off there.
+        self._g_split = os.environ.get("SMSUT_G_SPLIT", "1" if self._d_overlap else "0") not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
@@ -112,7 +124,10 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def _g1_phase(self, x_real, vec_ot, ids, y_real):
         """G(x_real -> x_fake) with the autograd graph retained for the G-step; returns (x_fake detached, seg statistics)."""
         with ops.wino_prepared(self.net, forms="f"):        # (scopes: the weights move in the optimizer steps only)
-            y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
+            if self._g_split:
+                y_fake, x_fake, feat_x = self.net._trunk(x_real, vec_ot)          # feat_x: the raw bottleneck features t_e5
+            else:
+                y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
         self._g1 = (y_fake, x_fake, feat_x)
         return x_fake.detach(), self.loss.stats(y_fake[:y_real.size(0)], y_real)
 
@@ -174,6 +189,12 @@ class UGANConsisTrainer(UGANShp0Trainer):
         multi-tensor add instead of one add kernel per parameter), L1, PatchNCE, the pseudo labels and the consistency
         term's Dice statistics.  Leaves its autograd graph for phase G2; returns the (local) statistics."""
         y_fake, x_fake, feat_x = self._g1
+        cut = None
+        if self._g_split:
+            # cut points of G(x_real)'s graph: this phase and G2a differentiate down to these leaves, G2c carries on from them
+            xd, td = x_fake.detach().requires_grad_(True), feat_x.detach().requires_grad_(True)
+            feat_x, _ = self.net.netF([td], patch_ids=[ids])
+            cut, x_fake = (xd, td), xd
         with ops.wino_prepared(self.net, forms="f"):
             y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
                                                                  {"sample_ids": [ids]})
@@ -184,8 +205,56 @@ class UGANConsisTrainer(UGANShp0Trainer):
             st = self.loss.stats(y_rec, pseudo)
         else:
             pseudo, st = None, torch.zeros(1, device=self.device)
-        self._g2 = (y_rec, pseudo, g_rec, g_nce)
+        self._g2 = (y_rec, pseudo, g_rec, g_nce) + ((cut,) if cut is not None else ())
         return st
+
+    def _g2a_phase(self, y_real, st_seg, st_semi, lambda_semi):
+        """SMSUT_G_SPLIT: losses that do not involve D and their backward, down to the cut points.  Returns
+        [G_rec, G_seg, G_semi, G_nce]."""
+        bs = y_real.size(0)
+        y_fake = self._g1[0]
+        y_rec, pseudo, g_rec, g_nce, _ = self._g2
+        g_seg = self.loss.from_stats(y_fake[:bs], y_real, st_seg)
+        if self._semi_on:
+            g_semi = self.loss.from_stats(y_rec, pseudo, st_semi)
+        else:
+            g_semi = torch.zeros((), device=self.device)
+        with ops.wino_prepared(self.net, forms="b"):
+            (self.lambda_rec * g_rec + self.lambda_seg * g_seg + lambda_semi * g_semi + 1.0 * g_nce).backward()
+        return torch.stack([t.detach().float() for t in (g_rec, g_seg, g_semi, g_nce)])
+
+    def _g2d_phase(self, modal_trg):
+        """SMSUT_G_SPLIT: D(x_fake) through the updated, frozen D and its data-gradient.  Returns [G_fake, G_cls]; the
+        gradient w.r.t. x_fake stays in ``self._gx_d`` for G2c."""
+        xd2 = self._g1[1].detach().requires_grad_(True)
+        with ops.wino_prepared(self.D):
+            with ops.first_order_pass():
+                out_src, out_cls = self.D(xd2)
+            g_fake = ops.mean_all(out_src, -1.0)
+            g_cls = ops.cross_entropy_rows(out_cls, modal_trg)
+            (g_fake + self.lambda_cls * g_cls).backward()
+        self._gx_d = xd2.grad
+        return torch.stack([t.detach().float() for t in (g_fake, g_cls)])
+
+    def _g2c_phase(self):
+        """SMSUT_G_SPLIT: the translation branch of G(x_real) from the gradients summed at the cut points, then the aliases'
+        gradients into the parameters'.  Returns a dummy (phases return a tensor)."""
+        _, x_fake, t_e5 = self._g1
+        xd, td = self._g2[4]
+        with ops.wino_prepared(self.net, forms="b"):
+            torch.autograd.backward([x_fake, t_e5], [xd.grad + self._gx_d, td.grad])
+        self._g1 = self._g2 = self._gx_d = None
+        main, extra = [], []
+        for name, p in self.net.named_parameters():
+            a = self._alias[name]
+            if a.grad is not None:
+                if p.grad is None:
+                    p.grad = a.grad
+                else:
+                    main.append(p.grad); extra.append(a.grad)
+        if main:
+            torch._foreach_add_(main, extra)
+        return torch.zeros(1, device=self.device)
 
     def _g2_phase(self, y_real, modal_trg, st_seg, st_semi, lambda_semi):
         """Rest of the G-step (:152-179) with D frozen: D(x_fake), the losses, backward through both generator passes.
@@ -264,7 +333,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def graph_report(self):
         """What actually ran: which phases are captured hipGraphs (bench.py prints this next to the timing)."""
         captured = sorted({k[0] for k in self._graphs if isinstance(k, tuple)})
-        mode = "graph" if len(captured) == 4 else ("eager" if not captured else "graph(" + ",".join(captured) + ")")
+        whole = set(captured) in ({"D", "G1", "G2", "G2gen"}, {"D", "G1", "G2a", "G2c", "G2d", "G2gen"})   # (G-step: one phase or three)
+        mode = "graph" if whole else ("eager" if not captured else "graph(" + ",".join(captured) + ")")
         return {"mode": mode, "captured": captured, "fallback": False,
                 "policy": os.environ.get("SMSUT_GRAPH", "default")}
 
@@ -332,19 +402,40 @@ class UGANConsisTrainer(UGANShp0Trainer):
             self.d_reducer.finish(d_work)
             self.d_optimizer.step()
         self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
-        if overlap:
-            cur.wait_stream(self._side)
-            d_scal.record_stream(cur)            # allocated on the side stream (eager mode), read by the final cat on this one
-        if self._probe:
-            self._finite_probe("D.step", list(self.D.named_parameters()))
-
-        # ------------------------------------------------------------ G-step (:150-180), the part that needs the updated D
-        for p in d_params:                                    # D frozen: its unused gradients are neither computed nor reduced
-            p.requires_grad_(False)
-        g_scal = self._run_phase("G2", self._g2_phase, (y_real, modal_trg, st_seg, st_semi, lam_t), g_params,
+        if self._g_split:
+            # ---------------------------------------------------- G-step in three pieces (see __init__): G2a needs no D at all
+            ga = self._run_phase("G2a", self._g2a_phase, (y_real, st_seg, st_semi, lam_t), g_params,
                                  rebind=list(self._alias.values()))
-        for p in d_params:
-            p.requires_grad_(True)
+            for p in d_params:                                # D frozen: its unused gradients are neither computed nor reduced
+                p.requires_grad_(False)
+            with torch.cuda.stream(self._side if overlap else cur):      # behind the D-step and Adam, beside G2gen + G2a
+                gb = self._run_phase("G2d", self._g2d_phase, (modal_trg,), [])
+            for p in d_params:
+                p.requires_grad_(True)
+            if overlap:
+                cur.wait_stream(self._side)
+                d_scal.record_stream(cur)        # allocated on the side stream (eager mode), read on this one
+                gb.record_stream(cur)
+                if self._gx_d is not None:       # (None on a replay: nothing was allocated)
+                    self._gx_d.record_stream(cur)
+            if self._probe:
+                self._finite_probe("D.step", list(self.D.named_parameters()))
+            self._run_phase("G2c", self._g2c_phase, (), [], rebind=g_params)
+            g_scal = torch.cat([gb[0:1], ga[0:1], gb[1:2], ga[1:4]])     # [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]
+        else:
+            if overlap:
+                cur.wait_stream(self._side)
+                d_scal.record_stream(cur)        # allocated on the side stream (eager mode), read by the final cat on this one
+            if self._probe:
+                self._finite_probe("D.step", list(self.D.named_parameters()))
+
+            # -------------------------------------------------------- G-step (:150-180), the part that needs the updated D
+            for p in d_params:                                # D frozen: its unused gradients are neither computed nor reduced
+                p.requires_grad_(False)
+            g_scal = self._run_phase("G2", self._g2_phase, (y_real, modal_trg, st_seg, st_semi, lam_t), g_params,
+                                     rebind=list(self._alias.values()))
+            for p in d_params:
+                p.requires_grad_(True)
         if self._probe:
             self._finite_probe("G2", [("g_scalars", g_scal)] + [("grad " + k, p.grad) for k, p in self.net.named_parameters()])
         self.g_reducer.reduce()
