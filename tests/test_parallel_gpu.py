@@ -119,6 +119,9 @@ def _worker(rank, world, port, q, backend="gloo"):
     # ---- 4. (RCCL only) the D-step on the side stream == the one-stream default, with both optimizers stepping
     if backend == "nccl":
         runs = []
+        # (the three-piece G-step, which the side stream turns on by default, sums a shared parameter's gradient in another order:
+        #  pinned off in BOTH runs so that the comparison isolates the stream placement and stays bit for bit)
+        os.environ["SMSUT_G_SPLIT"] = "0"
         for ov in ("0", "1"):
             os.environ["SMSUT_D_OVERLAP"] = ov
             t2 = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
@@ -136,6 +139,7 @@ def _worker(rank, world, port, q, backend="gloo"):
             runs.append((sc, [p.detach().cpu().clone() for p in t2.net.parameters()],
                          [p.detach().cpu().clone() for p in t2.D.parameters()]))
         os.environ.pop("SMSUT_D_OVERLAP", None)
+        os.environ.pop("SMSUT_G_SPLIT", None)
         (s_a, g_a, d_a), (s_b, g_b, d_b) = runs
         res["overlap_scalars_equal"] = s_a == s_b
         res["overlap_weights_equal"] = all(torch.equal(a, b) for a, b in zip(g_a + d_a, g_b + d_b))
