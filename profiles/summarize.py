@@ -69,10 +69,11 @@ for wl in ("ugan", "unet"):
     shutil.copy(src, os.path.join(PROF, f"{tag}_{wl}_kernel_stats.csv"))
     try:
         j = json.loads(json_line(os.path.join(OUT, f"{tag}_{wl}.log")))
-        head = (f"`bench.py` under the profiler: {j['ms_per_step']} ms/step, {j['value']} {j['unit']}  (kernel tracing takes the "
-                f"concurrency out of the run: the uganConsis iteration's side-stream chain -- D-step, Adam, D(x_fake) -- no longer "
-                f"overlaps the generator's backward; the same build un-profiled: 21.9 ms per uganConsis iteration, "
-                f"`gpurun_out/r03_bench_final3.json` / README)")
+        head = f"`bench.py` under the profiler: {j['ms_per_step']} ms/step, {j['value']} {j['unit']}"
+        if wl == "ugan":
+            head += ("  (kernel tracing takes the concurrency out of the run: the iteration's side-stream chain -- D-step, Adam, "
+                     "D(x_fake) -- no longer overlaps the generator's backward; un-profiled the same build runs the iteration in "
+                     "21.9 ms: README, profiles/r03_notes.md)")
     except (ValueError, IndexError):
         head = "(bench line unreadable)"
     md += [f"## {wl} workload", "", head, "", stats_table(src, STEPS), ""]
