@@ -6,16 +6,19 @@
 // them with a different economy:
 //
 //   * an item is a 16x16-pixel output tile of one image for 16*NTN output channels; its reduction is walked in 16-channel
-//     chunks, and per chunk BOTH operands are staged: the haloed input tile (as in the resident form) and the chunk's weight
-//     block, which every thread transforms ON THE FLY -- NTN (reduction channel, output channel) pairs per thread: nine
-//     weights prefetched one chunk ahead, 28 flops, sixteen LDS words -- so no transformed-weight buffer exists in HBM and the
-//     C ABI needs no workspace;
+//     chunks, and per chunk BOTH operands are staged into one of two LDS buffers, by LDS-DMA (global_load_lds_dwordx4: no
+//     staging registers, no ds_write): the haloed input tile, and the chunk's transformed weights from a PREPARED image when the
+//     caller bound one (smsut_wino_prepare / smsut_wino_bind_many: U = G g G^T of the whole tensor, written once per phase in
+//     this kernel's LDS order).  Without a binding every thread transforms NTN (reduction channel, output channel) pairs ON THE
+//     FLY -- nine weights prefetched one chunk ahead, 28 flops, sixteen LDS words -- so the plain C ABI needs no workspace; the
+//     input-side-IN form keeps register staging for its input (the values pass through the ALU);
 //   * NTN = 2 output-channel slabs per wave share one input transform (B^T d B, in registers, lane = (tile, channel quad)):
 //     128 position accumulators per lane, ONE wave per SIMD with the 512-register budget, and the latency hiding that a second
 //     wave would give is written into the instruction stream instead -- the B-fragment reads and the transform arithmetic of
-//     unit u+1 sit, fenced by sched_barriers, inside the 16-MFMA block of unit u;
+//     unit u+1 sit inside the 16-MFMA block of unit u, and a chunk is ROTATED around its barrier: the next chunk's first reads
+//     go out under this chunk's last unit (mma_chunk);
 //   * an item is long (>= 4 chunks x 128 MFMAs per wave), so its results are transformed (A^T m A), folded and stored right after
-//     its last chunk -- no deferred epilogue, no second accumulator set.
+//     its last chunk -- no deferred epilogue, no second accumulator set (its statistics follow the next barrier).
 //
 // Fused forms, same contracts as conv_mfma_fwd_p (the entry points of conv_mfma.hip route here by shape):
 //   STATS   per-tile {sum, sum of squares} of the result for the following InstanceNorm
