@@ -13,7 +13,10 @@ def timeit(fn, reps=25):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-for (h, ci, co) in [(256, 16, 16), (128, 16, 32), (256, 8, 16), (128, 32, 32)]:
+import os
+SH = [(256, 16, 16), (128, 16, 32), (256, 8, 16), (128, 32, 32)]
+if os.environ.get('AB_TS'): SH = [(128, 32, 32), (64, 64, 64), (32, 128, 128), (64, 128, 64), (32, 256, 128), (16, 256, 256), (128, 64, 32)]
+for (h, ci, co) in SH:
     x = torch.randn(B, h, h, ci, device='cuda'); gy = torch.randn(B, h, h, co, device='cuda')
     gw = torch.empty(9 * ci * co, device='cuda')
     res = {k: [] for k in libs}

@@ -1032,9 +1032,19 @@ constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows 
                              // H256 16->16 B32: uncapped 168 VGPR / 3 waves 104 us; cap 4 with the row loop rolled (94-111 VGPR)
                              // 103-126 us; cap 4 fully unrolled spills -- occupancy is not what limits this kernel)
 #endif
-#ifndef WTS_STRIDE_VALUE
-#define WTS_STRIDE_VALUE 48
+// WTS_ROLL (r03): lane (channel lm, k-slot kq) of the tap-split weight gradient covers FOUR CONSECUTIVE pixels 4kq .. 4kq+3 of a
+// tile row (MFMA ks takes pixel 4kq + ks) instead of the pixels kq, 4 + kq, ...: the three horizontal taps of its four pixels are
+// then the six pixels 4kq .. 4kq+5 of the haloed row -- six registers instead of twelve LDS reads -- and the three rows a tile
+// row needs roll through registers, ONE new row per tile row: 10 LDS reads per 36 MFMAs instead of 40.  The k-slot stride in LDS
+// becomes 4 pixels, so the pixel stride is 36 floats (4 x 36 = 16 mod 64 banks: the four k-slots of a read on disjoint bank
+// quarters; with the old stride of 48 they would collide four ways), 68 for the [gy | gs] tile of the fused-shortcut form.
+#ifndef WTS_ROLL
+#define WTS_ROLL 1
 #endif
+#ifndef WTS_STRIDE_VALUE
+#define WTS_STRIDE_VALUE (WTS_ROLL ? 36 : 48)
+#endif
+constexpr int WTS_STRIDE_SC = WTS_ROLL ? 68 : 80;   // ... of the fused-shortcut form's [gy 32 | gs 32 | pad] tile
 constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
 template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false, bool C8 = false, bool SC8 = false>
@@ -1301,7 +1311,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   static_assert(!SC || !INAFF, "fused shortcut weight gradient: plain / virtual-cat input");
   constexpr int KS = 3, KK = 9, PAD = 1, CIT = 2, COT = 2;
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
-  constexpr int CI_T = 32, CO_T = 32, SI = WTS_STRIDE, SO = SC ? 80 : WTS_STRIDE;
+  constexpr int CI_T = 32, CO_T = 32, SI = WTS_STRIDE, SO = SC ? WTS_STRIDE_SC : WTS_STRIDE;
   constexpr int NSLOT = KK * CIT * COT / 4;                    // 9 accumulator tiles per wave
   extern __shared__ float smem[];
   float* in_s = smem;                         // [IH][IW][SI]
@@ -1421,6 +1431,36 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     if (t - t_begin < 2) { STAMP(3 + 4 * (t - t_begin)); }
     if (t + 1 < t_end) prefetch();
     if (t - t_begin < 2) { STAMP(4 + 4 * (t - t_begin)); }
+#if WTS_ROLL
+    {
+      // this wave's unit k is tap k of ci tile wave >> 1 against co tile wave & 1 (see a_off above)
+      const float* ax = in_s + (4 * kq) * SI + (wave >> 1) * 16 + lm;
+      const float* bx = gy_s + (4 * kq) * SO + jt * 16 + lm;
+      float xr[3][6];
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int e = 0; e < 6; ++e) xr[dy][e] = ax[(dy * IW + e) * SI];
+#pragma unroll
+      for (int r = 0; r < WTH; ++r) {
+#pragma unroll
+        for (int e = 0; e < 6; ++e) xr[(r + 2) % 3][e] = ax[((r + 2) * IW + e) * SI];
+        float b[4];
+        [[maybe_unused]] float bs[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          b[ks] = bx[(r * TW + ks) * SO];
+          if constexpr (SC) bs[ks] = bx[(r * TW + ks) * SO + 32];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+          for (int k = 0; k < NSLOT; ++k) acc[k] = mfma16(xr[(r + k / KS) % 3][ks + k % KS], b[ks], acc[k]);
+          if constexpr (SC) acc_sc = mfma16(xr[(r + 1) % 3][ks + 1], bs[ks], acc_sc);
+        }
+      }
+    }
+#else
 #ifndef WTS_UNROLL
 #define WTS_UNROLL 8
 #endif
@@ -1436,6 +1476,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
         if constexpr (SC) acc_sc = mfma16(ap[a_off_sc], gy_s[(r * TW + px) * SO + 32 + jt * 16 + lm], acc_sc);
       }
     }
+#endif
     if (t - t_begin < 2) { STAMP(5 + 4 * (t - t_begin)); }
   }
   STAMP(10);
@@ -2739,7 +2780,7 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
       constexpr size_t sh = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE + 4) * sizeof(float);
       dim3 grid(p.splits, Cin / 32, Cout / 32);
       if (gs) {
-        constexpr size_t sh_sc = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * 80 + 4) * sizeof(float);
+        constexpr size_t sh_sc = (size_t)((WTH + 2) * (TW + 2) * WTS_STRIDE + WTH * TW * WTS_STRIDE_SC + 4) * sizeof(float);
         static bool attr = false;
         if (!attr) {
           (void)hipFuncSetAttribute((const void*)conv_mfma_wgrad_ts<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_sc);
