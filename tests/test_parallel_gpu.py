@@ -188,7 +188,7 @@ def _worker(rank, world, port, q, backend="gloo"):
     dist.destroy_process_group()
 
 
-def _two_ranks(backend):
+def _two_ranks(backend, overlap=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -218,7 +218,7 @@ def _two_ranks(backend):
             #  and 1 + 1 slices of 64x64 per rank is the noisiest case there is: 2.46e-2 with the r03 Winograd kernels, 1.9e-2 before)
             assert gerr < 3e-2, gerr
         assert res["ugan_graph"]["mode"].startswith("graph"), res["ugan_graph"]
-        assert res["ugan_overlap_default"] is False             # one stream under data parallelism
+        assert res["ugan_overlap_default"] is overlap           # one stream under data parallelism by default
         want, got, pos = res["resume"]
         assert want == got and pos == (7, 1), (rank, want, got, pos)
     assert out[0]["resume"][0] != out[1]["resume"][0]           # ... and the ranks' streams are different ones
@@ -227,6 +227,16 @@ def _two_ranks(backend):
 
 def test_two_rank_gloo_on_device():
     _two_ranks("gloo")
+
+
+def test_two_rank_gloo_on_device_side_stream(monkeypatch):
+    """The same two-rank checks with the multi-GPU A/B switch ON (``SMSUT_D_OVERLAP=1`` / ``bench.py --d-overlap 1``): D-step, its
+    gradient all-reduce, Adam and ``D(x_fake)`` on the side stream, the G-step's backward in three pieces on the main stream,
+    the Dice-statistics all-reduce between them -- the configuration that is NOT the data-parallel default because it has never
+    run over RCCL with two ranks; here its control flow runs with two real ranks and real collectives (gloo, one card) against
+    the CPU oracle on the global batch."""
+    monkeypatch.setenv("SMSUT_D_OVERLAP", "1")          # (spawned workers inherit the environment)
+    _two_ranks("gloo", overlap=True)
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 visible devices (one rank per device over RCCL)")
