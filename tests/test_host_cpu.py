@@ -152,3 +152,24 @@ def test_collectives_refuse_to_run_inside_a_capture():
             ops.all_reduce_dice_stats([(torch.zeros(3), torch.zeros(1))], None)
     finally:
         graphs._CAPTURING -= 1
+
+
+def test_wino_prepared_scope_is_inert_without_device_weights():
+    """``ops.wino_prepared`` (prepared Winograd weight images, bound for the convolutions inside the scope): a module whose
+    weights are not on a HIP device has nothing to prepare -- the scope must not touch the library -- and the bookkeeping it
+    hangs on the module survives ``copy.deepcopy`` (mean-teacher EMA copies) and stays out of ``state_dict``."""
+    import copy
+    import smsut_amd  # noqa: F401
+    from smsut_amd import ops
+    from smsut_amd.network.blocks import BasicBlock
+    blk = BasicBlock(64, 64, norm="instance", act="lrelu")
+    keys = set(blk.state_dict())
+    with ops.wino_prepared(blk):
+        pass
+    ws = blk.__dict__["_smsut_wino_set"]
+    assert ws.forms[0].n == 0 and ws.forms[1].n == 0
+    twin = copy.deepcopy(blk)
+    assert twin.__dict__.get("_smsut_wino_set") is None
+    with ops.wino_prepared(twin, blk, forms="f"):
+        pass
+    assert set(blk.state_dict()) == keys and set(twin.state_dict()) == keys
