@@ -391,8 +391,9 @@ def main():
         tr = UGANConsisTrainer("train", ns)
         tr.net.train(); tr.D.train()
         tr.iter, tr.epoch = 1000, 100                # consistency branch on
-        lb = SyntheticSliceLoader(B // 2, device=dev, labeled=True, rank=rank)
-        ul = SyntheticSliceLoader(B // 2, device=dev, labeled=False, rank=rank)
+        nb = args.warmup + args.steps                  # (the loader's default length is one epoch, 500: a longer run ran it dry)
+        lb = SyntheticSliceLoader(B // 2, device=dev, labeled=True, rank=rank, n_batches=nb)
+        ul = SyntheticSliceLoader(B // 2, device=dev, labeled=False, rank=rank, n_batches=nb)
         li, ui = iter(lb), iter(ul)
         batches = []                                   # a fresh batch per step, all resident in HBM before timing
         for _ in range(args.warmup + args.steps):
