@@ -356,7 +356,7 @@ def main():
     ap.add_argument("--no-step-profile", action="store_true", help="skip the per-shape replay profile (roofline.step_conv_frac)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel leg (the command the rocprofv3 stats / PMC passes profile)")
-    ap.add_argument("--d-overlap", choices=("default", "0", "1"), default="default",
+    ap.add_argument("--d-overlap", choices=("default", "0", "1", "2"), default="default",
                     help="D-step on a side stream beside the cycle pass (SMSUT_D_OVERLAP): default = on at one GPU, off under "
                          "data parallelism; an 8-GPU run can A/B it with --d-overlap 1")
     args = ap.parse_args()

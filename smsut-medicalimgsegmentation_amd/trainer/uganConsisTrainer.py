@@ -42,13 +42,18 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._d_async = os.environ.get("SMSUT_D_ASYNC_ALLREDUCE", "0") not in ("0", "")
         self._g1 = self._g2 = None
         self._side = None
-        # D-step (graph, gradient all-reduce, Adam) on a side stream under the cycle pass: default ON at one GPU (measured -0.3 %),
-        # OFF under data parallelism (world > 1, any backend) -- there everything runs on ONE stream, which is the configuration
-        # the 2-rank tests cover (gloo on one card here; nccl when >= 2 devices are visible).  The side-stream variant under RCCL
-        # has only ever run at one rank (SMSUT_FORCE_DIST=1: DP extras 0.6 ms with it, 1.45 ms without) and, with two gloo ranks
-        # sharing a card, degenerated to seconds per iteration (profiles/r02_notes.md): it stays reachable for an A/B on real
-        # multi-GPU hardware through SMSUT_D_OVERLAP=1 / ``bench.py --d-overlap 1`` but is not the default until such a run exists.
-        self._d_overlap = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "0") not in ("0", "")
+        # SMSUT_D_OVERLAP = 1: D-step (graph, gradient all-reduce, Adam) and D(x_fake) on a side stream beside the generator's
+        # cycle pass and D-independent backward -- the default at ONE GPU.  Under data parallelism (world > 1, any backend) that
+        # variant would issue collectives from two streams; it has only ever run at one rank over RCCL and with two gloo ranks, so
+        # it stays an A/B switch (``bench.py --d-overlap 1``).  The data-parallel default is 2 (below): the side stream carries
+        # captured COMPUTE only and every collective stays on the main stream.  0: everything on one stream.
+        ov = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "2")
+        self._d_overlap = ov == "1"
+        # SMSUT_D_OVERLAP=2 -- "compute-only side stream": only the captured D-step (collective-free) runs on the side stream,
+        # beside G2gen AND G2a; it is JOINED before its gradient all-reduce, so every collective (statistics, D gradients, G
+        # gradients) is issued from the main stream in program order -- for RCCL this is the one-stream configuration; Adam and
+        # D(x_fake) follow on the main stream.
+        self._d_side_compute = ov == "2"
         # Inside the D-step the twice-differentiated x_hat pass and the batched real | fake pass are independent until d_loss sums
         # them, and both are chains of small launches (8x8 / 4x4 planes: a fraction of the chip each): the x_hat pass runs on a
         # FORK stream, forward and -- autograd replays a node on its forward's stream -- both of its backward sweeps.  Default: on
@@ -70,7 +75,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # beside G2gen + G2a: the D-step's ~700 small launches hide under 12 ms of chip-filling kernels instead of 2.8.
         # Default: with the side stream (one GPU: 23.3 -> 21.9 ms per iteration); without it (data parallelism) the three
         # pieces run back to back and measure 0.5 % SLOWER than one backward (24.51 vs 24.38 ms): off there.
-        self._g_split = os.environ.get("SMSUT_G_SPLIT", "1" if self._d_overlap else "0") not in ("0", "")
+        self._g_split = os.environ.get("SMSUT_G_SPLIT", "1" if (self._d_overlap or self._d_side_compute) else "0") not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
@@ -382,30 +387,41 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # side stream UNDER the cycle pass (SMSUT_D_OVERLAP=0: one after the other).  D's weights are first needed by phase G2.
         cur = torch.cuda.current_stream()
         overlap = self._d_overlap
-        if overlap:
+        side_c = self._d_side_compute and not overlap
+        if overlap or side_c:
             if self._side is None:
                 self._side = torch.cuda.Stream()
             self._side.wait_stream(cur)
-        with torch.cuda.stream(self._side if overlap else cur):
+        d_work = None
+        with torch.cuda.stream(self._side if (overlap or side_c) else cur):
             d_scal = self._run_phase("D", self._d_phase, (x_real, x_fake, modal_org, alpha), d_params)
             if self._probe:
                 self._finite_probe("D", [("d_scalars", d_scal)] + [("grad " + k, p.grad) for k, p in self.D.named_parameters()])
-            # D's gradient all-reduce STARTS here (asynchronous: RCCL's own stream) and is collected after the cycle pass, which
-            # needs neither D's gradients nor its updated weights -- the collective is off the critical path under data parallelism
-            d_work = self.d_reducer.begin()
-            if d_work is None or overlap or not self._d_async:
-                self.d_reducer.finish(d_work)
-                self.d_optimizer.step()
-                d_work = None
+            if not side_c:
+                # D's gradient all-reduce STARTS here (asynchronous: RCCL's own stream) and is collected after the cycle pass,
+                # which needs neither D's gradients nor its updated weights -- off the critical path under data parallelism
+                d_work = self.d_reducer.begin()
+                if d_work is None or overlap or not self._d_async:
+                    self.d_reducer.finish(d_work)
+                    self.d_optimizer.step()
+                    d_work = None
         st_semi = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids), list(self._alias.values()))
         if d_work is not None:
             self.d_reducer.finish(d_work)
+            self.d_optimizer.step()
+
+        def join_d():                                          # side_c: the D-step's graph is done -> all-reduce, Adam (main stream)
+            cur.wait_stream(self._side)
+            d_scal.record_stream(cur)
+            self.d_reducer.finish(self.d_reducer.begin())
             self.d_optimizer.step()
         self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
         if self._g_split:
             # ---------------------------------------------------- G-step in three pieces (see __init__): G2a needs no D at all
             ga = self._run_phase("G2a", self._g2a_phase, (y_real, st_seg, st_semi, lam_t), g_params,
                                  rebind=list(self._alias.values()))
+            if side_c:
+                join_d()
             for p in d_params:                                # D frozen: its unused gradients are neither computed nor reduced
                 p.requires_grad_(False)
             with torch.cuda.stream(self._side if overlap else cur):      # behind the D-step and Adam, beside G2gen + G2a
@@ -423,6 +439,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
             self._run_phase("G2c", self._g2c_phase, (), [], rebind=g_params)
             g_scal = torch.cat([gb[0:1], ga[0:1], gb[1:2], ga[1:4]])     # [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]
         else:
+            if side_c:
+                join_d()
             if overlap:
                 cur.wait_stream(self._side)
                 d_scal.record_stream(cur)        # allocated on the side stream (eager mode), read by the final cat on this one

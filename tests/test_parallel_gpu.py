@@ -115,6 +115,7 @@ def _worker(rank, world, port, q, backend="gloo"):
     res["ugan"] = ugan
     res["ugan_graph"] = ut.graph_report()
     res["ugan_overlap_default"] = ut._d_overlap
+    res["ugan_side_compute"] = ut._d_side_compute
 
     # ---- 4. (RCCL only) the D-step on the side stream == the one-stream default, with both optimizers stepping
     if backend == "nccl":
@@ -122,7 +123,7 @@ def _worker(rank, world, port, q, backend="gloo"):
         # (the three-piece G-step, which the side stream turns on by default, sums a shared parameter's gradient in another order:
         #  pinned off in BOTH runs so that the comparison isolates the stream placement and stays bit for bit)
         os.environ["SMSUT_G_SPLIT"] = "0"
-        for ov in ("0", "1"):
+        for ov in ("0", "2", "1"):                         # one stream | compute-only side stream (the default) | full side chain
             os.environ["SMSUT_D_OVERLAP"] = ov
             t2 = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
             assert t2._d_overlap == (ov == "1")
@@ -140,9 +141,9 @@ def _worker(rank, world, port, q, backend="gloo"):
                          [p.detach().cpu().clone() for p in t2.D.parameters()]))
         os.environ.pop("SMSUT_D_OVERLAP", None)
         os.environ.pop("SMSUT_G_SPLIT", None)
-        (s_a, g_a, d_a), (s_b, g_b, d_b) = runs
-        res["overlap_scalars_equal"] = s_a == s_b
-        res["overlap_weights_equal"] = all(torch.equal(a, b) for a, b in zip(g_a + d_a, g_b + d_b))
+        (s_a, g_a, d_a) = runs[0]
+        res["overlap_scalars_equal"] = all(s_a == s_b for s_b, _, _ in runs[1:])
+        res["overlap_weights_equal"] = all(torch.equal(a, b) for _, g_b, d_b in runs[1:] for a, b in zip(g_a + d_a, g_b + d_b))
         # every rank must hold the same weights after 5 all-reduced steps
         flat = torch.cat([p.reshape(-1) for p in g_a + d_a]).to(dev)
         other = flat.clone()
@@ -218,7 +219,8 @@ def _two_ranks(backend, overlap=False):
             #  and 1 + 1 slices of 64x64 per rank is the noisiest case there is: 2.46e-2 with the r03 Winograd kernels, 1.9e-2 before)
             assert gerr < 3e-2, gerr
         assert res["ugan_graph"]["mode"].startswith("graph"), res["ugan_graph"]
-        assert res["ugan_overlap_default"] is overlap           # one stream under data parallelism by default
+        assert res["ugan_overlap_default"] is overlap           # collectives from ONE stream under data parallelism by default ...
+        assert res["ugan_side_compute"] is (not overlap)        # ... the side stream carries the captured D-step only
         want, got, pos = res["resume"]
         assert want == got and pos == (7, 1), (rank, want, got, pos)
     assert out[0]["resume"][0] != out[1]["resume"][0]           # ... and the ranks' streams are different ones
