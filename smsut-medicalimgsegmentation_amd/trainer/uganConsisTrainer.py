@@ -228,6 +228,27 @@ class UGANConsisTrainer(UGANShp0Trainer):
             (self.lambda_rec * g_rec + self.lambda_seg * g_seg + lambda_semi * g_semi + 1.0 * g_nce).backward()
         return torch.stack([t.detach().float() for t in (g_rec, g_seg, g_semi, g_nce)])
 
+    # Mode 2 (data parallelism) cuts G2a once more, so that D(x_fake) -- which there must follow D's all-reduce and Adam on the
+    # main stream's time line -- still has generator work to run beside: G2a1 = the cycle pass' terms, G2a2 = the segmentation
+    # term of G(x_real) (disjoint graphs and parameters: two backward calls, same values).
+    def _g2a1_phase(self, st_semi, lambda_semi):
+        """[G_rec, G_semi, G_nce] and their backward (cycle pass on the aliases, netF, down to the cut points)."""
+        y_rec, pseudo, g_rec, g_nce, _ = self._g2
+        if self._semi_on:
+            g_semi = self.loss.from_stats(y_rec, pseudo, st_semi)
+        else:
+            g_semi = torch.zeros((), device=self.device)
+        with ops.wino_prepared(self.net, forms="b"):
+            (self.lambda_rec * g_rec + lambda_semi * g_semi + 1.0 * g_nce).backward()
+        return torch.stack([t.detach().float() for t in (g_rec, g_semi, g_nce)])
+
+    def _g2a2_phase(self, y_real, st_seg):
+        """[G_seg] and its backward (segmentation branch of G(x_real))."""
+        g_seg = self.loss.from_stats(self._g1[0][:y_real.size(0)], y_real, st_seg)
+        with ops.wino_prepared(self.net, forms="b"):
+            (self.lambda_seg * g_seg).backward()
+        return g_seg.detach().float().reshape(1)
+
     def _g2d_phase(self, modal_trg):
         """SMSUT_G_SPLIT: D(x_fake) through the updated, frozen D and its data-gradient.  Returns [G_fake, G_cls]; the
         gradient w.r.t. x_fake stays in ``self._gx_d`` for G2c."""
@@ -338,7 +359,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def graph_report(self):
         """What actually ran: which phases are captured hipGraphs (bench.py prints this next to the timing)."""
         captured = sorted({k[0] for k in self._graphs if isinstance(k, tuple)})
-        whole = set(captured) in ({"D", "G1", "G2", "G2gen"}, {"D", "G1", "G2a", "G2c", "G2d", "G2gen"})   # (G-step: one phase or three)
+        whole = set(captured) in ({"D", "G1", "G2", "G2gen"}, {"D", "G1", "G2a", "G2c", "G2d", "G2gen"},
+                                  {"D", "G1", "G2a1", "G2a2", "G2c", "G2d", "G2gen"})      # (G-step: one phase, three, or four)
         mode = "graph" if whole else ("eager" if not captured else "graph(" + ",".join(captured) + ")")
         return {"mode": mode, "captured": captured, "fallback": False,
                 "policy": os.environ.get("SMSUT_GRAPH", "default")}
@@ -418,17 +440,22 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
         if self._g_split:
             # ---------------------------------------------------- G-step in three pieces (see __init__): G2a needs no D at all
-            ga = self._run_phase("G2a", self._g2a_phase, (y_real, st_seg, st_semi, lam_t), g_params,
-                                 rebind=list(self._alias.values()))
             if side_c:
-                join_d()
+                ga1 = self._run_phase("G2a1", self._g2a1_phase, (st_semi, lam_t), g_params, rebind=list(self._alias.values()))
+                join_d()                                      # D-step done: its all-reduce and Adam, on this stream
+                self._side.wait_stream(cur)
+            else:
+                ga = self._run_phase("G2a", self._g2a_phase, (y_real, st_seg, st_semi, lam_t), g_params,
+                                     rebind=list(self._alias.values()))
             for p in d_params:                                # D frozen: its unused gradients are neither computed nor reduced
                 p.requires_grad_(False)
-            with torch.cuda.stream(self._side if overlap else cur):      # behind the D-step and Adam, beside G2gen + G2a
+            with torch.cuda.stream(self._side if (overlap or side_c) else cur):   # beside generator work on the main stream
                 gb = self._run_phase("G2d", self._g2d_phase, (modal_trg,), [])
             for p in d_params:
                 p.requires_grad_(True)
-            if overlap:
+            if side_c:
+                ga2 = self._run_phase("G2a2", self._g2a2_phase, (y_real, st_seg), [], rebind=g_params)
+            if overlap or side_c:
                 cur.wait_stream(self._side)
                 d_scal.record_stream(cur)        # allocated on the side stream (eager mode), read on this one
                 gb.record_stream(cur)
@@ -437,7 +464,10 @@ class UGANConsisTrainer(UGANShp0Trainer):
             if self._probe:
                 self._finite_probe("D.step", list(self.D.named_parameters()))
             self._run_phase("G2c", self._g2c_phase, (), [], rebind=g_params)
-            g_scal = torch.cat([gb[0:1], ga[0:1], gb[1:2], ga[1:4]])     # [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]
+            if side_c:                           # [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]
+                g_scal = torch.cat([gb[0:1], ga1[0:1], gb[1:2], ga2, ga1[1:3]])
+            else:
+                g_scal = torch.cat([gb[0:1], ga[0:1], gb[1:2], ga[1:4]])
         else:
             if side_c:
                 join_d()

@@ -201,17 +201,26 @@ def test_full_size_iteration_scalars_vs_oracle(small_cfg):
     assert np.allclose(got, ref, rtol=1e-3, atol=1e-5), rep                  # all ten, D_gp included
 
 
-def test_config4_per_gpu_shape_scalars_vs_oracle(small_cfg):
+_CONFIG4_REF = {}       # oracle scalars of the two batches (15 s of CPU each), shared by the schedules below
+
+
+@pytest.mark.parametrize("schedule", ["2", "1", "0"], ids=["dp-default-compute-only-side-stream", "one-gpu-default-side-chain", "one-stream"])
+def test_config4_per_gpu_shape_scalars_vs_oracle(small_cfg, monkeypatch, schedule):
     """BASELINE config 4's per-GPU workload: 16 labeled + 16 unlabeled 256x256 slices, ``PatchNCELoss(16)``
     (reference uganShp0Trainer.py:59 with cfg.batch_size = 16; uganConsisTrainer.py:110-180), optimizers at lr 0.  An eager
     iteration on one batch and a hipGraph REPLAY on another, all ten scalars at 1e-3 against the CPU oracle -- the shape every
-    rank of the 8-GPU data-parallel run executes (tile / grid heuristics differ from the 8 + 8 shape of config 3)."""
+    rank of the 8-GPU data-parallel run executes (tile / grid heuristics differ from the 8 + 8 shape of config 3), under each
+    of the three schedules of the iteration (``SMSUT_D_OVERLAP``): 2 = what a data-parallel rank runs by default (captured D-step
+    on the side stream, G-step in four pieces, collectives on the main stream), 1 = the one-GPU default, 0 = one stream."""
     from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer, SCALARS
     from oracle import smsut_oracle as O
+    monkeypatch.setenv("SMSUT_D_OVERLAP", schedule)
     cfg = small_cfg
     cfg.input_size, cfg.batch_size = 256, 16
     tr = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
     assert tr.criterionNCE[0].batch_size == 16
+    assert (tr._d_overlap, tr._d_side_compute, tr._g_split) == {"2": (False, True, True), "1": (True, False, True),
+                                                                "0": (False, False, False)}[schedule]
     g_w = recipe.fill(recipe.ugan_shapes(1, 5, 4, 16), 191)
     d_w = recipe.fill(recipe.disc_shapes(256, 4, 16, 256), 192)
     tr.net.load_state_dict(g_w); tr.D.load_state_dict(d_w)
@@ -240,13 +249,15 @@ def test_config4_per_gpu_shape_scalars_vs_oracle(small_cfg):
     got_b = hip(b, 1)                      # replay on fresh inputs
     assert tr.graph_report()["mode"] == "graph"
     torch.set_num_threads(16)
-    for got, (x, y, modal, alpha, ids), mj in ((got_a, a, 3), (got_b, b, 1)):
-        gsd = {k: v.clone().requires_grad_(True) for k, v in g_w.items()}
-        dsd = {k: v.clone().requires_grad_(True) for k, v in d_w.items()}
-        logs, _ = O.ugan_consis_iteration(gsd, dsd, torch.optim.SGD(list(gsd.values()), lr=0.0),
-                                          torch.optim.Adam(list(dsd.values()), 0.0), x, y, modal, mj, alpha, [ids],
-                                          it=15000, epoch=100, nce_batch=16, base_lr=0.0)
-        ref = np.array([logs[k] for k in SCALARS])
+    for tag, got, (x, y, modal, alpha, ids), mj in (("a", got_a, a, 3), ("b", got_b, b, 1)):
+        if tag not in _CONFIG4_REF:
+            gsd = {k: v.clone().requires_grad_(True) for k, v in g_w.items()}
+            dsd = {k: v.clone().requires_grad_(True) for k, v in d_w.items()}
+            logs, _ = O.ugan_consis_iteration(gsd, dsd, torch.optim.SGD(list(gsd.values()), lr=0.0),
+                                              torch.optim.Adam(list(dsd.values()), 0.0), x, y, modal, mj, alpha, [ids],
+                                              it=15000, epoch=100, nce_batch=16, base_lr=0.0)
+            _CONFIG4_REF[tag] = np.array([logs[k] for k in SCALARS])
+        ref = _CONFIG4_REF[tag]
         assert np.allclose(got, ref, rtol=1e-3, atol=1e-5), dict(zip(SCALARS, zip(got, ref)))
 
 
