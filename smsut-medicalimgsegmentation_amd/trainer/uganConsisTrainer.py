@@ -54,28 +54,28 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # gradients) is issued from the main stream in program order -- for RCCL this is the one-stream configuration; Adam and
         # D(x_fake) follow on the main stream.
         self._d_side_compute = ov == "2"
-        # Inside the D-step the twice-differentiated x_hat pass and the batched real | fake pass are independent until d_loss sums
-        # them, and both are chains of small launches (8x8 / 4x4 planes: a fraction of the chip each): the x_hat pass runs on a
-        # FORK stream, forward and -- autograd replays a node on its forward's stream -- both of its backward sweeps.  Default: on
-        # at one GPU (24.6 -> 23.5 ms per iteration together with the G-step fork below), OFF under data parallelism: with every
-        # phase on one stream, as there, the forks measure neutral (24.46-24.52 ms with, 24.47-24.53 without), and a default that
-        # gains nothing should not put multi-stream graphs beside RCCL untested.  SMSUT_D_FORK / SMSUT_G2_FORK = 0 / 1 override.
-        fork_default = "1" if self.world == 1 else "0"
-        self._d_fork = os.environ.get("SMSUT_D_FORK", fork_default) not in ("0", "")
-        self._fork = None
-        self._g2_fork = os.environ.get("SMSUT_G2_FORK", fork_default) not in ("0", "")
-        # The G-step's backward in THREE pieces (SMSUT_G_SPLIT, default on), so that only what needs the updated D waits for it:
+        # The G-step's backward in THREE pieces (SMSUT_G_SPLIT; default: on whenever a side stream is in use), so that only what
+        # needs the updated D waits for it:
         #   G2a  backward of the D-independent terms (cycle L1, PatchNCE, both DiceCE values) -- the whole cycle pass and the
         #        segmentation branch of G(x_real), ~70 % of the generator's backward -- stopping at two cut points of G(x_real)'s
         #        graph: x_fake and the bottleneck features t_e5 (the cycle pass and netF read DETACHED copies of them);
         #   G2d  D(x_fake) through the updated D, forward and data-gradient: d(g_fake + lambda_cls g_cls) / d x_fake;
         #   G2c  the translation branch of G(x_real) from the summed cut-point gradients.
         # Same sums as one g_loss.backward() (autograd adds the same contributions at x_fake / t_e5; only the order in which a
-        # shared parameter's gradient is accumulated differs, 1e-7).  On one GPU the D-step, Adam and G2d run on the side stream
-        # beside G2gen + G2a: the D-step's ~700 small launches hide under 12 ms of chip-filling kernels instead of 2.8.
-        # Default: with the side stream (one GPU: 23.3 -> 21.9 ms per iteration); without it (data parallelism) the three
-        # pieces run back to back and measure 0.5 % SLOWER than one backward (24.51 vs 24.38 ms): off there.
+        # shared parameter's gradient is accumulated differs, 1e-7).  The D-step's ~700 small launches then hide under 12 ms of
+        # chip-filling generator kernels instead of 2.8 (one GPU: 23.3 -> 21.9 ms per iteration).  On ONE stream the pieces run
+        # back to back and measure 0.5 % slower than one backward (24.51 vs 24.38 ms): off there.
         self._g_split = os.environ.get("SMSUT_G_SPLIT", "1" if (self._d_overlap or self._d_side_compute) else "0") not in ("0", "")
+        # Forks INSIDE captured phases: the D-step's twice-differentiated x_hat pass (forward and -- autograd replays a node on its
+        # forward's stream -- both of its backward sweeps) beside the batched real | fake pass, and D(x_fake) of the one-piece
+        # G-step beside the segmentation branch's backward.  They shorten the D-step when it is on the critical path (one-piece
+        # G-step with the side stream: 24.6 -> 23.5 ms per iteration) -- and COST 2 % once the three-piece G-step has taken it
+        # off that path (22.0 with, 21.57 without: the D chain has slack there, and forking it only adds contention for the
+        # generator's kernels); on one stream they are neutral.  Default: on only in the configuration they help.
+        fork_default = "1" if (self.world == 1 and self._d_overlap and not self._g_split) else "0"
+        self._d_fork = os.environ.get("SMSUT_D_FORK", fork_default) not in ("0", "")
+        self._fork = None
+        self._g2_fork = os.environ.get("SMSUT_G2_FORK", fork_default) not in ("0", "")
         self._eager_done = False
         self._lambda_semi_t = torch.zeros((), device=self.device)
         self._probe = os.environ.get("SMSUT_DEBUG_FINITE", "0") not in ("0", "")
