@@ -44,3 +44,17 @@ print("generator chain on the current stream, D chain on a side stream (prio 0):
 print("generator chain on a HIGH-priority stream, D chain on prio 0:            %.3f ms" % t(seq(hi, lo)))
 print("generator chain on the current stream, D chain on a HIGH-priority stream: %.3f ms" % t(seq(None, hi)))
 print("all on one stream: %.3f ms" % t(lambda: [gs[k].replay() for k in ("G1", "D", "G2d", "G2gen", "G2a", "G2c")]))
+
+# ---- a LOWER-than-default priority for the D chain (HIP has three levels; torch's pool only exposes two): external stream
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+lo_p, hi_p = ctypes.c_int(), ctypes.c_int()
+hip.hipDeviceGetStreamPriorityRange(ctypes.byref(lo_p), ctypes.byref(hi_p))
+print("hipDeviceGetStreamPriorityRange: least", lo_p.value, "greatest", hi_p.value)
+for pr in sorted({lo_p.value, 0}):
+    h = ctypes.c_void_p()
+    rc = hip.hipStreamCreateWithPriority(ctypes.byref(h), 1, pr)      # hipStreamNonBlocking
+    if rc != 0:
+        print("hipStreamCreateWithPriority", pr, "rc", rc); continue
+    ext = torch.cuda.ExternalStream(h.value)
+    print("generator chain on the current stream, D chain on an external stream of priority %d: %.3f ms" % (pr, t(seq(None, ext))))
