@@ -58,3 +58,25 @@ for pr in sorted({lo_p.value, 0}):
         print("hipStreamCreateWithPriority", pr, "rc", rc); continue
     ext = torch.cuda.ExternalStream(h.value)
     print("generator chain on the current stream, D chain on an external stream of priority %d: %.3f ms" % (pr, t(seq(None, ext))))
+
+# ---- when does each chain finish?  (events at the end of G2a on the current stream and of G2d on the side stream)
+def timeline(reps=10):
+    cur = torch.cuda.current_stream()
+    acc = [0.0, 0.0, 0.0]
+    for _ in range(reps + 1):
+        e0, ea, ed, e1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        torch.cuda.synchronize()
+        e0.record(cur)
+        gs["G1"].replay()
+        lo.wait_stream(cur)
+        with torch.cuda.stream(lo):
+            gs["D"].replay(); gs["G2d"].replay(); ed.record(lo)
+        gs["G2gen"].replay(); gs["G2a"].replay(); ea.record(cur)
+        cur.wait_stream(lo)
+        gs["G2c"].replay(); e1.record(cur)
+        torch.cuda.synchronize()
+        if _ > 0:
+            acc[0] += e0.elapsed_time(ea); acc[1] += e0.elapsed_time(ed); acc[2] += e0.elapsed_time(e1)
+    print("from the start of G1: generator chain (G1 + G2gen + G2a) done at %.2f ms, D chain (D + G2d) done at %.2f ms, G2c done at %.2f ms"
+          % tuple(a / reps for a in acc))
+timeline()
