@@ -24,6 +24,7 @@
 // order; per-split slabs are summed by a second tiny kernel (deterministic, no atomics).
 #include "common.h"
 #include "conv_wino.h"
+#include "conv_wgrad_rr.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
@@ -2719,6 +2720,10 @@ inline bool wino_wg_shape(int N, int H, int W, int Cin, int Cout, const float* x
 int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int KS) {
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
   int64_t need = (int64_t)p.splits * KS * KS * Cin * Cout;
+  if (KS == 3) {                                       // the register-row kernel (conv_wgrad_rr.hip) plans its own split count
+    const int64_t rr = (int64_t)smsut_wgrad_rr_splits(N, H, W, Cin, Cout, nullptr, 0, false, false) * 9 * Cin * Cout;
+    if (rr > need) need = rr;
+  }
   if (KS == 3 && wino_wg_shape(N, H, W, Cin, Cout, nullptr, 0)) {
     const int64_t wn = smsut_wino_wg_ws(N, H, W, Cin, Cout);
     if (wn > need) need = wn;
@@ -2753,6 +2758,17 @@ static int wgrad_mfma_launch(const float* x, const float* gy, float* gw, float* 
     WinoAff wa;
     if (aff) wa = WinoAff{aff->mean, aff->rstd, aff->gamma, aff->beta, aff->slope};
     if (smsut_wino_wg_launch(x, x2, ca, gy, gw, workspace, N, H, W, Cin, Cout, aff ? &wa : nullptr, st) == 0) {
+      SMSUT_LAUNCH_CHECK();
+      return SMSUT_OK;
+    }
+  }
+  if (KS == 3 && smsut_wgrad_rr_eligible(N, H, W, Cin, Cout, x2, ca, aff != nullptr, gs != nullptr)) {
+    // register-row kernel (conv_wgrad_rr.hip): no LDS staging, no barrier in the main loop
+    RrAff ra;
+    if (aff) ra = RrAff{aff->mean, aff->rstd, aff->gamma, aff->beta, aff->slope};
+    if (smsut_wgrad_rr_launch(x, x2, ca, gy, gs, workspace, N, H, W, Cin, Cout, aff ? &ra : nullptr, st) == 0) {
+      launch_sum_splits(workspace, gw, (9 + (gs ? 1 : 0)) * Cin * Cout,
+                        smsut_wgrad_rr_splits(N, H, W, Cin, Cout, x2, ca, aff != nullptr, gs != nullptr), st);
       SMSUT_LAUNCH_CHECK();
       return SMSUT_OK;
     }
@@ -2841,7 +2857,8 @@ int smsut_conv2d_wgrad_sc_supported(int N, int H, int W, int Cin, int Cout) {
 }
 int64_t smsut_conv2d_wgrad_sc_ws(int N, int H, int W, int Cin, int Cout) {
   const WgradPlan p = plan_wgrad(N, H, W, Cin, Cout);
-  return (int64_t)p.splits * 10 * Cin * Cout;
+  const int rr = smsut_wgrad_rr_splits(N, H, W, Cin, Cout, nullptr, 0, false, true);
+  return (int64_t)(rr > p.splits ? rr : p.splits) * 10 * Cin * Cout;
 }
 int smsut_conv2d_wgrad_mfma_sc(const float* xa, const float* xb, int ca, const float* gy, const float* gs, float* gw10,
                                float* workspace, int N, int H, int W, int Cin, int Cout, void* stream) {
