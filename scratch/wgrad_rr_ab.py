@@ -11,10 +11,10 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 P = lambda t: ctypes.c_void_p(t.data_ptr() if t is not None else 0)
 
 
-def load(tag, env):
+def load(tag, env, src=LIB):
     d = tempfile.mkdtemp()
     path = os.path.join(d, f"libsmsut_{tag}.so")
-    shutil.copy(LIB, path)
+    shutil.copy(src, path)
     lib = ctypes.CDLL(path)
     lib.smsut_conv2d_wgrad_mfma_ws.restype = ctypes.c_int64
     lib.smsut_conv2d_wgrad_sc_ws.restype = ctypes.c_int64
@@ -27,6 +27,14 @@ for k, spec in enumerate(filter(None, os.environ.get("RR_ENVS", "").split(";")))
     env.update(dict(kv.split("=") for kv in spec.split(",")))
     arms[f"rr{k + 1}"] = load(f"rr{k + 1}", env)
     print(f"arm rr{k + 1}: {env}")
+
+
+for spec in filter(None, os.environ.get("RR_LIBS", "").split(";")):          # RR_LIBS="tag=path[,k=v...];..." (scratch/build_variant_rr.sh)
+    parts = spec.split(",")
+    tag, path = parts[0].split("=")
+    env = {"SMSUT_WGRAD_RR": "1"}
+    env.update(dict(kv.split("=") for kv in parts[1:]))
+    arms[tag] = load(tag, env, os.path.join(ROOT, path))
 
 
 def with_env(env, fn):

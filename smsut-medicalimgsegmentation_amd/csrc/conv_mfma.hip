@@ -2852,6 +2852,8 @@ int smsut_conv2d_wgrad_sc_supported(int N, int H, int W, int Cin, int Cout) {
   // fused (scratch/wsc_ab.py) -- those keep the two-kernel form.
   static const bool use_c8 = [] { const char* e = getenv("SMSUT_CONV_K8"); return !e || atoi(e) != 0; }();
   if (on && use_c8 && Cin == 8 && Cout >= 4 && Cout % 4 == 0 && Cout <= 32 && N > 0 && H > 0 && W > 0) return 1;   // 8-channel form (SC8)
+  // register-row kernel (conv_wgrad_rr.hip): one more accumulator tile per (ci tile, co tile) -- also on the 16-channel slabs
+  if (on && smsut_wgrad_rr_eligible(N, H, W, Cin, Cout, nullptr, 0, false, true)) return 1;
   return on && N > 0 && H > 0 && W > 0 && H % WTH == 0 && W % TW == 0 && Cin % 32 == 0 && Cout % 32 == 0 &&
          !plane_wgrad_applies(N, H, W, Cin, Cout) && (int64_t)N * H * W * (Cin > Cout ? Cin : Cout) < (1ll << 31);
 }

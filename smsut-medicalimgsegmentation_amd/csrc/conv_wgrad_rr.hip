@@ -56,10 +56,22 @@ struct RrArgs {
   int groups_per_split;                         // groups of WS wave-units a workgroup walks
   int total_wu;                                 // N * (H / RC) * (W / 16)
   RrAff aff;
+#ifdef SMSUT_STAMPS                             // diagnostic build only (scratch/rr_clock.py): per-workgroup cycle / real-time stamps
+  unsigned long long* dbg;                      // [workgroups][4]: s_memtime, s_memrealtime at the start and at the end of wave 0
+#endif
 };
 
+#ifndef RR_SPREAD
+#define RR_SPREAD 1
+#endif
+#ifndef RR_V4R8
+#define RR_V4R8 0      // 32 x 32 per wave: ring of 8 rows, 3 (2 with the fused shortcut) steps of loads in flight
+#endif
+#ifndef RR_OCC4
+#define RR_OCC4 1       // workgroups per CU the 32 x 32-per-wave form must allow (2 = at most 256 registers)
+#endif
 template <int CIW, int COW, int WI, int WJ, int R, int D, bool DUAL, bool INAFF, bool SC>
-__global__ void __launch_bounds__(TPB) wgrad_rr(const RrArgs a) {
+__global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgrad_rr(const RrArgs a) {
   static_assert(WI * WJ == 1 || WI * WJ == 2 || WI * WJ == 4, "sub-slabs per workgroup");
   static_assert(R >= D + 3, "ring: three live rows + D in flight");
   constexpr int WS = 4 / (WI * WJ);
@@ -76,6 +88,13 @@ __global__ void __launch_bounds__(TPB) wgrad_rr(const RrArgs a) {
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, RC = a.RC;
   const int NXS = W >> 4, NYC = H / RC;
 
+#ifdef SMSUT_STAMPS
+  const int wg_lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  if (a.dbg && threadIdx.x == 0) {
+    a.dbg[wg_lin * 4 + 0] = __builtin_amdgcn_s_memtime();
+    a.dbg[wg_lin * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   f32x4 acc[NT];
 #pragma unroll
   for (int k = 0; k < NT; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -97,9 +116,10 @@ __global__ void __launch_bounds__(TPB) wgrad_rr(const RrArgs a) {
     } else { xs[i] = a.x; cs[i] = Cin; cf[i] = c; }
   }
 
+  constexpr int G = (R % (D + 1) == 0) ? D + 1 : R;        // gy ring: the row in use + D in flight
   float xr[R][CIW][6];
-  float gr[R][COW][4];
-  [[maybe_unused]] float sr[SC ? R : 1][COW][4];
+  float gr[G][COW][4];
+  [[maybe_unused]] float sr[SC ? G : 1][COW][4];
 
   for (int g = 0; g < a.groups_per_split; ++g) {
     const int wu = uni((int)((blockIdx.x * a.groups_per_split + g) * WS + strip));
@@ -190,7 +210,7 @@ __global__ void __launch_bounds__(TPB) wgrad_rr(const RrArgs a) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       load_x((2 + d) % R, 2 + d);
-      load_g(d % R, d);
+      load_g(d % G, d);
       FENCE();
     }
     fix_x(0, 0);
@@ -200,81 +220,125 @@ __global__ void __launch_bounds__(TPB) wgrad_rr(const RrArgs a) {
 #pragma unroll
       for (int s = 0; s < R; ++s) {
         const int t = tb + s;
+#ifndef RR_ABL_NOLOAD                                               // (ablation builds, scratch/wgrad_rr_ab.py: results wrong by construction)
         load_x((s + 2 + D) % R, t + 2 + D);
-        load_g((s + D) % R, t + D);
-        FENCE();                          // (the scheduler would sink the loads to their uses)
+        load_g((s + D) % G, t + D);
+#endif
+#if !RR_SPREAD
+        FENCE();                                                    // (the scheduler would sink the loads to their uses)
+#endif
         fix_x((s + 2) % R, t + 2);
+        // taps of rows t, t+1 first: the row that is fixed up in this step (t+2) feeds the last third of the MFMAs only
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
-          for (int tap = 0; tap < 9; ++tap)
+          for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-            for (int i = 0; i < CIW; ++i)
+            for (int tap = half ? 6 : 0; tap < (half ? 9 : 6); ++tap)
 #pragma unroll
-              for (int j = 0; j < COW; ++j)
-                acc[(tap * CIW + i) * COW + j] =
-                    mfma16(xr[(s + tap / 3) % R][i][ks + tap % 3], gr[s % R][j][ks], acc[(tap * CIW + i) * COW + j]);
-          if constexpr (SC) {
+              for (int i = 0; i < CIW; ++i)
 #pragma unroll
-            for (int i = 0; i < CIW; ++i)
+                for (int j = 0; j < COW; ++j)
+                  acc[(tap * CIW + i) * COW + j] =
+                      mfma16(xr[(s + tap / 3) % R][i][ks + tap % 3], gr[s % G][j][ks], acc[(tap * CIW + i) * COW + j]);
+            if constexpr (SC) {
+              if (half == 0) {
 #pragma unroll
-              for (int j = 0; j < COW; ++j)
-                acs[i * COW + j] = mfma16(xr[(s + 1) % R][i][ks + 1], sr[s % R][j][ks], acs[i * COW + j]);
+                for (int i = 0; i < CIW; ++i)
+#pragma unroll
+                  for (int j = 0; j < COW; ++j)
+                    acs[i * COW + j] = mfma16(xr[(s + 1) % R][i][ks + 1], sr[s % G][j][ks], acs[i * COW + j]);
+              }
+            }
+          }
+#if RR_SPREAD
+        // issue order inside the step (one scheduling region): the step's loads and the fix-up VALU spread under the MFMAs of
+        // rows t, t+1 instead of a burst in front of them (one wave per SIMD has nobody else to fill the matrix pipe meanwhile)
+        {
+          constexpr int NLD = 6 * CIW + 4 * COW * (SC ? 2 : 1);
+#pragma unroll
+          for (int q = 0; q < NLD; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);        // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);       // VMEM read
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, INAFF ? 4 : 1, 0);   // VALU (fix-up)
           }
         }
+#endif
         FENCE();
       }
     }
   }
 
-  // ---- combine the WS strip waves of each sub-slab in a fixed order: (w0 + w2) + (w1 + w3) for WS = 4, w0 + w1 for WS = 2
+#ifdef SMSUT_STAMPS
+  if (a.dbg && threadIdx.x == 0) {
+    a.dbg[wg_lin * 4 + 2] = __builtin_amdgcn_s_memtime();
+    a.dbg[wg_lin * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+  // ---- epilogue: the WS strip waves of each sub-slab combine in a fixed order -- (w0 + w2) + (w1 + w3) for WS = 4, w0 + w1 for
+  // WS = 2 -- and ALL 256 threads store the slab as 16-byte rows (one wave storing 36 tiles dword by dword was ~4 us of tail).
   constexpr int NTA = NT + NTS;
-  if constexpr (WS > 1) {
+  constexpr int CIG = 16 * CIW * WI, COG = 16 * COW * WJ;        // the workgroup's slab
+  constexpr int LROW = COG + 4;                                   // LDS row stride: rows 4kq apart land on disjoint bank groups
+  constexpr int ROWS = (SC ? 10 : 9) * CIG;                       // slab rows [tap (9 = shortcut)][ci]
+  constexpr int P = WS >= 2 ? 2 : 1;                              // partial sums left for the last stage
+  if constexpr (WS == 4) {                                        // strips 2, 3 hand their tiles to strips 0, 1 (accumulator layout)
+    if (strip >= 2) {
+      float* dst = smem + ((size_t)((strip - 2) * WI * WJ + sub) * NTA) * 256;
 #pragma unroll
-    for (int half = WS / 2; half >= 1; half >>= 1) {
-      __syncthreads();
-      if (strip >= half && strip < 2 * half) {
-        float* dst = smem + ((size_t)((strip - half) * WI * WJ + sub) * NTA) * 256;
+      for (int k = 0; k < NT; ++k) *(f32x4*)(dst + ((size_t)k * 64 + lane) * 4) = acc[k];
+      if constexpr (SC) {
 #pragma unroll
-        for (int k = 0; k < NT; ++k) *(f32x4*)(dst + ((size_t)k * 64 + lane) * 4) = acc[k];
-        if constexpr (SC) {
-#pragma unroll
-          for (int k = 0; k < NTS; ++k) *(f32x4*)(dst + ((size_t)(NT + k) * 64 + lane) * 4) = acs[k];
-        }
-      }
-      __syncthreads();
-      if (strip < half) {
-        const float* src = smem + ((size_t)(strip * WI * WJ + sub) * NTA) * 256;
-#pragma unroll
-        for (int k = 0; k < NT; ++k) acc[k] += *(const f32x4*)(src + ((size_t)k * 64 + lane) * 4);
-        if constexpr (SC) {
-#pragma unroll
-          for (int k = 0; k < NTS; ++k) acs[k] += *(const f32x4*)(src + ((size_t)(NT + k) * 64 + lane) * 4);
-        }
+        for (int k = 0; k < NTS; ++k) *(f32x4*)(dst + ((size_t)(NT + k) * 64 + lane) * 4) = acs[k];
       }
     }
+    __syncthreads();
+    if (strip < 2) {
+      const float* src = smem + ((size_t)(strip * WI * WJ + sub) * NTA) * 256;
+#pragma unroll
+      for (int k = 0; k < NT; ++k) acc[k] += *(const f32x4*)(src + ((size_t)k * 64 + lane) * 4);
+      if constexpr (SC) {
+#pragma unroll
+        for (int k = 0; k < NTS; ++k) acs[k] += *(const f32x4*)(src + ((size_t)(NT + k) * 64 + lane) * 4);
+      }
+    }
+    __syncthreads();
   }
-  if (strip == 0) {
-    float* out = a.part + (size_t)blockIdx.x * (SC ? 10 : 9) * Cin * Cout;
+  if (strip < P) {                                                // row-major slab image [strip][tap][ci][co (+ pad)]
+    float* dst = smem + (size_t)strip * ROWS * LROW + (size_t)(wi * 16 * CIW + 4 * kq) * LROW + wj * 16 * COW + lm;
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int i = 0; i < CIW; ++i)
 #pragma unroll
-        for (int j = 0; j < COW; ++j) {
-          float* o = out + ((size_t)tap * Cin + ci0 + 16 * i + 4 * kq) * Cout + co0 + 16 * j + lm;
+        for (int j = 0; j < COW; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[(size_t)r * Cout] = acc[(tap * CIW + i) * COW + j][r];
-        }
+          for (int r = 0; r < 4; ++r)
+            dst[(size_t)(tap * CIG + 16 * i + r) * LROW + 16 * j] = acc[(tap * CIW + i) * COW + j][r];
     if constexpr (SC) {
 #pragma unroll
       for (int i = 0; i < CIW; ++i)
 #pragma unroll
-        for (int j = 0; j < COW; ++j) {
-          float* o = out + ((size_t)9 * Cin + ci0 + 16 * i + 4 * kq) * Cout + co0 + 16 * j + lm;
+        for (int j = 0; j < COW; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[(size_t)r * Cout] = acs[i * COW + j][r];
-        }
+          for (int r = 0; r < 4; ++r) dst[(size_t)(9 * CIG + 16 * i + r) * LROW + 16 * j] = acs[i * COW + j][r];
+    }
+  }
+  __syncthreads();
+  {
+    float* out = a.part + (size_t)blockIdx.x * (SC ? 10 : 9) * Cin * Cout + (size_t)(blockIdx.y * CIG) * Cout + blockIdx.z * COG;
+    constexpr int Q = COG / 4;                                    // 16-byte units per slab row
+#pragma unroll
+    for (int f0 = 0; f0 < ROWS * Q; f0 += TPB) {
+      const int f = f0 + threadIdx.x;
+      if (ROWS * Q % TPB == 0 || f < ROWS * Q) {
+        const int row = f / Q, q = f % Q;
+        f32x4 v = *(const f32x4*)(smem + (size_t)row * LROW + 4 * q);
+        if constexpr (P == 2) v += *(const f32x4*)(smem + (size_t)(ROWS + row) * LROW + 4 * q);
+        const int tap = row / CIG, cil = row % CIG;
+        *(f32x4*)(out + ((size_t)tap * Cin + cil) * Cout + 4 * q) = v;
+      }
     }
   }
 }
@@ -304,11 +368,10 @@ RrPlan plan_rr(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, 
   else if (Cin % 32 == 0 && Cout % 32 == 0) {
     p.variant = v32; p.slab_ci = 32; p.slab_co = 32; p.ws = v32 == 4 ? 4 : (v32 == 5 ? 1 : 2);
   } else return p;
-  if (sc && p.variant != 4 && p.variant != 5 && p.variant != 6) return RrPlan{};   // fused shortcut: the 32 x 32 slabs (as before)
   if (aff && x2) return RrPlan{};
-  p.R = (p.variant == 4) ? 4 : 8;
+  p.R = (p.variant == 4 && !RR_V4R8) ? 4 : 8;
   if (H % p.R) {
-    if (p.variant == 4 || H % 4) return RrPlan{};
+    if (H % 4) return RrPlan{};
     p.R = 4;
   }
   const int slabs = (Cin / p.slab_ci) * (Cout / p.slab_co);
@@ -341,7 +404,10 @@ template <int CIW, int COW, int WI, int WJ, int R, int D>
 int launch_v(const RrArgs& a, const RrPlan& p, hipStream_t st) {
   constexpr int WS = 4 / (WI * WJ);
   const bool sc = a.gs != nullptr, aff = a.aff.mean != nullptr, dual = a.x2 != nullptr;
-  const size_t sh = WS > 1 ? (size_t)(WS / 2) * WI * WJ * (9 + (sc ? 1 : 0)) * CIW * COW * 256 * sizeof(float) : 0;
+  constexpr int NTA_ = (9 + 1) * CIW * COW;                       // (with the shortcut's tiles: an upper bound without)
+  constexpr size_t sh1 = WS == 4 ? (size_t)2 * WI * WJ * NTA_ * 256 * sizeof(float) : 0;
+  constexpr size_t sh2 = (size_t)(WS >= 2 ? 2 : 1) * 10 * (16 * CIW * WI) * (16 * COW * WJ + 4) * sizeof(float);
+  const size_t sh = sh1 > sh2 ? sh1 : sh2;
   dim3 grid(p.splits, a.Cin / p.slab_ci, a.Cout / p.slab_co);
 #define RR_GO(DUAL, INAFF, SC)                                                                                          \
   do {                                                                                                                  \
@@ -358,6 +424,11 @@ int launch_v(const RrArgs& a, const RrPlan& p, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef SMSUT_STAMPS
+static unsigned long long* g_rr_dbg = nullptr;
+extern "C" void smsut_dbg_rr_stamps(unsigned long long* p) { g_rr_dbg = p; }
+#endif
 
 bool smsut_wgrad_rr_eligible(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, bool aff, bool sc) {
   return plan_rr(N, H, W, Cin, Cout, x2, ca, aff, sc).variant != 0;
@@ -376,11 +447,19 @@ int smsut_wgrad_rr_launch(const float* x, const float* x2, int ca, const float* 
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.RC = p.RC; a.groups_per_split = p.groups_per_split; a.total_wu = p.total_wu;
   if (aff) a.aff = *aff;
+#ifdef SMSUT_STAMPS
+  a.dbg = g_rr_dbg;
+#endif
   switch (p.variant) {
     case 1: return p.R == 8 ? launch_v<1, 1, 1, 1, 8, 3>(a, p, st) : launch_v<1, 1, 1, 1, 4, 1>(a, p, st);
     case 2: return p.R == 8 ? launch_v<2, 1, 1, 1, 8, 3>(a, p, st) : launch_v<2, 1, 1, 1, 4, 1>(a, p, st);
     case 3: return p.R == 8 ? launch_v<1, 2, 1, 1, 8, 3>(a, p, st) : launch_v<1, 2, 1, 1, 4, 1>(a, p, st);
+#if RR_V4R8
+    case 4: return p.R == 8 ? (gs ? launch_v<2, 2, 1, 1, 8, 2>(a, p, st) : launch_v<2, 2, 1, 1, 8, 3>(a, p, st))
+                            : launch_v<2, 2, 1, 1, 4, 1>(a, p, st);
+#else
     case 4: return launch_v<2, 2, 1, 1, 4, 1>(a, p, st);
+#endif
     case 5: return p.R == 8 ? launch_v<1, 1, 2, 2, 8, 3>(a, p, st) : launch_v<1, 1, 2, 2, 4, 1>(a, p, st);
     case 6: return p.R == 8 ? launch_v<2, 1, 1, 2, 8, 3>(a, p, st) : launch_v<2, 1, 1, 2, 4, 1>(a, p, st);
   }

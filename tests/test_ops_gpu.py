@@ -636,7 +636,9 @@ def test_fused_shortcut_data_gradient(ops, n, h, co, ci, split):
 
 @pytest.mark.parametrize("n,h,ci,co,cat", [(16, 64, 32, 64, 0), (16, 64, 64, 32, 1), (8, 32, 128, 64, 1), (6, 32, 64, 128, 0),
                                           (3, 128, 64, 32, 1), (5, 16, 256, 128, 1),
-                                          (4, 256, 8, 16, 0), (8, 128, 8, 16, 0), (2, 40, 8, 16, 0)])      # 8-channel (tap-pair) form
+                                          (4, 256, 8, 16, 0), (8, 128, 8, 16, 0), (2, 40, 8, 16, 0),      # 8-channel (tap-pair) form
+                                          (5, 256, 32, 16, 1), (3, 128, 16, 32, 0), (2, 64, 32, 16, 0),   # r04: 16-channel slabs
+                                          (16, 32, 16, 16, 0)])                                           # (register-row kernel)
 def test_fused_shortcut_weight_gradient(ops, n, h, ci, co, cat):
     """conv1's 3x3 weight gradient and the 1x1 shortcut's in one pass (both convs read x, reference network/blocks.py:66-80):
     rows 0..8 of the result are bit-identical to the plain entry point (same kernel, same order), row 9 matches the
@@ -644,7 +646,7 @@ def test_fused_shortcut_weight_gradient(ops, n, h, ci, co, cat):
     from smsut_amd import _hip as H
     st = H.stream_ptr()
     assert H.call("smsut_conv2d_wgrad_sc_supported", n, h, h, ci, co) == 1
-    assert H.call("smsut_conv2d_wgrad_sc_supported", n, h, h, 16, co) == 0          # 16-channel slabs keep the two-kernel form
+    # (r04: the 16-channel slabs are fused too -- the register-row kernel, csrc/conv_wgrad_rr.hip, carries the extra tile)
     g = torch.Generator(device="cpu").manual_seed(3)
     x = torch.randn(n, h, h, ci, generator=g).cuda(); gy = torch.randn(n, h, h, co, generator=g).cuda(); gs = torch.randn(n, h, h, co, generator=g).cuda()
     hw = h * h
