@@ -357,8 +357,9 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel leg (the command the rocprofv3 stats / PMC passes profile)")
     ap.add_argument("--d-overlap", choices=("default", "0", "1", "2"), default="default",
-                    help="D-step on a side stream beside the cycle pass (SMSUT_D_OVERLAP): default = on at one GPU, off under "
-                         "data parallelism; an 8-GPU run can A/B it with --d-overlap 1")
+                    help="D-step schedule (SMSUT_D_OVERLAP): 1 = D-step incl. its all-reduce on a side stream (default at one GPU), "
+                         "2 = only the captured D-step compute on the side stream, every collective on the main stream (default "
+                         "under data parallelism), 0 = one stream; an 8-GPU run can A/B with --d-overlap 0 / 1")
     args = ap.parse_args()
     if args.d_overlap != "default":
         os.environ["SMSUT_D_OVERLAP"] = args.d_overlap

@@ -47,7 +47,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # variant would issue collectives from two streams; it has only ever run at one rank over RCCL and with two gloo ranks, so
         # it stays an A/B switch (``bench.py --d-overlap 1``).  The data-parallel default is 2 (below): the side stream carries
         # captured COMPUTE only and every collective stays on the main stream.  0: everything on one stream.
-        ov = os.environ.get("SMSUT_D_OVERLAP", "1" if self.world == 1 else "2")
+        ov = os.environ.get("SMSUT_D_OVERLAP", "") or ("1" if self.world == 1 else "2")
+        if ov not in ("0", "1", "2"):        # ('true' / '3' used to select the one-stream schedule silently)
+            raise ValueError(f"SMSUT_D_OVERLAP must be 0, 1 or 2 (got {ov!r})")
         self._d_overlap = ov == "1"
         # SMSUT_D_OVERLAP=2 -- "compute-only side stream": only the captured D-step (collective-free) runs on the side stream,
         # beside G2gen AND G2a; it is JOINED before its gradient all-reduce, so every collective (statistics, D gradients, G
@@ -346,7 +348,10 @@ class UGANConsisTrainer(UGANShp0Trainer):
             for p in params:
                 p.grad = None
             return fn(*inputs)
-        key = (name, self._semi_on) + tuple(tuple(t.shape) for t in inputs)
+        # (the split G-step phases take their operands through hidden state -- self._g1 / _g2 / _gx_d -- so the
+        #  shapes of the explicit inputs do not identify the batch; the iteration's geometry is part of every key, else a
+        #  second batch / image size on the same trainer would replay G2a1 / G2a2 / G2d / G2c against the OLD pools)
+        key = (name, self._semi_on, self._geom) + tuple(tuple(t.shape) for t in inputs)
         g = self._graphs.get(key)
         if g is None:
             # A refused capture raises (r01 swallowed it and ran eagerly forever: after a partial capture p.grad points
@@ -368,6 +373,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
     def train_iteration(self, x_real, y_real, modal_org, mj=None, alpha=None, sample_ids=None):
         """One iteration; returns a float32 device tensor with the 10 scalars in ``SCALARS`` order."""
         lambda_semi = self.lambda_semi * self.sigmoid_rampup(self.epoch, cfg.max_epoch)       # :74
+        self._geom = (tuple(x_real.shape), tuple(y_real.shape))
         if mj is None:
             mj = random.randint(0, cfg.n_modal - 1)                                           # :114
         # modality ids go to the device through a pinned staging buffer (a pageable .to(device) would make the host

@@ -109,13 +109,53 @@ def _worker(rank, world, port, q, backend="gloo"):
                                  sample_ids=[ids.to(dev)])
         logs, _ = O.ugan_consis_iteration(gsd, dsd, g_opt, d_opt, x4, y2, modal, mj, alpha, [ids], it=15000 + it, epoch=100,
                                           nce_batch=2, base_lr=0.0)
-        ggrad = {k: _l2rel(p.grad, gsd[k].grad * 1.0) for k, p in ut.net.named_parameters()
-                 if k.startswith("seg_decoder") and gsd[k].grad is not None}
-        ugan.append((dict(zip(SCALARS, got.tolist())), logs, max(ggrad.values())))
+        # fp64 pass of the oracle on the same global batch: the yardstick for the gradients, and -- through |fp32 - fp64| of the
+        # oracle itself -- the reference arithmetic's own rounding sensitivity on THESE inputs (the trace_bands method)
+        g64 = {k: v.detach().clone().double().requires_grad_(True) for k, v in g_w.items()}
+        d64 = {k: v.detach().clone().double().requires_grad_(True) for k, v in d_w.items()}
+        O.ugan_consis_iteration(g64, d64, torch.optim.SGD(list(g64.values()), lr=0.0), torch.optim.Adam(list(d64.values()), 0.0),
+                                x4.double(), y2, modal, mj, alpha.double(), [ids], it=15000 + it, epoch=100, nce_batch=2, base_lr=0.0)
+        seg = [k for k, _ in ut.net.named_parameters() if k.startswith("seg_decoder") and g64[k].grad is not None]
+        e_hip = {k: _l2rel(dict(ut.net.named_parameters())[k].grad, g64[k].grad) for k in seg}
+        e_ref = {k: _l2rel(gsd[k].grad, g64[k].grad) for k in seg}
+        ugan.append((dict(zip(SCALARS, got.tolist())), logs,
+                     (float(np.median(list(e_hip.values()))), float(np.median(list(e_ref.values()))), max(e_hip.values()), max(e_ref.values()),
+                      e_hip["seg_decoder.fc.weight"])))
     res["ugan"] = ugan
     res["ugan_graph"] = ut.graph_report()
     res["ugan_overlap_default"] = ut._d_overlap
     res["ugan_side_compute"] = ut._d_side_compute
+
+    # ---- 3b. (VERDICT r03 #8 / ADVICE r03) the DEFAULT data-parallel schedule -- captured D-step on the side stream, G-step in four
+    #          pieces (mode 2) -- with BOTH optimizers stepping: (i) after four iterations every rank holds bit-identical weights,
+    #          (ii) they equal the one-stream schedule's (SMSUT_D_OVERLAP=0) to fp32 summation order (a shared parameter's gradient
+    #          is accumulated over the pieces in another order; bit equality is not expected)
+    finals = {}
+    for ov in (None, "0"):
+        if ov is None:
+            os.environ.pop("SMSUT_D_OVERLAP", None)
+        else:
+            os.environ["SMSUT_D_OVERLAP"] = ov
+        t3 = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+        if ov is None:
+            assert t3._d_side_compute and t3._g_split and not t3._d_overlap          # this IS the default under world > 1
+        t3.net.load_state_dict(g_w); t3.D.load_state_dict(d_w); t3.net.train(); t3.D.train()
+        t3.epoch, t3.iter = 100, 15000
+        for it in range(4):                                   # eager, capture, two replays; all-reduces + Adam / SGD in between
+            x4, y2, _, mj, alpha, ids = recipe.trace_inputs(it, b=4, size=64, base=900)
+            modal = torch.tensor([1, 1, 3, 3])
+            sel = [rank, 2 + rank]
+            t3.train_iteration(x4[sel].to(dev), y2[rank:rank + 1].to(dev), modal[sel], mj=mj, alpha=alpha[sel].to(dev),
+                               sample_ids=[ids.to(dev)])
+        torch.cuda.synchronize()
+        finals[ov] = torch.cat([p.detach().reshape(-1).float() for p in list(t3.net.parameters()) + list(t3.D.parameters())])
+    os.environ.pop("SMSUT_D_OVERLAP", None)
+    mine = finals[None].clone()
+    other = mine.clone()
+    dist.broadcast(other, src=0)
+    res["default_ranks_in_sync"] = bool(torch.equal(mine, other))
+    res["default_vs_one_stream"] = float((finals[None] - finals["0"]).norm() / finals["0"].norm())
+    res["default_finite"] = bool(torch.isfinite(mine).all())
 
     # ---- 4. (RCCL only) the D-step on the side stream == the one-stream default, with both optimizers stepping
     if backend == "nccl":
@@ -215,10 +255,26 @@ def _two_ranks(backend, overlap=False):
             # from the 2 + 2 single-process ones, so G_nce is not comparable; D_gp / WGAN terms are per-sample means
             for k in ("G_seg", "G_semi"):                   # global-batch Dice statistics: identical on every rank
                 assert abs(got[k] - logs[k]) < 1e-3 * abs(logs[k]), (k, got[k], logs[k])
-            # (worst seg_decoder parameter over four iterations; the reference's own fp32-vs-fp64 worst is 1.5e-2 -- DESIGN section 5 --
-            #  and 1 + 1 slices of 64x64 per rank is the noisiest case there is: 2.46e-2 with the r03 Winograd kernels, 1.9e-2 before)
-            assert gerr < 3e-2, gerr
+            # seg_decoder gradients against the fp64 pass (profiles/r04_winograd_evidence.md, tests/test_winograd_evidence_gpu.py):
+            #  * the LAST layer's weight gradient sits in front of every discrete decision of the backward pass: fp32 rounding only;
+            #  * WORST tensor: one discrete event (a LeakyReLU sign / MaxPool argmax decided differently at one layer) offsets every
+            #    layer upstream of it by 1-2.5e-2 -- the direct kernels have one at iteration 1 (1.46e-2 from dec3 on), the Winograd
+            #    forms one at iteration 0 (2.45e-2 from dec2 on), the reference's own fp32 has them too (1.27e-1 on
+            #    tsl_decoder.fc.bias): bounded by 3e-2, the r02 bar of 2e-2 was one build's luck, not a property of the direct form;
+            #  * MEDIAN over the tensors (checked below over the four iterations: an event near the head of the decoder moves most of
+            #    its tensors, so it is a per-iteration statement only where no event fell).
+            med_hip, med_ref, worst_hip, worst_ref, fc_hip = gerr
+            assert fc_hip < 5e-6, gerr
+            assert worst_hip < 3e-2, gerr
+        # event-free iterations (at least half of the four; measured: 3 of 4 for either form): the median seg_decoder error is within
+        # 1.5x of the reference arithmetic's own fp32-vs-fp64 median on the same inputs (+ 1e-3)
+        calm = [g for _, _, g in res["ugan"] if g[0] <= 1.5 * g[1] + 1e-3]
+        assert len(calm) >= 2, [g for _, _, g in res["ugan"]]
         assert res["ugan_graph"]["mode"].startswith("graph"), res["ugan_graph"]
+        assert res["default_finite"] and res["default_ranks_in_sync"], res.get("default_vs_one_stream")   # default schedule: ranks bit-identical
+        # (Adam's first steps move every D weight by +-lr whatever the gradient's size: a 1e-7 difference in summation order is
+        #  amplified through D within four iterations -- the bound is on the order of the trajectory's own chaos, not 1e-5)
+        assert res["default_vs_one_stream"] < 5e-2, res["default_vs_one_stream"]
         assert res["ugan_overlap_default"] is overlap           # collectives from ONE stream under data parallelism by default ...
         assert res["ugan_side_compute"] is (not overlap)        # ... the side stream carries the captured D-step only
         want, got, pos = res["resume"]
