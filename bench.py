@@ -11,8 +11,11 @@ config 3); N>1 is pure data parallel, one process per GPU, flat RCCL all-reduce 
 ``--workload unet`` times BASELINE config 2 instead (U-Net fwd + DiceCE + bwd + SGD, 32x1x256x256, 5 classes).
 
 Rank 0 prints ONE JSON line.  ``roofline`` is measured live with HIP events on the launch stream around the
-dominant kernel (the 3x3 conv at the layer shape that carries most FLOPs); ``cpu_baseline`` times the CPU oracle
-(``oracle/``, kind "port") on a bounded sample of the same workload on this host's cores (rank 0, N=1 only).
+dominant kernel -- the device kernel with the largest total time in the committed rocprofv3 summary of the iteration
+(profiles/r04_ugan_kernel_stats.csv: the register-row 3x3 weight gradient, input-side-IN form), launched through the
+entry point and with the arguments ops.py uses; ``roofline_fwd`` is the Winograd forward conv of r03's line, in the form
+the step launches it; ``cpu_baseline`` times the CPU oracle (``oracle/``, kind "port") on a bounded sample of the same
+workload on this host's cores (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -33,7 +36,7 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0
 EXECUTED_GFLOP_PER_SLICE_UGAN = 1475.4 / 16     # conv FLOPs one uganConsis iteration of THIS build executes (census, 8 + 8 slices)
 REFERENCE_GFLOP_PER_SLICE_UGAN = 1710.0 / 16    # the reference's iteration: G(x_real) twice
-PMC_FILE = "r03_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
+PMC_FILE = "r04_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
 
 
 def host_cores():
@@ -54,7 +57,7 @@ def conv_flops(n, h, w, cin, cout, k):
 
 
 def pmc_traffic_per_slice():
-    """HBM bytes per slice of the dominant kernel from the committed PMC passes (profiles/r02_pmc_dominant.json:
+    """HBM bytes per slice of the dominant kernel from the committed PMC passes (profiles/<PMC_FILE>:
     FETCH_SIZE and WRITE_SIZE collected in two separate ``rocprofv3 --pmc`` runs of ``bench.py --roofline-only``,
     FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md section HBM).  Counters cannot be read from
     inside the process, so the live line carries the profiled per-slice figure scaled to this run's batch; the
@@ -66,13 +69,78 @@ def pmc_traffic_per_slice():
         return None
 
 
+def _events(st, launch, reps=20, warm=3):
+    for _ in range(warm):
+        launch()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        launch()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def dominant_wgrad_call(batch, size=256):
+    """(entry point, integer / float arguments) of the roofline leg's call as ``profiling.record_step`` keys it."""
+    h = size // 2
+    return "smsut_conv2d_wgrad_mfma_inaff", (0.01, batch, h, h, 32, 32)
+
+
+def measure_dominant_wgrad(dev, batch, size=256):
+    """HIP-event timing of the kernel that carries the most time of the iteration (committed profile: profiles/r04_summary.md):
+    the register-row 3x3 weight gradient ``wgrad_rr<2,2,1,1,4,1,false,true,false>`` (csrc/conv_wgrad_rr.hip), i.e. conv2's weight
+    gradient of a BasicBlock (reference network/blocks.py:70-72 backward) with the input-side InstanceNorm + LeakyReLU form: x is
+    the RAW conv1 output y1, normalised while the operands are loaded.  Launched exactly as the step launches it
+    (ops.py BasicBlockFn.backward: ``smsut_conv2d_wgrad_mfma_inaff(y1, gy2, gw2, ws, mean, rstd, gamma, beta, slope, N, H, W, C, C)``) at
+    the level-2 shape N x (size/2)^2 x 32 -> 32; that call is two launches (the kernel + the 5-us split-slab reduction), so the
+    kernel ALONE is also timed through ``smsut_conv2d_wgrad_mfma_slabs`` (same kernel, same arguments, no reduction): that is the
+    duration rocprofv3 lists and the one ``achieved`` is computed from.  Direct products: algorithmic FLOPs = executed FLOPs."""
+    from smsut_amd import ops, _hip as H
+    name, (slope, n, h, w, ci, co) = dominant_wgrad_call(batch, size)
+    cl = torch.channels_last
+    y1 = torch.randn(n, ci, h, w, device=dev).contiguous(memory_format=cl)
+    gy2 = torch.randn(n, co, h, w, device=dev).contiguous(memory_format=cl)
+    gw2 = ops.new_weight(co, ci, 3, 3, device=dev)
+    ws = torch.empty(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), device=dev)
+    mean, rstd = torch.randn(n, ci, device=dev) * 0.3, torch.rand(n, ci, device=dev) + 0.5
+    gamma, beta = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.2
+    st = torch.cuda.current_stream()
+    slabs = H.call("smsut_conv2d_wgrad_mfma_slabs", y1, gy2, ws, mean, rstd, gamma, beta, slope, n, h, w, ci, co, st.cuda_stream)
+    assert slabs > 0, "register-row weight gradient not available for the roofline shape"
+    call_ms = _events(st, lambda: H.call(name, y1, gy2, gw2, ws, mean, rstd, gamma, beta, slope, n, h, w, ci, co, st.cuda_stream))
+    ms = _events(st, lambda: H.call("smsut_conv2d_wgrad_mfma_slabs", y1, gy2, ws, mean, rstd, gamma, beta, slope, n, h, w, ci, co,
+                                    st.cuda_stream))
+    fl = conv_flops(n, h, w, ci, co, 3)
+    achieved = fl / (ms * 1e-3) / 1e12
+    byts = 4.0 * n * h * w * (ci + co) + 4.0 * slabs * 9 * ci * co       # both operands read once + the split slabs written
+    per_slice = pmc_traffic_per_slice() if size == 256 else None
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "achieved_note": "algorithmic = executed FLOPs (direct products, 2 N H W Cin Cout 9) / the kernel's own launch time",
+            "traffic": None if per_slice is None else round(per_slice * batch),
+            "traffic_unit": f"HBM bytes per launch (PMC, profiles/{PMC_FILE})",
+            "traffic_source": "PROFILED, not live: FETCH_SIZE x2 + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes "
+                              "(counters cannot be read in-process), per slice, scaled to this run's batch",
+            "kernel": "wgrad_rr<2,2,1,1,4,1,false,true,false> (csrc/conv_wgrad_rr.hip) via smsut_conv2d_wgrad_mfma_inaff",
+            "kernel_match": "wgrad_rr<2, 2, 1, 1, 4, 1, false, true, false>",
+            "kernel_kind": "mfma", "selected_by": "largest total time per device kernel in the committed rocprofv3 summary of the iteration",
+            "entry_point": name, "entry_args": [slope, n, h, w, ci, co],
+            "shape": f"N{n} {h}x{w} 32->32 k3 weight gradient, x = lrelu(IN(raw conv1 output)) applied while loading, {slabs} split slabs",
+            "avg_launch_ms": round(ms, 4), "call_ms_with_reduction": round(call_ms, 4),
+            "algorithmic_gflop_per_launch": round(fl / 1e9, 3), "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
+            "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
+
+
 def measure_dominant_conv(dev, batch, size=256, f16=False):
-    """HIP-event timing of the dominant kernel AS THE STEP LAUNCHES IT: conv3x3 s1 p1 of the decoder-level-1 block
-    (blocks.py dec layer1.conv1: cat([up, skip]) [B,16+16,256,256] -> 16 ch), i.e. the persistent resident-weight kernel
-    with the InstanceNorm-statistics epilogue and the virtual-cat input (``smsut_conv2d_fwd_mfma_stats_cat``); since r03 its
-    fp32 form is Winograd F(2x2,3x3) (``conv_mfma_fwd_p<3,16,1,2,STATS,..,DUAL,..,WINO>``: 16 products per 2x2 output tile
-    instead of 36).  ``achieved`` is ALGORITHMIC FLOPs (2 N H W Cin Cout 9, SURVEY 8d) / launch time, as the contract defines it;
-    ``executed_mfma_*`` is what the matrix pipes actually did (algorithmic / 2.25).  Returns the roofline dict."""
+    """HIP-event timing of the forward 3x3 conv of the decoder-level-1 block AS THE STEP LAUNCHES IT (blocks.py dec layer1:
+    cat([up, skip]) [B,16+16,256,256] -> 16 ch, conv1 + the block's 1x1 shortcut): the persistent resident-weight kernel with the
+    InstanceNorm-statistics epilogue, the virtual-cat input and -- fp32 -- the FUSED SHORTCUT (``smsut_conv2d_fwd_mfma_stats_sc``,
+    ops.py BasicBlockFn.forward; r03's line timed the ``_stats_cat`` form, which the fp32 step has not launched since the shortcut
+    fusion); fp16 operands (config 5) keep ``_stats_cat_f16``, which that mode does launch.  Since r03 the fp32 form is Winograd
+    F(2x2,3x3) (16 products per 2x2 output tile instead of 36; the fused 1x1 runs on the raw pixels).  ``achieved`` is ALGORITHMIC FLOPs
+    (2 N H W Cin Cout (9 + 1)) / launch time; ``executed_mfma_*`` is what the matrix pipes did.  Returns the roofline dict."""
     from smsut_amd import ops, _hip as H
     cin, cout, h = 32, 16, size
     cl = torch.channels_last
@@ -86,24 +154,23 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
     assert H.call("smsut_conv2d_mfma_cat_supported", batch, h, h, cin, cout), "virtual-cat form not available for this shape"
     st = torch.cuda.current_stream()
 
+    sc = not f16 and bool(H.call("smsut_conv2d_fwd_sc_supported", batch, h, h, cin, cout, 1))
+    if sc:
+        wsc = ops.new_weight(cout, cin, 1, 1, device=dev)
+        wsc.copy_(torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5)
+        s_out = ops.new_act(batch, cout, h, h, xa)
+        part_s = torch.empty_like(part)
+
     def launch():
-        H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16 else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y, part, batch, h, h,
-               cin, cout, st.cuda_stream)
-    for _ in range(3):
-        launch()
-    torch.cuda.synchronize()
-    reps = 20
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(reps):
-        launch()
-    e1.record(st)
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    fl = conv_flops(batch, h, h, cin, cout, 3)
+        if sc:
+            H.call("smsut_conv2d_fwd_mfma_stats_sc", xa, xb, w, wsc, y, s_out, part, part_s, batch, h, h, cin, cout, st.cuda_stream)
+        else:
+            H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16 else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y, part, batch, h, h,
+                   cin, cout, st.cuda_stream)
+    ms = _events(st, launch)
+    fl = conv_flops(batch, h, h, cin, cout, 3) * (10.0 / 9.0 if sc else 1.0)
     achieved = fl / (ms * 1e-3) / 1e12
-    byts = 4.0 * batch * h * h * (cin + cout)
-    per_slice = pmc_traffic_per_slice() if (size == 256 and not f16) else None
+    byts = 4.0 * batch * h * h * (cin + cout * (2 if sc else 1))
     if f16:
         # fp16 operands: 36 FLOP/B against a ridge of 2500 / 8 ~ 310 FLOP/B -> the kernel is HBM-bound
         gbs = byts / (ms * 1e-3) / 1e9
@@ -114,28 +181,27 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
                 "algorithmic_gbytes_per_launch": round(byts / 1e9, 4), "tflops": round(achieved, 2),
                 "frac_of_fp16_mfma_peak": round(achieved / FP16_MFMA_PEAK_TFLOPS, 4),
                 "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4)}
-    wino = os.environ.get("SMSUT_WINOGRAD", "1") not in ("0", "") and size % 16 == 0
-    kname = ("conv_mfma_fwd_p<3,16,1,2,STATS,DUAL,WINO> (Winograd F(2x2,3x3))" if wino else "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL>") + \
-        " via smsut_conv2d_fwd_mfma_stats_cat"
-    executed = achieved / 2.25 if wino else achieved
+    form = H.call("smsut_conv2d_mfma_form", batch, h, h, cin, cout, 0)
+    wino = form != 0
+    kname = ("conv_mfma_fwd_p<3,16,1,2,STATS,DUAL,SC,WINO> (Winograd F(2x2,3x3) + fused 1x1 shortcut)" if wino else
+             "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,SC>") + " via smsut_conv2d_fwd_mfma_stats_sc"
+    executed = achieved * (0.5 if sc else 16.0 / 36.0) if wino else achieved
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "achieved_note": "algorithmic conv FLOPs / launch time; the Winograd form executes 1/2.25 of them on the matrix pipes" if wino
-                             else "algorithmic = executed FLOPs (direct form)",
+            "achieved_note": "algorithmic conv FLOPs / launch time; the Winograd form executes 16 of 36 products per 3x3 tap set (20 of 40 "
+                             "with the fused 1x1) on the matrix pipes" if wino else "algorithmic = executed FLOPs (direct form)",
             "executed_mfma_tflops": round(executed, 3), "executed_mfma_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None if per_slice is None else round(per_slice * batch),
-            "traffic_unit": f"HBM bytes per launch (PMC, profiles/{PMC_FILE})",
-            "traffic_source": "PROFILED, not live: FETCH_SIZE x2 + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes "
-                              "(counters cannot be read in-process), per slice, scaled to this run's batch",
-            "kernel": kname, "kernel_kind": "mfma",
-            "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
+            "traffic": None, "kernel": kname, "kernel_kind": "mfma", "entry_point": "smsut_conv2d_fwd_mfma_stats_sc",
+            "entry_args": [batch, h, h, cin, cout],
+            "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3 + 1x1 shortcut, IN-statistics epilogues, virtual cat",
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
             "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
 
 
-def measure_step_conv(step, label):
-    """Per-shape replay profile of ONE eager step (smsut_amd.profiling): conv FLOPs / conv kernel time over the step."""
+def measure_step_conv(step, label, find=None):
+    """Per-shape replay profile of ONE eager step (smsut_amd.profiling): conv FLOPs / conv kernel time over the step.
+    ``find``: {tag: (entry point, integer / float arguments)} -- reported under ``has_call`` (is that call part of the step?)."""
     from smsut_amd import profiling
     prev = os.environ.get("SMSUT_GRAPH")
     os.environ["SMSUT_GRAPH"] = "0"                      # record an eager pass (same kernels, same shapes)
@@ -151,6 +217,10 @@ def measure_step_conv(step, label):
     rows = profiling.replay(rec)
     out = profiling.summarize(rows, FP32_MFMA_PEAK_TFLOPS)
     out["calls"] = len(rec)
+    if find:
+        keys = {(r.name, tuple(round(a, 6) if isinstance(a, float) else a for a in r.args)) for r in rows}
+        out["has_call"] = {tag: (name, tuple(round(a, 6) if isinstance(a, float) else a for a in args)) in keys
+                           for tag, (name, args) in find.items()}
     log(f"{label}: per-shape replay of one step ({len(rec)} C-ABI calls)\n" + profiling.table(rows, 0.012))
     if os.environ.get("SMSUT_PROFILE_DUMP"):             # full per-shape table, sorted by time above the roofline
         with open(f"{os.environ['SMSUT_PROFILE_DUMP']}_{label}.txt", "w") as f:
@@ -381,7 +451,11 @@ def main():
     random.seed(cfg.seed + rank)                       # target-modality draws (uganConsisTrainer.py:114)
     if args.roofline_only:
         B = args.per_gpu_batch or (16 if args.workload == "ugan" else 32)
-        print(json.dumps({"roofline": measure_dominant_conv(dev, B, args.size, args.dtype == "f16")}))
+        if args.dtype == "f16":
+            print(json.dumps({"roofline": measure_dominant_conv(dev, B, args.size, True)}))
+        else:
+            print(json.dumps({"roofline": measure_dominant_wgrad(dev, B, args.size),
+                              "roofline_fwd": measure_dominant_conv(dev, B, args.size, False)}))
         return
     ns = types.SimpleNamespace(fold=0, expr_name=None, write_env=False)
 
@@ -451,6 +525,32 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # ---- end to end ("report both"): the same iteration WITH the host reading its scalars back every step, as the
+    # reference's loop does (11 .item() syncs per iteration, trainer/uganConsisTrainer.py:148-149,157,183-188; here ONE 40-byte
+    # fetch of the ten scalars the iteration returns, trainer/uganConsisTrainer.py train_epoch) -- the host cannot run ahead of the
+    # device.  A second timed loop over the same resident batches (cyclically), every rank takes part (collectives).
+    e2e_steps = min(args.steps, 20)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for i in range(e2e_steps):
+        b = batches[(args.warmup + i) % len(batches)]
+        r = tr.train_iteration(*b) if args.workload == "ugan" else tr.train_step(*b)
+        r.reshape(-1).tolist()                               # device -> host fetch + sync, every iteration
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_e2e = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([dt_e2e], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_e2e = float(t.item())
+    dist_info = {"initialized": bool(dist.is_available() and dist.is_initialized())}
+    if dist_info["initialized"]:
+        dist_info.update(backend=dist.get_backend(), world_size=dist.get_world_size(), rank=dist.get_rank())
+    else:
+        dist_info.update(backend=None, world_size=1, rank=0)
     if rank != 0:
         dist.barrier()                      # leave together with rank 0 (which still measures the roofline leg)
         dist.destroy_process_group()
@@ -463,7 +563,14 @@ def main():
            "data": "synthetic",
            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
                       "parallelism": f"dp{world}", "weights": "random init (reference initialisers)"},
-           "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])]}
+           "last_step_scalars": [round(float(v), 5) for v in (last.reshape(-1).tolist() if last is not None else [])],
+           "end_to_end_ms_per_step": round(dt_e2e / e2e_steps * 1e3, 3),
+           "end_to_end": {"steps": e2e_steps, "ms_per_step": round(dt_e2e / e2e_steps * 1e3, 3),
+                          "slices_per_s": round(B * world * e2e_steps / dt_e2e, 3),
+                          "what": "the timed iteration plus a device -> host fetch of its scalars every step (the reference reads 11 "
+                                  ".item() values per iteration, uganConsisTrainer.py:148-149,157,183-188); ms_per_step above syncs once, "
+                                  "after the last step"},
+           "dist": dist_info}
     log(f"timed region done: {ms:.2f} ms/step")
     out["graph"] = tr.graph_report()
     # converting copies ops.nhwc()/hwio() had to make inside the timed region (0 = every tensor arrived in the kernels' layout;
@@ -488,9 +595,11 @@ def main():
     scale = (args.size / 256.0) ** 2
     gflop_slice = (19.61 if args.workload == "unet" else EXECUTED_GFLOP_PER_SLICE_UGAN) * scale
     tf = value / world * gflop_slice / 1e3
-    out["whole_step"] = {"executed_gflop_per_slice": round(gflop_slice, 3), "achieved_tflops_per_gpu": round(tf, 2),
+    out["whole_step"] = {"algorithmic_gflop_per_slice": round(gflop_slice, 3), "achieved_tflops_per_gpu": round(tf, 2),
                          "frac_of_fp32_mfma_peak": round(tf / FP32_MFMA_PEAK_TFLOPS, 4), "peak_tflops": FP32_MFMA_PEAK_TFLOPS,
-                         "flops_source": "constant (census of r02)"}
+                         "flops_source": "constant (census of r02)",
+                         "note": "algorithmic conv FLOPs of the convolutions this build runs (2 N H W Cin Cout k^2 per pass); the Winograd "
+                                 "forms execute fewer products: mfma_executed_* below"}
     if args.workload != "unet":
         ref_tf = value / world * REFERENCE_GFLOP_PER_SLICE_UGAN * scale / 1e3
         out["whole_step"]["reference_equivalent"] = {
@@ -502,17 +611,28 @@ def main():
         out["whole_step"]["note_f16"] = ("fp16-operand convolutions are HBM-bound (the fp16 dense MFMA peak is 16x the fp32 one): "
                                          "the fp32-MFMA fraction above is a common yardstick with the f32 run, not this path's roofline")
     if not args.no_roofline:
-        out["roofline"] = measure_dominant_conv(dev, B, args.size, args.dtype == "f16")
+        if args.dtype == "f16":
+            out["roofline"] = measure_dominant_conv(dev, B, args.size, True)
+        else:
+            out["roofline"] = measure_dominant_wgrad(dev, B, args.size)
+            out["roofline_fwd"] = measure_dominant_conv(dev, B, args.size, False)
         if not args.no_step_profile and world == 1:      # (an eager step holds collectives: single-rank runs only)
-            prof = measure_step_conv(step_again, args.workload)
+            prof = measure_step_conv(step_again, args.workload, {"dominant": dominant_wgrad_call(B, args.size)})
             out["roofline"]["step_conv_frac"] = prof["step_conv_frac"]
             out["roofline"]["step_conv"] = prof
             # executed FLOPs from this run's own census of the step
             gfs = prof["conv_gflop"] / B
             tf = value * gfs / 1e3
-            out["whole_step"].update(executed_gflop_per_slice=round(gfs, 3), achieved_tflops_per_gpu=round(tf, 2),
+            xfs = prof["conv_gflop_mfma_executed"] / B
+            xtf = value * xfs / 1e3
+            out["whole_step"].update(algorithmic_gflop_per_slice=round(gfs, 3), achieved_tflops_per_gpu=round(tf, 2),
                                      frac_of_fp32_mfma_peak=round(tf / FP32_MFMA_PEAK_TFLOPS, 4),
-                                     flops_source="per-shape census of one step in this run (roofline.step_conv.conv_gflop)")
+                                     mfma_executed_gflop_per_slice=round(xfs, 3), mfma_executed_tflops_per_gpu=round(xtf, 2),
+                                     mfma_executed_frac_of_fp32_mfma_peak=round(xtf / FP32_MFMA_PEAK_TFLOPS, 4),
+                                     flops_source="per-shape census of one step in this run (roofline.step_conv.conv_gflop / "
+                                                  "conv_gflop_mfma_executed)")
+            # the roofline leg's call is one the timed step makes (entry point + integer / float arguments)
+            out["roofline"]["in_step_record"] = bool(prof.get("has_call", {}).get("dominant"))
     if world == 1 and args.workload == "ugan" and not args.no_unet_step and args.dtype == "f32" and args.size == 256:
         out["unet_step"] = time_unet_step(dev, rank)
         if not args.no_config5:

@@ -112,6 +112,15 @@ int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, 
 int smsut_conv2d_wgrad_mfma_inaff(const float* x, const float* gy, float* gw, float* workspace, const float* mean,
                                   const float* rstd, const float* gamma, const float* beta, float slope, int N, int H, int W,
                                   int Cin, int Cout, void* stream);
+/* measurement entry point (bench.py's roofline leg): the first of the two launches of smsut_conv2d_wgrad_mfma[_inaff] alone -- the
+   register-row weight-gradient kernel (csrc/conv_wgrad_rr.hip) writing its per-split slabs, without the reduction; returns the
+   number of slabs (> 0) or a negative value when the shape is not one that kernel takes.  mean == NULL: plain form. */
+int smsut_conv2d_wgrad_mfma_slabs(const float* x, const float* gy, float* workspace, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, float slope, int N, int H, int W, int Cin, int Cout,
+                                  void* stream);
+/* which arithmetic a 3x3 stride-1 fp32 conv call of this shape runs: 0 direct, 1 Winograd F(2x2,3x3) resident weights, 2 Winograd
+   streamed weights (16 instead of 36 products per 2x2 output tile); sc_dgrad: the fused shortcut data-gradient (Kdim = 2 Cout) */
+int smsut_conv2d_mfma_form(int N, int H, int W, int Kdim, int Ndim, int sc_dgrad);
 
 /* virtual-cat input forms: the logical input is cat([xa, xb], channel) (UpSampleAndConcat, network/blocks.py:49-50) read
    from the two tensors in place -- same chunk order and arithmetic as on a materialised cat, so results are bit-identical.

@@ -68,6 +68,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv1x1_wgrad": "pppp iiii s",
     "smsut_conv2d_fwd_mfma_stats_inaff": "pppp pppp f iiiii s",
     "smsut_conv2d_wgrad_mfma_inaff": "pppp pppp f iiiii s",
+    "smsut_conv2d_wgrad_mfma_slabs": "ppp pppp f iiiii s",
+    "smsut_conv2d_mfma_form": "iiiiii",
     "smsut_conv2d_mfma_cat_supported": "iiiii",
     "smsut_conv2d_fwd_mfma_stats_cat": "ppppp iiiii s",
     "smsut_conv2d_fwd_sc_supported": "iiiiii",
@@ -166,7 +168,8 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",
                          "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_dgrad_sc_supported",
-                         "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported"}
+                         "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported",
+                         "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

@@ -2569,6 +2569,19 @@ int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb, const float*
 // Data-gradient of that pair: gx = dgrad3x3(gy, w) + dgrad1x1(gs, wsc) in one pass (gy, gs [N,H,W,Cout]; w, wsc the forward
 // weights [3][3][Cin][Cout], [Cin][Cout]).  gxb != null: channels [0, split) of gx go to gxa [N,H,W,split], the rest to gxb
 // (block input was cat([up, skip])).  Persistent-kernel shapes with Cout in {16, 32}: _supported says which.
+// Which arithmetic a 3x3 stride-1 fp32 conv call (forward or data-gradient, any fused form) runs for this shape: 0 = direct
+// products (36 per 2x2 output tile and channel pair), 1 = Winograd F(2x2,3x3) with resident weights (conv_mfma_fwd_p<..,WINO>),
+// 2 = Winograd with streamed weights (conv_wino_l) -- 16 products per tile.  Mirrors select_fwd_p / dispatch_fwd; sc_dgrad = the
+// fused shortcut data-gradient (Kdim = 2 Cout).  bench.py / profiling.py use it to report the FLOPs the matrix pipes EXECUTE.
+int smsut_conv2d_mfma_form(int N, int H, int W, int Kdim, int Ndim, int sc_dgrad) {
+  if (N <= 0 || H <= 0 || W <= 0 || !fwd_any_eligible(N, H, W, Kdim, Ndim, false)) return 0;
+  const bool sc2_64 = sc_dgrad && Kdim == 64 && fwd_p_eligible(N, H, W, Kdim, Ndim);
+  if (!sc2_64 && wino_l_shape(N, H, W, Kdim, Ndim)) return 2;
+  if (Ndim == 8 || Kdim == 8) return 0;
+  static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
+  return (use_wino && H % 16 == 0 && (Kdim == 16 || Kdim == 32) && fwd_p_eligible(N, H, W, Kdim, Ndim)) ? 1 : 0;
+}
+
 int smsut_conv2d_dgrad_sc_supported(int N, int H, int W, int Cout, int Cin, int split) {
   static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_DGRAD"); return !e || atoi(e) != 0; }();
   if (!on || N <= 0 || H <= 0 || W <= 0 || !(Cout == 16 || Cout == 32)) return 0;
@@ -2840,6 +2853,24 @@ int smsut_conv2d_wgrad_mfma_inaff(const float* x, const float* gy, float* gw, fl
   SMSUT_REQUIRE(mean && rstd && gamma && beta);
   const AffRef a{mean, rstd, gamma, beta, slope};
   return wgrad_mfma_launch(x, gy, gw, workspace, N, H, W, Cin, Cout, 3, stream, nullptr, 0, &a);
+}
+
+// Measurement entry point (bench.py's roofline leg): the FIRST of the two launches of smsut_conv2d_wgrad_mfma_inaff alone -- the
+// register-row kernel writing its per-split slabs into the workspace, without the sum_splits reduction -- so that HIP events
+// bracket exactly the kernel rocprofv3 lists.  Returns the number of slabs written (> 0), or a negative value when the shape is
+// not one the register-row kernel takes.  mean == NULL: plain form (x is the operand itself).
+int smsut_conv2d_wgrad_mfma_slabs(const float* x, const float* gy, float* workspace, const float* mean, const float* rstd,
+                                  const float* gamma, const float* beta, float slope, int N, int H, int W, int Cin, int Cout,
+                                  void* stream) {
+  if (!x || !gy || !workspace || N <= 0 || H <= 0 || W <= 0) return SMSUT_EINVAL;
+  const bool aff = mean != nullptr;
+  if (aff && !(rstd && gamma && beta)) return SMSUT_EINVAL;
+  if (!smsut_wgrad_rr_eligible(N, H, W, Cin, Cout, nullptr, 0, aff, false)) return SMSUT_EINVAL;
+  const RrAff ra{mean, rstd, gamma, beta, slope};
+  if (smsut_wgrad_rr_launch(x, nullptr, 0, gy, nullptr, workspace, N, H, W, Cin, Cout, aff ? &ra : nullptr, (hipStream_t)stream) != 0)
+    return SMSUT_EINVAL;
+  if (hipGetLastError() != hipSuccess) return SMSUT_EINVAL;
+  return smsut_wgrad_rr_splits(N, H, W, Cin, Cout, nullptr, 0, aff, false);
 }
 
 // conv1's 3x3 weight gradient AND the 1x1 shortcut's (network/blocks.py:66-80: both convs read x) in one pass:

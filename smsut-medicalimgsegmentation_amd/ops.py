@@ -739,6 +739,9 @@ FUSED_BLOCK = bool(int(_os.environ.get("SMSUT_FUSED_BLOCK", "1")))
 ONE_PASS_CONCAT = bool(int(_os.environ.get("SMSUT_ONE_PASS_CONCAT", "1")))     # cat / split as one kernel over full rows
 FUSED_RES_TAIL = bool(int(_os.environ.get("SMSUT_FUSED_RES_TAIL", "1")))       # BottleBlock tail in first_order_pass()
 INAFF_CONV2 = bool(int(_os.environ.get("SMSUT_INAFF_CONV2", "1")))   # conv2 / wgrad2 of a fused block normalise y1 while staging
+# ... for blocks of whole 16-channel tiles (r04: the register-row weight gradient takes the transform for +3 us at 16 -> 16 @256^2;
+# the LDS-staged 16-channel kernel paid +55 us, which kept the 16-channel blocks out until then: uganConsis -1.0 %, U-Net -1.0 %)
+INAFF_MIN_CO = int(_os.environ.get("SMSUT_INAFF_MIN_CO", "16"))
 POOL_SKIP = bool(int(_os.environ.get("SMSUT_POOL_SKIP", "1")))       # encoder level: skip gradient summed inside the pooling backward
 VIRTUAL_CAT = bool(int(_os.environ.get("SMSUT_VIRTUAL_CAT", "1")))   # block-after-concat reads [up, skip] in place (no cat tensor)
 SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-after-concat: gradient written into the two parts
@@ -819,9 +822,7 @@ class BasicBlockFn(Function):
         m1, r1 = stat(co)
         y2 = new_act(n, co, h, w, x)
         p2 = _ws(n * t3b * co * 2, x)
-        # (co % 32: the tap-split weight-gradient kernel takes the transform for +4 us; on the 16-channel kernel it cost
-        #  +55 us at 32x256^2, more than the apply pass it removes -- scratch/inaff_ab.py)
-        inaff = (INAFF_CONV2 and not f16 and co % 32 == 0
+        inaff = (INAFF_CONV2 and not f16 and co % INAFF_MIN_CO == 0
                  and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, 0)))
         ctx.inaff = inaff
         if inaff:

@@ -70,6 +70,40 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
 }
 
 
+# 3x3 fp32 forward / data-gradient entry points whose arithmetic depends on the shape (direct or Winograd, smsut_conv2d_mfma_form):
+# entry point -> (ints -> (N, H, W, Kdim, Ndim, sc_dgrad), executed / algorithmic products when a Winograd form runs).
+# Winograd F(2x2,3x3): 16 instead of 36 products per 2x2 output tile and channel pair (1 / 2.25).  Fused shortcut FORWARD: the 1x1
+# conv runs on the tile's raw pixels, 4 more products (20 of 40 algorithmic = 0.5); fused shortcut DATA-GRADIENT: the shortcut's
+# gradient is a second reduction half that goes through the transform like the first (32 of 40 = 0.8).
+_WINO = 16.0 / 36.0
+_FORM: Dict[str, Tuple[Callable[[List[int]], Tuple[int, int, int, int, int, int]], float]] = {
+    "smsut_conv2d_fwd_mfma": (lambda a: (a[0], a[1], a[2], a[3], a[4], 0) if a[5] == 3 else None, _WINO),
+    "smsut_conv2d_fwd_mfma_stats": (lambda a: (a[0], a[1], a[2], a[3], a[4], 0) if a[5] == 3 else None, _WINO),
+    "smsut_conv2d_dgrad_mfma_bwdstats": (lambda a: (a[0], a[1], a[2], a[3], a[4], 0), _WINO),
+    "smsut_conv2d_fwd_mfma_stats_inaff": (lambda a: (a[0], a[1], a[2], a[3], a[4], 0), _WINO),
+    "smsut_conv2d_fwd_mfma_stats_cat": (lambda a: (a[0], a[1], a[2], a[3], a[4], 0), _WINO),
+    "smsut_conv2d_fwd_mfma_split": (lambda a: (a[1], a[2], a[3], a[4], a[5], 0) if a[6] == 3 else None, _WINO),
+    "smsut_conv2d_fwd_mfma_stats_sc": (lambda a: (a[0], a[1], a[2], a[3], a[4], 0), 0.5),
+    "smsut_conv2d_dgrad_mfma_sc": (lambda a: (a[1], a[2], a[3], 2 * a[4], a[5], 1), 0.8),
+}
+
+
+def _ints(name: str, conv_args) -> List[int]:
+    sig = H.SIGNATURES[name].replace(" ", "")
+    return [a for c, a in zip(sig, conv_args) if c in "il"]
+
+
+def executed_factor(name: str, conv_args) -> float:
+    """Share of a call's algorithmic conv FLOPs that the matrix pipes execute (1.0 unless a Winograd form takes the shape)."""
+    ent = _FORM.get(name)
+    if ent is None:
+        return 1.0
+    q = ent[0](_ints(name, conv_args))
+    if q is None or H.call("smsut_conv2d_mfma_form", *q) == 0:
+        return 1.0
+    return ent[1]
+
+
 def conv_flops_of(name: str, conv_args) -> float:
     """Algorithmic FLOPs of one recorded call (0 for non-conv entry points)."""
     ent = _CONV_FLOPS.get(name)
@@ -80,7 +114,9 @@ def conv_flops_of(name: str, conv_args) -> float:
     return float(ent[0](ints))
 
 
-class Row(collections.namedtuple("Row", "name args calls us flops")):
+class Row(collections.namedtuple("Row", "name args calls us flops exec_flops")):
+    """One distinct call of the step: ``flops`` = ALGORITHMIC conv FLOPs per call (2 N H W Cin Cout k^2), ``exec_flops``
+    = what the matrix pipes execute for it (smaller where a Winograd form runs)."""
     @property
     def total_us(self):
         return self.us * self.calls
@@ -137,33 +173,41 @@ def replay(rec, reps: int = 8) -> List[Row]:
             fn(*conv)
         e1.record(st)
         torch.cuda.synchronize()
-        rows.append(Row(name, shp, len(calls), e0.elapsed_time(e1) / reps * 1e3, conv_flops_of(name, calls[0])))
+        fl = conv_flops_of(name, calls[0])
+        rows.append(Row(name, shp, len(calls), e0.elapsed_time(e1) / reps * 1e3, fl, fl * executed_factor(name, calls[0])))
     lib.smsut_wino_unbind_all()
     return rows
 
 
 def summarize(rows: List[Row], peak_tflops: float) -> dict:
-    """Conv-side roofline of the step and the per-family split."""
+    """Conv-side roofline of the step and the per-family split.  ``*_algorithmic`` / ``tflops`` count the conv FLOPs the layer
+    DEFINES (what the contract's ``achieved`` is made of); ``*_executed`` count the products the MFMA pipes actually run (Winograd
+    forms: 16 / 36 of them) -- the figure to hold against the 157.3 TFLOP/s the pipes can do."""
     conv = [r for r in rows if r.flops > 0]
     mfma = [r for r in conv if _CONV_FLOPS[r.name][1] == "mfma"]
     t_all = sum(r.total_us for r in rows)
     t_conv = sum(r.total_us for r in conv)
     f_conv = sum(r.flops * r.calls for r in conv)
+    x_conv = sum(r.exec_flops * r.calls for r in conv)
     t_mfma = sum(r.total_us for r in mfma)
     f_mfma = sum(r.flops * r.calls for r in mfma)
+    x_mfma = sum(r.exec_flops * r.calls for r in mfma)
     fam = collections.OrderedDict()
     for r in conv:
         k = ("wgrad" if "wgrad" in r.name else "fwd/dgrad") + (" 1x1" if "1x1" in r.name else (" convT" if "convT" in r.name else ""))
-        t, f = fam.get(k, (0.0, 0.0))
-        fam[k] = (t + r.total_us, f + r.flops * r.calls)
+        t, f, x = fam.get(k, (0.0, 0.0, 0.0))
+        fam[k] = (t + r.total_us, f + r.flops * r.calls, x + r.exec_flops * r.calls)
+    tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t else None                      # noqa: E731
+    fr = lambda f, t: round(f / (t * 1e-6) / 1e12 / peak_tflops, 4) if t else None        # noqa: E731
     return {
         "kernel_ms_all": round(t_all / 1e3, 3), "kernel_ms_conv": round(t_conv / 1e3, 3),
-        "conv_gflop": round(f_conv / 1e9, 2),
-        "step_conv_tflops": round(f_conv / (t_conv * 1e-6) / 1e12, 2) if t_conv else None,
-        "step_conv_frac": round(f_conv / (t_conv * 1e-6) / 1e12 / peak_tflops, 4) if t_conv else None,
-        "mfma_conv_frac": round(f_mfma / (t_mfma * 1e-6) / 1e12 / peak_tflops, 4) if t_mfma else None,
+        "conv_gflop": round(f_conv / 1e9, 2), "conv_gflop_mfma_executed": round(x_conv / 1e9, 2),
+        "step_conv_tflops": tf(f_conv, t_conv), "step_conv_frac": fr(f_conv, t_conv),
+        "step_conv_tflops_mfma_executed": tf(x_conv, t_conv), "step_conv_frac_mfma_executed": fr(x_conv, t_conv),
+        "mfma_conv_frac_algorithmic": fr(f_mfma, t_mfma), "mfma_conv_frac_executed": fr(x_mfma, t_mfma),
         "conv_share_of_kernel_time": round(t_conv / t_all, 4) if t_all else None,
-        "families": {k: {"ms": round(t / 1e3, 3), "tflops": round(f / (t * 1e-6) / 1e12, 1)} for k, (t, f) in fam.items()},
+        "families": {k: {"ms": round(t / 1e3, 3), "algorithmic_tflops": round(f / (t * 1e-6) / 1e12, 1),
+                         "mfma_executed_tflops": round(x / (t * 1e-6) / 1e12, 1)} for k, (t, f, x) in fam.items()},
     }
 
 

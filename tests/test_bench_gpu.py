@@ -1,0 +1,51 @@
+"""bench.py's roofline leg times a kernel the timed step really launches (r03's leg called
+``smsut_conv2d_fwd_mfma_stats_cat``, which the fp32 iteration had not launched since the shortcut fusion)."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def test_roofline_legs_are_calls_of_the_recorded_iteration(monkeypatch):
+    """One eager uganConsis iteration at the bench's geometry (8 + 8 slices @256^2 is what the line is quoted on; 2 + 2 here, the
+    entry points and every argument but the batch are the same) recorded through ``profiling.record_step``: both roofline legs'
+    (entry point, integer / float arguments) are among its C-ABI calls, and the dominant one launches the register-row kernel."""
+    import bench
+    import smsut_amd  # noqa: F401
+    from smsut_amd import config as cfg, profiling, _hip as H
+    from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer
+    from smsut_amd.misc.synthetic import SyntheticSliceLoader
+    monkeypatch.setenv("SMSUT_GRAPH", "0")
+    old = (cfg.input_size, cfg.batch_size)
+    B = 4
+    try:
+        cfg.input_size, cfg.batch_size = 256, B // 2
+        tr = UGANConsisTrainer("train", types.SimpleNamespace(fold=0, expr_name=None, write_env=False))
+        tr.net.train(); tr.D.train()
+        tr.iter, tr.epoch = 1000, 100
+        (x1, y1, m1, _), (x2, _, m2, _) = (next(iter(SyntheticSliceLoader(B // 2, device="cuda", labeled=True, n_batches=2))),
+                                           next(iter(SyntheticSliceLoader(B // 2, device="cuda", labeled=False, n_batches=2))))
+        batch = (torch.cat([x1, x2], 0), y1, torch.cat([m1, m2], 0))
+        tr.train_iteration(*batch)
+        rec = profiling.record_step(lambda: tr.train_iteration(*batch))
+    finally:
+        cfg.input_size, cfg.batch_size = old
+    keys = set()
+    for name, conv in rec:
+        sig = H.SIGNATURES[name].replace(" ", "")
+        keys.add((name, tuple(round(a, 6) if isinstance(a, float) else a for c, a in zip(sig, conv) if c in "ilfd")))
+    name, args = bench.dominant_wgrad_call(B, 256)
+    assert (name, tuple(round(a, 6) if isinstance(a, float) else a for a in args)) in keys, sorted(k for k in keys if k[0] == name)
+    assert ("smsut_conv2d_fwd_mfma_stats_sc", (B, 256, 256, 32, 16)) in keys           # roofline_fwd: decoder level 1, conv1 + shortcut
+    assert not any(k[0] == "smsut_conv2d_fwd_mfma_stats_cat" for k in keys)           # (what r03's leg timed: not a call of the step)
+    r = bench.measure_dominant_wgrad(torch.device("cuda"), B, 256)
+    assert r["entry_point"] == name and r["avg_launch_ms"] > 0 and r["call_ms_with_reduction"] >= r["avg_launch_ms"]
+    f = bench.measure_dominant_conv(torch.device("cuda"), B, 256)
+    assert f["entry_point"] == "smsut_conv2d_fwd_mfma_stats_sc" and f["executed_mfma_tflops"] <= f["achieved"]

@@ -629,9 +629,13 @@ def test_fused_shortcut_data_gradient(ops, n, h, co, ci, split):
     w3d = w3.double().view(3, 3, ci, co).permute(3, 2, 0, 1).contiguous()           # [co, ci, 3, 3] = conv_transpose2d weight layout
     d = torch.nn.functional.conv_transpose2d(gy[:k].double().permute(0, 3, 1, 2), w3d, padding=1).permute(0, 2, 3, 1)
     d = d + gs[:k].double() @ w1.double().view(ci, co).t()
-    # (r03: the composition's 3x3 pass may run the Winograd form, whose shorter fp32 sum chains land closer to fp64 than the direct
-    #  form's -- 1.4e-6 vs 4.2e-6 at 32 -> 16 @128^2 -- so the bar is 3x + 2e-6, not 2x + 1e-6)
-    assert (got[:k].double() - d).abs().max() <= 3 * (ref[:k].double() - d).abs().max() + 2e-6
+    # Both against fp64 on their own, in absolute terms (values ~ N(0, 1.4): sums of 10 co products of unit-variance factors scaled by
+    # 1 / sqrt(9 co)).  r02 compared the fused form with 2x the composition's error; since r03 either side may run the Winograd form,
+    # whose shorter fp32 sum chains land CLOSER to fp64 than the direct form's (measured at 32 -> 16 @128^2: 1.4e-6 Winograd, 4.2e-6
+    # direct), so a ratio between the two says which form each side drew, not how accurate the fused kernel is.  Measured over the
+    # parameter list: fused <= 6.2e-6, composition <= 6.2e-6.
+    e_got, e_ref = float((got[:k].double() - d).abs().max()), float((ref[:k].double() - d).abs().max())
+    assert e_got <= 1e-5 and e_ref <= 1e-5, (e_got, e_ref)
 
 
 @pytest.mark.parametrize("n,h,ci,co,cat", [(16, 64, 32, 64, 0), (16, 64, 64, 32, 1), (8, 32, 128, 64, 1), (6, 32, 64, 128, 0),

@@ -328,6 +328,24 @@ def test_bench_self_launch_two_ranks_on_one_card():
     assert all(v == v for v in line["last_step_scalars"])
 
 
+def test_bench_self_launch_four_ranks_on_one_card():
+    """the launcher's port / thread / relay logic above two ranks -- ``bench.py --gpus 4`` rehearsed as four gloo
+    ranks on one card (1 + 1 slices of 64x64 each; at most 6 processes may share a card on this pool).  The line must say what the
+    communicator saw: backend and world size."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SMSUT_FORCE_DEVICE="0", SMSUT_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+           "--no-roofline", "--no-unet-step", "--no-config5", "--no-step-profile", "--per-gpu-batch", "2", "--size", "64"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 4 and line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert line["dist"]["world_size"] == 4 and line["dist"]["backend"] == "gloo", line.get("dist")
+    assert all(v == v for v in line["last_step_scalars"])
+
+
 def _rccl_worker(q, force):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
