@@ -73,19 +73,32 @@ int smsut_conv2d_fwd_mfma_cfg(const float* x, const float* w, float* y, int N, i
  *                                       this library's layout [3][3][Cin][Cout]; transposed[i] = 0: image of the forward conv
  *                                       (Kdim[i] = Cin, Ndim[i] = Cout), 1: of its data-gradient (Kdim[i] = Cout, Ndim[i] = Cin);
  *                                       u[i]: device float[smsut_wino_image_floats(Kdim[i], Ndim[i])].  The five arrays are HOST arrays;
- *   smsut_wino_bind(w, transposed, u, Kdim, Ndim)  from now on a conv call with these weights (same pointer, same form, same
- *                                       dimensions) copies u instead of transforming w; u = NULL unbinds.  The CALLER keeps u in
- *                                       step with w: re-prepare (or unbind) after every change of w;
- *   smsut_wino_unbind_all()             forgets every binding.
- * Results are bit-identical with and without a binding (same arithmetic, done once instead of per workgroup). */
+ *   *_pre entry points (below)         the conv entry points that may run that kernel, with one more argument: wu = the image the
+ *                                       CALLER prepared for this weight tensor and form (same Kdim, Ndim, same bit 0 of `transposed`),
+ *                                       or NULL = transform on the fly.  The caller keeps wu in step with w (re-prepare after every
+ *                                       change of w).  The library holds NO table of images and no other process-wide mutable state
+ *                                       (r03's smsut_wino_bind* registry is gone): an image is an argument like any other.
+ * Results are bit-identical with and without an image (same arithmetic, done once instead of per workgroup). */
 int64_t smsut_wino_image_floats(int Kdim, int Ndim);
 int smsut_wino_prepare(const float* const* w, float* const* u, const int* Kdim, const int* Ndim, const int* transposed, int count,
                        void* stream);
-int smsut_wino_bind(const float* w, int transposed, const float* u, int Kdim, int Ndim);
-/* smsut_wino_bind for `count` tensors at once (host arrays as in smsut_wino_prepare); u = NULL (or u[i] = NULL) unbinds */
-int smsut_wino_bind_many(const float* const* w, const float* const* u, const int* Kdim, const int* Ndim, const int* transposed,
-                         int count);
-int smsut_wino_unbind_all(void);
+int smsut_conv2d_fwd_mfma_pre(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
+                              int transposed, const float* wu, void* stream);
+int smsut_conv2d_fwd_mfma_stats_pre(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
+                                    int Ndim, int KS, const float* wu, void* stream);
+int smsut_conv2d_dgrad_mfma_bwdstats_pre(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                         const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                         float slope, int N, int H, int W, int Kdim, int Ndim, const float* wu, void* stream);
+int smsut_conv2d_fwd_mfma_stats_inaff_pre(const float* x, const float* w, float* y, float* stats, const float* mean,
+                                          const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
+                                          int W, int Kdim, int Ndim, const float* wu, void* stream);
+int smsut_conv2d_fwd_mfma_stats_cat_pre(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
+                                        int W, int Kdim, int Ndim, const float* wu, void* stream);
+int smsut_conv2d_fwd_mfma_split_pre(const float* x, const float* w, float* ya, float* yb, int split, int N, int H, int W,
+                                    int Kdim, int Ndim, int transposed, const float* wu, void* stream);
+int smsut_conv2d_fwd_mfma_stats_sc_pre(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
+                                       float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, const float* wu,
+                                       void* stream);
 int smsut_conv2d_wgrad_mfma_supported(int KS, int stride, int pad, int Cin, int Cout);
 int64_t smsut_conv2d_wgrad_mfma_ws(int N, int H, int W, int Cin, int Cout, int KS);
 int smsut_conv2d_wgrad_mfma(const float* x, const float* gy, float* gw, float* workspace, int N, int H, int W, int Cin,

@@ -38,16 +38,16 @@ SIGNATURES: Dict[str, str] = {
     # conv_mfma.hip
     "smsut_conv2d_mfma_supported": "iiiii",
     "smsut_conv2d_fwd_mfma": "ppp iiiiii i s",
+    "smsut_conv2d_fwd_mfma_pre": "ppp iiiiii i p s",
     "smsut_conv2d_mfma_tiles": "iiiiiii",
     "smsut_conv2d_mfma_persistent": "iiiiiii",
     "smsut_conv2d_dgrad_mfma_bwdstats": "ppppppppp f iiiii s",
+    "smsut_conv2d_dgrad_mfma_bwdstats_pre": "ppppppppp f iiiii p s",
     "smsut_conv2d_fwd_mfma_stats": "pppp iiiiii s",
+    "smsut_conv2d_fwd_mfma_stats_pre": "pppp iiiiii p s",
     "smsut_conv2d_fwd_mfma_cfg": "ppp iiiiii ii s",
     "smsut_wino_image_floats": "ii",
     "smsut_wino_prepare": "ppppp i s",
-    "smsut_wino_bind": "p i p ii",
-    "smsut_wino_bind_many": "ppppp i",
-    "smsut_wino_unbind_all": "",
     "smsut_conv2d_wgrad_mfma_supported": "iiiii",
     "smsut_conv2d_wgrad_mfma_ws": "iiiiii",
     "smsut_conv2d_wgrad_mfma": "pppp iiiiii s",
@@ -67,13 +67,16 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv1x1_wgrad_ws": "iiii",
     "smsut_conv1x1_wgrad": "pppp iiii s",
     "smsut_conv2d_fwd_mfma_stats_inaff": "pppp pppp f iiiii s",
+    "smsut_conv2d_fwd_mfma_stats_inaff_pre": "pppp pppp f iiiii p s",
     "smsut_conv2d_wgrad_mfma_inaff": "pppp pppp f iiiii s",
     "smsut_conv2d_wgrad_mfma_slabs": "ppp pppp f iiiii s",
     "smsut_conv2d_mfma_form": "iiiiii",
     "smsut_conv2d_mfma_cat_supported": "iiiii",
     "smsut_conv2d_fwd_mfma_stats_cat": "ppppp iiiii s",
+    "smsut_conv2d_fwd_mfma_stats_cat_pre": "ppppp iiiii p s",
     "smsut_conv2d_fwd_sc_supported": "iiiiii",
     "smsut_conv2d_fwd_mfma_stats_sc": "pppppppp iiiii s",
+    "smsut_conv2d_fwd_mfma_stats_sc_pre": "pppppppp iiiii p s",
     "smsut_conv2d_dgrad_sc_supported": "iiiiii",
     "smsut_conv2d_dgrad_mfma_sc": "pppppp iiiiii s",
     "smsut_conv2d_wgrad_sc_supported": "iiiii",
@@ -101,6 +104,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv1x1_wgrad_cat": "pp i ppp iiii s",
     "smsut_conv2d_mfma_split_supported": "iiiiii",
     "smsut_conv2d_fwd_mfma_split": "pppp iiiiiii s",
+    "smsut_conv2d_fwd_mfma_split_pre": "pppp iiiiiii p s",
     "smsut_conv1x1_fwd_split": "pppp iiiiii s",
     "smsut_conv1x1_thin_supported": "ii",
     "smsut_conv1x1_thin_dgrad": "ppp iiii s",

@@ -1975,7 +1975,7 @@ inline bool fwd_any_eligible(int N, int H, int W, int Kdim, int Ndim, bool f16) 
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
-                        const ScRef* sc = nullptr) {
+                        const ScRef* sc = nullptr, const float* wu = nullptr) {
 #define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc
   // (the fused shortcut data-gradient at 64 reduction channels stays on the direct resident-weight form: 107 us vs 142 us at
   //  16 x 128^2 (32 + 32) -> 64 -- its second-half chunks are a run-time branch inside the staging parts, r03 notes)
@@ -1986,7 +1986,7 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
     if (aff) wa = WinoAff{aff->mean, aff->rstd, aff->gamma, aff->beta, aff->slope};
     if (sc) ws = WinoSc{sc->w, sc->y, sc->stats};
     return smsut_wino_l_launch(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, tiles_out, bst ? &wb : nullptr,
-                               aff ? &wa : nullptr, sc ? &ws : nullptr, st);
+                               aff ? &wa : nullptr, sc ? &ws : nullptr, st, wu);
   }
   if (Ndim == 8) {                                   // 8 result channels (see conv_mfma_fwd_p, N8): data-gradient forms
     if (Kdim == 16) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, false, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, false, true>(PARGS);
@@ -2022,7 +2022,8 @@ inline bool fwd_p_n8_eligible(int N, int H, int W, int Kdim, int Ndim) {
 template <int KS>
 int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr,
-                 const float* x2 = nullptr, float* y2 = nullptr, int split = 0, bool f16 = false, const float* gsc = nullptr) {
+                 const float* x2 = nullptr, float* y2 = nullptr, int split = 0, bool f16 = false, const float* gsc = nullptr,
+                 const float* wu = nullptr) {
 #define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, isc, osc, G, ntap_out, st, stats, tiles_out, x2, y2, split, f16, gsc
   // From the r01 sweep (scratch/bench_conv.py, B=32, U-Net shapes): 8-row tiles win everywhere; 32 output channels
   // per workgroup (grid.z walks the rest) beat 64, and 16 win when the grid would otherwise be < ~4 WGs per CU.
@@ -2035,7 +2036,7 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
     // (-1) shapes it does not cover.  SMSUT_CONV_PERSISTENT=0 keeps the per-tile kernel (A/B switch).
     if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && fwd_any_eligible(N, H, W, Kdim, Ndim, f16)) {
       if (select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, nullptr, y2, split, x2, nullptr, f16,
-                       gsc) == 0)
+                       gsc, nullptr, wu) == 0)
         return 0;
     }
     if (isc == 1 && osc == 1 && G == 1 && ntap_out == 1 && (transposed & 1) && !stats && !tiles_out && !x2 && !y2 && !f16 &&
@@ -2515,31 +2516,46 @@ int smsut_conv2d_mfma_supported(int KS, int stride, int pad, int Kdim, int Ndim)
 // Forward (transposed = 0): x [N,H,W,Kdim], w [KS*KS][Kdim][Ndim] -> y [N,H,W,Ndim].
 // Data-gradient (transposed = 1): x = gy [N,H,W,Kdim = Cout], w = the forward weights [KS*KS][Ndim = Cin][Kdim = Cout],
 // y = gx [N,H,W,Ndim = Cin].
-int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
-                          int transposed, void* stream) {
+// `_pre` forms (every 3x3 entry point that may run the streamed-weight Winograd kernel, conv_wino.hip): wu = the caller's prepared
+// image of w for this form -- smsut_wino_prepare with the same (Kdim, Ndim) and the same bit 0 of `transposed` -- or NULL = the
+// weights are transformed on the fly.  The image is only read when that kernel takes the shape; results are bit-identical either
+// way.  The library keeps no table of images (r03 did): what is prepared, for how long it is valid and when it is passed is the
+// caller's business (no process-wide mutable state behind the C ABI).
+int smsut_conv2d_fwd_mfma_pre(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
+                              int transposed, const float* wu, void* stream) {
   SMSUT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0);
   SMSUT_REQUIRE(smsut_conv2d_mfma_supported(KS, 1, (KS - 1) / 2, Kdim, Ndim));
   SMSUT_REQUIRE(!transposed || (Kdim % 4) == 0);
   hipStream_t st = (hipStream_t)stream;
   if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
-  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st);
+  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st, nullptr, nullptr, nullptr, nullptr, 0, false, nullptr, wu);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
+                          int transposed, void* stream) {
+  return smsut_conv2d_fwd_mfma_pre(x, w, y, N, H, W, Kdim, Ndim, KS, transposed, nullptr, stream);
 }
 
 // conv2 of a BasicBlock on the RAW conv1 output: y = conv3x3(lrelu(IN(x; mean, rstd, gamma, beta))) + statistics of y, the
 // normalisation applied while the tiles are staged (a1 never exists in HBM).  Persistent-kernel shapes only
 // (smsut_conv2d_mfma_persistent); statistics tiles as smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3).
-int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, float* stats, const float* mean,
-                                      const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
-                                      int W, int Kdim, int Ndim, void* stream) {
+int smsut_conv2d_fwd_mfma_stats_inaff_pre(const float* x, const float* w, float* y, float* stats, const float* mean,
+                                          const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
+                                          int W, int Kdim, int Ndim, const float* wu, void* stream) {
   SMSUT_REQUIRE(x && w && y && stats && mean && rstd && gamma && beta && N > 0 && H > 0 && W > 0);
   SMSUT_REQUIRE(fwd_any_eligible(N, H, W, Kdim, Ndim, false));
   const AffRef a{mean, rstd, gamma, beta, slope};
-  const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, nullptr, &a);
+  const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, nullptr, &a,
+                              false, nullptr, nullptr, wu);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats_inaff(const float* x, const float* w, float* y, float* stats, const float* mean,
+                                      const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
+                                      int W, int Kdim, int Ndim, void* stream) {
+  return smsut_conv2d_fwd_mfma_stats_inaff_pre(x, w, y, stats, mean, rstd, gamma, beta, slope, N, H, W, Kdim, Ndim, nullptr, stream);
 }
 
 // conv1 of a BasicBlock fused with the block's 1x1 shortcut conv (network/blocks.py:66-80; both read the block input):
@@ -2555,33 +2571,25 @@ int smsut_conv2d_fwd_sc_supported(int N, int H, int W, int Kdim, int Ndim, int c
   return 1;
 }
 
-int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
-                                   float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+int smsut_conv2d_fwd_mfma_stats_sc_pre(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
+                                       float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, const float* wu,
+                                       void* stream) {
   SMSUT_REQUIRE(x && w && wsc && y && ysc && stats && stats_sc && smsut_conv2d_fwd_sc_supported(N, H, W, Kdim, Ndim, xb != nullptr));
   const ScRef sc{wsc, ysc, stats_sc};
   const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb, nullptr,
-                              false, nullptr, &sc);
+                              false, nullptr, &sc, wu);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
+                                   float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  return smsut_conv2d_fwd_mfma_stats_sc_pre(x, xb, w, wsc, y, ysc, stats, stats_sc, N, H, W, Kdim, Ndim, nullptr, stream);
 }
 
 // Data-gradient of that pair: gx = dgrad3x3(gy, w) + dgrad1x1(gs, wsc) in one pass (gy, gs [N,H,W,Cout]; w, wsc the forward
 // weights [3][3][Cin][Cout], [Cin][Cout]).  gxb != null: channels [0, split) of gx go to gxa [N,H,W,split], the rest to gxb
 // (block input was cat([up, skip])).  Persistent-kernel shapes with Cout in {16, 32}: _supported says which.
-// Which arithmetic a 3x3 stride-1 fp32 conv call (forward or data-gradient, any fused form) runs for this shape: 0 = direct
-// products (36 per 2x2 output tile and channel pair), 1 = Winograd F(2x2,3x3) with resident weights (conv_mfma_fwd_p<..,WINO>),
-// 2 = Winograd with streamed weights (conv_wino_l) -- 16 products per tile.  Mirrors select_fwd_p / dispatch_fwd; sc_dgrad = the
-// fused shortcut data-gradient (Kdim = 2 Cout).  bench.py / profiling.py use it to report the FLOPs the matrix pipes EXECUTE.
-int smsut_conv2d_mfma_form(int N, int H, int W, int Kdim, int Ndim, int sc_dgrad) {
-  if (N <= 0 || H <= 0 || W <= 0 || !fwd_any_eligible(N, H, W, Kdim, Ndim, false)) return 0;
-  const bool sc2_64 = sc_dgrad && Kdim == 64 && fwd_p_eligible(N, H, W, Kdim, Ndim);
-  if (!sc2_64 && wino_l_shape(N, H, W, Kdim, Ndim)) return 2;
-  if (Ndim == 8 || Kdim == 8) return 0;
-  static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
-  return (use_wino && H % 16 == 0 && (Kdim == 16 || Kdim == 32) && fwd_p_eligible(N, H, W, Kdim, Ndim)) ? 1 : 0;
-}
-
 int smsut_conv2d_dgrad_sc_supported(int N, int H, int W, int Cout, int Cin, int split) {
   static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_DGRAD"); return !e || atoi(e) != 0; }();
   if (!on || N <= 0 || H <= 0 || W <= 0 || !(Cout == 16 || Cout == 32)) return 0;
@@ -2602,6 +2610,20 @@ int smsut_conv2d_dgrad_mfma_sc(const float* gy, const float* gs, const float* w,
   return SMSUT_OK;
 }
 
+// Which arithmetic a 3x3 stride-1 fp32 conv call (forward or data-gradient, any fused form) runs for this shape: 0 = direct
+// products (36 per 2x2 output tile and channel pair), 1 = Winograd F(2x2,3x3) with resident weights (conv_mfma_fwd_p<..,WINO>),
+// 2 = Winograd with streamed weights (conv_wino_l) -- 16 products per tile.  Mirrors select_fwd_p / dispatch_fwd; sc_dgrad = the
+// fused shortcut data-gradient (Kdim = 2 Cout).  bench.py / profiling.py use it to report the FLOPs the matrix pipes EXECUTE.
+int smsut_conv2d_mfma_form(int N, int H, int W, int Kdim, int Ndim, int sc_dgrad) {
+  if (N <= 0 || H <= 0 || W <= 0 || !fwd_any_eligible(N, H, W, Kdim, Ndim, false)) return 0;
+  const bool sc2_64 = sc_dgrad && Kdim == 64 && fwd_p_eligible(N, H, W, Kdim, Ndim);
+  if (!sc2_64 && wino_l_shape(N, H, W, Kdim, Ndim)) return 2;
+  if (Ndim == 8 || Kdim == 8) return 0;
+  static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
+  return (use_wino && H % 16 == 0 && (Kdim == 16 || Kdim == 32) && fwd_p_eligible(N, H, W, Kdim, Ndim)) ? 1 : 0;
+}
+
+
 // Forward 3x3 conv + InstanceNorm partials (as smsut_conv2d_fwd_mfma_stats) of the virtual cat([xa, xb]) of two
 // [N,H,W,Kdim/2] tensors, read in place.  Persistent kernel, Kdim in {32, 64}: _supported says whether the shape is covered;
 // the statistics tiles are those of smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3).
@@ -2611,13 +2633,18 @@ int smsut_conv2d_mfma_cat_supported(int N, int H, int W, int Kdim, int Ndim) {
          (int64_t)N * H * W * (Kdim > Ndim ? Kdim : Ndim) < (1ll << 31);
 }
 
-int smsut_conv2d_fwd_mfma_stats_cat(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
-                                    int W, int Kdim, int Ndim, void* stream) {
+int smsut_conv2d_fwd_mfma_stats_cat_pre(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
+                                        int W, int Kdim, int Ndim, const float* wu, void* stream) {
   SMSUT_REQUIRE(xa && xb && w && y && stats && smsut_conv2d_mfma_cat_supported(N, H, W, Kdim, Ndim));
-  const int rc = dispatch_fwd<3>(xa, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, (hipStream_t)stream, stats, nullptr, xb);
+  const int rc = dispatch_fwd<3>(xa, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, (hipStream_t)stream, stats, nullptr, xb, nullptr, 0, false,
+                                 nullptr, wu);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats_cat(const float* xa, const float* xb, const float* w, float* y, float* stats, int N, int H,
+                                    int W, int Kdim, int Ndim, void* stream) {
+  return smsut_conv2d_fwd_mfma_stats_cat_pre(xa, xb, w, y, stats, N, H, W, Kdim, Ndim, nullptr, stream);
 }
 
 // 3x3 conv (any `transposed` form of smsut_conv2d_fwd_mfma) whose result channels [0, split) go to ya [N,H,W,split] and
@@ -2631,15 +2658,19 @@ int smsut_conv2d_mfma_split_supported(int N, int H, int W, int Kdim, int Ndim, i
   return 1;          // a persistent variant that cannot split at `split` declines and the per-tile kernel takes over
 }
 
-int smsut_conv2d_fwd_mfma_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int H, int W,
-                                int Kdim, int Ndim, int transposed, void* stream) {
+int smsut_conv2d_fwd_mfma_split_pre(const float* x, const float* w, float* ya, float* yb, int split, int N, int H, int W,
+                                    int Kdim, int Ndim, int transposed, const float* wu, void* stream) {
   SMSUT_REQUIRE(x && w && ya && yb && N > 0 && H > 0 && W > 0 && (transposed & ~3) == 0);
   SMSUT_REQUIRE(smsut_conv2d_mfma_split_supported(N, H, W, Kdim, Ndim, split));
   const int rc = dispatch_fwd<3>(x, w, ya, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, (hipStream_t)stream, nullptr, nullptr,
-                                 nullptr, yb, split);
+                                 nullptr, yb, split, false, nullptr, wu);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_split(const float* x, const float* w, float* ya, float* yb, int split, int N, int H, int W,
+                                int Kdim, int Ndim, int transposed, void* stream) {
+  return smsut_conv2d_fwd_mfma_split_pre(x, w, ya, yb, split, N, H, W, Kdim, Ndim, transposed, nullptr, stream);
 }
 
 // ConvTranspose2d(k=2, s=2, bias=False) (network/blocks.py:41), weights [kh][kw][Cin][Cout]:
@@ -2682,31 +2713,41 @@ int smsut_conv2d_mfma_persistent(int N, int H, int W, int Kdim, int Ndim, int KS
   return KS == 3 && fwd_any_eligible(N, H, W, Kdim, Ndim, f16 != 0) ? 1 : 0;
 }
 
-int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
-                                int Ndim, int KS, void* stream) {
+int smsut_conv2d_fwd_mfma_stats_pre(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
+                                    int Ndim, int KS, const float* wu, void* stream) {
   SMSUT_REQUIRE(x && w && y && stats && N > 0 && H > 0 && W > 0);
   SMSUT_REQUIRE(smsut_conv2d_mfma_supported(KS, 1, (KS - 1) / 2, Kdim, Ndim));
   hipStream_t st = (hipStream_t)stream;
   if (KS == 1) dispatch_fwd<1>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats);
-  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats);
+  else dispatch_fwd<3>(x, w, y, N, H, W, Kdim, Ndim, 0, 1, 1, 1, 1, st, stats, nullptr, nullptr, nullptr, 0, false, nullptr, wu);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats(const float* x, const float* w, float* y, float* stats, int N, int H, int W, int Kdim,
+                                int Ndim, int KS, void* stream) {
+  return smsut_conv2d_fwd_mfma_stats_pre(x, w, y, stats, N, H, W, Kdim, Ndim, KS, nullptr, stream);
 }
 
 // Data-gradient of a 3x3 conv whose input was a = LeakyReLU(IN(y1)) (conv2 of a BasicBlock): writes gz = g * mask(y1) and the
 // per-tile partials {sum gz, sum gz * xhat} [N][tiles][Ndim][2] of the InstanceNorm backward (tiles =
 // smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3)).  Only where smsut_conv2d_mfma_persistent(...) == 1; -1 otherwise.
-int smsut_conv2d_dgrad_mfma_bwdstats(const float* gy, const float* w, float* gz, float* stats, const float* y1,
-                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
-                                     float slope, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+int smsut_conv2d_dgrad_mfma_bwdstats_pre(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                         const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                         float slope, int N, int H, int W, int Kdim, int Ndim, const float* wu, void* stream) {
   SMSUT_REQUIRE(gy && w && gz && stats && y1 && mean && rstd && gamma && beta && N > 0 && H > 0 && W > 0);
   SMSUT_REQUIRE(fwd_any_eligible(N, H, W, Kdim, Ndim, false));
   const BstRef b{y1, mean, rstd, gamma, beta, slope};
   hipStream_t st = (hipStream_t)stream;
-  const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b);
+  const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, st, stats, nullptr, &b, nullptr, 0, nullptr, nullptr, false, nullptr,
+                              nullptr, wu);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_conv2d_dgrad_mfma_bwdstats(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                     const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                     float slope, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  return smsut_conv2d_dgrad_mfma_bwdstats_pre(gy, w, gz, stats, y1, mean, rstd, gamma, beta, slope, N, H, W, Kdim, Ndim, nullptr, stream);
 }
 
 int smsut_conv2d_fwd_mfma_cfg(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,

@@ -13,10 +13,12 @@ bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim);
 // ADDED to what y holds.  x2: the input is the virtual cat([x, x2]) of two Kdim/2-channel tensors; with sc->w and bit 0 set it is
 // the fused shortcut data-gradient instead (second half = the shortcut's gradient, 1x1 weights sc->w).  sc (forward): fused 1x1
 // shortcut conv (sc->w, result sc->y, InstanceNorm partials sc->stats).  y2 / split: split output.  tiles_out: only report the
-// statistics tiles per image.  Returns 0 when launched (or reported), -1 when the form is not covered (nothing launched).
+// statistics tiles per image.  wu: the caller's prepared image of w for THIS form (smsut_wino_prepare with the same Kdim, Ndim and
+// transposed bit 0) or null = transform the weights on the fly; the library keeps no table of images (r03 did: SURVEY 8b rules
+// process-wide mutable state out).  Returns 0 when launched (or reported), -1 when the form is not covered (nothing launched).
 int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W,
                         int Kdim, int Ndim, int transposed, float* stats, int* tiles_out, const WinoBst* bst, const WinoAff* aff,
-                        const WinoSc* sc, hipStream_t st);
+                        const WinoSc* sc, hipStream_t st, const float* wu = nullptr);
 
 // ---- Winograd weight gradient F(3x3, 2x2): gw[3][3][Cin][Cout] = sum_p x[p + tap] (x) gy[p] through
 //      dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G  (16 products per 2x2 tile of gy instead of 36).

@@ -36,7 +36,6 @@
 #include <stdlib.h>
 #include <mutex>
 #include <type_traits>
-#include <unordered_map>
 
 namespace {
 
@@ -803,16 +802,6 @@ __global__ void __launch_bounds__(TPB) wino_u_prepare(PrepTable t) {
   for (int pos = 0; pos < 16; ++pos) out[(size_t)pos * 64] = make_float4(uu[0][pos], uu[1][pos], uu[2][pos], uu[3][pos]);
 }
 
-struct BoundU { const float* u; int kd, nd; };
-std::mutex g_bind_mu;
-std::unordered_map<uintptr_t, BoundU> g_bound;           // key: weight address * 2 + transposed
-inline const float* bound_image(const float* w, int tr, int kd, int nd) {
-  std::lock_guard<std::mutex> lk(g_bind_mu);
-  if (g_bound.empty()) return nullptr;
-  auto it = g_bound.find((uintptr_t)w * 2 + (uintptr_t)(tr & 1));
-  return (it != g_bound.end() && it->second.kd == kd && it->second.nd == nd) ? it->second.u : nullptr;
-}
-
 inline int device_cus() {
   static const int cus = [] {
     int dev = 0, n = 256;
@@ -824,11 +813,10 @@ inline int device_cus() {
 
 template <auto Kern>
 inline void allow_big_lds(size_t bytes) {
-  static bool done = false;
-  if (!done && bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    done = true;
-  }
+  // once per instantiation, safe when forward and autograd's backward thread arrive together (r03 had a plain flag here)
+  static std::once_flag once;
+  if (bytes > 64 * 1024)
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
 }
 
 template <int NTN>
@@ -1243,7 +1231,7 @@ bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim) {
 
 int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W,
                         int Kdim, int Ndim, int transposed, float* stats, int* tiles_out, const WinoBst* bst, const WinoAff* aff,
-                        const WinoSc* sc, hipStream_t st) {
+                        const WinoSc* sc, hipStream_t st, const float* wu_in) {
   if (!smsut_wino_l_eligible(N, H, W, Kdim, Ndim)) return -1;
   if (y2 && (split <= 0 || split >= Ndim || split % 16 != 0 || (Ndim - split) % 16 != 0 || stats || bst)) return -1;
   if (tiles_out) { *tiles_out = (W / TW) * (H / TH); return 0; }
@@ -1253,9 +1241,9 @@ int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* 
   const int64_t items = (int64_t)N * (W / TW) * (H / TH);
   int ntn = (Ndim % 32 == 0 && !(y2 && split % 32 != 0) && items * (Ndim / 32) >= device_cus()) ? 2 : 1;
   if (force == 1 || (force == 2 && Ndim % 32 == 0 && !(y2 && split % 32 != 0))) ntn = force;
-  // prepared weights (smsut_wino_prepare + smsut_wino_bind by the caller): copied by LDS-DMA instead of transformed per chunk
+  // prepared weights (smsut_wino_prepare by the caller, passed with the call): copied by LDS-DMA instead of transformed per chunk
   const bool sc2 = sc && (transposed & 1);
-  const float* wu = sc2 ? nullptr : bound_image(w, transposed & 1, Kdim, Ndim);
+  const float* wu = sc2 ? nullptr : wu_in;
   if (ntn == 2) return launch_ntn<2>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
   return launch_ntn<1>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
 }
@@ -1282,34 +1270,6 @@ int smsut_wino_prepare(const float* const* w, float* const* u, const int* Kdim, 
     wino_u_prepare<<<blk, TPB, 0, (hipStream_t)stream>>>(t);
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
-}
-
-int smsut_wino_bind(const float* w, int transposed, const float* u, int Kdim, int Ndim) {
-  if (!w) return -1;
-  std::lock_guard<std::mutex> lk(g_bind_mu);
-  const uintptr_t key = (uintptr_t)w * 2 + (uintptr_t)(transposed & 1);
-  if (!u) g_bound.erase(key);
-  else g_bound[key] = BoundU{u, Kdim, Ndim};
-  return 0;
-}
-
-int smsut_wino_bind_many(const float* const* w, const float* const* u, const int* Kdim, const int* Ndim, const int* transposed,
-                         int count) {
-  if (count < 0 || (count > 0 && (!w || !transposed || (u && (!Kdim || !Ndim))))) return -1;
-  std::lock_guard<std::mutex> lk(g_bind_mu);
-  for (int i = 0; i < count; ++i) {
-    if (!w[i]) return -1;
-    const uintptr_t key = (uintptr_t)w[i] * 2 + (uintptr_t)(transposed[i] & 1);
-    if (!u || !u[i]) g_bound.erase(key);
-    else g_bound[key] = BoundU{u[i], Kdim[i], Ndim[i]};
-  }
-  return 0;
-}
-
-int smsut_wino_unbind_all(void) {
-  std::lock_guard<std::mutex> lk(g_bind_mu);
-  g_bound.clear();
-  return 0;
 }
 
 }  // extern "C"

@@ -75,7 +75,10 @@ class GraphedPhase:
                  grad_params: Iterable[torch.nn.Parameter], warmup: int = 2,
                  rebind_params: Iterable[torch.nn.Parameter] = ()):
         global _CAPTURING
-        self.fn = fn
+        # ``fn`` (normally a bound method of the trainer that owns this object) is used for the warm-up and the capture only and
+        # is NOT kept: trainer -> GraphedPhase -> fn -> trainer was a reference cycle, so a trainer's graph execs were freed only
+        # by the cyclic collector, at a moment nobody chose (r03: an abort when that moment fell into another capture).  Without
+        # the cycle, ``del trainer`` (or ``trainer.close()``) frees them right there.
         self.params = list(grad_params)
         self.static_in = [t.detach().clone() for t in example_inputs]
         if warmup:
@@ -92,10 +95,10 @@ class GraphedPhase:
         # under torch.distributed the RCCL watchdog thread polls events while we capture: with the default "global" error
         # mode any such call from ANOTHER thread can invalidate the capture; "thread_local" polices this thread only
         mode = "thread_local" if (torch.distributed.is_available() and torch.distributed.is_initialized()) else "global"
-        # The cyclic garbage collector must not run while a capture records: it may finalise an OLDER trainer's graphs / streams /
-        # events (trainer <-> GraphedPhase.fn is a reference cycle, so only the collector frees them), and destroying a graph
-        # exec while another stream captures aborts the process (seen once in the full test suite, inside this constructor).
-        # torch.cuda.graph() collects once on entry; from there to the end of the capture the collector stays off.
+        # The cyclic garbage collector must not run while a capture records: it may finalise someone else's graphs / streams /
+        # events, and destroying a graph exec while another stream captures aborts the process (seen once in r03's full test
+        # suite, inside this constructor; this package's own phases no longer depend on the collector -- see above -- but user
+        # objects may).  torch.cuda.graph() collects once on entry; from there to the end of the capture the collector stays off.
         import gc
         gc_was_on = gc.isenabled()
         gc.collect()
@@ -108,21 +111,22 @@ class GraphedPhase:
             _CAPTURING -= 1
             if gc_was_on:
                 gc.enable()
-        seen, self._bound = set(), []
+        seen, self._bound, self._gmap = set(), [], {}
         for p in list(self.params) + list(rebind_params):
             if id(p) not in seen and p.grad is not None:
                 seen.add(id(p))
                 self._bound.append((p, p.grad))
-        # this capture re-pointed the .grad of its parameters: older graphs that bound the same parameters re-install
-        # their own buffers before their next replay (and mark this one in turn)
+                self._gmap[id(p)] = p.grad
+        # this capture re-pointed the .grad of its parameters: older graphs that bound a DIFFERENT tensor to one of them
+        # re-install their own buffers before their next replay (and mark this one in turn)
         self._dirty = False
+        self._ids = seen
         for r in list(_LIVE):
             g = r()
             if g is None:
                 _LIVE.remove(r)
-            elif seen & g._ids:
+            elif self._conflicts(g):
                 g._dirty = True
-        self._ids = seen
         _LIVE.append(weakref.ref(self))
         self.graph.replay()          # capture records without executing: run it once so static_out holds real values
 
@@ -130,16 +134,53 @@ class GraphedPhase:
         for p in self.params:
             p.grad = None
 
+    def _conflicts(self, other) -> bool:
+        """True when installing THIS phase's gradient tensors re-points a parameter ``other`` writes through another tensor.
+        Phases that recorded the SAME tensor for every shared parameter (G2a1 / G2a2 / G2c accumulate into one buffer) leave each
+        other alone -- ADVICE r03: marking on shared ids alone never settled, every replay re-assigned every .grad."""
+        return any(other._gmap[i] is not self._gmap[i] for i in (self._ids & other._ids))
+
+    def close(self):
+        """Free the graph exec and its pool NOW (idempotent).  Never inside a capture: destroying an exec while a stream records
+        aborts the process."""
+        if getattr(self, "graph", None) is None:
+            return
+        if capturing():
+            raise RuntimeError("GraphedPhase.close() inside a hipGraph capture")
+        torch.cuda.synchronize()
+        self.graph.reset()
+        self.graph = None
+        self.static_in = self.static_out = None
+        self._bound, self._gmap, self.params, self._ids = [], {}, [], set()
+        for r in list(_LIVE):
+            if r() is self or r() is None:
+                _LIVE.remove(r)
+
     def __call__(self, *inputs: torch.Tensor) -> torch.Tensor:
         if self._dirty:
             for p, g in self._bound:
                 p.grad = g
             self._dirty = False
-            for r in _LIVE:                              # ... which un-binds every other graph over the same parameters
+            for r in _LIVE:                              # ... which un-binds every graph that bound OTHER tensors to them
                 o = r()
-                if o is not None and o is not self and (self._ids & o._ids):
+                if o is not None and o is not self and self._conflicts(o):
                     o._dirty = True
         for s, i in zip(self.static_in, inputs):
             s.copy_(i, non_blocking=True)
         self.graph.replay()
         return self.static_out
+
+
+def close_all(phases) -> int:
+    """``close()`` every GraphedPhase in ``phases`` (a dict's values, a list, nested tuples) and return how many were open -- what
+    ``BaseTrainer.close()`` calls; outside any capture."""
+    n = 0
+    stack = list(phases.values()) if isinstance(phases, dict) else list(phases)
+    while stack:
+        o = stack.pop()
+        if isinstance(o, GraphedPhase):
+            n += o.graph is not None
+            o.close()
+        elif isinstance(o, (tuple, list)):
+            stack.extend(o)
+    return n

@@ -176,13 +176,27 @@ def conv_dtype() -> str:
 
 # ------------------------------------------------------------------------------------------- prepared Winograd weights
 # The large-reduction Winograd kernel (csrc/conv_wino.hip, reductions >= 64 channels) transforms its weights U = G g G^T per
-# workgroup and chunk -- about a tenth of its time -- unless a prepared image of the weight tensor is BOUND (smsut_wino_prepare /
-# smsut_wino_bind_many): then it copies the image by LDS-DMA.  An image is only right while the weights it was made from are
+# workgroup and chunk -- about a tenth of its time -- unless a prepared image of the weight tensor comes WITH THE CALL (smsut_wino_prepare,
+# passed with the call): then it copies the image by LDS-DMA.  An image is only right while the weights it was made from are
 # unchanged, so images are made on entry of a scope in which the caller guarantees exactly that (a trainer's forward / backward
-# phase: weights change in optimizer.step(), between phases) and their bindings are dropped when it closes; a module called
+# phase: weights change in optimizer.step(), between phases) and forgotten when it closes; a module called
 # outside such a scope runs the on-the-fly form.  Results are bit-identical either way.  ``SMSUT_WINO_PREPARED=0`` turns the scopes into no-ops.
 WINO_PREPARED = _os.environ.get("SMSUT_WINO_PREPARED", "1") not in ("0", "")
 _WINO_MIN_K = 64
+# Images in force: (weight data_ptr, form 0 forward / 1 data-gradient) -> device address.  HOST-side state of this wrapper, filled
+# and emptied by the ``wino_prepared`` scopes; the C-ABI library keeps none (r03's smsut_wino_bind* registry is gone): the image
+# travels as an argument of the `_pre` entry points.
+_WINO_ACTIVE = {}
+
+
+def _conv3(name, w, transposed, *args):
+    """``H.call(name, *args)`` for a conv entry point that may run the streamed-weight Winograd kernel -- through its ``_pre`` form,
+    with the prepared image of ``w`` for this form as the argument before the stream, when an enclosing ``wino_prepared`` scope
+    holds one (fp32 entry points only).  ``args[-1]`` is the stream."""
+    wu = _WINO_ACTIVE.get((w.data_ptr(), transposed & 1)) if (_WINO_ACTIVE and not name.endswith("_f16")) else None
+    if wu is None:
+        return H.call(name, *args)
+    return H.call(name + "_pre", *args[:-1], wu, args[-1])
 
 
 class _WinoForm:
@@ -204,6 +218,8 @@ class _WinoForm:
         self._keep = (PA(*[w.data_ptr() for w in self.weights]), PA(*[base + 4 * o for o in offs]), IA(*[e[2] for e in ent]),
                       IA(*[e[3] for e in ent]), IA(*[e[1] for e in ent]))
         self._addr = tuple(ctypes.addressof(a) for a in self._keep)
+        # (weight address, form) -> device address of its image: what _conv3 passes to the `_pre` entry points inside a scope
+        self._entries = [((w.data_ptr(), e[1]), base + 4 * o) for w, e, o in zip(self.weights, ent, offs)]
 
     def enter(self):
         if self.n == 0:
@@ -212,12 +228,12 @@ class _WinoForm:
         # contents -- the fused optimizers (torch.optim.SGD / Adam(fused=True), what the trainers use) update in place without
         # moving it, and so does anything that writes through ``.data``
         H.call("smsut_wino_prepare", *self._addr, self.n, _s())
-        H.call("smsut_wino_bind_many", *self._addr, self.n)
+        for key, addr in self._entries:
+            _WINO_ACTIVE[key] = addr
 
     def exit(self):
-        if self.n:
-            a = self._addr
-            H.call("smsut_wino_bind_many", a[0], None, a[2], a[3], a[4], self.n)
+        for key, _ in (self._entries if self.n else ()):
+            _WINO_ACTIVE.pop(key, None)
 
 
 class _WinoSet:
@@ -325,14 +341,14 @@ def _conv_fwd_launch(x, w, bias, stride, pad, want_stats=False, f16=False):
             # instnorm_act picks up from the tensor object (side channel; autograd is unaffected)
             tiles = H.call("smsut_conv2d_mfma_tiles", n, h, wd, ci, co, kh, int(f16))
             part = _ws(n * tiles * co * 2, x)
-            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", x, w, y, part, n, h, wd, ci, co,
+            _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w, 0, x, w, y, part, n, h, wd, ci, co,
                    kh, _s())
             y._smsut_in_partials = (part, tiles)
             return y
         if f16:
             H.call("smsut_conv2d_fwd_mfma_f16", x, w, y, None, n, h, wd, ci, co, kh, 0, _s())
         else:
-            H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, wd, ci, co, kh, 0, _s())
+            _conv3("smsut_conv2d_fwd_mfma", w, 0, x, w, y, n, h, wd, ci, co, kh, 0, _s())
         if bias is not None:
             H.call("smsut_bias_add", y, bias, y, n * ho * wo, co, _s())
     elif (kh == 4 and kw == 4 and stride == 1 and pad == 1 and not FORCE_GENERIC_CONV
@@ -364,7 +380,7 @@ def _conv_dgrad_launch(gy, w, h, wd, stride, pad, f16=False):
         if f16 and H.call("smsut_conv2d_f16_supported", kh, co, ci):
             H.call("smsut_conv2d_fwd_mfma_f16", gy, w, gx, _grad_scale(gy), n, h, wd, co, ci, kh, 1, _s())
         else:
-            H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
+            _conv3("smsut_conv2d_fwd_mfma", w, 1, gy, w, gx, n, h, wd, co, ci, kh, 1, _s())
     elif (kh == 4 and kw == 4 and stride == 1 and pad == 1 and not FORCE_GENERIC_CONV
           and H.call("smsut_conv2d_k4_supported", ci, co)):
         H.call("smsut_conv2d_k4_fwd", gy, w, gx, n, h, wd, ci, co, 1, _s())
@@ -812,13 +828,13 @@ class BasicBlockFn(Function):
         if fused_sc:
             s = new_act(n, co, h, w, x)
             ps, t1 = _ws(n * t3 * co * 2, x), t3
-            H.call("smsut_conv2d_fwd_mfma_stats_sc", xa if virtual else x, xb if virtual else None, w1, ws, y1, s, p1, ps,
+            _conv3("smsut_conv2d_fwd_mfma_stats_sc", w1, 0, xa if virtual else x, xb if virtual else None, w1, ws, y1, s, p1, ps,
                    n, h, w, ci, co, st)
         elif virtual:
-            H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w1, y1, p1, n, h, w,
+            _conv3("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_cat", w1, 0, xa, xb, w1, y1, p1, n, h, w,
                    ci, co, st)
         else:
-            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16a else "smsut_conv2d_fwd_mfma_stats", x, w1, y1, p1, n, h, w, ci, co, 3, st)
+            _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16a else "smsut_conv2d_fwd_mfma_stats", w1, 0, x, w1, y1, p1, n, h, w, ci, co, 3, st)
         m1, r1 = stat(co)
         y2 = new_act(n, co, h, w, x)
         p2 = _ws(n * t3b * co * 2, x)
@@ -829,11 +845,11 @@ class BasicBlockFn(Function):
             # conv2 (and later its weight gradient) normalise the raw conv1 output while staging their tiles: a1 is never built
             a1 = None
             H.call("smsut_in_finalize_fwd", p1, t3, m1, r1, n, hw, co, IN_EPS, st)
-            H.call("smsut_conv2d_fwd_mfma_stats_inaff", y1, w2, y2, p2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+            _conv3("smsut_conv2d_fwd_mfma_stats_inaff", w2, 0, y1, w2, y2, p2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
         else:
             a1 = new_act(n, co, h, w, x)
             H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
-            H.call("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", a1, w2, y2, p2, n, h, w, co, co, 3, st)
+            _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w2, 0, a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
         H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
         if fused_sc:
@@ -920,14 +936,14 @@ class BasicBlockFn(Function):
             if f16:
                 H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, sc2, slope, n, h, w, co, co, st)
             else:
-                H.call("smsut_conv2d_dgrad_mfma_bwdstats", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+                _conv3("smsut_conv2d_dgrad_mfma_bwdstats", w2, 1, gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
             H.call("smsut_in_finalize_bwd", pb, tb, a1m, b1m, n, hw, co, st)
             H.call("smsut_in_apply_bwd", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, n, hw, co, st)
         else:
             if f16:
                 H.call("smsut_conv2d_fwd_mfma_f16", gy2, w2, ga1, sc2, n, h, w, co, co, 3, 1, st)
             else:
-                H.call("smsut_conv2d_fwd_mfma", gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
+                _conv3("smsut_conv2d_fwd_mfma", w2, 1, gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
             H.call("smsut_instnorm_bwd", ga1, y1, b1, m1, r1, g1, gy1, a1m, b1m, gg1, gb1, _ws(n * chunks * co * 3, x),
                    n, hw, co, slope, st)
         gw2 = new_weight(co, co, 3, 3, device=dev)
@@ -994,7 +1010,7 @@ class BasicBlockFn(Function):
                     if f16a:
                         H.call("smsut_conv2d_fwd_mfma_split_f16", gy1, w1, ga, gb, sc1, ca, n, h, w, co, ci, 3, st)
                     else:
-                        H.call("smsut_conv2d_fwd_mfma_split", gy1, w1, ga, gb, ca, n, h, w, co, ci, 3, st)
+                        _conv3("smsut_conv2d_fwd_mfma_split", w1, 1, gy1, w1, ga, gb, ca, n, h, w, co, ci, 3, st)
                 else:
                     gx = new_act(n, ci, h, w, x)
                     if H.call("smsut_conv1x1_supported", co, ci):
@@ -1004,7 +1020,7 @@ class BasicBlockFn(Function):
                     if f16a:
                         H.call("smsut_conv2d_fwd_mfma_f16", gy1, w1, gx, sc1, n, h, w, co, ci, 3, 3, st)
                     else:
-                        H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
+                        _conv3("smsut_conv2d_fwd_mfma", w1, 1, gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
                     H.call("smsut_concat2", ga, ca, gb, cb, gx, n * hw, 1, st)
             return None, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, ga, gb
         if ctx.needs_input_grad[0]:
@@ -1025,7 +1041,7 @@ class BasicBlockFn(Function):
             if f16a:
                 H.call("smsut_conv2d_fwd_mfma_f16", gy1, w1, gx, sc1, n, h, w, co, ci, 3, 3, st)
             else:
-                H.call("smsut_conv2d_fwd_mfma", gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
+                _conv3("smsut_conv2d_fwd_mfma", w1, 1, gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
         return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
 
 

@@ -88,6 +88,11 @@ _FORM: Dict[str, Tuple[Callable[[List[int]], Tuple[int, int, int, int, int, int]
 }
 
 
+def _base(name: str) -> str:
+    """`_pre` entry points (same call + the caller's prepared Winograd image) count as the entry point they extend."""
+    return name[:-4] if name.endswith("_pre") else name
+
+
 def _ints(name: str, conv_args) -> List[int]:
     sig = H.SIGNATURES[name].replace(" ", "")
     return [a for c, a in zip(sig, conv_args) if c in "il"]
@@ -95,7 +100,7 @@ def _ints(name: str, conv_args) -> List[int]:
 
 def executed_factor(name: str, conv_args) -> float:
     """Share of a call's algorithmic conv FLOPs that the matrix pipes execute (1.0 unless a Winograd form takes the shape)."""
-    ent = _FORM.get(name)
+    ent = _FORM.get(_base(name))
     if ent is None:
         return 1.0
     q = ent[0](_ints(name, conv_args))
@@ -106,7 +111,7 @@ def executed_factor(name: str, conv_args) -> float:
 
 def conv_flops_of(name: str, conv_args) -> float:
     """Algorithmic FLOPs of one recorded call (0 for non-conv entry points)."""
-    ent = _CONV_FLOPS.get(name)
+    ent = _CONV_FLOPS.get(_base(name))
     if ent is None:
         return 0.0
     sig = H.SIGNATURES[name].replace(" ", "")
@@ -140,8 +145,6 @@ def record_step(step: Callable[[], object]):
     return rec
 
 
-_HOST_ONLY = {"smsut_wino_bind_many", "smsut_wino_bind", "smsut_wino_unbind_all"}      # registry calls: no device work
-
 
 def replay(rec, reps: int = 8) -> List[Row]:
     """Replay each distinct (entry point, non-pointer arguments) ``reps`` times between HIP events."""
@@ -153,17 +156,12 @@ def replay(rec, reps: int = 8) -> List[Row]:
         groups.setdefault(key, []).append(conv)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     st = torch.cuda.current_stream()
-    # every prepared-weight binding the recorded step made (ops.wino_prepared scopes) is in force during the replay, so that the
-    # convolutions run the form they ran in the step (timing only: the images may be one optimizer step old); dropped at the end
-    for name, conv in rec:
-        if name == "smsut_wino_bind_many" and conv[1]:
-            getattr(lib, name)(*conv)
+    # (`_pre` calls carry their prepared Winograd image as an argument: the replay runs the form the step ran; the image memory
+    #  belongs to the module's ``_smsut_wino_set`` and may be one optimizer step old -- timing only)
     rows = []
     for (name, shp), calls in groups.items():
         conv = list(calls[0])
         fn = getattr(lib, name)
-        if name in _HOST_ONLY:
-            continue
         conv[-1] = st.cuda_stream                        # the recorded stream may have been a capture stream
         for _ in range(2):
             fn(*conv)
@@ -175,7 +173,6 @@ def replay(rec, reps: int = 8) -> List[Row]:
         torch.cuda.synchronize()
         fl = conv_flops_of(name, calls[0])
         rows.append(Row(name, shp, len(calls), e0.elapsed_time(e1) / reps * 1e3, fl, fl * executed_factor(name, calls[0])))
-    lib.smsut_wino_unbind_all()
     return rows
 
 
@@ -184,7 +181,7 @@ def summarize(rows: List[Row], peak_tflops: float) -> dict:
     DEFINES (what the contract's ``achieved`` is made of); ``*_executed`` count the products the MFMA pipes actually run (Winograd
     forms: 16 / 36 of them) -- the figure to hold against the 157.3 TFLOP/s the pipes can do."""
     conv = [r for r in rows if r.flops > 0]
-    mfma = [r for r in conv if _CONV_FLOPS[r.name][1] == "mfma"]
+    mfma = [r for r in conv if _CONV_FLOPS[_base(r.name)][1] == "mfma"]
     t_all = sum(r.total_us for r in rows)
     t_conv = sum(r.total_us for r in conv)
     f_conv = sum(r.flops * r.calls for r in conv)

@@ -313,5 +313,24 @@ class BaseTrainer(abc.ABC):
         np.savetxt(pjoin(expr_root, "dice_matrix.csv"), mo, delimiter=",", fmt="%.6f")
         return mo
 
+    def close(self):
+        """Drop every captured phase of this trainer NOW, outside any capture (``graphs.GraphedPhase.close``): graph execs are
+        freed at a chosen moment, never by the cyclic collector in the middle of somebody else's capture.
+        The trainer stays usable: the next step captures again.  Returns the number of phases that were open."""
+        from .. import graphs
+        n = 0
+        g = self.__dict__.get("_graphs")
+        if isinstance(g, dict):
+            n += graphs.close_all(g)
+            g.clear()
+        g = self.__dict__.get("_graph")
+        if g is not None:
+            n += graphs.close_all([g])
+            self._graph = None
+        for k in ("_g1", "_g2", "_gx_d"):
+            if k in self.__dict__:
+                self.__dict__[k] = None
+        return n
+
     def poly_lr(self):
         return cfg.lr * (1.0 - self.iter / (cfg.max_epoch * cfg.num_iter_per_epoch)) ** 0.9

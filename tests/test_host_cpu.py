@@ -173,3 +173,92 @@ def test_wino_prepared_scope_is_inert_without_device_weights():
     with ops.wino_prepared(twin, blk, forms="f"):
         pass
     assert set(blk.state_dict()) == keys and set(twin.state_dict()) == keys
+
+
+def test_graphed_phases_hold_no_cycle_and_close_frees_them(monkeypatch):
+    """a trainer's captured phases must be freed at a chosen moment, not by the cyclic collector.  CPU stand-ins for
+    the CUDA graph objects (the ownership logic is host code): (1) GraphedPhase does not keep ``fn`` -- owner -> phase -> bound
+    method -> owner was the cycle -- so with the collector OFF ``del owner`` frees the phases and their graph objects right there;
+    (2) ``graphs.close_all`` / ``GraphedPhase.close`` reset every graph exactly once, are idempotent, and refuse to run inside a
+    capture; (3) phases that bound the SAME gradient tensor to a shared parameter do not mark each other dirty."""
+    import contextlib
+    import gc
+    import weakref
+    import pytest
+    import smsut_amd  # noqa: F401
+    from smsut_amd import graphs
+
+    resets = []
+
+    class FakeGraph:
+        def replay(self):
+            pass
+
+        def reset(self):
+            resets.append(id(self))
+
+    @contextlib.contextmanager
+    def fake_capture(g, capture_error_mode="global"):
+        yield
+    monkeypatch.setattr(torch.cuda, "CUDAGraph", FakeGraph)
+    monkeypatch.setattr(torch.cuda, "graph", fake_capture)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+
+    class Owner:
+        def __init__(self):
+            self.w = torch.nn.Parameter(torch.ones(3))
+            self.buf = None
+            self._graphs = {}
+
+        def phase_a(self, x):
+            if self.buf is None:
+                self.buf = torch.zeros(3)
+            self.w.grad = self.buf                       # both phases accumulate into ONE gradient tensor
+            self.buf += x
+            return x * 2
+
+        def phase_b(self, x):
+            self.w.grad = self.buf
+            self.buf += 2 * x
+            return x * 3
+
+    gc_was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        o = Owner()
+        x = torch.ones(3)
+        o._graphs["a"] = graphs.GraphedPhase(o.phase_a, (x,), [o.w], warmup=0)
+        o._graphs["b"] = graphs.GraphedPhase(o.phase_b, (x,), [], warmup=0, rebind_params=[o.w])
+        a, b = o._graphs["a"], o._graphs["b"]
+        assert not hasattr(a, "fn")
+        assert a._gmap[id(o.w)] is b._gmap[id(o.w)]
+        assert not a._dirty and not b._dirty              # (3) same tensor: the second capture did not un-bind the first
+        graphs.invalidate_grad_bindings()
+        assert a._dirty and b._dirty
+        a(x)                                             # re-installs its tensor; b holds the same one -> b needs no re-binding
+        assert not a._dirty
+        refs = [weakref.ref(o), weakref.ref(a), weakref.ref(b), weakref.ref(a.graph), weakref.ref(b.graph)]
+        del a, b
+        del o                                            # (1) collector off: only reference counting can have freed them
+        assert all(r() is None for r in refs), [r() for r in refs]
+
+        o = Owner()
+        o._graphs["a"] = graphs.GraphedPhase(o.phase_a, (x,), [o.w], warmup=0)
+        o._graphs["t"] = ("key", graphs.GraphedPhase(o.phase_b, (x,), [], warmup=0, rebind_params=[o.w]))
+        ga = o._graphs["a"].graph
+        n0 = len(resets)
+        graphs._CAPTURING += 1                           # (2) never inside a capture
+        try:
+            with pytest.raises(RuntimeError):
+                o._graphs["a"].close()
+        finally:
+            graphs._CAPTURING -= 1
+        assert graphs.close_all(o._graphs) == 2 and len(resets) == n0 + 2 and id(ga) in resets
+        assert graphs.close_all(o._graphs) == 0 and len(resets) == n0 + 2        # idempotent
+        assert o._graphs["a"].graph is None and o._graphs["a"].static_out is None
+        assert not any(r() is o._graphs["a"] for r in graphs._LIVE)
+    finally:
+        if gc_was:
+            gc.enable()

@@ -32,7 +32,8 @@ def _dgrad64(gy, w):          # gradient of conv w.r.t. its input
 
 
 class _Prepared:
-    """smsut_wino_prepare + smsut_wino_bind_many for one weight tensor, both forms (the images are kept alive by the object)."""
+    """smsut_wino_prepare for one weight tensor, both forms; the images are kept alive by the object and PASSED to the `_pre` entry
+    points by ``_call`` (r04: the library keeps no table of images -- an image is an argument)."""
 
     def __init__(self, H, w, ci, co):
         import ctypes
@@ -42,20 +43,20 @@ class _Prepared:
         self.arr = (PA(w.data_ptr(), w.data_ptr()), PA(*[u.data_ptr() for u in self.u]), IA(ci, co), IA(co, ci), IA(0, 1))
         addr = [ctypes.addressof(a) for a in self.arr]
         H.call("smsut_wino_prepare", *addr, 2, H.stream_ptr())
-        H.call("smsut_wino_bind_many", *addr, 2)
-        self.H = H
 
-    def close(self):
-        self.H.call("smsut_wino_unbind_all")
+
+def _call(H, keep, name, tr, *args):
+    """the entry point, or -- with prepared images -- its `_pre` form with the image of this form (tr: 0 forward, 1 data-gradient)
+    as the argument in front of the stream"""
+    if keep is None:
+        return H.call(name, *args)
+    return H.call(name + "_pre", *args[:-1], keep.u[tr & 1], args[-1])
 
 
 @pytest.fixture(params=[False, True], ids=["on-the-fly", "prepared"])
 def prepared(request):
-    """every form test runs twice: weights transformed inside the kernel, and copied from a bound prepared image"""
-    yield request.param
-    import smsut_amd  # noqa: F401
-    from smsut_amd import _hip as H
-    H.call("smsut_wino_unbind_all")
+    """every form test runs twice: weights transformed inside the kernel, and copied from the caller's prepared image"""
+    return request.param
 
 
 def _rel(a, b):
@@ -71,11 +72,11 @@ def test_forward_datagrad_accumulate_statistics(n, h, ci, co, prepared):
     keep = _Prepared(H, w, ci, co) if prepared else None  # noqa: F841
     ref = _conv64(x, w)
     y = torch.full((n, h, h, co), float("nan"), device="cuda")
-    H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, h, ci, co, 3, 0, st)
+    _call(H, keep, "smsut_conv2d_fwd_mfma", 0, x, w, y, n, h, h, ci, co, 3, 0, st)
     assert _rel(y, ref) < 2e-6
     tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3, 0)
     ys, part = torch.full_like(y, float("nan")), torch.full((n * tiles * co * 2,), float("nan"), device="cuda")
-    H.call("smsut_conv2d_fwd_mfma_stats", x, w, ys, part, n, h, h, ci, co, 3, st)
+    _call(H, keep, "smsut_conv2d_fwd_mfma_stats", 0, x, w, ys, part, n, h, h, ci, co, 3, st)
     assert torch.equal(ys, y)                                     # same kernel, same order
     p = part.view(n, tiles, co, 2).double().sum(1)
     assert torch.allclose(p[..., 0], ys.double().sum((1, 2)), rtol=1e-5, atol=1e-3)
@@ -83,11 +84,11 @@ def test_forward_datagrad_accumulate_statistics(n, h, ci, co, prepared):
     gy = torch.randn(n, h, h, co, generator=g).cuda()
     refd = _dgrad64(gy, w)
     gx = torch.full((n, h, h, ci), float("nan"), device="cuda")
-    H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, h, co, ci, 3, 1, st)
+    _call(H, keep, "smsut_conv2d_fwd_mfma", 1, gy, w, gx, n, h, h, co, ci, 3, 1, st)
     assert _rel(gx, refd) < 2e-6
     base = torch.randn(n, h, h, ci, generator=g).cuda()
     acc = base.clone()
-    H.call("smsut_conv2d_fwd_mfma", gy, w, acc, n, h, h, co, ci, 3, 3, st)                 # accumulate form
+    _call(H, keep, "smsut_conv2d_fwd_mfma", 1, gy, w, acc, n, h, h, co, ci, 3, 3, st)                 # accumulate form
     assert _rel(acc, refd + base.double()) < 2e-6
 
 
@@ -110,7 +111,7 @@ def test_input_side_instnorm_and_bst_forms(n, h, c, prepared):
     ref = _conv64(a1, w)
     tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3, 0)
     y2, part = torch.full((n, h, h, c), float("nan"), device="cuda"), torch.zeros(n * tiles * c * 2, device="cuda")
-    H.call("smsut_conv2d_fwd_mfma_stats_inaff", y1, w, y2, part, mean.float().contiguous(), rstd.float().contiguous(), gam, bet, slope,
+    _call(H, keep, "smsut_conv2d_fwd_mfma_stats_inaff", 0, y1, w, y2, part, mean.float().contiguous(), rstd.float().contiguous(), gam, bet, slope,
            n, h, h, c, c, st)
     assert _rel(y2, ref) < 5e-6
     p = part.view(n, tiles, c, 2).double().sum(1)
@@ -121,7 +122,7 @@ def test_input_side_instnorm_and_bst_forms(n, h, c, prepared):
     mask = torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, slope))
     refz = _dgrad64(gy, w) * mask
     gz, pb = torch.full((n, h, h, c), float("nan"), device="cuda"), torch.zeros(n * tiles * c * 2, device="cuda")
-    H.call("smsut_conv2d_dgrad_mfma_bwdstats", gy, w, gz, pb, y1, mean.float().contiguous(), rstd.float().contiguous(), gam, bet, slope,
+    _call(H, keep, "smsut_conv2d_dgrad_mfma_bwdstats", 1, gy, w, gz, pb, y1, mean.float().contiguous(), rstd.float().contiguous(), gam, bet, slope,
            n, h, h, c, c, st)
     flips = (gz.double() - refz).abs() > 1e-4 * refz.abs().max()                    # (a pre-activation within rounding of 0 may flip)
     assert flips.float().mean() < 1e-4
@@ -146,19 +147,19 @@ def test_virtual_cat_split_and_fused_shortcut_forms(n, h, ci, co, prepared):
     ref = _conv64(x, w)
     tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3, 0)
     y, part = torch.full((n, h, h, co), float("nan"), device="cuda"), torch.zeros(n * tiles * co * 2, device="cuda")
-    H.call("smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y, part, n, h, h, ci, co, st)
+    _call(H, keep, "smsut_conv2d_fwd_mfma_stats_cat", 0, xa, xb, w, y, part, n, h, h, ci, co, st)
     assert _rel(y, ref) < 2e-6
     gy = torch.randn(n, h, h, co, generator=g).cuda()
     refd = _dgrad64(gy, w)
     ga, gb = torch.full((n, h, h, ca), float("nan"), device="cuda"), torch.full((n, h, h, ci - ca), float("nan"), device="cuda")
     assert H.call("smsut_conv2d_mfma_split_supported", n, h, h, co, ci, ca) == 1
-    H.call("smsut_conv2d_fwd_mfma_split", gy, w, ga, gb, ca, n, h, h, co, ci, 1, st)
+    _call(H, keep, "smsut_conv2d_fwd_mfma_split", 1, gy, w, ga, gb, ca, n, h, h, co, ci, 1, st)
     assert _rel(torch.cat([ga, gb], 3), refd) < 2e-6
     if H.call("smsut_conv2d_fwd_sc_supported", n, h, h, ci, co, 1):
         w1 = (torch.randn(ci, co, generator=g) / np.sqrt(ci)).cuda()
         y2, s2 = torch.full_like(y, float("nan")), torch.full_like(y, float("nan"))
         p2, q2 = torch.zeros_like(part), torch.zeros_like(part)
-        H.call("smsut_conv2d_fwd_mfma_stats_sc", xa, xb, w, w1, y2, s2, p2, q2, n, h, h, ci, co, st)
+        _call(H, keep, "smsut_conv2d_fwd_mfma_stats_sc", 0, xa, xb, w, w1, y2, s2, p2, q2, n, h, h, ci, co, st)
         assert torch.equal(y2, y)
         refs = (x.double().reshape(-1, ci) @ w1.double()).reshape(n, h, h, co)
         assert _rel(s2, refs) < 2e-6
@@ -173,37 +174,30 @@ def test_virtual_cat_split_and_fused_shortcut_forms(n, h, ci, co, prepared):
 
 
 @pytest.mark.parametrize("n,h,ci,co", [(3, 32, 64, 64), (2, 16, 256, 128), (5, 16, 96, 32), (2, 32, 128, 48)])
-def test_prepared_weights_are_bit_identical_and_scoped(n, h, ci, co):
-    """A bound prepared image gives the bits of the on-the-fly transform (same arithmetic, done once); a binding of other
-    dimensions or after smsut_wino_bind(..., NULL) is not used; stale images are the caller's business -- shown here on purpose:
-    the kernel really reads the image."""
+def test_prepared_weights_are_bit_identical_and_explicit(n, h, ci, co):
+    """A prepared image passed with the call gives the bits of the on-the-fly transform (same arithmetic, done once); the library
+    remembers nothing between calls (r04: no binding table) -- the plain entry point right after a `_pre` call transforms on the fly
+    again; a stale image is the caller's business -- shown here on purpose: the kernel really reads the image it is handed."""
     import smsut_amd  # noqa: F401
     from smsut_amd import _hip as H
     st = H.stream_ptr()
     g, x, w = _mk(n, h, ci, co, 21)
     gy = torch.randn(n, h, h, co, generator=g).cuda()
-    H.call("smsut_wino_unbind_all")
 
-    def run():
+    def run(keep):
         y, gx = torch.full((n, h, h, co), float("nan"), device="cuda"), torch.full((n, h, h, ci), float("nan"), device="cuda")
-        H.call("smsut_conv2d_fwd_mfma", x, w, y, n, h, h, ci, co, 3, 0, st)
-        H.call("smsut_conv2d_fwd_mfma", gy, w, gx, n, h, h, co, ci, 3, 1, st)
+        _call(H, keep, "smsut_conv2d_fwd_mfma", 0, x, w, y, n, h, h, ci, co, 3, 0, st)
+        _call(H, keep, "smsut_conv2d_fwd_mfma", 1, gy, w, gx, n, h, h, co, ci, 3, 1, st)
         return y, gx
-    y0, g0 = run()
+    y0, g0 = run(None)
     keep = _Prepared(H, w, ci, co)
-    y1, g1 = run()
+    y1, g1 = run(keep)
     assert torch.equal(y0, y1) and torch.equal(g0, g1)
     keep.u[0].mul_(2.0)                                    # the forward image no longer matches the weights ...
-    y2, g2 = run()
+    y2, g2 = run(keep)
     assert torch.equal(y2, 2.0 * y0) and torch.equal(g2, g0)   # ... and it is the image that is read (x2 is exact in fp32)
-    H.call("smsut_wino_bind", w, 0, None, 0, 0)            # unbind the forward form: back to the weights
-    y3, g3 = run()
+    y3, g3 = run(None)                                     # nothing was remembered: the plain entry points read the weights
     assert torch.equal(y3, y0) and torch.equal(g3, g0)
-    H.call("smsut_wino_bind", w, 0, keep.u[1], co, ci)     # an image of other dimensions under this key is ignored
-    if ci != co:
-        y4, _ = run()
-        assert torch.equal(y4, y0)
-    keep.close()
 
 
 def test_prepared_scope_in_a_training_step_is_bit_identical():
