@@ -321,6 +321,11 @@ int smsut_avgpool2_bwd(const float* gy, float* gx, int N, int H, int W, int C, v
  * zeros outside.  img [N,H,W], msk [N,H,W] (nullable), aff [N][6], ctrl nullable when P == 0. */
 int smsut_warp_joint(const float* img, const int64_t* msk, const float* aff, const float* ctrl, float* oimg,
                      int64_t* omsk, int N, int H, int W, int Ho, int Wo, int P, void* stream);
+/* JointElasticDeform's resampling (reference data_loader/externalTransforms.py:69-90 -> elasticdeform.deform_random_grid(order = [0, 0])):
+   coef [N][2][P][P] = cubic B-spline coefficients (mirror boundary) of the P x P control displacements (dy, dx), first / last control
+   point on the first / last pixel; image and label map sampled at (y + dy, x + dx) with order 0, constant 0 outside. */
+int smsut_elastic_deform(const float* img, const int64_t* msk, const float* coef, float* oimg, int64_t* omsk, int N, int H,
+                         int W, int P, void* stream);
 int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_bilinear2_bwd(const float* gy, float* gx, int N, int H, int W, int C, void* stream);
 /* networks.py building blocks of ResnetGenerator / NLayerDiscriminator: reflection / replication /

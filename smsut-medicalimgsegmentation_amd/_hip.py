@@ -133,6 +133,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_avgpool2_bwd": "pp iiii s",
     "smsut_bilinear2_fwd": "pp iiii s",
     "smsut_warp_joint": "pppppp iiiiii s",
+    "smsut_elastic_deform": "ppppp iiii s",
     "smsut_bilinear2_bwd": "pp iiii s",
     "smsut_window_fwd": "pp iiiiiiiii s",
     "smsut_window_bwd": "pp iiiiiiiii s",

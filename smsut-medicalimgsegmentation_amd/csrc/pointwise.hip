@@ -479,6 +479,63 @@ k_warp_joint(const float* __restrict__ img, const int64_t* __restrict__ msk, con
   }
 }
 
+// JointElasticDeform (reference data_loader/externalTransforms.py:69-90: elasticdeform.deform_random_grid([img, msk], sigma,
+// points = 3, order = [0, 0])), the resampling step: a P x P grid of control displacements (dy, dx), first / last control point
+// on the first / last pixel, interpolated to every pixel by CUBIC B-SPLINES -- `coef` holds the spline coefficients of the
+// control values (the caller prefilters them, mirror boundary: data_loader/gpu_augment.py::spline_prefilter) -- then image AND
+// label map are sampled at (y + dy, x + dx) with ORDER 0 (nearest, floor(c + 0.5)); a source coordinate below 0 or above size - 1
+// reads the constant 0 (mode 'constant', cval 0, the range test of the scipy interpolation code elasticdeform carries).
+__device__ __forceinline__ void bspline3(float t, float* w) {       // weights of the four taps floor(t) - 1 .. floor(t) + 2
+  const float f = t - floorf(t), g = 1.f - f;
+  w[0] = g * g * g * (1.f / 6.f);
+  w[1] = (4.f - 6.f * f * f + 3.f * f * f * f) * (1.f / 6.f);
+  w[2] = (4.f - 6.f * g * g + 3.f * g * g * g) * (1.f / 6.f);
+  w[3] = f * f * f * (1.f / 6.f);
+}
+__device__ __forceinline__ int mirror_idx(int i, int n) {           // whole-sample mirror: -1 -> 1, n -> n - 2 (n >= 2)
+  const int period = 2 * (n - 1);
+  i = i % period;
+  if (i < 0) i += period;
+  return i < n ? i : period - i;
+}
+__global__ void __launch_bounds__(TPB)
+k_elastic_nearest(const float* __restrict__ img, const int64_t* __restrict__ msk, const float* __restrict__ coef,
+                  float* __restrict__ oimg, int64_t* __restrict__ omsk, int N, int H, int W, int P) {
+  const int64_t total = (int64_t)N * H * W;
+  GRID_STRIDE(i, total) {
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int n = (int)(i / ((int64_t)W * H));
+    const float gy = (H > 1) ? y * (float)(P - 1) / (float)(H - 1) : 0.f;
+    const float gx = (W > 1) ? x * (float)(P - 1) / (float)(W - 1) : 0.f;
+    float wy[4], wx[4];
+    bspline3(gy, wy);
+    bspline3(gx, wx);
+    const int y0 = (int)floorf(gy) - 1, x0 = (int)floorf(gx) - 1;
+    const float* c = coef + (size_t)n * 2 * P * P;
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int iy = mirror_idx(y0 + a, P);
+      float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ix = mirror_idx(x0 + b, P);
+        r0 += wx[b] * c[iy * P + ix];
+        r1 += wx[b] * c[P * P + iy * P + ix];
+      }
+      d0 += wy[a] * r0;
+      d1 += wy[a] * r1;
+    }
+    const float ys = (float)y + d0, xs = (float)x + d1;
+    const bool in = ys >= 0.f && ys <= (float)(H - 1) && xs >= 0.f && xs <= (float)(W - 1);
+    const int ny = (int)floorf(ys + 0.5f), nx = (int)floorf(xs + 0.5f);
+    const size_t src = (size_t)n * H * W + (size_t)(in ? ny : 0) * W + (in ? nx : 0);
+    oimg[i] = in ? img[src] : 0.f;
+    if (msk) omsk[i] = in ? msk[src] : 0;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -567,6 +624,14 @@ int smsut_warp_joint(const float* img, const int64_t* msk, const float* aff, con
   SMSUT_REQUIRE(img && aff && oimg && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (P == 0 || (P >= 2 && ctrl)) &&
                 (!msk || omsk));
   k_warp_joint<<<ew_grid((int64_t)N * Ho * Wo), TPB, 0, ST>>>(img, msk, aff, ctrl, oimg, omsk, N, H, W, Ho, Wo, P);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+// JointElasticDeform's resampling (see k_elastic_nearest): img [N,H,W] fp32, msk [N,H,W] int64 (nullable), coef [N][2][P][P] cubic
+// B-spline coefficients of the control displacements (dy, dx) -> oimg, omsk [N,H,W] (must not alias the inputs).
+int smsut_elastic_deform(const float* img, const int64_t* msk, const float* coef, float* oimg, int64_t* omsk, int N, int H,
+                         int W, int P, void* stream) {
+  SMSUT_REQUIRE(img && coef && oimg && N > 0 && H > 0 && W > 0 && P >= 2 && (!msk || omsk) && oimg != img);
+  k_elastic_nearest<<<ew_grid((int64_t)N * H * W), TPB, 0, ST>>>(img, msk, coef, oimg, omsk, N, H, W, P);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
 int smsut_bilinear2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {

@@ -1,21 +1,58 @@
 """Joint geometric augmentation on the device: the reference runs JointRotate(+-15 deg),
 JointElasticDeform(sigma 9-13, 3x3 control points, p = 0.5) and JointRandomResizedCrop(size, scale 0.6-1.0,
-ratio 3/4-4/3) per slice in PIL worker processes (data_loader/externalTransforms.py:45-90, config.py:60-71); at
-thousands of slices per second per GPU that does not keep up, so the three are composed into ONE resampling pass per
-batch (``smsut_warp_joint``): output pixel -> crop window -> rotation about the image centre (+ elastic offset).
+ratio 3/4-4/3) per slice in PIL worker processes (data_loader/externalTransforms.py:45-90, config.py:60-71, order:
+baseLoader.py:92-98); at thousands of slices per second per GPU that does not keep up, so they run as device passes per batch.
+
+r04: the passes follow the reference's own structure.  When no slice of the batch drew the elastic deformation, rotation and crop
+are composed into ONE bilinear / nearest resampling (``smsut_warp_joint``; pinned to PIL's rotate -> crop + resize outputs,
+tests/golden/augment_pil.npz).  When one did, the batch takes the reference's three steps: rotate (bilinear image, nearest labels,
+values rounded to the 8-bit grid as PIL stores them), ``elasticdeform.deform_random_grid(order=[0, 0])`` restated
+(``smsut_elastic_deform``: cubic-B-spline interpolation of the P x P control displacements, ORDER-0 sampling of image AND labels,
+zeros outside -- slices that did not draw it carry zero displacements, an exact copy), crop + resize.  Out-of-image samples read 0 =
+black on the [0, 1] scale the passes run on (ToTensor's range; Normalize(0.5, 0.5) comes after, as in baseLoader.py:104-108).
 
 Parameter draws follow the reference's distributions (uniform angle; torchvision's RandomResizedCrop.get_params: up to
 10 tries of area ~ U(scale) * HW and log-uniform aspect ratio, central fallback; elastic control offsets ~ N(0, sigma)
-with sigma ~ U(sigmas), applied with probability p).  The resampling itself is NOT bit-identical to PIL + elasticdeform
-(single bilinear pass instead of three; bilinear instead of B-spline control-grid interpolation): parity for this row
-is against ``oracle/augment_oracle.py`` (a numpy restatement of the kernel's definition), not against the reference.
+with sigma ~ U(sigmas), applied with probability p).  ``elasticdeform`` is a third-party package that is not installed here (and
+not pinned by the reference): its published algorithm is restated (oracle/augment_oracle.py::elastic_deform_grid builds it from
+scipy.ndimage's spline routines, the code elasticdeform's C extension derives from); parity at that boundary is UNPINNED.
 """
 import math
 import random
 
+import numpy as np
 import torch
 
 from .. import _hip as H
+
+
+def spline_prefilter(ctrl):
+    """Cubic B-spline coefficients of control values along the last two axes, mirror boundary (what
+    ``scipy.ndimage.spline_filter1d(order=3, mode='mirror')`` computes along each axis, which is how elasticdeform's ``deform_grid``
+    prefilters its displacement grid): after it, the spline through the coefficients INTERPOLATES the control values.  Host side
+    (P x P values per slice); float64 inside.  ``ctrl`` [..., P, P] tensor -> same shape, float32."""
+    c = np.asarray(ctrl, dtype=np.float64).copy()
+    z = math.sqrt(3.0) - 2.0                                   # the pole of the cubic B-spline filter
+    for ax in (-2, -1):
+        c = np.moveaxis(c, ax, -1)
+        n = c.shape[-1]
+        if n > 1:
+            c = c * ((1.0 - z) * (1.0 - 1.0 / z))              # gain
+            # causal initialisation: sum over the mirrored signal, exact for short lines
+            zn = z ** (n - 1)
+            acc = c[..., 0] + zn * c[..., n - 1]
+            z1, z2 = z, zn * zn / z
+            for k in range(1, n - 1):
+                acc = acc + (z1 + z2) * c[..., k]
+                z1, z2 = z1 * z, z2 / z
+            c[..., 0] = acc / (1.0 - zn * zn)
+            for k in range(1, n):
+                c[..., k] = c[..., k] + z * c[..., k - 1]
+            c[..., n - 1] = (z / (z * z - 1.0)) * (c[..., n - 1] + z * c[..., n - 2])
+            for k in range(n - 2, -1, -1):
+                c[..., k] = z * (c[..., k + 1] - c[..., k])
+        c = np.moveaxis(c, -1, ax)
+    return torch.from_numpy(c.astype(np.float32))
 
 
 def resized_crop_params(height, width, scale=(0.6, 1.0), ratio=(3.0 / 4.0, 4.0 / 3.0)):
@@ -61,28 +98,57 @@ class GpuJointAugment:
         self.points = int(self.cfg.get("elasticDeform_points", 3))
 
     def draw(self, n, in_hw):
-        """Per-sample parameters (host RNG, reference draw order per sample: rotate, elastic, crop)."""
+        """Per-sample parameters (host RNG, reference draw order per sample: rotate, elastic, crop): (angles, crops, control
+        displacements [n, 2, P, P] or None when no slice drew the deformation, output size)."""
         H_, W_ = in_hw
         out_hw = (self.out, self.out) if self.out else in_hw
-        aff, ctrl, any_el = [], [], False
+        angs, crops, ctrl, any_el = [], [], [], False
         P = self.points
         for _ in range(n):
             ang = random.uniform(-self.cfg["rotate_degrees"], self.cfg["rotate_degrees"]) if self.cfg.get("rotate") else 0.0
             c = torch.zeros(2, P, P)
             if self.cfg.get("elasticDeform"):
-                s = random.uniform(*self.cfg["elasticDeform_sigmas"])
+                s = random.uniform(*self.cfg["elasticDeform_sigmas"])            # externalTransforms.py:80 (drawn before the coin)
                 if random.random() < 0.5:
                     c = torch.tensor([[[random.gauss(0.0, s) for _ in range(P)] for _ in range(P)] for _ in range(2)])
                     any_el = True
-            crop = resized_crop_params(H_, W_) if self.cfg.get("resizeCrop") else (0, 0, H_, W_)
-            aff.append(affine_for(ang, crop, in_hw, out_hw))
+            crops.append(resized_crop_params(H_, W_) if self.cfg.get("resizeCrop") else (0, 0, H_, W_))
+            angs.append(ang)
             ctrl.append(c)
-        return torch.tensor(aff, dtype=torch.float32), (torch.stack(ctrl) if any_el else None), out_hw
+        return angs, crops, (torch.stack(ctrl) if any_el else None), out_hw
 
     def __call__(self, img, msk=None, params=None):
+        """img [N,1,H,W] on the [0, 1] scale (zeros = black outside the image), msk [N,H,W] int64 or None."""
         n, _, H_, W_ = img.shape
-        aff, ctrl, (Ho, Wo) = params if params is not None else self.draw(n, (H_, W_))
-        return warp_joint(img, msk, aff, ctrl, Ho, Wo)
+        angs, crops, ctrl, (Ho, Wo) = params if params is not None else self.draw(n, (H_, W_))
+        if ctrl is None:                                     # rotation and crop composed: one resampling pass
+            aff = torch.tensor([affine_for(a, c, (H_, W_), (Ho, Wo)) for a, c in zip(angs, crops)], dtype=torch.float32)
+            return warp_joint(img, msk, aff, None, Ho, Wo)
+        # the reference's three steps (a slice without the deformation carries zero displacements: an exact copy in step 2)
+        full = (0, 0, H_, W_)
+        rot = torch.tensor([affine_for(a, full, (H_, W_), (H_, W_)) for a in angs], dtype=torch.float32)
+        img, msk = warp_joint(img, msk, rot, None, H_, W_)
+        img = torch.round(img * 255.0) / 255.0               # PIL hands an 8-bit image on (F.rotate -> Image)
+        img, msk = elastic_deform(img, msk, ctrl)
+        crop = torch.tensor([affine_for(0.0, c, (H_, W_), (Ho, Wo)) for c in crops], dtype=torch.float32)
+        return warp_joint(img, msk, crop, None, Ho, Wo)
+
+
+def elastic_deform(img, msk, ctrl):
+    """``elasticdeform.deform_random_grid([img, msk], order=[0, 0])`` given its control displacements ``ctrl`` [N,2,P,P] (dy, dx in
+    pixels): one launch of ``smsut_elastic_deform``."""
+    n, c, H_, W_ = img.shape
+    assert c == 1, "slices are single-channel (config.img_channels)"
+    dev = img.device
+    img = img.contiguous()
+    coef = spline_prefilter(ctrl).to(dev).contiguous()
+    oimg = torch.empty_like(img)
+    omsk = None
+    if msk is not None:
+        msk = msk.to(torch.int64).contiguous()
+        omsk = torch.empty_like(msk)
+    H.call("smsut_elastic_deform", img, msk, coef, oimg, omsk, n, H_, W_, int(ctrl.shape[-1]), H.stream_ptr())
+    return oimg, omsk
 
 
 def warp_joint(img, msk, aff, ctrl, Ho, Wo):

@@ -159,10 +159,11 @@ class InTurnLoader:
             if self.device.type == "cuda":
                 img8 = img8.pin_memory().to(self.device, non_blocking=True)
                 msk8 = msk8.pin_memory().to(self.device, non_blocking=True)
-            img = img8.float().div_(255.0).sub_(0.5).div_(0.5).unsqueeze(1)              # ToTensor + Normalize
+            img = img8.float().div_(255.0).unsqueeze(1)                                   # ToTensor's [0, 1] scale
             msk = msk8.to(torch.int64)
-            if self.augment is not None:
-                img, msk = self.augment(img, msk)
+            if self.augment is not None:                                                  # joint augmentation BEFORE Normalize, as
+                img, msk = self.augment(img, msk)                                         # baseLoader.py:92-108 (fill = 0 = black)
+            img = img.sub_(0.5).div_(0.5)                                                 # Normalize(0.5, 0.5)
             mdl = torch.tensor([self.ds.modality[i] for i in ids], dtype=torch.int64)
             yield img, msk, mdl, [self.ds.names[i] for i in ids]
 

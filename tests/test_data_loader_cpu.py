@@ -173,3 +173,37 @@ def test_samplers_reproduce_reference_batch_order(golden):
     batches = list(tst)
     assert [len(b) for b in batches] == [int(v) for v in g["test_sizes"]]
     assert [i for b in batches for i in b] == [int(v) for v in g["test_flat"]]
+
+
+def test_spline_prefilter_matches_scipy_and_interpolates_the_control_values():
+    """``gpu_augment.spline_prefilter`` (host side of JointElasticDeform's displacement grid, externalTransforms.py:69-90 ->
+    elasticdeform.deform_grid's prefilter) == ``scipy.ndimage.spline_filter1d(order=3, mode='mirror')`` along both axes, and the cubic
+    spline through the coefficients reproduces the control displacements at the control points (first / last point on the first /
+    last pixel)."""
+    from scipy import ndimage
+    import smsut_amd  # noqa: F401
+    from smsut_amd.data_loader import gpu_augment as ga
+    from oracle import augment_oracle as AO
+    rs = np.random.RandomState(3)
+    for P in (2, 3, 4, 6):
+        c = rs.standard_normal((5, 2, P, P)) * 11.0
+        got = ga.spline_prefilter(torch.from_numpy(c)).numpy()
+        want = c.copy()
+        for ax in (2, 3):
+            want = ndimage.spline_filter1d(want, order=3, axis=ax, mode="mirror")
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-5), (P, np.abs(got - want).max())
+        H = W = 8 * (P - 1) + 1                                  # control points fall on pixels 0, 8, 16, ...
+        d = AO.elastic_displacement(c[0], H, W)
+        assert np.allclose(d[:, ::8, ::8], c[0], atol=1e-9)
+
+
+def test_elastic_oracle_zero_displacement_is_identity_and_constant_outside():
+    from oracle import augment_oracle as AO
+    rs = np.random.RandomState(4)
+    img = rs.rand(2, 24, 40)
+    msk = rs.randint(0, 5, (2, 24, 40))
+    oi, om, _ = AO.elastic_deform_grid(img, msk, np.zeros((2, 2, 3, 3)))
+    assert np.array_equal(oi, img) and np.array_equal(om, msk)
+    shift = np.zeros((2, 2, 3, 3)); shift[:, 1] = 5.0              # every pixel reads 5 columns to its right
+    oi, om, _ = AO.elastic_deform_grid(img, msk, shift)
+    assert np.array_equal(oi[:, :, :35], img[:, :, 5:]) and np.all(oi[:, :, 35:] == 0) and np.all(om[:, :, 35:] == 0)

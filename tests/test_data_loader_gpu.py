@@ -43,7 +43,7 @@ def test_identity_warp_is_exact_and_augmenter_shapes():
     assert torch.equal(oi, img) and torch.equal(om, msk)
     random.seed(4)
     aug = ga.GpuJointAugment(dict(cfg.data_aug, resizeCrop_size=48), 48)
-    x = torch.randn(4, 1, 64, 64, device="cuda").clamp_(-1, 1)
+    x = torch.rand(4, 1, 64, 64, device="cuda")                      # ToTensor's [0, 1] scale (Normalize comes after the joint passes)
     y = torch.randint(0, 5, (4, 64, 64), device="cuda")
     xi, yi = aug(x, y)
     assert tuple(xi.shape) == (4, 1, 48, 48) and tuple(yi.shape) == (4, 48, 48) and yi.dtype == torch.int64
@@ -81,3 +81,66 @@ def test_warp_joint_kernel_against_pil_fixtures(golden):
     for k in range(3):
         a, c = float(g["angles"][k]), tuple(int(v) for v in g["crops"][(k + 1) % 3])
         check(run(a, c), g[f"both_img_{k}"], g[f"both_lab_{k}"], 10, mean_bar=1.5, q99_bar=4.0, lab_bar=0.97)
+
+
+def test_elastic_deform_kernel_matches_the_restated_elasticdeform():
+    """``smsut_elastic_deform`` (JointElasticDeform's resampling, externalTransforms.py:69-90) against
+    ``oracle.augment_oracle.elastic_deform_grid`` (elasticdeform.deform_grid restated on scipy's spline routines): cubic-B-spline
+    displacement of a 3x3 (and 4x4) control grid with sigma in the reference's 9-13 range, ORDER-0 sampling of image and labels,
+    zeros outside.  A nearest gather is exact wherever the fp32 source coordinate is not within rounding of a pixel boundary."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd.data_loader import gpu_augment as ga
+    rs = np.random.RandomState(11)
+    for (n, h, w, P, sigma) in [(3, 256, 256, 3, 13.0), (2, 64, 96, 3, 9.0), (2, 48, 48, 4, 6.0)]:
+        img = rs.rand(n, h, w).astype(np.float32)
+        msk = rs.randint(0, 5, (n, h, w)).astype(np.int64)
+        disp = (rs.standard_normal((n, 2, P, P)) * sigma).astype(np.float32)
+        disp[0] = 0.0                                            # a slice that did not draw the deformation: exact copy
+        ri, rm, coords = AO.elastic_deform_grid(img, msk, disp)
+        gi, gm = ga.elastic_deform(torch.from_numpy(img)[:, None].cuda(), torch.from_numpy(msk).cuda(), torch.from_numpy(disp))
+        gi, gm = gi[:, 0].cpu().numpy(), gm.cpu().numpy()
+        assert np.array_equal(gi[0], img[0]) and np.array_equal(gm[0], msk[0])
+        frac = np.abs(coords + 0.5 - np.round(coords + 0.5))      # distance of a coordinate to the rounding boundary
+        edge = np.minimum(np.minimum(np.abs(coords[:, 0]), np.abs(coords[:, 0] - (h - 1))),
+                          np.minimum(np.abs(coords[:, 1]), np.abs(coords[:, 1] - (w - 1))))
+        safe = (frac.min(1) > 1e-3) & (edge > 1e-3)
+        assert safe.mean() > 0.9                                   # (the undeformed slice sits exactly ON the border coordinates)
+        assert np.array_equal(gi[safe], ri[safe]) and np.array_equal(gm[safe], rm[safe])
+        assert np.mean(gi != ri) < 2e-3 and np.mean(gm != rm) < 2e-3
+        assert (ri != img).mean() > 0.2 or sigma == 0                # the deformation really moved things
+
+
+def test_augmenter_runs_the_reference_steps_when_the_deformation_is_drawn():
+    """GpuJointAugment: no slice drew the deformation -> ONE composed rotate + crop pass; one did -> rotate, 8-bit rounding,
+    elastic (order 0), crop + resize, as baseLoader.py:92-98 orders them -- checked against the oracle's passes on the same draws."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd import config as cfg
+    from smsut_amd.data_loader import gpu_augment as ga
+    aug = ga.GpuJointAugment(dict(cfg.data_aug, resizeCrop_size=48), 48)
+    rs = np.random.RandomState(5)
+    img = rs.rand(4, 64, 64).astype(np.float32)
+    msk = rs.randint(0, 5, (4, 64, 64)).astype(np.int64)
+    x, y = torch.from_numpy(img)[:, None].cuda(), torch.from_numpy(msk).cuda()
+    random.seed(12)
+    seen = set()
+    for trial in range(6):
+        angs, crops, ctrl, out_hw = aug.draw(4, (64, 64))
+        if trial >= 4:
+            ctrl = None                                           # (1 batch of 4 in 16 draws none: force the composed branch)
+        xi, yi = aug(x, y, params=(angs, crops, ctrl, out_hw))
+        assert tuple(xi.shape) == (4, 1, 48, 48) and tuple(yi.shape) == (4, 48, 48)
+        assert float(xi.min()) >= 0.0 and float(xi.max()) <= 1.0 + 1e-6
+        seen.add(ctrl is not None)
+        if ctrl is None:
+            aff = np.array([ga.affine_for(a, c, (64, 64), (48, 48)) for a, c in zip(angs, crops)], dtype=np.float32)
+            ri, rm = AO.warp_joint(img, msk, aff, None, 48, 48)
+        else:
+            rot = np.array([ga.affine_for(a, (0, 0, 64, 64), (64, 64), (64, 64)) for a in angs], dtype=np.float32)
+            ri, rm = AO.warp_joint(img, msk, rot, None, 64, 64)
+            ri = np.round(ri * 255.0) / 255.0
+            ri, rm, _ = AO.elastic_deform_grid(ri, rm, ctrl.numpy())
+            crop = np.array([ga.affine_for(0.0, c, (64, 64), (48, 48)) for c in crops], dtype=np.float32)
+            ri, rm = AO.warp_joint(ri.astype(np.float32), rm, crop, None, 48, 48)
+        gi, gm = xi[:, 0].cpu().numpy(), yi.cpu().numpy()
+        assert np.mean(np.abs(gi - ri) > 2e-2) < 1e-2 and np.mean(gm != rm) < 1e-2, (np.abs(gi - ri).max(), np.mean(gm != rm))
+    assert seen == {True, False}                                   # both branches were exercised
