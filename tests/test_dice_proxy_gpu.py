@@ -23,3 +23,25 @@ def test_trained_dice_matches_oracle_within_half_a_point():
     for a, b in zip(res["dice_per_organ_hip"], res["dice_per_organ_oracle"]):
         assert abs(a - b) <= 0.015, res
     assert res["prediction_agreement"] > 0.98, res
+
+
+def test_trained_dice_through_the_ugan_consis_trainer_matches_oracle():
+    """VERDICT r03 missing #4: the same claim on the trainer BASELINE.json's metric names.  ``UGANConsisTrainer`` (HIP path, hipGraph
+    replays) and ``oracle.ugan_consis_iteration`` train the generator for 300 iterations on identical batches and RNG draws; both are
+    validated the reference's way (trainer/uganShp0Trainer.py:250-287, baseTrainer.py:246-252, utils.py:180-203).  The iteration is a
+    GAN: its trajectory is chaotic, and at 300 iterations the Dice still climbs -- measured (scratch/dice_ugan_spread.py,
+    gpurun_out/r04_dice_spread.log): the ORACLE against itself with its initial weights perturbed by 1e-6 relative ends 0.15-0.44 pt
+    apart, HIP against perturbed HIP 0.09-0.68 pt, HIP against the oracle -0.71 / -0.02 (300 iterations) and -0.26 / +0.63 pt (600)
+    on two seeds: no systematic offset.  So: the MEAN over two seeds within north_star's 0.5 pt, every single run within 1.0 pt
+    (the chaos band), both sides well trained, per-pixel agreement high."""
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    runs = [dice_proxy.run_ugan(steps=300, size=64, seed=s, log=lambda *a: None) for s in (2021, 2022)]
+    json.dump(runs, open(os.path.join(out, "dice_proxy_ugan_test.json"), "w"), indent=1)
+    for r in runs:
+        assert r["graph"]["mode"] == "graph", r["graph"]
+        assert r["dice_mean_oracle"] > 0.93 and r["dice_mean_hip"] > 0.93, r          # both actually learned the task
+        assert abs(r["delta_mean_dice_pt"]) <= 1.0, r
+        assert r["prediction_agreement"] > 0.97, r
+    mean_delta = sum(r["delta_mean_dice_pt"] for r in runs) / len(runs)
+    assert abs(mean_delta) <= 0.5, (mean_delta, [r["delta_mean_dice_pt"] for r in runs])
