@@ -379,7 +379,7 @@ RrPlan plan_rr(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, 
   const int target = p.variant == 4 ? t_big : t_small;
   int want = (target + slabs - 1) / slabs;
   if (want < 1) want = 1;
-  static const int rc_max = env_int("SMSUT_RR_RCMAX", 32);
+  static const int rc_max = env_int("SMSUT_RR_RCMAX", 64);      // (64-row units where the grid still fills: B32 256^2 16->16 83 -> 78 us)
   int rc = p.R;
   for (int c = rc_max; c >= p.R; c >>= 1) {
     if (c % p.R || H % c) continue;

@@ -181,6 +181,9 @@ class BaseTrainer(abc.ABC):
             else:
                 seed_all(cfg.seed + 1000003 * (self.iter + 1))            # (seed_all adds the rank)
         self._resume_loader_states = ranks[self.rank]["loaders"] if same_world else None
+        # (building the loaders after resume() draws from the host RNG -- the inTurn samplers shuffle with the global
+        #  ``random`` at world == 1 -- so the restored streams are put back once more when the loaders are adopted)
+        self._resume_rng = ranks[self.rank]["rng"] if (restore_rng and same_world) else None
         self.model_idx = self.model_idx or model_idx
         self.info(f"[*] Resumed from {path}: iter {self.iter}, epoch {self.epoch}, rank {self.rank}/{self.world}"
                   f"{'' if same_world else ' (world size changed: reseeded, fresh data order)'}.")
@@ -193,6 +196,12 @@ class BaseTrainer(abc.ABC):
                 if st is not None and hasattr(ld, "load_state_dict"):
                     ld.load_state_dict(st)
             self._resume_loader_states = None
+        rng = self.__dict__.get("_resume_rng")
+        if rng is not None:                                  # exact continuation: the streams as they were checkpointed
+            import random as _random
+            _random.setstate(rng["python"]); np.random.set_state(rng["numpy"])
+            torch.set_rng_state(rng["torch"]); torch.cuda.set_rng_state(rng["cuda"], self.device)
+            self._resume_rng = None
 
     # ------------------------------------------------------------------ loaders
     def get_loaders(self, loader_type):
