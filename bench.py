@@ -630,7 +630,11 @@ def main():
                                      mfma_executed_gflop_per_slice=round(xfs, 3), mfma_executed_tflops_per_gpu=round(xtf, 2),
                                      mfma_executed_frac_of_fp32_mfma_peak=round(xtf / FP32_MFMA_PEAK_TFLOPS, 4),
                                      flops_source="per-shape census of one step in this run (roofline.step_conv.conv_gflop / "
-                                                  "conv_gflop_mfma_executed)")
+                                                  "conv_gflop_mfma_executed)",
+                                     algorithmic_gbytes_per_slice=round(prof["algorithmic_gbytes"] / B, 4),
+                                     bytes_note="every tensor of every conv / InstanceNorm / residual-tail / pooling call read once and "
+                                                "written once (fp32): the traffic floor of the launches this build makes, the figure the "
+                                                "PMC traffic of profiles/*_step_*_classes.md stands against (SURVEY 8d's rule, call by call)")
             # the roofline leg's call is one the timed step makes (entry point + integer / float arguments)
             out["roofline"]["in_step_record"] = bool(prof.get("has_call", {}).get("dominant"))
     if world == 1 and args.workload == "ugan" and not args.no_unet_step and args.dtype == "f32" and args.size == 256:

@@ -21,6 +21,10 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace $common -d $out/${tag}_pmc_write -- py
 rm -rf $out/${tag}_pmc_sq
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace $common -d $out/${tag}_pmc_sq -- python3 bench.py --roofline-only > $out/${tag}_pmc_sq.log 2>&1
 python3 profiles/summarize.py $tag
+# 3b. algorithmic bytes of the step's launches (bench.py's per-shape census: every tensor of every conv / InstanceNorm / tail / pooling
+#     call read once + written once), un-profiled: the floor the PMC traffic below stands against
+python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-unet-step > $out/${tag}_bytes_ugan.log 2>/dev/null
+python3 bench.py --workload unet --steps 3 --warmup 2 --no-cpu-baseline --no-unet-step > $out/${tag}_bytes_unet.log 2>/dev/null
 # 4. whole-step counters per layer class (profiles/step_pmc.py: eager steps between two marker dispatches; four passes each:
 #    durations without counters, FETCH_SIZE, WRITE_SIZE, SQ) -> profiles/<tag>_step_<wl>_classes.{json,md}
 for wl in unet ugan; do

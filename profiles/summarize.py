@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 DOMINANT = None   # instantiation of conv_mfma_fwd the roofline leg launches, read from its own stats below
-STEPS = 7     # 2 warm-up + 5 timed steps in collect.sh
+STEPS = 12    # 2 warm-up + 5 timed + 5 end-to-end (scalar fetch every step) iterations in collect.sh
 
 
 def one(pattern):
@@ -41,7 +41,7 @@ def short(name):
 def stats_table(path, steps):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    lines = [f"all kernels of the process (7 steps + initialisation + synthetic batches) / 7: {tot / steps / 1e6:.2f} ms/step, "
+    lines = [f"all kernels of the process ({steps} steps + initialisation + synthetic batches) / {steps}: {tot / steps / 1e6:.2f} ms/step, "
              f"{sum(int(r['Calls']) for r in rows) / steps:.0f} launches/step", "",
              "| kernel | launches/step | avg us | ms/step | share |", "|---|---:|---:|---:|---:|"]
     for r in rows[:28]:
@@ -72,17 +72,21 @@ for wl in ("ugan", "unet"):
         head = f"`bench.py` under the profiler: {j['ms_per_step']} ms/step, {j['value']} {j['unit']}"
         if wl == "ugan":
             head += ("  (kernel tracing takes the concurrency out of the run: the iteration's side-stream chain -- D-step, Adam, "
-                     "D(x_fake) -- no longer overlaps the generator's backward; un-profiled the same build runs the iteration in "
-                     "21.9 ms: README, profiles/r03_notes.md)")
+                     "D(x_fake) -- no longer overlaps the generator's backward; the un-profiled number is the driver's BENCH line / README)")
     except (ValueError, IndexError):
         head = "(bench line unreadable)"
     md += [f"## {wl} workload", "", head, "", stats_table(src, STEPS), ""]
 
 src = one(f"{tag}_roof/**/*_kernel_stats.csv")
 shutil.copy(src, os.path.join(PROF, f"{tag}_roofline_kernel_stats.csv"))
-roof = max((r for r in csv.DictReader(open(src)) if "conv_mfma_fwd" in r["Name"]), key=lambda r: int(r["Calls"]))
+live_all = json.loads(json_line(os.path.join(OUT, f"{tag}_roof.log")))
+live = live_all["roofline"]
+# the kernel the roofline leg names (bench.py: roofline.kernel_match); r01-r03 lines had none: the most-launched conv_mfma_fwd
+match = live.get("kernel_match")
+norm = lambda n: n.replace("(anonymous namespace)::", "")      # noqa: E731
+cands = [r for r in csv.DictReader(open(src)) if (match in norm(r["Name"]) if match else "conv_mfma_fwd" in r["Name"])]
+roof = max(cands, key=lambda r: int(r["Calls"]))
 DOMINANT = short(roof["Name"])
-live = json.loads(json_line(os.path.join(OUT, f"{tag}_roof.log")))["roofline"]
 
 fetch, frows, cols = pmc_rows(one(f"{tag}_pmc_fetch/**/*_counter_collection.csv"), "FETCH_SIZE")
 write, wrows, _ = pmc_rows(one(f"{tag}_pmc_write/**/*_counter_collection.csv"), "WRITE_SIZE")
@@ -137,5 +141,14 @@ md += ["## dominant kernel (roofline leg, `bench.py --roofline-only`)", "",
        f"PMC: FETCH_SIZE {fetch_kb:.1f} KB (x2 gfx950 correction), WRITE_SIZE {write_kb:.1f} KB per launch -> "
        f"{hbm / 1e6:.1f} MB HBM traffic vs {dom['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic "
        f"(x{dom['traffic_over_algorithmic']}).", "", sq_note, ""]
+fwd = live_all.get("roofline_fwd")
+if fwd:
+    rows = [r for r in csv.DictReader(open(src)) if "conv_mfma_fwd_p" in r["Name"]]
+    if rows:
+        r2 = max(rows, key=lambda r: int(r["Calls"]))
+        md += ["## second leg (`roofline_fwd`): the Winograd forward conv + fused 1x1 shortcut the step launches", "",
+               f"`{short(r2['Name'])}` at {fwd['shape']}: rocprofv3 average {float(r2['AverageNs']) / 1e3:.2f} us over {r2['Calls']} launches; HIP events "
+               f"{fwd['avg_launch_ms'] * 1e3:.2f} us -> {fwd['achieved']} TFLOP/s algorithmic ({fwd['frac'] * 100:.1f} % of peak), "
+               f"{fwd.get('executed_mfma_tflops')} TFLOP/s executed on the matrix pipes.", ""]
 open(os.path.join(PROF, f"{tag}_summary.md"), "w").write("\n".join(md))
 print("\n".join(md[-4:]))

@@ -29,7 +29,7 @@ SIMDS = 256 * 4
 # first match wins
 CLASSES = [
     ("3x3 fwd/dgrad (MFMA)", r"conv_mfma_fwd_p<3|conv_mfma_fwd<3|conv_k4_fwd|conv_wino_l"),
-    ("3x3 wgrad (MFMA)", r"conv_mfma_wgrad<3|conv_mfma_wgrad_ts|conv_f16_wgrad|plane_wgrad|sum_splits|conv_k4_wgrad"),
+    ("3x3 wgrad (MFMA)", r"wgrad_rr|conv_mfma_wgrad<3|conv_mfma_wgrad_ts|conv_f16_wgrad|plane_wgrad|sum_splits|conv_k4_wgrad"),
     ("ConvT 2x2", r"convT|conv_mfma_fwd<1|conv_mfma_fwd_p<1|conv_mfma_wgrad<1|ps_"),
     ("1x1 convs", r"conv1x1|thin1x1|sum_parts"),
     ("stems / heads (direct)", r"small_fwd|small_dgrad|flat_wgrad|flat_sum|stem|conv_fwd_naive|conv_dgrad_naive|conv_wgrad_partial|conv_full_window"),
@@ -133,11 +133,25 @@ def main():
                                "ms_in_launches_under_256_wgs": round(a["small_grid_us"] / K / 1e3, 3)}
         tot["ms"] += ms; tot["bytes"] += byts; tot["launches"] += a["launches"] / K
     lower = 0.62e9 * slices if wl == "unet" else None
+    # the floor of THIS build's launches (bench.py census: every tensor of every conv / InstanceNorm / residual-tail / pooling call
+    # read once + written once, fp32; profiling._BYTES) -- SURVEY 8d's rule applied call by call; for the ugan iteration it is the
+    # only stated bound (8d derives a fused bound for the U-Net only)
+    census = None
+    try:
+        line = [ln for ln in open(os.path.join(OUT, f"{tag}_bytes_{wl}.log")).read().splitlines() if ln.startswith("{")][-1]
+        j = json.loads(line)
+        census = {"gb_per_slice": j["whole_step"]["algorithmic_gbytes_per_slice"],
+                  "by_class": j["roofline"]["step_conv"]["algorithmic_bytes_by_class"]}
+    except (OSError, IndexError, KeyError, ValueError):
+        pass
     res["step_total"] = {"kernel_ms": round(tot["ms"], 3), "launches": round(tot["launches"], 1),
                          "hbm_gb": round(tot["bytes"] / 1e9, 3), "hbm_gb_per_slice": round(tot["bytes"] / 1e9 / slices, 4),
                          "avg_hbm_gbs": round(tot["bytes"] / (tot["ms"] * 1e-3) / 1e9, 1),
                          "fused_lower_bound_gb": None if lower is None else round(lower / 1e9, 3),
-                         "traffic_over_lower_bound": None if lower is None else round(tot["bytes"] / lower, 3)}
+                         "traffic_over_lower_bound": None if lower is None else round(tot["bytes"] / lower, 3),
+                         "launch_floor_gb_per_slice": None if census is None else census["gb_per_slice"],
+                         "traffic_over_launch_floor": None if census is None else round(tot["bytes"] / 1e9 / slices / census["gb_per_slice"], 3),
+                         "launch_floor_by_class": None if census is None else census["by_class"]}
     res["top_kernels_ms_per_step"] = {k: round(v / K / 1e3, 3) for k, v in names.most_common(25)}
     json.dump(res, open(os.path.join(PROF, f"{tag}_step_{wl}_classes.json"), "w"), indent=1)
     md = [f"# {tag}: whole-step counters per layer class, {wl} ({slices} slices per step, eager dispatch, {K} steps measured)", "",
@@ -152,6 +166,13 @@ def main():
     if lower is not None:
         md.append(f"SURVEY 8d fused lower bound: 0.62 GB per slice = {st['fused_lower_bound_gb']} GB per step -> traffic ratio "
                   f"**{st['traffic_over_lower_bound']}x**.")
+    if census is not None:
+        md += ["", f"Floor of this build's launches (every tensor of every conv / InstanceNorm / residual-tail / pooling call read once + "
+                   f"written once, fp32; `bench.py` census, `profiling._BYTES`): **{census['gb_per_slice']} GB per slice** -> measured traffic / "
+                   f"floor = **{st['traffic_over_launch_floor']}x**.  Per class (GB per step, and the rate of ALGORITHMIC bytes its calls reach "
+                   f"in isolation):", "", "| class | algorithmic GB/step | ms (replayed alone) | GB/s |", "|---|---:|---:|---:|"]
+        for k, v in census["by_class"].items():
+            md.append(f"| {k} | {v['gbytes']} | {v['ms']} | {v['gbs']} |")
     open(os.path.join(PROF, f"{tag}_step_{wl}_classes.md"), "w").write("\n".join(md) + "\n")
     print("\n".join(md))
 

@@ -36,6 +36,7 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_wgrad_mfma": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
     "smsut_conv2d_fwd_mfma_stats_inaff": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_mfma_inaff": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_wgrad_mfma_slabs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),   # (bench's roofline leg only)
     "smsut_conv2d_fwd_mfma_stats_cat": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_mfma_cat": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * _k2(a, 6), "mfma"),
     "smsut_conv2d_fwd_mfma_split": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
@@ -119,7 +120,71 @@ def conv_flops_of(name: str, conv_args) -> float:
     return float(ent[0](ints))
 
 
-class Row(collections.namedtuple("Row", "name args calls us flops exec_flops")):
+# ---- algorithmic bytes: every tensor a call must at least READ ONCE and WRITE ONCE (fp32), the rule SURVEY 8d derives its
+# 0.62 GB-per-slice lower bound of the U-Net step from (conv inputs + conv outputs + InstanceNorm element passes), applied call by
+# call to what THIS build launches -- so a class's measured HBM traffic (profiles/*_step_*_classes.md) has a floor to stand against.
+# entry point (``_pre`` stripped) -> lambda(ints) -> bytes.  Calls that are not listed count 0 (the sum stays a lower bound).
+def _cv(n, h, w, cin, cout, extra_out=0, extra_in=0):
+    return 4.0 * n * h * w * (cin + extra_in + cout + extra_out)
+
+
+_BYTES: Dict[str, Callable[[List[int]], float]] = {
+    "smsut_conv2d_fwd_mfma": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
+    "smsut_conv2d_fwd_mfma_stats": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
+    "smsut_conv2d_dgrad_mfma_bwdstats": lambda a: _cv(a[0], a[1], a[2], a[3], a[4], extra_in=a[4]),     # + y1 (the mask)
+    "smsut_conv2d_fwd_mfma_stats_inaff": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
+    "smsut_conv2d_fwd_mfma_stats_cat": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
+    "smsut_conv2d_fwd_mfma_split": lambda a: _cv(a[1], a[2], a[3], a[4], a[5]),
+    "smsut_conv2d_fwd_mfma_stats_sc": lambda a: _cv(a[0], a[1], a[2], a[3], a[4], extra_out=a[4]),
+    "smsut_conv2d_dgrad_mfma_sc": lambda a: _cv(a[1], a[2], a[3], 2 * a[4], a[5]),
+    "smsut_conv2d_wgrad_mfma": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
+    "smsut_conv2d_wgrad_mfma_inaff": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
+    "smsut_conv2d_wgrad_mfma_cat": lambda a: _cv(a[1], a[2], a[3], a[4], a[5]),
+    "smsut_conv2d_wgrad_mfma_sc": lambda a: _cv(a[1], a[2], a[3], a[4], 2 * a[5]),
+    "smsut_conv1x1_fwd": lambda a: 4.0 * a[0] * a[1] * (a[2] + a[3]),
+    "smsut_conv1x1_wgrad": lambda a: 4.0 * a[0] * a[1] * (a[2] + a[3]),
+    "smsut_convT2x2_fwd_mfma": lambda a: 4.0 * a[0] * a[1] * a[2] * (a[3] + 4 * a[4]),
+    "smsut_convT2x2_dgrad_mfma": lambda a: 4.0 * a[0] * a[1] * a[2] * (a[3] + 4 * a[4]),
+    "smsut_convT2x2_wgrad_mfma": lambda a: 4.0 * a[0] * a[1] * a[2] * (a[3] + 4 * a[4]),
+    "smsut_convT2x2_fwd_ps": lambda a: 4.0 * a[0] * a[1] * a[2] * (a[3] + 4 * a[4]),
+    "smsut_convT2x2_wgrad_ps": lambda a: 4.0 * a[0] * a[1] * a[2] * (a[3] + 4 * a[4]),
+    # InstanceNorm / residual tails: (n, hw, c) -> tensor passes of n * hw * c floats
+    "smsut_restail_fwd": lambda a: 4.0 * a[0] * a[1] * a[2] * 3,            # y2, s (or x) -> out
+    "smsut_restail_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * 5,            # g, y2, s -> gy2, gs (one ideal pass; the kernel needs two)
+    "smsut_in_apply_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * 3,           # gz, y1 -> gy1
+    "smsut_instnorm_fwd": lambda a: 4.0 * a[0] * a[1] * a[2] * 2,
+    "smsut_instnorm_fwd_partials": lambda a: 4.0 * a[1] * a[2] * a[3] * 2,
+    "smsut_instnorm_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * 3,
+    "smsut_instnorm_bwd2": lambda a: 4.0 * a[0] * a[1] * a[2] * 5,
+    "smsut_maxpool2_fwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 1.25,
+    "smsut_maxpool2_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 2.25,
+    "smsut_maxpool2_bwd_add": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 3.25,
+    "smsut_avgpool2_fwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 1.25,
+    "smsut_avgpool2_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 1.25,
+    "smsut_add_act": lambda a: 4.0 * a[0] * 3,
+    "smsut_act_bwd": lambda a: 4.0 * a[0] * 3,
+    "smsut_tanh_fwd": lambda a: 4.0 * a[0] * 2,
+    "smsut_tanh_bwd": lambda a: 4.0 * a[0] * 3,
+}
+
+
+def bytes_of(name: str, conv_args) -> float:
+    ent = _BYTES.get(_base(name))
+    return float(ent(_ints(name, conv_args))) if ent else 0.0
+
+
+def _byte_class(name: str) -> str:
+    n = _base(name)
+    if "conv" in n:
+        return "convolutions"
+    if "restail" in n:
+        return "residual tails"
+    if "instnorm" in n or "in_apply" in n:
+        return "InstanceNorm"
+    return "pooling / pointwise"
+
+
+class Row(collections.namedtuple("Row", "name args calls us flops exec_flops abytes")):
     """One distinct call of the step: ``flops`` = ALGORITHMIC conv FLOPs per call (2 N H W Cin Cout k^2), ``exec_flops``
     = what the matrix pipes execute for it (smaller where a Winograd form runs)."""
     @property
@@ -172,7 +237,8 @@ def replay(rec, reps: int = 8) -> List[Row]:
         e1.record(st)
         torch.cuda.synchronize()
         fl = conv_flops_of(name, calls[0])
-        rows.append(Row(name, shp, len(calls), e0.elapsed_time(e1) / reps * 1e3, fl, fl * executed_factor(name, calls[0])))
+        rows.append(Row(name, shp, len(calls), e0.elapsed_time(e1) / reps * 1e3, fl, fl * executed_factor(name, calls[0]),
+                        bytes_of(name, calls[0])))
     return rows
 
 
@@ -194,6 +260,12 @@ def summarize(rows: List[Row], peak_tflops: float) -> dict:
         k = ("wgrad" if "wgrad" in r.name else "fwd/dgrad") + (" 1x1" if "1x1" in r.name else (" convT" if "convT" in r.name else ""))
         t, f, x = fam.get(k, (0.0, 0.0, 0.0))
         fam[k] = (t + r.total_us, f + r.flops * r.calls, x + r.exec_flops * r.calls)
+    byc = collections.OrderedDict()
+    for r in rows:
+        if r.abytes > 0:
+            k = _byte_class(r.name)
+            t, b = byc.get(k, (0.0, 0.0))
+            byc[k] = (t + r.total_us, b + r.abytes * r.calls)
     tf = lambda f, t: round(f / (t * 1e-6) / 1e12, 2) if t else None                      # noqa: E731
     fr = lambda f, t: round(f / (t * 1e-6) / 1e12 / peak_tflops, 4) if t else None        # noqa: E731
     return {
@@ -203,6 +275,11 @@ def summarize(rows: List[Row], peak_tflops: float) -> dict:
         "step_conv_tflops_mfma_executed": tf(x_conv, t_conv), "step_conv_frac_mfma_executed": fr(x_conv, t_conv),
         "mfma_conv_frac_algorithmic": fr(f_mfma, t_mfma), "mfma_conv_frac_executed": fr(x_mfma, t_mfma),
         "conv_share_of_kernel_time": round(t_conv / t_all, 4) if t_all else None,
+        # every tensor of a call read once + written once (fp32): the floor of this build's launches, per class (GB per step) with
+        # the rate these calls reach against it (GB/s of ALGORITHMIC bytes; HBM peak 8000)
+        "algorithmic_gbytes": round(sum(b for _, b in byc.values()) / 1e9, 3),
+        "algorithmic_bytes_by_class": {k: {"gbytes": round(b / 1e9, 3), "ms": round(t / 1e3, 3), "gbs": round(b / (t * 1e-6) / 1e9, 1)}
+                                       for k, (t, b) in byc.items()},
         "families": {k: {"ms": round(t / 1e3, 3), "algorithmic_tflops": round(f / (t * 1e-6) / 1e12, 1),
                          "mfma_executed_tflops": round(x / (t * 1e-6) / 1e12, 1)} for k, (t, f, x) in fam.items()},
     }

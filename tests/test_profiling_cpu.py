@@ -19,8 +19,19 @@ def _args(name, **ints):
 def test_conv_entry_points_have_flop_formulas():
     conv_like = [n for n in H.SIGNATURES if re.search(r"conv(2d|1x1|T2x2)_.*(fwd|dgrad|wgrad)", n)
                  and not re.search(r"_ws$|supported|tiles|persistent|_cfg$", n)]          # (_cfg: tuning hook, never called by a trainer)
-    missing = [n for n in conv_like if n not in profiling._CONV_FLOPS]
+    # (`_pre` entry points = the same call + the caller's prepared Winograd image: they count as the entry point they extend)
+    missing = [n for n in conv_like if profiling._base(n) not in profiling._CONV_FLOPS]
     assert not missing, missing
+
+
+def test_executed_flops_and_algorithmic_bytes_tables_cover_the_pre_forms():
+    """``_pre`` calls are accounted like their base entry point (FLOPs, executed factor table, algorithmic bytes)."""
+    a = _args("smsut_conv2d_fwd_mfma_stats_pre", N=4, H=64, W=64, K=64, Nd=64, KS=3)
+    b = _args("smsut_conv2d_fwd_mfma_stats", N=4, H=64, W=64, K=64, Nd=64, KS=3)
+    assert profiling.conv_flops_of("smsut_conv2d_fwd_mfma_stats_pre", a) == profiling.conv_flops_of("smsut_conv2d_fwd_mfma_stats", b) > 0
+    assert profiling.bytes_of("smsut_conv2d_fwd_mfma_stats_pre", a) == 4.0 * 4 * 64 * 64 * (64 + 64)
+    assert profiling.bytes_of("smsut_restail_bwd", _args("smsut_restail_bwd", n=16, hw=65536, c=16)) == 4.0 * 16 * 65536 * 16 * 5
+    assert profiling._base("smsut_conv2d_fwd_mfma_stats_sc_pre") in profiling._FORM
 
 
 @pytest.mark.parametrize("name,ints,taps", [
