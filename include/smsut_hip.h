@@ -271,6 +271,10 @@ int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float*
                                 float slope, int has_act, void* stream);
 int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float* rstd, int N, int HW, int C, float eps,
                           void* stream);
+/* the same for TWO partial sets of one (N, HW, C) in one launch (conv2's and the shortcut's statistics of a BasicBlock,
+   network/blocks.py:66-80, are both due when the residual tail starts) */
+int smsut_in_finalize_fwd2(const float* pa, int chunks_a, float* mean_a, float* rstd_a, const float* pb, int chunks_b, float* mean_b,
+                           float* rstd_b, int N, int HW, int C, float eps, void* stream);
 /* InstanceNorm backward fed by the dgrad epilogue (smsut_conv2d_dgrad_mfma_bwdstats): finalise the {sum gz, sum gz*xhat}
  * partials into a / b, then gx = gamma*rstd*(gz - a - xhat*b) on the ALREADY masked gz (+ affine gradients, nullable). */
 int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, float* b_mean, int N, int HW, int C, void* stream);

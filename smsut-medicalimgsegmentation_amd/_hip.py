@@ -22,6 +22,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_instnorm_fwd": "ppppppp iii ff i s",
     "smsut_instnorm_fwd_partials": "ppppppp iiii ff i s",
     "smsut_in_finalize_fwd": "p i pp iii f s",
+    "smsut_in_finalize_fwd2": "p i pp p i pp iii f s",
     "smsut_in_finalize_bwd": "p i pp iii s",
     "smsut_in_apply_bwd": "pppppppp pp iii s",
     "smsut_restail_fwd": "pppppppppp p iii f s",

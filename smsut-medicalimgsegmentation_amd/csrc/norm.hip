@@ -199,9 +199,8 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
 // combine chunk partials in fp64 -> per-(n,c) means.  MODE 0 writes (mean, rstd).
 // 16 channels x 16 chunk-lanes per block: independent loads in flight, fixed-order tree (deterministic).
 template <int MODE>
-__global__ void __launch_bounds__(TPB)
-in_moments_final(const float* __restrict__ part, int chunks, int C, int HW, float eps,
-                 float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+__device__ __forceinline__ void in_moments_final_body(const float* __restrict__ part, int chunks, int C, int HW, float eps,
+                                                      float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
   constexpr int NS = NSums<MODE>::n;
   __shared__ double sm[TPB * 3];
   const int n = blockIdx.y;
@@ -254,6 +253,21 @@ in_moments_final(const float* __restrict__ part, int chunks, int C, int HW, floa
     o1[n * C + c] = (float)(s[1] * inv);
     if (MODE == 2) o2[n * C + c] = (float)(s[NS - 1] * inv);
   }
+}
+template <int MODE>
+__global__ void __launch_bounds__(TPB)
+in_moments_final(const float* __restrict__ part, int chunks, int C, int HW, float eps,
+                 float* __restrict__ o0, float* __restrict__ o1, float* __restrict__ o2) {
+  in_moments_final_body<MODE>(part, chunks, C, HW, eps, o0, o1, o2);
+}
+// TWO statistics sets of the same (N, C, HW) in one launch (blockIdx.z picks the set): conv2's and the shortcut's partials of a
+// BasicBlock are both complete when the residual tail needs them -- one launch of this latency-bound kernel instead of two.
+__global__ void __launch_bounds__(TPB)
+in_moments_final_pair(const float* __restrict__ pa, int chunks_a, float* __restrict__ mean_a, float* __restrict__ rstd_a,
+                      const float* __restrict__ pb, int chunks_b, float* __restrict__ mean_b, float* __restrict__ rstd_b, int C,
+                      int HW, float eps) {
+  if (blockIdx.z == 0) in_moments_final_body<0>(pa, chunks_a, C, HW, eps, mean_a, rstd_a, nullptr);
+  else in_moments_final_body<0>(pb, chunks_b, C, HW, eps, mean_b, rstd_b, nullptr);
 }
 
 // VEC consecutive per-channel values (statistics / affine parameters) as ONE load: c is a multiple of VEC and the
@@ -784,6 +798,16 @@ int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float*
                           void* stream) {
   SMSUT_REQUIRE(partials && mean && rstd && chunks > 0 && N > 0 && HW > 0 && C > 0);
   in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, (hipStream_t)stream>>>(partials, chunks, C, HW, eps, mean, rstd, nullptr);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// smsut_in_finalize_fwd for TWO partial sets of the same (N, HW, C) in one launch (chunk counts may differ)
+int smsut_in_finalize_fwd2(const float* pa, int chunks_a, float* mean_a, float* rstd_a, const float* pb, int chunks_b, float* mean_b,
+                           float* rstd_b, int N, int HW, int C, float eps, void* stream) {
+  SMSUT_REQUIRE(pa && pb && mean_a && rstd_a && mean_b && rstd_b && chunks_a > 0 && chunks_b > 0 && N > 0 && HW > 0 && C > 0);
+  in_moments_final_pair<<<dim3((C + 15) / 16, N, 2), TPB, 0, (hipStream_t)stream>>>(pa, chunks_a, mean_a, rstd_a, pb, chunks_b, mean_b,
+                                                                                   rstd_b, C, HW, eps);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

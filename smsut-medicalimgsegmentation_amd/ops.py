@@ -851,10 +851,13 @@ class BasicBlockFn(Function):
             H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
             _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w2, 0, a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
-        H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
         if fused_sc:
-            ms, rs = stat(co)
-            H.call("smsut_in_finalize_fwd", ps, t1, ms, rs, n, hw, co, IN_EPS, st)
+            ms, rs = stat(co)                                # both sets are due now: ONE launch of the latency-bound finalize
+            H.call("smsut_in_finalize_fwd2", p2, t3b, m2, r2, ps, t1, ms, rs, n, hw, co, IN_EPS, st)
+        else:
+            H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
+        if fused_sc:
+            pass
         elif has_sc:
             s = new_act(n, co, h, w, x)
             t1 = H.call("smsut_conv1x1_tiles", n, hw, co) if H.call("smsut_conv1x1_supported", ci, co) else 0
