@@ -92,3 +92,47 @@ class Meter:
     def reset_cur(self):
         self.cur_values = self._zeros()
         self.n = self._zeros()
+
+
+class ScalarFetcher:
+    """Per-iteration logging without stalling the device: the reference reads its loss scalars with ``.item()`` right after every
+    iteration (trainer/uganConsisTrainer.py:148-149,157,183-188 -- 11 host syncs), which keeps the host from enqueueing iteration
+    i + 1 while i runs.  Here the scalars of iteration i go to pinned host memory with a non-blocking copy and are HANDED OUT ONE
+    ITERATION LATER (``push`` returns the previous item, whose copy has long finished); ``flush`` returns the last one.  Same values,
+    same order -- the meter / log just see them one iteration late, and the device never waits for the host."""
+
+    def __init__(self, numel: int, device):
+        import torch
+        self._torch = torch
+        self._bufs = [torch.empty(numel, dtype=torch.float32).pin_memory() if torch.device(device).type == "cuda"
+                      else torch.empty(numel, dtype=torch.float32) for _ in range(2)]
+        self._events = [None, None]
+        self._tags = [None, None]
+        self._cur = 0
+        self._pending = None
+
+    def _take(self, slot):
+        if self._events[slot] is not None:
+            self._events[slot].synchronize()
+        return self._bufs[slot].tolist(), self._tags[slot]
+
+    def push(self, scalars, tag=None):
+        """Enqueue the device -> host copy of ``scalars`` (1-D float tensor); returns ``(values, tag)`` of the PREVIOUS push or None."""
+        torch = self._torch
+        prev = self._take(self._pending) if self._pending is not None else None
+        slot = self._cur
+        self._bufs[slot].copy_(scalars.detach().reshape(-1).float(), non_blocking=True)
+        if scalars.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(scalars.device))
+            self._events[slot] = ev
+        self._tags[slot] = tag
+        self._pending, self._cur = slot, 1 - slot
+        return prev
+
+    def flush(self):
+        if self._pending is None:
+            return None
+        out = self._take(self._pending)
+        self._pending = None
+        return out

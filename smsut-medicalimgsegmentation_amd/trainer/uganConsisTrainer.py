@@ -508,6 +508,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self.net.train(); self.D.train()
         lb_itr, ul_itr = iter(lb_loader), iter(ul_loader)
         tic = time.time()
+        from ..misc.utils import ScalarFetcher
+        fetch = ScalarFetcher(len(SCALARS), self.device)
         for i in range(self.n_critic * cfg.num_iter_per_epoch):
             try:
                 x1, y_real, mo1, _ = next(lb_itr)
@@ -520,15 +522,25 @@ class UGANConsisTrainer(UGANShp0Trainer):
             x_real = torch.cat([x1.to(self.device, non_blocking=True), x2.to(self.device, non_blocking=True)], 0)
             modal_org = torch.cat([mo1, mo2], 0)
             scal = self.train_iteration(x_real, y_real.to(self.device, non_blocking=True), modal_org)
-            if meter is not None or (i + 1) % (self.n_critic * self.log_step) == 0:
-                vals = scal.tolist()                                                          # the one host sync
-                if meter is not None:
-                    v, n = meter.collect_loss_by(vals[SCALARS.index("G_seg")], mo1[0].item(), cfg.batch_size)
-                    meter.accumulate(v, n)
-                if (i + 1) % (self.n_critic * self.log_step) == 0:
-                    self.info("Iter: %d/%d(%d), elapsed: %.2fs, " % (i, cfg.num_iter_per_epoch, self.iter, time.time() - tic)
-                              + " ".join("%s: %.4f," % kv for kv in zip(SCALARS, vals)))
-                    tic = time.time()
+            # the iteration's ten scalars travel to pinned host memory without a sync and are consumed ONE ITERATION LATER
+            # (misc.utils.ScalarFetcher): same values in the same order for the meter and the log, no device stall
+            done = fetch.push(scal, (i, self.iter, int(mo1[0])))
+            if done is not None:
+                tic = self._consume_scalars(done, meter, tic)
+        done = fetch.flush()
+        if done is not None:
+            self._consume_scalars(done, meter, tic)
+
+    def _consume_scalars(self, done, meter, tic):
+        vals, (i, it, modality) = done
+        if meter is not None:
+            v, n = meter.collect_loss_by(vals[SCALARS.index("G_seg")], modality, cfg.batch_size)
+            meter.accumulate(v, n)
+        if (i + 1) % (self.n_critic * self.log_step) == 0:
+            self.info("Iter: %d/%d(%d), elapsed: %.2fs, " % (i, cfg.num_iter_per_epoch, it, time.time() - tic)
+                      + " ".join("%s: %.4f," % kv for kv in zip(SCALARS, vals)))
+            tic = time.time()
+        return tic
 
     def translate_all(self, x_fixed, modal_org):
         """The per-epoch sample grid of :205-214 / saving_pseudo :216-: x translated to every modality (no grad)."""

@@ -84,6 +84,14 @@ class UnetTrainer(BaseTrainer):
     def train_epoch(self, lb_loader, ul_loader, meter):
         self.net.train()
         it = iter(lb_loader)
+        from ..misc.utils import ScalarFetcher
+        fetch = ScalarFetcher(1, self.device)                # (the loss reaches the meter one iteration late: no device stall)
+
+        def consume(done):
+            if done is not None:
+                (val,), (modality, bsz) = done
+                v, n = meter.collect_loss_by(val, modality, bsz)
+                meter.accumulate(v, n)
         for _ in range(cfg.num_iter_per_epoch):
             try:
                 img, msk, mdl, _ = next(it)
@@ -91,8 +99,8 @@ class UnetTrainer(BaseTrainer):
                 it = iter(lb_loader)
                 img, msk, mdl, _ = next(it)
             loss = self.train_step(img.to(self.device, non_blocking=True), msk.to(self.device, non_blocking=True))
-            v, n = meter.collect_loss_by(loss.item(), mdl[0].item(), img.size(0))
-            meter.accumulate(v, n)
+            consume(fetch.push(loss.reshape(1), (int(mdl[0]), img.size(0))))
+        consume(fetch.flush())
 
 
 def main(argv=None):

@@ -262,3 +262,20 @@ def test_graphed_phases_hold_no_cycle_and_close_frees_them(monkeypatch):
     finally:
         if gc_was:
             gc.enable()
+
+
+def test_scalar_fetcher_hands_out_every_item_once_one_push_late():
+    """misc.utils.ScalarFetcher (the trainers' per-iteration logging without a device stall): values and tags come back in order,
+    each exactly once, one push late; flush returns the last."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd.misc.utils import ScalarFetcher
+    f = ScalarFetcher(3, "cpu")
+    outs = []
+    for i in range(5):
+        r = f.push(torch.tensor([i, i + 0.5, -i], dtype=torch.float32), tag=("it", i))
+        if r is not None:
+            outs.append(r)
+    outs.append(f.flush())
+    assert f.flush() is None
+    assert [t for _, t in outs] == [("it", i) for i in range(5)]
+    assert [v for v, _ in outs] == [[float(i), i + 0.5, float(-i)] for i in range(5)]
