@@ -547,9 +547,6 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       zero[i] = (u_flag[i] & pflags) != 0;
-#ifdef SMSUT_DBG_NO_PREFETCH
-      if (c == 12345)
-#endif
       rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : u_off[i]));
     }
     if (INAFF) {                                     // every unit of a thread carries the channel quad tid & 3
@@ -648,14 +645,6 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       }
     }
     float* yb = yo + (((size_t)en * H + ety * TH) * W + etx * TW) * os + oc0;
-#ifdef SMSUT_DBG_NO_STORE            // scratch builds only (scratch/loop_ablation.py): results are dropped unless a NaN shows up
-    bool keep = false;
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-      for (int j = 0; j < NR; ++j) keep |= pacc[i][j][0] != pacc[i][j][0];
-    if (!keep) return;
-#endif
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -773,12 +762,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
         for (int b = 0; b < 4; ++b)
           t[b] = xi == 0 ? sub4(dx[b], d2[b]) : xi == 1 ? add4(d1[b], d2[b]) : xi == 2 ? sub4(d2[b], d1[b]) : sub4(d1[b], dx[b]);
-#ifdef SMSUT_WDBG_NO_INXF            // scratch builds (scratch/wino_ablation.py): results wrong by construction, only the time matters
-        const f32x4 v[4] = {dx[0], d1[1], d2[2], dx[3]};
-        (void)t;
-#else
         const f32x4 v[4] = {sub4(t[0], t[2]), add4(t[1], t[2]), sub4(t[2], t[1]), sub4(t[1], t[3])};
-#endif
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
           const int pos = xi * 4 + nu;
@@ -787,11 +771,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
             const f32x4 b = *(const f32x4*)(wc + ((size_t)pos * K4 * CO_T + j * 16) * 4);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-#ifdef SMSUT_WDBG_NO_MFMA
-              macc[pos][j][s] += v[nu][s] * b[s];
-#else
               macc[pos][j] = mfma16(v[nu][s], b[s], macc[pos][j]);
-#endif
           }
         }
       }
@@ -804,13 +784,8 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
             c0[nu] = add4(add4(macc[0 + nu][j], macc[4 + nu][j]), macc[8 + nu][j]);
             c1[nu] = sub4(sub4(macc[4 + nu][j], macc[8 + nu][j]), macc[12 + nu][j]);
           }
-#ifdef SMSUT_WDBG_NO_OUTXF
-          const f32x4 o00 = macc[0][j], o01 = macc[5][j], o10 = macc[10][j], o11 = macc[15][j];
-          (void)c0; (void)c1;
-#else
           const f32x4 o00 = add4(add4(c0[0], c0[1]), c0[2]), o01 = sub4(sub4(c0[1], c0[2]), c0[3]);
           const f32x4 o10 = add4(add4(c1[0], c1[1]), c1[2]), o11 = sub4(sub4(c1[1], c1[2]), c1[3]);
-#endif
           // acc[2*dy + dx][j][r] = o[dy][dx][r]: no repacking (the epilogue stores element by element anyway)
           acc[0][j] = o00; acc[1][j] = o01; acc[2][j] = o10; acc[3][j] = o11;
 #pragma unroll
@@ -886,49 +861,11 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       return;
     }
     const float* wc = w_s + (size_t)(c * 4) * CO_T * 4;
-#ifdef SMSUT_FRAG_PIPELINE
-    // EXPERIMENT (r02, measured slower, off by default): fragment reads ONE TAP AHEAD of the MFMAs.  Left to itself the
-    // scheduler sinks a tap's ds_reads below the previous tap's MFMAs (ISA: rrr s_waitcnt lgkmcnt(0) MMMMMMMM rrr ...), which
-    // looks like exposed LDS latency (r02 SQ counters: matrix pipes busy 66 %, waves issue-stalled 65 %).  With the look-ahead
-    // (sched_barrier 0x77 keeps DS / MFMA order, lets ALU / VMEM cross) the waits become lgkmcnt(3) -- and the kernel gets
-    // SLOWER: two-library A/B (scratch/conv_ab.py) 16->16 @256^2 B32 statistics form 101.4 -> 106.4 us, accumulate form
-    // 99.4 -> 129.0 us (the second fragment set costs occupancy), 32-channel reductions +-1 %.  The other resident waves
-    // already cover that latency; see profiles/r02_notes.md.
-    f32x4 fa[2][MR], fb[2][NR];
-    auto ldfrag = [&](int tap, f32x4* a, f32x4* b) {
-      const int kh = tap / KS, kw = tap % KS;
-#pragma unroll
-      for (int i = 0; i < MR; ++i) a[i] = *(const f32x4*)(in_s + ((wave * MR + i + kh) * IW + lm + kw) * SPIX + 4 * kq);
-#pragma unroll
-      for (int j = 0; j < NR; ++j) b[j] = *(const f32x4*)(wc + (((size_t)(tap * K4 + kq) * CO_T) + j * 16 + lm) * 4);
-    };
-    ldfrag(0, fa[0], fb[0]);
-#pragma unroll
-    for (int tap = 0; tap < KK; ++tap) {
-      if (tap + 1 < KK) ldfrag(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0x77);       // ALU + VMEM may cross; DS and MFMA may not
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < MR; ++i)
-#pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] = mfma16(fa[tap & 1][i][s], fb[tap & 1][j][s], acc[i][j]);
-      __builtin_amdgcn_sched_barrier(0x77);
-    }
-#else
-#ifdef SMSUT_SETPRIO
-    __builtin_amdgcn_s_setprio(SMSUT_SETPRIO);       // waves in their MFMA phase win the issue arbitration over side work
-#endif
 #pragma unroll
     for (int tap = 0; tap < KK; ++tap) {
       if (SC2 && c >= NCH / 2 && tap != KK / 2) continue;       // the shortcut's gradient: centre tap only
-#ifdef SMSUT_DBG_NO_LDSREAD
-      const int kh = 0, kw = 0;                       // every tap reads tap 0's fragments: the compiler keeps them in registers
-      const int tapw = 0;
-#else
       const int kh = tap / KS, kw = tap % KS;
       const int tapw = tap;
-#endif
       f32x4 a[MR], b[NR];
 #pragma unroll
       for (int i = 0; i < MR; ++i)
@@ -956,10 +893,6 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         }
       }
     }
-#ifdef SMSUT_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-#endif
   };
 
   STAMP(1);
@@ -988,18 +921,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       }
       mma_chunk(c);
       if (item == item0 + 1 && c < 2) { STAMP(3 + 4 * c); }
-#ifndef SMSUT_DBG_NO_BARRIER
       __syncthreads();                                // in_s is free; red[par] is complete
-#endif
       if (item == item0 + 1 && c < 2) { STAMP(4 + 4 * c); }
       if (c == 0 && !FIRST) { stats_out(par); par ^= 1; }
-#ifndef SMSUT_DBG_NO_PUBLISH
       if (more) publish();
-#endif
       if (item == item0 + 1 && c < 2) { STAMP(5 + 4 * c); }
-#ifndef SMSUT_DBG_NO_BARRIER
       __syncthreads();
-#endif
       if (item == item0 + 1 && c < 2) { STAMP(6 + 4 * c); }
     }
     // item done: keep its accumulators for the next region's epilogue
@@ -1039,13 +966,10 @@ constexpr int WTH = 8;       // pixel tile rows; each wave takes WTH/4 = 2 rows 
 // row needs roll through registers, ONE new row per tile row: 10 LDS reads per 36 MFMAs instead of 40.  The k-slot stride in LDS
 // becomes 4 pixels, so the pixel stride is 36 floats (4 x 36 = 16 mod 64 banks: the four k-slots of a read on disjoint bank
 // quarters; with the old stride of 48 they would collide four ways), 68 for the [gy | gs] tile of the fused-shortcut form.
-#ifndef WTS_ROLL
-#define WTS_ROLL 1
-#endif
 #ifndef WTS_STRIDE_VALUE
-#define WTS_STRIDE_VALUE (WTS_ROLL ? 36 : 48)
+#define WTS_STRIDE_VALUE 36
 #endif
-constexpr int WTS_STRIDE_SC = WTS_ROLL ? 68 : 80;   // ... of the fused-shortcut form's [gy 32 | gs 32 | pad] tile
+constexpr int WTS_STRIDE_SC = 68;   // ... of the fused-shortcut form's [gy 32 | gs 32 | pad] tile
 constexpr int WTS_STRIDE = WTS_STRIDE_VALUE;   // pixel stride (floats) of the tap-split wgrad's LDS tiles (32 channels + pad)
 
 template <int KS, int CIT, int COT, bool DUAL = false, bool INAFF = false, bool C8 = false, bool SC8 = false>
@@ -1292,13 +1216,8 @@ conv_mfma_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float
 // row-split kernel above (each wave 1/4 of the rows, all 36 tiles = 144 accumulator registers, one wave per SIMD,
 // three LDS combine rounds at the end) this needs 36 accumulator registers, keeps two workgroups per CU resident and
 // has no cross-wave combine: each wave stores its own tiles.  PMC r01 (64->64 @64^2): row-split 46 % MFMA busy.
-#ifdef WTS_F4
-typedef float4 wvec;
-#define WZERO make_float4(0.f, 0.f, 0.f, 0.f)
-#else
 typedef f32x4 wvec;
 #define WZERO ((f32x4){0.f, 0.f, 0.f, 0.f})
-#endif
 template <bool DUAL = false, bool INAFF = false, bool SC = false>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H,
@@ -1327,20 +1246,12 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
   const int t_begin = split * tiles_per_split;
   const int t_end = min(t_begin + tiles_per_split, total_tiles);
 
-  // unit u = wave + 4*slot = (tap*CIT + i)*COT + j  ->  j = wave & 1 for every slot of this wave
+  // this wave's unit k is tap k of ci tile wave >> 1 against co tile wave & 1
   const int jt = wave & 1;
-  int a_off[NSLOT];
-#pragma unroll
-  for (int k = 0; k < NSLOT; ++k) {
-    const int ti = (wave + 4 * k) >> 1;                        // tap*CIT + i
-    const int tap = ti >> 1, i = ti & 1;
-    a_off[k] = ((tap / KS) * IW + (tap % KS)) * SI + i * 16;
-  }
   f32x4 acc[NSLOT];
 #pragma unroll
   for (int k = 0; k < NSLOT; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   [[maybe_unused]] f32x4 acc_sc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  [[maybe_unused]] const int a_off_sc = (PAD * IW + PAD) * SI + (wave >> 1) * 16;
 
   // Staging descriptors, computed once (full tiles and full 32-channel slabs only -- the host checks H % 8 == 0,
   // W % 16 == 0, Cin % 32 == 0, Cout % 32 == 0 and 32-bit element offsets): element offset of the unit relative to the
@@ -1432,9 +1343,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     if (t - t_begin < 2) { STAMP(3 + 4 * (t - t_begin)); }
     if (t + 1 < t_end) prefetch();
     if (t - t_begin < 2) { STAMP(4 + 4 * (t - t_begin)); }
-#if WTS_ROLL
     {
-      // this wave's unit k is tap k of ci tile wave >> 1 against co tile wave & 1 (see a_off above)
       const float* ax = in_s + (4 * kq) * SI + (wave >> 1) * 16 + lm;
       const float* bx = gy_s + (4 * kq) * SO + jt * 16 + lm;
       float xr[3][6];
@@ -1461,23 +1370,6 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
         }
       }
     }
-#else
-#ifndef WTS_UNROLL
-#define WTS_UNROLL 8
-#endif
-#pragma unroll WTS_UNROLL
-    for (int r = 0; r < WTH; ++r) {
-#pragma unroll
-      for (int ks = 0; ks < TW / 4; ++ks) {
-        const int px = ks * 4 + kq;                 // this lane's pixel (the MFMA k index) within the row
-        const float b = gy_s[(r * TW + px) * SO + jt * 16 + lm];
-        const float* ap = in_s + (r * IW + px) * SI + lm;
-#pragma unroll
-        for (int k = 0; k < NSLOT; ++k) acc[k] = mfma16(ap[a_off[k]], b, acc[k]);
-        if constexpr (SC) acc_sc = mfma16(ap[a_off_sc], gy_s[(r * TW + px) * SO + 32 + jt * 16 + lm], acc_sc);
-      }
-    }
-#endif
     if (t - t_begin < 2) { STAMP(5 + 4 * (t - t_begin)); }
   }
   STAMP(10);
@@ -1489,11 +1381,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
     float* o = out + (tap * Cin + i * 16) * Cout;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#ifdef WTS_NT_STORE
-      __builtin_nontemporal_store(acc[k][r], o + r * Cout);
-#else
       o[r * Cout] = acc[k][r];
-#endif
     }
   }
   if constexpr (SC) {                           // slab row KK: the shortcut's [Cin][Cout] gradient, this wave's (ci tile, co tile)
@@ -1765,9 +1653,6 @@ inline void launch_sum_splits(const float* part, float* out, int wsize, int spli
   // splits) made the whole weight-gradient call 10-24 % slower at 256^2 / 128^2; 32 / 64 columns win from 32x32 / 64x64
   // weights on (longer contiguous rows per request).
   (void)splits;
-#ifdef WTS_SKIP_SUM
-  if (!dbg_force) return;
-#endif
   if (wsize >= 32768) sum_splits<64><<<(wsize + 255) / 256, TPB, 0, st>>>(part, out, wsize, splits);
   else if (wsize >= 8192) sum_splits<32><<<(wsize + 127) / 128, TPB, 0, st>>>(part, out, wsize, splits);
   else sum_splits<16><<<(wsize + 63) / 64, TPB, 0, st>>>(part, out, wsize, splits);
@@ -2001,10 +1886,8 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
   static const bool use_wino = [] { const char* e = getenv("SMSUT_WINOGRAD"); return !e || atoi(e) != 0; }();
   if (use_wino && !f16 && H % 16 == 0 && (Kdim == 16 || Kdim == 32))
     return Kdim == 16 ? launch_fwd_p<3, 16, 1, 1, false, false, true>(PARGS) : launch_fwd_p<3, 16, 1, 2, false, false, true>(PARGS);
-#ifndef SMSUT_P_OLD_TABLE
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
   if (Kdim == 32 && Ndim % 32 == 0 && !(y2 && split % 32 != 0)) return launch_fwd_p<3, 8, 2, 2>(PARGS);   // (32-channel slabs must not straddle a split)
-#endif
   if (Kdim == 16) return launch_fwd_p<3, 8, 1, 1>(PARGS);
   if (Kdim == 32) return launch_fwd_p<3, 8, 1, 2>(PARGS);
   if (Kdim == 64) return launch_fwd_p<3, 8, 1, 4>(PARGS);

@@ -330,20 +330,6 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
   constexpr int NP = NI + NWG + NWR;                    // staging parts
   // part p of the region that multiplies from buffer b: publish into b ^ 1, then request
   auto stage_part = [&](int p_, int b) {
-#ifdef SMSUT_WLDBG_NO_STAGE_IN
-    if (p_ < NI) return;
-#endif
-#ifdef SMSUT_WLDBG_NO_STAGE_W
-    if (p_ >= NI) return;
-#endif
-#ifdef SMSUT_WLDBG_NO_PF
-    if (p_ < NI) { if constexpr (!GLI) pub_in(p_, b ^ 1); } else if (p_ >= NI + NWG) { pub_w(p_ - NI - NWG, b ^ 1); }
-    return;
-#endif
-#ifdef SMSUT_WLDBG_NO_PUB
-    if (p_ < NI) { pf_in(p_); } else if (p_ >= NI + NWG) { pf_w(p_ - NI - NWG); }
-    return;
-#endif
     if (p_ < NI) {
       if constexpr (GLI) gl_in(p_, b ^ 1);
       else { pub_in(p_, b ^ 1); pf_in(p_); }
@@ -500,9 +486,6 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
         return;                                          // (SC2 has no ACC / BST operands to request)
       }
     }
-#ifdef SMSUT_WLDBG_NO_LDA
-    if (c >= 0) dp = smem + 2 * BUF;                     // (every window read hits the same few words: no LDS bandwidth)
-#endif
     if constexpr (PH == 0 || PH == 1) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
@@ -555,21 +538,11 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     //  parameter kept them in scratch memory in several instantiations)
     auto ld_b = [&](int u, int sel) __attribute__((always_inline)) {
       const int xi = XO[u / NR], j = u % NR;
-#ifdef SMSUT_WLDBG_NO_LDB
-      if (c >= 0) {
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) bf[sel][nu] = (f32x4){(float)xi, (float)j, (float)nu, 1.f};
-        return;
-      }
-#endif
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) bf[sel][nu] = *(const f32x4*)(wc + ((size_t)(xi * 4 + nu) * 4 * CO_T + j * 16) * 4);
     };
     auto xform = [&](int g, int sel) __attribute__((always_inline)) {
       const int xi = XO[g];
-#ifdef SMSUT_WLDBG_NO_XFORM
-      vv[sel][0] = d1[0]; vv[sel][1] = d1[1]; vv[sel][2] = d2[2]; vv[sel][3] = d2[3]; (void)xi; return;
-#endif
       f32x4 t[4];                                        // row combination xi of B^T: d0-d2 | d1+d2 | d2-d1 | d1-d3
 #pragma unroll
       for (int b = 0; b < 4; ++b) t[b] = xi == 0 ? d0[b] - d2[b] : xi == 1 ? d1[b] + d2[b] : xi == 2 ? d2[b] - d1[b] : d1[b] - d3[b];
@@ -589,11 +562,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
 #pragma unroll
       for (int p_ = 0; p_ < NP; ++p_)
         if (PH != 3)
-#ifdef SMSUT_WLDBG_NO_STAGE          // scratch builds (scratch/wino_l_ablation.py): results wrong by construction, only the time matters
-        if (part_unit(p_) == u && c < 0) stage_part(p_, buf);
-#else
         if (part_unit(p_) == u) stage_part(p_, buf);     // this unit's share of the staging work, in the shadow of its MFMAs
-#endif
       if (PH != 3 && u + 1 < NU) {
         ld_b(u + 1, (u + 1) & 1);
         if ((u + 1) % NR == 0) xform(g + 1, (g + 1) & 1);
@@ -613,23 +582,10 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu)
-#ifdef SMSUT_WLDBG_NO_MFMA
-          macc[XO[g] * 4 + nu][j][s] += vv[g & 1][nu][s] * bf[u & 1][nu][s];
-#else
           macc[XO[g] * 4 + nu][j] = mfma16(vv[g & 1][nu][s], bf[u & 1][nu][s], macc[XO[g] * 4 + nu][j]);
-#endif
       // SMSUT_WL_IGROUP: force an interleave -- after every MFMA up to six VALU, two LDS and two global-memory instructions of
       // this region.  Off: with the staging done by LDS-DMA the region has ~2 other instructions per MFMA and the scheduler's
       // own order measures 1-2 us (of 50) faster than any forced one (6/2, 4/1, 3/1, 2/1 tried: profiles/r03_notes.md)
-#ifdef SMSUT_WL_IGROUP
-#pragma unroll
-      for (int m_ = 0; m_ < 16; ++m_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, SMSUT_WL_IG_VALU, 0);
-        __builtin_amdgcn_sched_group_barrier(0x080, SMSUT_WL_IG_DS, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
-      }
-#endif
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -706,9 +662,7 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     WL_STAMP(ts3);
     if constexpr (GLI || PRE) glds_wait();               // this wave's LDS-DMA pieces of the next chunk have landed
     WL_STAMP(ts4);
-#ifndef SMSUT_WLDBG_NO_BARRIER
     __syncthreads();                                     // buffer buf is free, buf ^ 1 is complete; red[] is complete
-#endif
     if constexpr (!ROT) {
       if constexpr (last) stats_out(cn, cty, ctx);
     } else {
