@@ -109,3 +109,27 @@ def test_wino_kernels_leave_m0_to_the_dma_statements(tmp_path):
         assert lines[i + 1].startswith("s_nop") and lines[i + 2].startswith("global_load_lds_dwordx4"), lines[i:i + 3]
     n_dma = sum(ln.startswith("global_load_lds_dwordx4") for ln in lines)
     assert n_dma == len(uses)
+
+
+def test_weight_gradient_workspace_covers_every_kernel_plan():
+    """Host logic only (no launch): the workspace the callers allocate from ``smsut_conv2d_wgrad_mfma_ws`` / ``_sc_ws`` must hold the split
+    slabs of whichever kernel takes the shape -- the LDS-staged ones or the register-row one (csrc/conv_wgrad_rr.hip plans its own split
+    count) -- and ``smsut_conv2d_wgrad_sc_supported`` covers the 16-channel slabs since r04."""
+    import ctypes
+    import smsut_amd  # noqa: F401
+    from smsut_amd import _hip as H
+    lib = H.load()
+    lib.smsut_conv2d_wgrad_mfma_ws.restype = ctypes.c_int64
+    lib.smsut_conv2d_wgrad_sc_ws.restype = ctypes.c_int64
+    for n in (1, 3, 16, 32):
+        for (h, w) in ((256, 256), (128, 128), (64, 64), (20, 48), (16, 16), (8, 8), (4, 4)):
+            for (ci, co) in ((16, 16), (32, 16), (16, 32), (32, 32), (64, 32), (128, 128), (256, 256), (8, 16), (48, 80)):
+                need = lib.smsut_conv2d_wgrad_mfma_ws(n, h, w, ci, co, 3)
+                assert need >= 9 * ci * co, (n, h, w, ci, co, need)
+                assert need % (9 * ci * co) == 0 or need > 9 * ci * co
+                assert need <= 64 * (1 << 20), (n, h, w, ci, co, need)          # bounded slabs (sum_splits re-reads them)
+                if lib.smsut_conv2d_wgrad_sc_supported(n, h, w, ci, co):
+                    assert lib.smsut_conv2d_wgrad_sc_ws(n, h, w, ci, co) >= 10 * ci * co
+    assert lib.smsut_conv2d_wgrad_sc_supported(16, 256, 256, 32, 16) == 1            # r04: the register-row kernel carries the extra tile
+    assert lib.smsut_conv2d_wgrad_sc_supported(16, 128, 128, 16, 32) == 1
+    assert lib.smsut_conv2d_wgrad_sc_supported(16, 256, 256, 48, 80) == 0
