@@ -148,6 +148,10 @@ int smsut_conv2d_fwd_sc_supported(int N, int H, int W, int Kdim, int Ndim, int c
 int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb /*nullable*/, const float* w, const float* wsc, float* y,
                                    float* ysc, float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim,
                                    void* stream);
+/* the same with fp16 operands (config 5): persistent kernel's direct form, Kdim in {16, 32, 64}; tiles with f16 = 1 */
+int smsut_conv2d_fwd_sc_f16_supported(int N, int H, int W, int Kdim, int Ndim, int cat);
+int smsut_conv2d_fwd_mfma_stats_sc_f16(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
+                                       float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream);
 /* ... and the data-gradient of that pair in one pass: gx = dgrad3x3(gy, w) + dgrad1x1(gs, wsc) (the backward of
  * `out = conv1(x) ... + shortcut(x)` w.r.t. x, blocks.py:66-80).  gxb nullable: non-null = channels [0, split) of gx go to
  * gxa, the rest to gxb (the block input was cat([up, skip])).  _supported(..., split or 0) first. */

@@ -77,6 +77,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_fwd_mfma_stats_cat_pre": "ppppp iiiii p s",
     "smsut_conv2d_fwd_sc_supported": "iiiiii",
     "smsut_conv2d_fwd_mfma_stats_sc": "pppppppp iiiii s",
+    "smsut_conv2d_fwd_mfma_stats_sc_f16": "pppppppp iiiii s",
+    "smsut_conv2d_fwd_sc_f16_supported": "iiiiii",
     "smsut_conv2d_fwd_mfma_stats_sc_pre": "pppppppp iiiii p s",
     "smsut_conv2d_dgrad_sc_supported": "iiiiii",
     "smsut_conv2d_dgrad_mfma_sc": "pppppp iiiiii s",
@@ -173,7 +175,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",
-                         "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_dgrad_sc_supported",
+                         "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_fwd_sc_f16_supported", "smsut_conv2d_dgrad_sc_supported",
                          "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported",
                          "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
 

@@ -368,7 +368,8 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // The 1x1 conv is the centre tap with its own weights: the A fragments of tap (1,1) feed a second accumulator set (+1/9 MFMAs),
   // the epilogue stores the second result sc.y and its InstanceNorm partials sc.stats -- the separate 1x1 kernel and its re-read
   // of the block input (HBM-bound, 5 FLOP/B) disappear.  Forward statistics forms (plain or virtual-cat input), fp32.
-  static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !F16 && KS == 3), "fused shortcut: forward statistics forms");
+  static_assert(!SC || (STATS && !ACC && !BST && !INAFF && KS == 3), "fused shortcut: forward statistics forms");
+  static_assert(!(SC && F16 && (K8 || WINO)), "fused shortcut with fp16 operands: the direct 16-channel-chunk form");
   // SC2: the DATA-GRADIENT of that pair in one pass: gx = dgrad3x3(gy1, w1) + dgrad1x1(gs, ws).  The two gradients are the
   // virtual cat [gy1, gs] along the reduction (DUAL staging, unchanged); the chunks of the second half only run the centre
   // tap, against the 1x1 weights (sc.w) -- +1/9 MFMAs instead of a 1x1 kernel plus an accumulate pass over gx.
@@ -422,6 +423,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   [[maybe_unused]] float* red_sc = wsc_s + Kdim * CO_T;               // SC: [2][4][CO_T][2] + dummy
   [[maybe_unused]] _Float16* in_h = reinterpret_cast<_Float16*>(smem);       // F16: [IH][IW][SPIXH] + dummy pixel
   [[maybe_unused]] _Float16* w_h = reinterpret_cast<_Float16*>(w_s);         // F16: [KK][NCH][CO_T][WROWH]
+  [[maybe_unused]] _Float16* wsc_h = reinterpret_cast<_Float16*>(wsc_s);     // F16 + SC: [NCH][CO_T][WROWH]
   [[maybe_unused]] const float gs = (F16 && gsc) ? gsc[0] : 1.f, gi = (F16 && gsc) ? gsc[1] : 1.f;
 
   const int tid = threadIdx.x;
@@ -508,7 +510,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     for (int u = tid; u < K4 * CO_T; u += TPB) {
       const int n = u % CO_T, k4 = u / CO_T;
       const float* p = sc.w + (size_t)(4 * k4) * Ndim + co0 + n;
-      *(float4*)(wsc_s + (size_t)u * 4) = make_float4(p[0], p[Ndim], p[2 * (size_t)Ndim], p[3 * (size_t)Ndim]);
+      const float4 v = make_float4(p[0], p[Ndim], p[2 * (size_t)Ndim], p[3 * (size_t)Ndim]);
+      if (F16) *(h4*)(wsc_h + ((size_t)(k4 >> 2) * CO_T + n) * WROWH + 4 * (k4 & 3)) = to_h4(v);
+      else *(float4*)(wsc_s + (size_t)u * 4) = v;
     }
   }
 
@@ -857,6 +861,17 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
         for (int i = 0; i < MR; ++i)
 #pragma unroll
           for (int j = 0; j < NR; ++j) acc[i][j] = mfma16h(a[i], b[j], acc[i][j]);
+        if constexpr (SC) {
+          if (tap == KK / 2) {                             // the 1x1 shortcut (r04, config 5): centre tap, its own weights, same A fragments
+            h4 bs[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) bs[j] = *(const h4*)(wsc_h + ((size_t)c * CO_T + j * 16 + lm) * WROWH + 4 * kq);
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+              for (int j = 0; j < NR; ++j) acs[i][j] = mfma16h(a[i], bs[j], acs[i][j]);
+          }
+        }
       }
       return;
     }
@@ -1734,9 +1749,9 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (aff && (!stats || bst || y2 || x2 || transposed)) return -1;              // input-side IN: forward statistics form
   const bool sc2 = sc && (transposed & 1);                                      // fused shortcut DATA-gradient (see SC2)
   if (sc2 && (K8 || KS != 3 || NCH % 2 != 0 || !x2 || stats || bst || aff || (transposed & 2) || f16 || !sc->w)) return -1;
-  if (sc && !sc2 && (KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || f16 || !sc->w || !sc->y || !sc->stats ||
-                     (K8 && x2)))
-    return -1;                                                                  // fused shortcut: forward statistics forms, fp32
+  if (sc && !sc2 && (KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || !sc->w || !sc->y || !sc->stats ||
+                     (K8 && x2) || (f16 && (K8 || WINO))))
+    return -1;                                                                  // fused shortcut: forward statistics forms
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = N8 ? 1 : Ndim / (16 * NTN);
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
@@ -1805,7 +1820,19 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true><<<grid, TPB, sh_sc, st>>>(
           x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
     } else if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
-      if (x2) {
+      if (f16) {                                   // fp16 operands (config 5; r04): direct form, plain or virtual-cat input
+        if constexpr (!WINO) {
+          if (x2) {
+            if constexpr (NCH % 2 == 0)
+              conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, true, false, true><<<grid, TPB, sh_sc, st>>>(
+                  x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc);
+            else return -1;
+          } else {
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, true><<<grid, TPB, sh_sc, st>>>(
+                x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+          }
+        } else return -1;
+      } else if (x2) {
         if constexpr (NCH % 2 == 0)
           conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true, false, false, WINO><<<grid, TPB, sh_sc, st>>>(
               x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc);
@@ -2468,6 +2495,24 @@ int smsut_conv2d_fwd_mfma_stats_sc_pre(const float* x, const float* xb, const fl
 int smsut_conv2d_fwd_mfma_stats_sc(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
                                    float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
   return smsut_conv2d_fwd_mfma_stats_sc_pre(x, xb, w, wsc, y, ysc, stats, stats_sc, N, H, W, Kdim, Ndim, nullptr, stream);
+}
+// ... with fp16 operands (BASELINE config 5): the persistent kernel's direct form, Kdim in {16, 32, 64} (the fp16-operand mode has
+// no Winograd forms); statistics tiles = smsut_conv2d_mfma_tiles(N, H, W, Kdim, Ndim, 3, /*f16=*/1).
+int smsut_conv2d_fwd_sc_f16_supported(int N, int H, int W, int Kdim, int Ndim, int cat) {
+  static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_F16"); return !e || atoi(e) != 0; }();
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  if (cat && Kdim % 32 != 0) return 0;
+  return 1;
+}
+int smsut_conv2d_fwd_mfma_stats_sc_f16(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
+                                       float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(x && w && wsc && y && ysc && stats && stats_sc && smsut_conv2d_fwd_sc_f16_supported(N, H, W, Kdim, Ndim, xb != nullptr));
+  const ScRef sc{wsc, ysc, stats_sc};
+  const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb, nullptr,
+                              true, nullptr, &sc);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
 }
 
 // Data-gradient of that pair: gx = dgrad3x3(gy, w) + dgrad1x1(gs, wsc) in one pass (gy, gs [N,H,W,Cout]; w, wsc the forward

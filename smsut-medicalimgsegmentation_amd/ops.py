@@ -824,12 +824,13 @@ class BasicBlockFn(Function):
         y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
         # conv1 and the 1x1 shortcut read the same block input: one pass (the shortcut is conv1's centre tap with its own weights)
-        fused_sc = (has_sc and not f16a and bool(H.call("smsut_conv2d_fwd_sc_supported", n, h, w, ci, co, 1 if virtual else 0)))
+        fused_sc = has_sc and bool(H.call("smsut_conv2d_fwd_sc_f16_supported" if f16a else "smsut_conv2d_fwd_sc_supported",
+                                          n, h, w, ci, co, 1 if virtual else 0))
         if fused_sc:
             s = new_act(n, co, h, w, x)
             ps, t1 = _ws(n * t3 * co * 2, x), t3
-            _conv3("smsut_conv2d_fwd_mfma_stats_sc", w1, 0, xa if virtual else x, xb if virtual else None, w1, ws, y1, s, p1, ps,
-                   n, h, w, ci, co, st)
+            _conv3("smsut_conv2d_fwd_mfma_stats_sc_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_sc", w1, 0, xa if virtual else x,
+                   xb if virtual else None, w1, ws, y1, s, p1, ps, n, h, w, ci, co, st)
         elif virtual:
             _conv3("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_cat", w1, 0, xa, xb, w1, y1, p1, n, h, w,
                    ci, co, st)
