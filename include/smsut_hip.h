@@ -197,6 +197,12 @@ int smsut_conv2d_fwd_mfma_stats_cat_f16(const float* xa, const float* xb, const 
                                         int W, int Kdim, int Ndim, void* stream);
 int smsut_conv2d_fwd_mfma_split_f16(const float* x, const float* w, float* ya, float* yb, const float* gsc /*nullable*/,
                                     int split, int N, int H, int W, int Kdim, int Ndim, int transposed, void* stream);
+/* the fused-shortcut data-gradient with fp16 operands (config 5): gsc = {s, 1/s} of smsut_absmax_scale2(gy, gs) (the two gradients
+ * share accumulators, hence ONE scale); Cout in {16, 32}, Cin >= 16, persistent-kernel shapes */
+int smsut_conv2d_dgrad_sc_f16_supported(int N, int H, int W, int Cout, int Cin, int split);
+int smsut_conv2d_dgrad_mfma_sc_f16(const float* gy, const float* gs, const float* w, const float* wsc, float* gxa,
+                                   float* gxb /*nullable*/, const float* gsc, int split, int N, int H, int W, int Cout, int Cin,
+                                   void* stream);
 int smsut_conv2d_dgrad_mfma_bwdstats_f16(const float* gy, const float* w, float* gz, float* stats, const float* y1,
                                          const float* mean, const float* rstd, const float* gamma, const float* beta,
                                          const float* gsc /*nullable*/, float slope, int N, int H, int W, int Kdim, int Ndim,
@@ -207,9 +213,17 @@ int smsut_conv2d_wgrad_f16_supported(int N, int H, int W, int Cin, int Cout);
 int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout);
 int smsut_conv2d_wgrad_f16(const float* x, const float* x2 /*nullable*/, int ca, const float* gy, float* gw, float* workspace,
                            const float* gsc /*nullable*/, int N, int H, int W, int Cin, int Cout, void* stream);
-/* out2[2] = {s, 1/s}, s = 2^k with max|x| * s in [2^13, 2^14] (s = 1 for an all-zero tensor); workspace: _ws floats */
+/* ... plus the 1x1 shortcut's weight gradient in the same pass (fp16 twin of smsut_conv2d_wgrad_mfma_sc): gw10 [10][Cin][Cout],
+ * rows 0..8 the 3x3 taps, row 9 the shortcut; gsc from smsut_absmax_scale2(gy, gs) */
+int smsut_conv2d_wgrad_sc_f16_supported(int N, int H, int W, int Cin, int Cout);
+int64_t smsut_conv2d_wgrad_sc_f16_ws(int N, int H, int W, int Cin, int Cout);
+int smsut_conv2d_wgrad_sc_f16(const float* x, const float* x2 /*nullable*/, int ca, const float* gy, const float* gs, float* gw10,
+                              float* workspace, const float* gsc, int N, int H, int W, int Cin, int Cout, void* stream);
+/* out2[2] = {s, 1/s}, s = 2^k with max|x| * s in [2^13, 2^14] (s = 1 for an all-zero tensor); workspace: _ws floats.
+ * _scale2: one scale for two tensors (max over both; the same workspace size serves it) */
 int64_t smsut_absmax_scale_ws(int64_t n);
 int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace, void* stream);
+int smsut_absmax_scale2(const float* x, int64_t n, const float* x2, int64_t n2, float* out2, float* workspace, void* stream);
 
 /* 4x4 stride-1 pad-1 convolutions on the matrix cores: networks.NLayerDiscriminator / PatchDiscriminator (reference
  * network/networks.py:977-1032, 64 -> 128 -> 256 -> 512 channels).  (H, W) = extents of the conv's forward input; the output

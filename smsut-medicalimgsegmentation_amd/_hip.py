@@ -103,6 +103,12 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_wgrad_f16": "pp i pppp iiiii s",
     "smsut_absmax_scale_ws": "l",
     "smsut_absmax_scale": "p l pp s",
+    "smsut_absmax_scale2": "p l p l pp s",
+    "smsut_conv2d_dgrad_sc_f16_supported": "iiiiii",
+    "smsut_conv2d_dgrad_mfma_sc_f16": "ppppppp iiiiii s",
+    "smsut_conv2d_wgrad_sc_f16_supported": "iiiii",
+    "smsut_conv2d_wgrad_sc_f16_ws": "iiiii",
+    "smsut_conv2d_wgrad_sc_f16": "pp i ppppp iiiii s",
     "smsut_conv1x1_fwd_cat": "pp i ppp iiii s",
     "smsut_conv1x1_wgrad_cat": "pp i ppp iiii s",
     "smsut_conv2d_mfma_split_supported": "iiiiii",
@@ -168,7 +174,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_patchnce_fwd": "pppp iii f s",
     "smsut_patchnce_bwd": "pppp iii f s",
 }
-_RET_I64 = {"smsut_wino_image_floats", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
+_RET_I64 = {"smsut_wino_image_floats", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_conv2d_wgrad_sc_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws",
             "smsut_conv1x1_thin_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
@@ -176,6 +182,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",
                          "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_fwd_sc_f16_supported", "smsut_conv2d_dgrad_sc_supported",
+                         "smsut_conv2d_dgrad_sc_f16_supported", "smsut_conv2d_wgrad_sc_f16_supported",
                          "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported",
                          "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
 

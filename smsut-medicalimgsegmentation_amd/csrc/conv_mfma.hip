@@ -373,7 +373,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // SC2: the DATA-GRADIENT of that pair in one pass: gx = dgrad3x3(gy1, w1) + dgrad1x1(gs, ws).  The two gradients are the
   // virtual cat [gy1, gs] along the reduction (DUAL staging, unchanged); the chunks of the second half only run the centre
   // tap, against the 1x1 weights (sc.w) -- +1/9 MFMAs instead of a 1x1 kernel plus an accumulate pass over gx.
-  static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !F16 && !K8 && !SC && KS == 3), "fused shortcut data-gradient");
+  // (F16: both gradients are scaled by ONE power of two, gsc -- smsut_absmax_scale2 -- since they share the accumulators.)
+  static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !K8 && !SC && KS == 3), "fused shortcut data-gradient");
+  static_assert(!(SC2 && F16 && (WINO || N8)), "fused shortcut data-gradient with fp16 operands: the direct form, >= 16 result channels");
   // N8: the result has 8 channels (Ndim == 8: the data-gradient of the first block after the stem, 16 -> 8 @256^2, ran on the per-tile
   // kernel at 35 TFLOP/s).  The weight block is padded to 16 columns with zeros, lanes lm >= 8 neither load nor store.
   static_assert(!N8 || (NTN == 1 && !STATS && !BST && !INAFF && !F16 && !K8 && !SC), "8 result channels: plain / accumulate / SC2 data-gradient forms");
@@ -849,6 +851,7 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     if constexpr (F16) {
 #pragma unroll
       for (int tap = 0; tap < KK; ++tap) {
+        if (SC2 && c >= NCH / 2 && tap != KK / 2) continue;     // the shortcut's gradient: centre tap only
         const int kh = tap / KS, kw = tap % KS;
         h4 a[MR], b[NR];
 #pragma unroll
@@ -1419,20 +1422,25 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
 //   TS  (2 x 2 tiles of 16 channels): the 36 accumulator tiles are dealt to the 4 waves, each wave walks all 8 tile rows;
 //   !TS (1 x 1, 1 x 2, 2 x 1): every wave keeps all 9*CIT*COT tiles for 2 of the 8 rows, fixed-order combine at the end.
 // Full tiles only (H % 8 == 0, W % 16 == 0), Cin % (16*CIT) == 0, Cout % (16*COT) == 0 -- checked by the host.
-template <int CIT, int COT, bool DUAL>
+// SC (r04, config 5): the weight gradient of the block's 1x1 shortcut in the same pass (network/blocks.py:66-80; the fp32 twin is
+// conv_mfma_wgrad_ts<.., SC>): a TENTH tap row -- x at the centre-tap offset against the shortcut's gradient gs, staged beside gy
+// with the same scale gsc (smsut_absmax_scale2) -- so the slab is [10][Cin][Cout], row 9 = the 1x1 weights' gradient.
+template <int CIT, int COT, bool DUAL, bool SC = false>
 __global__ void __launch_bounds__(TPB)
 conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H, int W,
                int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, const float* __restrict__ x2, int ca,
-               const float* __restrict__ gsc) {
+               const float* __restrict__ gsc, const float* __restrict__ gsh = nullptr) {
   constexpr int KS = 3, KK = 9, PAD = 1;
+  constexpr int KR = SC ? 10 : 9;                          // tap rows of the slab
   constexpr bool TS = (CIT == 2 && COT == 2);
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int NPX = IH * IW, NPG = WTH * TW;              // pixels of the haloed x tile / of the gy tile
   constexpr int CI_T = 16 * CIT, CO_T = 16 * COT;
-  constexpr int NACC = TS ? 9 : KK * CIT * COT;
+  constexpr int NACC = TS ? KR : KR * CIT * COT;
   extern __shared__ float smem[];
   _Float16* x_h = reinterpret_cast<_Float16*>(smem);       // [CIT][NPX][16]
   _Float16* g_h = x_h + CIT * NPX * 16;                    // [COT][NPG][16]
+  [[maybe_unused]] _Float16* s_h = g_h + COT * NPG * 16;   // SC: [COT][NPG][16], the shortcut's gradient
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, kq = lane >> 4;
@@ -1456,6 +1464,7 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
   constexpr int UGY = NPG * (CO_T / 4), NGY = UGY / TPB;
   static_assert(UGY % TPB == 0, "gy tile units divide evenly");
   f32x4 rin[NIN], rgy[NGY];
+  [[maybe_unused]] f32x4 rgs[SC ? NGY : 1];
   int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
   const CatSrc xsrc = DUAL ? cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4))) : CatSrc{x, Cin, 0};
 #pragma unroll
@@ -1466,7 +1475,7 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
     const int q = uu % (CI_T / 4), pix = uu / (CI_T / 4);
     const int iy = pix / IW, ix = pix % IW;
     in_off[i] = (iy * W + ix) * xsrc.stride + 4 * q;
-    in_lds[i] = real ? ((q >> 2) * NPX + pix) * 16 + 4 * (q & 3) : (CIT * NPX + COT * NPG) * 16;      // dummy slot behind both images
+    in_lds[i] = real ? ((q >> 2) * NPX + pix) * 16 + 4 * (q & 3) : (CIT * NPX + (SC ? 2 : 1) * COT * NPG) * 16;   // dummy slot behind the images
     in_flag[i] = (iy < PAD ? 1 : 0) | (iy >= WTH + PAD ? 2 : 0) | (ix < PAD ? 4 : 0) | (ix >= TW + PAD ? 8 : 0);
   }
 #pragma unroll
@@ -1491,6 +1500,11 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
     }
 #pragma unroll
     for (int i = 0; i < NGY; ++i) rgy[i] = *(const f32x4*)(gb + gy_off[i]);
+    if constexpr (SC) {
+      const float* sb = gsh + (gb - gy);
+#pragma unroll
+      for (int i = 0; i < NGY; ++i) rgs[i] = *(const f32x4*)(sb + gy_off[i]);
+    }
     if (++ptx == tiles_x) { ptx = 0; if (++pty == tiles_y) { pty = 0; ++pn; } }
   };
   auto tr_read = [&](const _Float16* plane_pix) -> h4 {       // plane_pix: first pixel of the 16-pixel row segment
@@ -1512,6 +1526,13 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
       const f32x4 v = rgy[i] * gs;
       *(h4*)(g_h + gy_lds[i]) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
     }
+    if constexpr (SC) {
+#pragma unroll
+      for (int i = 0; i < NGY; ++i) {
+        const f32x4 v = rgs[i] * gs;
+        *(h4*)(s_h + gy_lds[i]) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+      }
+    }
     __syncthreads();
     if (t + 1 < t_end) prefetch();
     if constexpr (TS) {
@@ -1525,6 +1546,11 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
           const int tap = ti >> 1, i = ti & 1;
           const h4 a = tr_read(x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16);
           acc[k] = mfma16h(a, b, acc[k]);
+        }
+        if constexpr (SC) {                                    // k = 9 is tap row 9 on every wave: (wave + 36) >> 1 = 18 | 19
+          const h4 bs = tr_read(s_h + (jt * NPG + r * TW) * 16);
+          const h4 a = tr_read(x_h + ((wave >> 1) * NPX + (r + 1) * IW + 1) * 16);
+          acc[9] = mfma16h(a, bs, acc[9]);
         }
       }
     } else {
@@ -1542,15 +1568,26 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
 #pragma unroll
             for (int j = 0; j < COT; ++j) acc[(tap * CIT + i) * COT + j] = mfma16h(a, b[j], acc[(tap * CIT + i) * COT + j]);
           }
+        if constexpr (SC) {
+          h4 bs[COT];
+#pragma unroll
+          for (int j = 0; j < COT; ++j) bs[j] = tr_read(s_h + (j * NPG + r * TW) * 16);
+#pragma unroll
+          for (int i = 0; i < CIT; ++i) {
+            const h4 a = tr_read(x_h + (i * NPX + (r + 1) * IW + 1) * 16);
+#pragma unroll
+            for (int j = 0; j < COT; ++j) acc[(9 * CIT + i) * COT + j] = mfma16h(a, bs[j], acc[(9 * CIT + i) * COT + j]);
+          }
+        }
       }
     }
   }
   // ---- store: acc[.][r] is (ci = tile*16 + 4*kq + r, co = tile*16 + lm)
   if constexpr (TS) {
     const int jt = wave & 1;
-    float* out = part + (size_t)split * KK * Cin * Cout + (size_t)(ci0 + 4 * kq) * Cout + co0 + jt * 16 + lm;
+    float* out = part + (size_t)split * KR * Cin * Cout + (size_t)(ci0 + 4 * kq) * Cout + co0 + jt * 16 + lm;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
+    for (int k = 0; k < KR; ++k) {
       const int ti = (wave + 4 * k) >> 1;
       float* o = out + ((ti >> 1) * Cin + (ti & 1) * 16) * Cout;
 #pragma unroll
@@ -1571,9 +1608,9 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
       }
     }
     if (wave == 0) {
-      float* out = part + (size_t)split * KK * Cin * Cout;
+      float* out = part + (size_t)split * KR * Cin * Cout;
 #pragma unroll
-      for (int tap = 0; tap < KK; ++tap)
+      for (int tap = 0; tap < KR; ++tap)
 #pragma unroll
         for (int i = 0; i < CIT; ++i)
 #pragma unroll
@@ -1748,7 +1785,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (x2 && !(sc && (transposed & 1)) && (NCH % 2 != 0 || !stats || bst || y2 || transposed)) return -1;   // virtual-cat input: forward statistics form
   if (aff && (!stats || bst || y2 || x2 || transposed)) return -1;              // input-side IN: forward statistics form
   const bool sc2 = sc && (transposed & 1);                                      // fused shortcut DATA-gradient (see SC2)
-  if (sc2 && (K8 || KS != 3 || NCH % 2 != 0 || !x2 || stats || bst || aff || (transposed & 2) || f16 || !sc->w)) return -1;
+  if (sc2 && (K8 || KS != 3 || NCH % 2 != 0 || !x2 || stats || bst || aff || (transposed & 2) || (f16 && (WINO || N8)) || !sc->w)) return -1;
   if (sc && !sc2 && (KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || !sc->w || !sc->y || !sc->stats ||
                      (K8 && x2) || (f16 && (K8 || WINO))))
     return -1;                                                                  // fused shortcut: forward statistics forms
@@ -1811,10 +1848,16 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   } else if (sc2) {
     // (every `if constexpr` below ends in `else return -1`: a form this instantiation does not have must report
     //  "nothing launched", never fall through to `return 0` with y / ysc / the statistics left unwritten)
-    if constexpr (!K8 && KS == 3 && NCH % 2 == 0)
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, false, WINO><<<grid, TPB, sh, st>>>(
-          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
-    else return -1;
+    if constexpr (!K8 && KS == 3 && NCH % 2 == 0) {
+      if (f16) {
+        if constexpr (!WINO)
+          conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, true, false, false, true><<<grid, TPB, sh, st>>>(
+              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, gsc, *sc);
+        else return -1;
+      } else
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, false, WINO><<<grid, TPB, sh, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
+    } else return -1;
   } else if (sc) {
     if constexpr (K8 && KS == 3 && sh_sc <= 64 * 1024) {
       conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true><<<grid, TPB, sh_sc, st>>>(
@@ -2538,6 +2581,25 @@ int smsut_conv2d_dgrad_mfma_sc(const float* gy, const float* gs, const float* w,
   return SMSUT_OK;
 }
 
+// ... with fp16 operands (config 5): gsc = {s, 1/s} of smsut_absmax_scale2(gy, gs) -- the two gradients share the accumulators, so
+// they share the scale.  Direct resident-weight form (16 / 32 -> Cin >= 16).  SMSUT_FUSE_SHORTCUT_DGRAD_F16=0 switches it off.
+int smsut_conv2d_dgrad_sc_f16_supported(int N, int H, int W, int Cout, int Cin, int split) {
+  static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_DGRAD_F16"); return !e || atoi(e) != 0; }();
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Cout == 16 || Cout == 32) || Cin < 16 || !fwd_p_eligible(N, H, W, 2 * Cout, Cin)) return 0;
+  if (split && (split <= 0 || split >= Cin || split % 16 != 0 || (Cin - split) % 16 != 0)) return 0;
+  return 1;
+}
+int smsut_conv2d_dgrad_mfma_sc_f16(const float* gy, const float* gs, const float* w, const float* wsc, float* gxa, float* gxb,
+                                   const float* gsc, int split, int N, int H, int W, int Cout, int Cin, void* stream) {
+  SMSUT_REQUIRE(gy && gs && w && wsc && gxa && gsc && smsut_conv2d_dgrad_sc_f16_supported(N, H, W, Cout, Cin, gxb ? split : 0));
+  const ScRef sc{wsc, nullptr, nullptr};
+  const int rc = select_fwd_p(gy, w, gxa, N, H, W, 2 * Cout, Cin, 1, (hipStream_t)stream, nullptr, nullptr, nullptr, gxb, gxb ? split : 0,
+                              gs, nullptr, true, gsc, &sc);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
 // Which arithmetic a 3x3 stride-1 fp32 conv call (forward or data-gradient, any fused form) runs for this shape: 0 = direct
 // products (36 per 2x2 output tile and channel pair), 1 = Winograd F(2x2,3x3) with resident weights (conv_mfma_fwd_p<..,WINO>),
 // 2 = Winograd with streamed weights (conv_wino_l) -- 16 products per tile.  Mirrors select_fwd_p / dispatch_fwd; sc_dgrad = the
@@ -2947,31 +3009,62 @@ static WgradPlan plan_wgrad_f16(int N, int H, int W, int Cin, int Cout) {
 int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout) {
   return (int64_t)plan_wgrad_f16(N, H, W, Cin, Cout).splits * 9 * Cin * Cout;
 }
-// x2 (nullable): x is the virtual cat([x, x2]) with ca channels in x (ca % 16 == 0)
+// x2 (nullable): x is the virtual cat([x, x2]) with ca channels in x (ca % 16 == 0).  gs != null: the fused-shortcut form (slab of
+// 10 tap rows, see conv_f16_wgrad<.., SC>).
+static void launch_wgrad_f16(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* workspace,
+                             const float* gsc, int N, int H, int W, int Cin, int Cout, const WgradPlan& p, hipStream_t st) {
+  constexpr int NPX = (WTH + 2) * (TW + 2), NPG = WTH * TW;
+#define F16_WGRAD(CI, CO, SCF)                                                                                              \
+  do {                                                                                                                      \
+    constexpr size_t stage = (size_t)((CI * NPX + (SCF ? 2 : 1) * CO * NPG) * 16 + 8) * sizeof(_Float16);                   \
+    constexpr size_t red = (CI == 2 && CO == 2) ? 0 : (size_t)(SCF ? 10 : 9) * CI * CO * 64 * 4 * sizeof(float);             \
+    constexpr size_t sh = stage > red ? stage : red;                                                                        \
+    dim3 grid(p.splits, Cin / (16 * CI), Cout / (16 * CO));                                                                 \
+    if (x2) conv_f16_wgrad<CI, CO, true, SCF><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x,        \
+                                                                    p.tiles_y, p.tiles_per_split, x2, ca, gsc, gs);       \
+    else conv_f16_wgrad<CI, CO, false, SCF><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x,          \
+                                                                  p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, gs);    \
+  } while (0)
+#define F16_WGRAD_FORMS(SCF)                                  \
+  do {                                                        \
+    if (p.cit == 2 && p.cot == 2) F16_WGRAD(2, 2, SCF);       \
+    else if (p.cit == 2) F16_WGRAD(2, 1, SCF);                \
+    else if (p.cot == 2) F16_WGRAD(1, 2, SCF);                \
+    else F16_WGRAD(1, 1, SCF);                                \
+  } while (0)
+  if (gs) F16_WGRAD_FORMS(true);
+  else F16_WGRAD_FORMS(false);
+#undef F16_WGRAD_FORMS
+#undef F16_WGRAD
+}
 int smsut_conv2d_wgrad_f16(const float* x, const float* x2, int ca, const float* gy, float* gw, float* workspace,
                            const float* gsc, int N, int H, int W, int Cin, int Cout, void* stream) {
   SMSUT_REQUIRE(x && gy && gw && workspace && smsut_conv2d_wgrad_f16_supported(N, H, W, Cin, Cout));
   SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0));
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
-  constexpr int NPX = (WTH + 2) * (TW + 2), NPG = WTH * TW;
-#define F16_WGRAD(CI, CO)                                                                                                   \
-  do {                                                                                                                      \
-    constexpr size_t stage = (size_t)((CI * NPX + CO * NPG) * 16 + 8) * sizeof(_Float16);                                   \
-    constexpr size_t red = (CI == 2 && CO == 2) ? 0 : (size_t)9 * CI * CO * 64 * 4 * sizeof(float);                         \
-    constexpr size_t sh = stage > red ? stage : red;                                                                        \
-    dim3 grid(p.splits, Cin / (16 * CI), Cout / (16 * CO));                                                                 \
-    if (x2) conv_f16_wgrad<CI, CO, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,  \
-                                                               p.tiles_per_split, x2, ca, gsc);                            \
-    else conv_f16_wgrad<CI, CO, false><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y,    \
-                                                             p.tiles_per_split, nullptr, 0, gsc);                         \
-  } while (0)
-  if (p.cit == 2 && p.cot == 2) F16_WGRAD(2, 2);
-  else if (p.cit == 2) F16_WGRAD(2, 1);
-  else if (p.cot == 2) F16_WGRAD(1, 2);
-  else F16_WGRAD(1, 1);
-#undef F16_WGRAD
+  launch_wgrad_f16(x, x2, ca, gy, nullptr, workspace, gsc, N, H, W, Cin, Cout, p, st);
   launch_sum_splits(workspace, gw, 9 * Cin * Cout, p.splits, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+// ... and the block's 1x1 shortcut weight gradient in the same pass: gw10 [10][Cin][Cout], rows 0..8 = the 3x3 taps, row 9 = the
+// shortcut's (as smsut_conv2d_wgrad_mfma_sc); gsc = smsut_absmax_scale2(gy, gs).  SMSUT_FUSE_SHORTCUT_WGRAD_F16=0 switches it off.
+int smsut_conv2d_wgrad_sc_f16_supported(int N, int H, int W, int Cin, int Cout) {
+  static const bool on = [] { const char* e = getenv("SMSUT_FUSE_SHORTCUT_WGRAD_F16"); return !e || atoi(e) != 0; }();
+  return on && smsut_conv2d_wgrad_f16_supported(N, H, W, Cin, Cout);
+}
+int64_t smsut_conv2d_wgrad_sc_f16_ws(int N, int H, int W, int Cin, int Cout) {
+  return (int64_t)plan_wgrad_f16(N, H, W, Cin, Cout).splits * 10 * Cin * Cout;
+}
+int smsut_conv2d_wgrad_sc_f16(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* gw10,
+                              float* workspace, const float* gsc, int N, int H, int W, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(x && gy && gs && gw10 && workspace && gsc && smsut_conv2d_wgrad_sc_f16_supported(N, H, W, Cin, Cout));
+  SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0));
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
+  launch_wgrad_f16(x, x2, ca, gy, gs, workspace, gsc, N, H, W, Cin, Cout, p, st);
+  launch_sum_splits(workspace, gw10, 10 * Cin * Cout, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -2985,6 +3078,19 @@ int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace,
   blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
   k_absmax_partial<<<blocks, TPB, 0, st>>>(x, n, workspace);
   k_absmax_final<<<1, TPB, 0, st>>>(workspace, blocks, out2);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// ... of two tensors at once (one scale for both: the fused shortcut data-/weight-gradient reads [gy | gs] as one operand)
+int smsut_absmax_scale2(const float* x, int64_t n, const float* x2, int64_t n2, float* out2, float* workspace, void* stream) {
+  SMSUT_REQUIRE(x && x2 && out2 && workspace && n > 0 && n2 > 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2)) & 15) == 0);
+  hipStream_t st = (hipStream_t)stream;
+  auto nb = [](int64_t m) { const int b = (int)cdiv64(m >> 2, TPB * 4); return b < 1 ? 1 : (b > 512 ? 512 : b); };
+  const int b1 = nb(n), b2 = nb(n2);
+  k_absmax_partial<<<b1, TPB, 0, st>>>(x, n, workspace);
+  k_absmax_partial<<<b2, TPB, 0, st>>>(x2, n2, workspace + b1);
+  k_absmax_final<<<1, TPB, 0, st>>>(workspace, b1 + b2, out2);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

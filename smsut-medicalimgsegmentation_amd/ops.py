@@ -306,6 +306,14 @@ def _grad_scale(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _grad_scale2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """One scale for two gradient tensors that feed the same fp16 accumulators (the fused-shortcut data- / weight-gradient reads
+    [gy | gs] as one operand): max over both."""
+    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    H.call("smsut_absmax_scale2", a, a.numel(), b, b.numel(), out, _ws(H.call("smsut_absmax_scale_ws", a.numel()), a), _s())
+    return out
+
+
 def _ws(numel: int, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(max(int(numel), 1), dtype=torch.float32, device=like.device)
 
@@ -963,15 +971,24 @@ class BasicBlockFn(Function):
             else:
                 H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, wws2, n, h, w, co, co, 3, st)
         # ---- conv1 and the shortcut
-        sc1 = _grad_scale(gy1) if f16a else None
-        fused_wsc = (ctx.has_sc and not f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_supported", n, h, w, ci, co)))
+        split_c = ctx.cat_split[0] if ctx.cat_split is not None else 0
+        fused_wsc16 = ctx.has_sc and f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_f16_supported", n, h, w, ci, co))
+        fused_dsc16 = (ctx.has_sc and f16a and (ctx.needs_input_grad[0] or ctx.needs_input_grad[11] or ctx.needs_input_grad[12])
+                       and bool(H.call("smsut_conv2d_dgrad_sc_f16_supported", n, h, w, co, ci, split_c)))
+        # fp16 operands: the fused-shortcut kernels read [gy1 | gs_t] as ONE operand -> one scale over both tensors
+        sc1 = (_grad_scale2(gy1, gs_t) if (fused_wsc16 or fused_dsc16) else _grad_scale(gy1)) if f16a else None
+        fused_wsc = fused_wsc16 or (ctx.has_sc and not f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_supported", n, h, w, ci, co)))
         if fused_wsc:
             # both weight gradients in one pass over x: rows 0..8 = conv1's taps, row 9 = the 1x1 shortcut's
             g10 = torch.empty(10 * ci * co, dtype=torch.float32, device=dev)
             gw1 = torch.as_strided(g10, (co, ci, 3, 3), hwio_strides(co, ci, 3, 3))
             gws = torch.as_strided(g10, (co, ci, 1, 1), hwio_strides(co, ci, 1, 1), 9 * ci * co)
-            H.call("smsut_conv2d_wgrad_mfma_sc", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
-                   g10, _ws(H.call("smsut_conv2d_wgrad_sc_ws", n, h, w, ci, co), x), n, h, w, ci, co, st)
+            if fused_wsc16:
+                H.call("smsut_conv2d_wgrad_sc_f16", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
+                       g10, _ws(H.call("smsut_conv2d_wgrad_sc_f16_ws", n, h, w, ci, co), x), sc1, n, h, w, ci, co, st)
+            else:
+                H.call("smsut_conv2d_wgrad_mfma_sc", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1,
+                       gs_t, g10, _ws(H.call("smsut_conv2d_wgrad_sc_ws", n, h, w, ci, co), x), n, h, w, ci, co, st)
         else:
             gw1 = new_weight(co, ci, 3, 3, device=dev)
         if fused_wsc:
@@ -1003,7 +1020,9 @@ class BasicBlockFn(Function):
             if ctx.needs_input_grad[11] or ctx.needs_input_grad[12]:
                 ca, cb = ctx.cat_split
                 ga, gb = new_act(n, ca, h, w, x), new_act(n, cb, h, w, x)
-                if ctx.has_sc and not f16a and H.call("smsut_conv2d_dgrad_sc_supported", n, h, w, co, ci, ca):
+                if fused_dsc16:
+                    H.call("smsut_conv2d_dgrad_mfma_sc_f16", gy1, gs_t, w1, ws, ga, gb, sc1, ca, n, h, w, co, ci, st)
+                elif ctx.has_sc and not f16a and H.call("smsut_conv2d_dgrad_sc_supported", n, h, w, co, ci, ca):
                     # conv1's and the shortcut's data-gradients in ONE pass (the shortcut's is the centre tap of a second
                     # reduction half), written straight into (ga, gb): no 1x1 kernel, no accumulate pass
                     H.call("smsut_conv2d_dgrad_mfma_sc", gy1, gs_t, w1, ws, ga, gb, ca, n, h, w, co, ci, st)
@@ -1030,6 +1049,10 @@ class BasicBlockFn(Function):
         if ctx.needs_input_grad[0]:
             # the shortcut's gradient lands in gx first; the 3x3 data-gradient then accumulates into it in its store
             # epilogue (transposed | 2), which replaces a separate 3-pass add
+            if fused_dsc16:
+                gx = new_act(n, ci, h, w, x)
+                H.call("smsut_conv2d_dgrad_mfma_sc_f16", gy1, gs_t, w1, ws, gx, None, sc1, 0, n, h, w, co, ci, st)
+                return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
             if ctx.has_sc and not f16a and H.call("smsut_conv2d_dgrad_sc_supported", n, h, w, co, ci, 0):
                 gx = new_act(n, ci, h, w, x)
                 H.call("smsut_conv2d_dgrad_mfma_sc", gy1, gs_t, w1, ws, gx, None, 0, n, h, w, co, ci, st)

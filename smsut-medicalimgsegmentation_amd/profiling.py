@@ -54,6 +54,8 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_fwd_mfma_split_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
     "smsut_conv2d_dgrad_mfma_bwdstats_f16": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
+    "smsut_conv2d_dgrad_mfma_sc_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 10, "mfma"),
+    "smsut_conv2d_wgrad_sc_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 10, "mfma"),
     "smsut_conv1x1_fwd": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "mfma"),
     "smsut_conv1x1_wgrad": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "mfma"),
     "smsut_conv1x1_fwd_cat": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4], "mfma"),
@@ -139,6 +141,8 @@ _BYTES: Dict[str, Callable[[List[int]], float]] = {
     "smsut_conv2d_fwd_mfma_stats_sc": lambda a: _cv(a[0], a[1], a[2], a[3], a[4], extra_out=a[4]),
     "smsut_conv2d_fwd_mfma_stats_sc_f16": lambda a: _cv(a[0], a[1], a[2], a[3], a[4], extra_out=a[4]),
     "smsut_conv2d_dgrad_mfma_sc": lambda a: _cv(a[1], a[2], a[3], 2 * a[4], a[5]),
+    "smsut_conv2d_dgrad_mfma_sc_f16": lambda a: _cv(a[1], a[2], a[3], 2 * a[4], a[5]),
+    "smsut_conv2d_wgrad_sc_f16": lambda a: _cv(a[1], a[2], a[3], a[4], 2 * a[5]),
     "smsut_conv2d_wgrad_mfma": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
     "smsut_conv2d_wgrad_mfma_inaff": lambda a: _cv(a[0], a[1], a[2], a[3], a[4]),
     "smsut_conv2d_wgrad_mfma_cat": lambda a: _cv(a[1], a[2], a[3], a[4], a[5]),

@@ -262,3 +262,66 @@ def test_fused_shortcut_forward_with_fp16_operands(ops, n, h, ci, co, cat):
     q = q1.view(n, tiles, co, 2).double().sum(1)
     assert torch.allclose(q[..., 0], s1.double().sum((1, 2)), rtol=1e-4, atol=1e-2)
     assert torch.allclose(q[..., 1], (s1.double() ** 2).sum((1, 2)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("n,h,co,ci,split", [(4, 128, 16, 32, 0), (8, 128, 16, 32, 16), (4, 128, 32, 64, 32), (2, 256, 16, 16, 0),
+                                              (16, 64, 32, 32, 16)])
+def test_fused_shortcut_data_gradient_with_fp16_operands(ops, n, h, co, ci, split):
+    """gx = dgrad3x3(gy1, w1) + dgrad1x1(gs, ws) in ONE pass with fp16 operands and ONE power-of-two scale over both gradients
+    (``smsut_absmax_scale2``), split output for blocks after a concat (network/blocks.py:66-80).  Against fp64 at what fp16
+    operands allow: each operand carries 2^-11 relative rounding, the sums run over 9 co + co products (bound: max-norm 2e-3)."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_conv2d_dgrad_sc_f16_supported", n, h, h, co, ci, split) == 1
+    g = torch.Generator(device="cpu").manual_seed(11)
+    gy = (torch.randn(n, h, h, co, generator=g) * 2e-7).cuda()
+    gs = (torch.randn(n, h, h, co, generator=g) * 5e-8).cuda()
+    w3 = (torch.randn(3, 3, ci, co, generator=g) / np.sqrt(9 * ci)).cuda()          # forward layouts [kh][kw][Cin][Cout], [Cin][Cout]
+    w1 = (torch.randn(ci, co, generator=g) / np.sqrt(ci)).cuda()
+    sc = torch.empty(2, device="cuda")
+    H.call("smsut_absmax_scale2", gy, gy.numel(), gs, gs.numel(), sc, torch.empty(1024, device="cuda"), st)
+    m = max(float(gy.abs().max()), float(gs.abs().max()))
+    assert 2.0 ** 13 <= m * float(sc[0]) <= 2.0 ** 14 and float(sc[0] * sc[1]) == 1.0
+    if split:
+        ga = torch.full((n, h, h, split), float("nan"), device="cuda")
+        gb = torch.full((n, h, h, ci - split), float("nan"), device="cuda")
+        H.call("smsut_conv2d_dgrad_mfma_sc_f16", gy, gs, w3, w1, ga, gb, sc, split, n, h, h, co, ci, st)
+        got = torch.cat([ga, gb], 3)
+    else:
+        got = torch.full((n, h, h, ci), float("nan"), device="cuda")
+        H.call("smsut_conv2d_dgrad_mfma_sc_f16", gy, gs, w3, w1, got, None, sc, 0, n, h, h, co, ci, st)
+    wt = w3.double().permute(3, 2, 0, 1)                                            # [Cout, Cin, 3, 3]
+    ref = F.conv_transpose2d(gy.double().permute(0, 3, 1, 2), wt, padding=1).permute(0, 2, 3, 1)
+    ref = ref + (gs.double().reshape(-1, co) @ w1.double().t()).reshape(n, h, h, ci)
+    assert float((got.double() - ref).abs().max() / ref.abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("n,h,ci,co,cat", [(4, 64, 16, 32, 0), (4, 64, 32, 16, 1), (2, 128, 32, 64, 0), (3, 64, 64, 32, 1),
+                                           (2, 64, 16, 16, 0), (2, 32, 128, 64, 1)])
+def test_fused_shortcut_weight_gradient_with_fp16_operands(ops, n, h, ci, co, cat):
+    """conv1's weight gradient + the 1x1 shortcut's in one pass over x with fp16 operands (10 tap rows).  Rows 0..8 are
+    BIT-IDENTICAL to the unfused fp16-operand weight gradient run with the same scale (same kernel, same accumulators, same
+    slab order); row 9 matches fp64 at fp16-operand accuracy (sum over N*H*W products with random signs: l2-relative 2e-3)."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_conv2d_wgrad_sc_f16_supported", n, h, h, ci, co) == 1
+    g = torch.Generator(device="cpu").manual_seed(13)
+    x = torch.randn(n, h, h, ci, generator=g).cuda()
+    gy = (torch.randn(n, h, h, co, generator=g) * 2e-7).cuda()
+    gs = (torch.randn(n, h, h, co, generator=g) * 6e-7).cuda()
+    sc = torch.empty(2, device="cuda")
+    H.call("smsut_absmax_scale2", gy, gy.numel(), gs, gs.numel(), sc, torch.empty(1024, device="cuda"), st)
+    if cat:
+        xa, xb, ca = x[..., :ci // 2].contiguous(), x[..., ci // 2:].contiguous(), ci // 2
+    else:
+        xa, xb, ca = x, None, 0
+    g9 = torch.full((9 * ci * co,), float("nan"), device="cuda")
+    H.call("smsut_conv2d_wgrad_f16", xa, xb, ca, gy, g9, torch.empty(H.call("smsut_conv2d_wgrad_f16_ws", n, h, h, ci, co), device="cuda"),
+           sc, n, h, h, ci, co, st)
+    g10 = torch.full((10 * ci * co,), float("nan"), device="cuda")
+    H.call("smsut_conv2d_wgrad_sc_f16", xa, xb, ca, gy, gs, g10,
+           torch.empty(H.call("smsut_conv2d_wgrad_sc_f16_ws", n, h, h, ci, co), device="cuda"), sc, n, h, h, ci, co, st)
+    assert torch.equal(g10[:9 * ci * co], g9)
+    ref = x.double().reshape(-1, ci).t() @ gs.double().reshape(-1, co)             # [Cin][Cout]
+    got = g10[9 * ci * co:].view(ci, co).double()
+    assert float((got - ref).norm() / ref.norm()) < 2e-3
