@@ -224,6 +224,9 @@ int smsut_conv2d_wgrad_sc_f16(const float* x, const float* x2 /*nullable*/, int 
 int64_t smsut_absmax_scale_ws(int64_t n);
 int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace, void* stream);
 int smsut_absmax_scale2(const float* x, int64_t n, const float* x2, int64_t n2, float* out2, float* workspace, void* stream);
+/* the same scale from maxima the PRODUCING kernels handed over (smsut_restail_bwd_amax, smsut_in_apply_bwd_amax: one slot per
+ * workgroup and output tensor): out2 = scale of max(amax[0..n)) -- no pass over the gradient tensor */
+int smsut_absmax_finish(const float* amax, int n, float* out2, void* stream);
 
 /* 4x4 stride-1 pad-1 convolutions on the matrix cores: networks.NLayerDiscriminator / PatchDiscriminator (reference
  * network/networks.py:977-1032, 64 -> 128 -> 256 -> 512 channels).  (H, W) = extents of the conv's forward input; the output
@@ -299,6 +302,12 @@ int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, floa
 int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
                        const float* a_mean, const float* b_mean, float* gx, float* ggamma /*nullable*/,
                        float* gbeta /*nullable*/, int N, int HW, int C, void* stream);
+/* ... that also hands over max|gx|: every workgroup writes the maximum of what it stored into its own slot, amax[0 .. B),
+ * B = smsut_amax_blocks(N, HW, C) (no atomics, no zeroing); fp16-operand consumers reduce the slots with smsut_absmax_finish */
+int smsut_amax_blocks(int N, int HW, int C);
+int smsut_in_apply_bwd_amax(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            const float* a_mean, const float* b_mean, float* gx, float* ggamma /*nullable*/,
+                            float* gbeta /*nullable*/, float* amax, int N, int HW, int C, void* stream);
 /* residual tail of BasicBlock (blocks.py:60-79): out = act(IN(y2) + (IN(s) | s)), forward and backward in one pass each */
 int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
                       const float* ms /*nullable: identity*/, const float* rs, const float* gs, const float* bs, float* out,
@@ -308,6 +317,12 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
                       const float* rs, const float* gs_, const float* bs /*nullable*/, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
                       float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, int N, int HW, int C,
                       float slope, void* stream);
+/* ... that also hands over max|gy2| in amax[0 .. B) and max|gs| in amax[B .. 2B), B = smsut_amax_blocks(N, HW, C) */
+int smsut_restail_bwd_amax(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                           const float* g2, const float* b2 /*nullable*/, const float* s, const float* ms /*nullable*/,
+                           const float* rs, const float* gs_, const float* bs /*nullable*/, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
+                           float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, float* amax, int N, int HW,
+                           int C, float slope, void* stream);
 int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta /*nullable: no activation*/, const float* mean,
                        const float* rstd, const float* gamma, float* gx, float* a_mean, float* b_mean,
                        float* ggamma /*nullable*/, float* gbeta /*nullable*/, float* workspace, int N, int HW, int C,

@@ -27,6 +27,10 @@ SIGNATURES: Dict[str, str] = {
     "smsut_in_apply_bwd": "pppppppp pp iii s",
     "smsut_restail_fwd": "pppppppppp p iii f s",
     "smsut_restail_bwd": "pppppppppppp pp ppp pppp p iii f s",
+    "smsut_restail_bwd_amax": "pppppppppppp pp ppp pppp pp iii f s",
+    "smsut_in_apply_bwd_amax": "pppppppp pp p iii s",
+    "smsut_absmax_finish": "p i p s",
+    "smsut_amax_blocks": "iii",
     "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
     "smsut_instnorm_bwd2": "ppppppppppp ppp pp iii f s",
     # conv_naive.hip
@@ -177,7 +181,7 @@ SIGNATURES: Dict[str, str] = {
 _RET_I64 = {"smsut_wino_image_floats", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_conv2d_wgrad_sc_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws",
             "smsut_conv1x1_thin_wgrad_ws"}
-_NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
+_NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_amax_blocks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",
                          "smsut_convT2x2_mfma_supported", "smsut_conv2d_small_supported",
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",

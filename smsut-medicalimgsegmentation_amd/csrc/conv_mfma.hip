@@ -3082,6 +3082,13 @@ int smsut_absmax_scale(const float* x, int64_t n, float* out2, float* workspace,
   return SMSUT_OK;
 }
 
+// ... from maxima the producing kernels handed over (smsut_restail_bwd_amax / smsut_in_apply_bwd_amax): the scale of max(amax[0..n))
+int smsut_absmax_finish(const float* amax, int n, float* out2, void* stream) {
+  SMSUT_REQUIRE(amax && out2 && n > 0);
+  k_absmax_final<<<1, TPB, 0, (hipStream_t)stream>>>(amax, n, out2);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
 // ... of two tensors at once (one scale for both: the fused shortcut data-/weight-gradient reads [gy | gs] as one operand)
 int smsut_absmax_scale2(const float* x, int64_t n, const float* x2, int64_t n2, float* out2, float* workspace, void* stream) {
   SMSUT_REQUIRE(x && x2 && out2 && workspace && n > 0 && n2 > 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x2)) & 15) == 0);

@@ -338,12 +338,32 @@ in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const 
     });
 }
 
+// fp16-operand convolutions scale a gradient operand by a power of two derived from its absolute maximum (smsut_absmax_scale).
+// The kernels that WRITE such a gradient hand the maximum over (amax, nullable): every workgroup stores the maximum of what it
+// wrote in its own slot amax[block] -- no atomics (a first version with one atomicMax per wave on a single float cost 3 ms per
+// config-5 iteration in same-address contention), no zeroing, any order -- and smsut_absmax_finish reduces the slots.
+__device__ __forceinline__ void amax_emit(float m, float* slots) {
+  __shared__ float sm_amax[TPB / 64];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sm_amax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 1; k < TPB / 64; ++k) m = fmaxf(m, sm_amax[k]);
+    slots[blockIdx.y * gridDim.x + blockIdx.x] = m;
+  }
+  __syncthreads();
+}
+
 template <int VEC>
 __global__ void __launch_bounds__(TPB)
 in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
              const float* __restrict__ am, const float* __restrict__ bm, float* __restrict__ gx,
-             int HW, int C, float slope, int N, float* __restrict__ ggamma, float* __restrict__ gbeta) {
+             int HW, int C, float slope, int N, float* __restrict__ ggamma, float* __restrict__ gbeta,
+             float* __restrict__ amax = nullptr) {
+  float mx = 0.f;
   if (ggamma && blockIdx.x == 0 && blockIdx.y == 0) {   // affine gradients ride along in one block: ggamma = sum_n M*b, gbeta = sum_n M*a
     for (int c = threadIdx.x; c < C; c += TPB) {
       double sa = 0.0, sb = 0.0;
@@ -376,9 +396,11 @@ in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const fl
         const float gz = beta ? g[j] * lrelu_mask(in_affine(xv[j], p.mu[j], r, gm, p.bt[j]), slope) : g[j];
         const float xh = (xv[j] - p.mu[j]) * r;
         g[j] = gm * r * (gz - p.av[j] - xh * p.bv[j]);
+        mx = fmaxf(mx, fabsf(g[j]));
       }
       if constexpr (VEC == 4) *(float4*)(gx + i * 4) = *(float4*)g; else gx[i] = g[0];
     });
+  if (amax) amax_emit(mx, amax);
 }
 
 template <int VEC>
@@ -609,8 +631,9 @@ __global__ void __launch_bounds__(TPB)
 restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
                   const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
                   float* __restrict__ gs, int HW, int C, float slope, int N, float* __restrict__ gg2,
-                  float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs) {
+                  float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs, float* __restrict__ amax = nullptr) {
   constexpr bool remask = REMASK;             // see restail_bwd_partial
+  float mx1 = 0.f, mx2 = 0.f;                 // amax: {max |gy2|, max |gs|}
   if (blockIdx.x == 0 && blockIdx.y == 0) {   // affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (both norms), ggs = sum_n M*bs
     for (int c = threadIdx.x; c < C; c += TPB) {
       double sa = 0.0, s2 = 0.0, ss = 0.0;
@@ -649,10 +672,12 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
         const float a = p.av[j];
         o1[j] = p.g2[j] * p.r2[j] * (gz - a - ((y[j] - p.m2[j]) * p.r2[j]) * p.b2v[j]);
         o2[j] = t.ms ? p.gsv[j] * p.rsv[j] * (gz - a - ((sv[j] - p.msv[j]) * p.rsv[j]) * p.bsv[j]) : gz;
+        mx1 = fmaxf(mx1, fabsf(o1[j])); mx2 = fmaxf(mx2, fabsf(o2[j]));
       }
       if constexpr (VEC == 4) { *(float4*)(gy2 + i * 4) = *(float4*)o1; *(float4*)(gs + i * 4) = *(float4*)o2; }
       else { gy2[i] = o1[0]; gs[i] = o2[0]; }
     });
+  if (amax) { amax_emit(mx1, amax); amax_emit(mx2, amax + gridDim.x * gridDim.y); }
 }
 
 inline bool fin_emit_on() {                         // SMSUT_IN_ONE_CHUNK=0: always launch in_moments_final (A/B switch)
@@ -824,9 +849,9 @@ int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, floa
 
 // gx = gamma*rstd*(gz - a - xhat*b) with gz ALREADY masked (output of smsut_conv2d_dgrad_mfma_bwdstats); ggamma / gbeta
 // (nullable) are the affine gradients sum_n HW*b, sum_n HW*a.
-int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
-                       const float* a_mean, const float* b_mean, float* gx, float* ggamma, float* gbeta, int N, int HW, int C,
-                       void* stream) {
+static int in_apply_bwd_launch(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* a_mean, const float* b_mean, float* gx, float* ggamma, float* gbeta, float* amax, int N,
+                               int HW, int C, void* stream) {
   SMSUT_REQUIRE(gz && x && mean && rstd && gamma && a_mean && b_mean && gx && N > 0 && HW > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
   float* gg = (ggamma && gbeta) ? ggamma : nullptr;
@@ -834,12 +859,30 @@ int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   if (C % 4 == 0)
     in_apply_bwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, 0.f,
-                                                        N, gg, gbeta);
+                                                        N, gg, gbeta, amax);
   else
     in_apply_bwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, 0.f,
-                                                    N, gg, gbeta);
+                                                    N, gg, gbeta, amax);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_in_apply_bwd(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* a_mean, const float* b_mean, float* gx, float* ggamma, float* gbeta, int N, int HW, int C,
+                       void* stream) {
+  return in_apply_bwd_launch(gz, x, mean, rstd, gamma, a_mean, b_mean, gx, ggamma, gbeta, nullptr, N, HW, C, stream);
+}
+// workgroups of the per-image apply kernels (= amax slots per output tensor of the _amax entry points)
+int smsut_amax_blocks(int N, int HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 0;
+  const dim3 g = img_grid((int64_t)HW * (C % 4 == 0 ? C / 4 : C), N);
+  return (int)(g.x * g.y);
+}
+// ... that also hands over max |gx| (amax: smsut_amax_blocks floats, one per workgroup, see amax_emit) for smsut_absmax_finish
+int smsut_in_apply_bwd_amax(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
+                            const float* a_mean, const float* b_mean, float* gx, float* ggamma, float* gbeta, float* amax, int N,
+                            int HW, int C, void* stream) {
+  SMSUT_REQUIRE(amax);
+  return in_apply_bwd_launch(gz, x, mean, rstd, gamma, a_mean, b_mean, gx, ggamma, gbeta, amax, N, HW, C, stream);
 }
 
 // out = act(IN(y2) + (IN(s) | s)); ms == null: s is added as it is (identity shortcut).
@@ -862,10 +905,10 @@ int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const f
 // is not read (8 tensor passes instead of 10); otherwise the mask is the sign of `out`.
 // gy2, gs: gradients w.r.t. the two raw conv outputs (gs = gradient of the identity when ms == null);
 // gg2/gb2/ggs/gbs: affine gradients (ggs/gbs nullable when ms == null).
-int smsut_restail_bwd(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
-                      const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
-                      const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
-                      float* gbs, float* workspace, int N, int HW, int C, float slope, void* stream) {
+static int restail_bwd_launch(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                              const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
+                              const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
+                              float* gbs, float* workspace, float* amax, int N, int HW, int C, float slope, void* stream) {
   SMSUT_REQUIRE(gout && out && y2 && m2 && r2 && g2 && s && gy2 && gs && a_mean && b2_mean && bs_mean && gg2 && gb2 &&
                 workspace && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs_ && ggs && gbs)));
   TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs_, bs};
@@ -885,12 +928,28 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
 #define TAIL_APPLY(V, R)                                                                                                \
   restail_bwd_apply<V, R><<<img_grid((int64_t)HW * (C / V), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, HW, C, \
-                                                              slope, N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr)
+                                                              slope, N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr, amax)
   if (C % 4 == 0) { if (remask) TAIL_APPLY(4, true); else TAIL_APPLY(4, false); }
   else { if (remask) TAIL_APPLY(1, true); else TAIL_APPLY(1, false); }
 #undef TAIL_APPLY
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_restail_bwd(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                      const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
+                      const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
+                      float* gbs, float* workspace, int N, int HW, int C, float slope, void* stream) {
+  return restail_bwd_launch(gout, out, y2, m2, r2, g2, b2, s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean, bs_mean, gg2, gb2, ggs, gbs,
+                            workspace, nullptr, N, HW, C, slope, stream);
+}
+// ... that also hands over max |gy2| (amax[0 .. B)) and max |gs| (amax[B .. 2B)), B = smsut_amax_blocks, for smsut_absmax_finish
+int smsut_restail_bwd_amax(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                           const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
+                           const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
+                           float* gbs, float* workspace, float* amax, int N, int HW, int C, float slope, void* stream) {
+  SMSUT_REQUIRE(amax);
+  return restail_bwd_launch(gout, out, y2, m2, r2, g2, b2, s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean, bs_mean, gg2, gb2, ggs, gbs,
+                            workspace, amax, N, HW, C, slope, stream);
 }
 
 }  // extern "C"

@@ -306,6 +306,13 @@ def _grad_scale(t: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _grad_scale_from(amax: torch.Tensor) -> torch.Tensor:
+    """The same scale from maxima the producing kernels handed over (``amax``: a slice of device floats): no pass over the tensors."""
+    out = torch.empty(2, dtype=torch.float32, device=amax.device)
+    H.call("smsut_absmax_finish", amax, amax.numel(), out, _s())
+    return out
+
+
 def _grad_scale2(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """One scale for two gradient tensors that feed the same fp16 accumulators (the fused-shortcut data- / weight-gradient reads
     [gy | gs] as one operand): max over both."""
@@ -772,6 +779,7 @@ SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-aft
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
 REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
+AMAX_HANDOVER = bool(int(_os.environ.get("SMSUT_AMAX_HANDOVER", "1")))    # fp16 operands: gradient maxima from the producing kernels
 
 
 def basic_block_fusable(x, w1, ws):
@@ -931,16 +939,25 @@ class BasicBlockFn(Function):
         a_t, b2_t, bs_t = vec(n, co), vec(n, co), vec(n, co)
         gg2, gb2 = vec(co), vec(co)
         ggs, gbs = (vec(co), vec(co)) if ctx.has_sc else (None, None)
-        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
-               ggs, gbs, _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
+        f16a, f16 = ctx.f16                                  # fp16 operands for conv1 / conv2 and their gradients
+        # fp16 operands: the kernels that write gy2 / gs_t / gy1 hand their absolute maxima over (one slot per workgroup:
+        # [gy2 | gs_t | gy1], nb each), the scales of the gradient operands come from those slots instead of a pass over each tensor
+        nb = H.call("smsut_amax_blocks", n, hw, co) if (f16 or f16a) and AMAX_HANDOVER else 0
+        amax = torch.empty(3 * nb, dtype=torch.float32, device=dev) if nb else None
+        if amax is not None:
+            H.call("smsut_restail_bwd_amax", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
+                   ggs, gbs, _ws(n * chunks * co * 3, x), amax, n, hw, co, slope, st)
+        else:
+            H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
+                   ggs, gbs, _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
         # (forking the three weight-gradient launches to a second stream inside this node was measured 1-3 % SLOWER
         #  than the single-stream order below -- profiles/r01_notes.md)
         # ---- conv2 data-gradient + IN1 / LeakyReLU backward (mask recomputed from y1)
         ga1 = new_act(n, co, h, w, x)
         gy1 = new_act(n, co, h, w, x)
         a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
-        f16a, f16 = ctx.f16                                  # fp16 operands for conv1 / conv2 and their gradients
-        sc2 = _grad_scale(gy2) if f16 else None              # one absmax pass serves conv2's data- and weight-gradient
+        sc2 = (_grad_scale_from(amax[:nb]) if amax is not None else _grad_scale(gy2)) if f16 else None   # serves conv2's data- and weight-gradient
+        amax1 = False                                        # amax[2] = max |gy1| written
         if FUSED_BWD_STATS and H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, int(f16)):
             # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
             tb = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3, int(f16))
@@ -950,7 +967,11 @@ class BasicBlockFn(Function):
             else:
                 _conv3("smsut_conv2d_dgrad_mfma_bwdstats", w2, 1, gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
             H.call("smsut_in_finalize_bwd", pb, tb, a1m, b1m, n, hw, co, st)
-            H.call("smsut_in_apply_bwd", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, n, hw, co, st)
+            if amax is not None and f16a:
+                H.call("smsut_in_apply_bwd_amax", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, amax[2 * nb:], n, hw, co, st)
+                amax1 = True
+            else:
+                H.call("smsut_in_apply_bwd", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, n, hw, co, st)
         else:
             if f16:
                 H.call("smsut_conv2d_fwd_mfma_f16", gy2, w2, ga1, sc2, n, h, w, co, co, 3, 1, st)
@@ -976,7 +997,12 @@ class BasicBlockFn(Function):
         fused_dsc16 = (ctx.has_sc and f16a and (ctx.needs_input_grad[0] or ctx.needs_input_grad[11] or ctx.needs_input_grad[12])
                        and bool(H.call("smsut_conv2d_dgrad_sc_f16_supported", n, h, w, co, ci, split_c)))
         # fp16 operands: the fused-shortcut kernels read [gy1 | gs_t] as ONE operand -> one scale over both tensors
-        sc1 = (_grad_scale2(gy1, gs_t) if (fused_wsc16 or fused_dsc16) else _grad_scale(gy1)) if f16a else None
+        if not f16a:
+            sc1 = None
+        elif fused_wsc16 or fused_dsc16:
+            sc1 = _grad_scale_from(amax[nb:]) if amax1 else _grad_scale2(gy1, gs_t)
+        else:
+            sc1 = _grad_scale_from(amax[2 * nb:]) if amax1 else _grad_scale(gy1)
         fused_wsc = fused_wsc16 or (ctx.has_sc and not f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_supported", n, h, w, ci, co)))
         if fused_wsc:
             # both weight gradients in one pass over x: rows 0..8 = conv1's taps, row 9 = the 1x1 shortcut's

@@ -325,3 +325,30 @@ def test_fused_shortcut_weight_gradient_with_fp16_operands(ops, n, h, ci, co, ca
     ref = x.double().reshape(-1, ci).t() @ gs.double().reshape(-1, co)             # [Cin][Cout]
     got = g10[9 * ci * co:].view(ci, co).double()
     assert float((got - ref).norm() / ref.norm()) < 2e-3
+
+
+@pytest.mark.parametrize("n,h,ci,co", [(5, 128, 16, 32), (8, 128, 16, 16), (4, 128, 64, 32)])
+def test_gradient_scales_from_producer_maxima_are_the_absmax_pass(ops, monkeypatch, n, h, ci, co):
+    """fp16 operands: ``smsut_restail_bwd_amax`` / ``smsut_in_apply_bwd_amax`` hand max|gy2|, max|gs|, max|gy1| to
+    ``smsut_absmax_finish`` instead of one ``smsut_absmax_scale`` pass per gradient tensor -- the same maxima, hence the same
+    power-of-two scales: every block gradient is BIT-IDENTICAL to the run with the separate passes."""
+    x = rnd(n, ci, h, h, seed=1).cuda().contiguous(memory_format=torch.channels_last)
+    has_sc = ci != co
+    ws_ = [hwio(ops, rnd(co, ci, 3, 3, seed=2) / np.sqrt(9 * ci)), (1 + 0.1 * rnd(co, seed=3)).cuda(), (0.1 * rnd(co, seed=4)).cuda(),
+           hwio(ops, rnd(co, co, 3, 3, seed=5) / np.sqrt(9 * co)), (1 + 0.1 * rnd(co, seed=6)).cuda(), (0.1 * rnd(co, seed=7)).cuda(),
+           hwio(ops, rnd(co, ci, 1, 1, seed=8) / np.sqrt(ci)) if has_sc else None,
+           (1 + 0.1 * rnd(co, seed=9)).cuda() if has_sc else None, (0.1 * rnd(co, seed=10)).cuda() if has_sc else None]
+    gout = (rnd(n, co, h, h, seed=11) * 3e-7).cuda().contiguous(memory_format=torch.channels_last)
+    from smsut_amd import profiling
+    res = {}
+    rec = profiling.record_step(lambda: res.update(r=_block(ops, x, ws_, gout, "f16")))
+    o1, g1 = res["r"]
+    names = [r[0] for r in rec]
+    assert "smsut_restail_bwd_amax" in names and "smsut_in_apply_bwd_amax" in names and "smsut_absmax_scale" not in names
+    monkeypatch.setattr(ops, "AMAX_HANDOVER", False)
+    rec = profiling.record_step(lambda: res.update(r=_block(ops, x, ws_, gout, "f16")))
+    o0, g0 = res["r"]
+    assert "smsut_absmax_scale" in [r[0] for r in rec]
+    assert torch.equal(o0, o1)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
