@@ -197,6 +197,19 @@ int smsut_conv2d_fwd_mfma_stats_cat_f16(const float* xa, const float* xb, const 
                                         int W, int Kdim, int Ndim, void* stream);
 int smsut_conv2d_fwd_mfma_split_f16(const float* x, const float* w, float* ya, float* yb, const float* gsc /*nullable*/,
                                     int split, int N, int H, int W, int Kdim, int Ndim, int transposed, void* stream);
+/* fp16 STORAGE of a BasicBlock's internal raw conv outputs y1, y2, s (config 5, "_hs" = half storage): the conv epilogues store
+ * fp16 [N,H,W,Ndim] (InstanceNorm partials still from the fp32 accumulators), the consumers below and in the InstanceNorm section
+ * read fp16 and compute in fp32.  Persistent-kernel shapes, Kdim in {16, 32, 64}; xb nullable (virtual cat). */
+int smsut_conv2d_f16_hs_supported(int N, int H, int W, int Kdim, int Ndim, int cat);
+int smsut_conv2d_fwd_mfma_stats_f16_hs(const float* x, const float* xb /*nullable*/, const float* w, void* y16, float* stats, int N,
+                                       int H, int W, int Kdim, int Ndim, void* stream);
+int smsut_conv2d_fwd_mfma_stats_sc_f16_hs(const float* x, const float* xb /*nullable*/, const float* w, const float* wsc, void* y16,
+                                          void* ysc16, float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim,
+                                          void* stream);
+int smsut_conv2d_dgrad_mfma_bwdstats_f16_hs(const float* gy, const float* w, float* gz, float* stats, const void* y1_16,
+                                            const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                            const float* gsc /*nullable*/, float slope, int N, int H, int W, int Kdim, int Ndim,
+                                            void* stream);
 /* the fused-shortcut data-gradient with fp16 operands (config 5): gsc = {s, 1/s} of smsut_absmax_scale2(gy, gs) (the two gradients
  * share accumulators, hence ONE scale); Cout in {16, 32}, Cin >= 16, persistent-kernel shapes */
 int smsut_conv2d_dgrad_sc_f16_supported(int N, int H, int W, int Cout, int Cin, int split);
@@ -290,6 +303,10 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
 int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                 float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
                                 float slope, int has_act, void* stream);
+/* ... reading an fp16 x (half storage, see smsut_conv2d_f16_hs_supported); y stays fp32; C % 4 == 0 */
+int smsut_instnorm_fwd_partials_hs(const void* x16, const float* gamma, const float* beta, float* y, float* mean,
+                                   float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                   float slope, int has_act, void* stream);
 int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float* rstd, int N, int HW, int C, float eps,
                           void* stream);
 /* the same for TWO partial sets of one (N, HW, C) in one launch (conv2's and the shortcut's statistics of a BasicBlock,
@@ -308,6 +325,10 @@ int smsut_amax_blocks(int N, int HW, int C);
 int smsut_in_apply_bwd_amax(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
                             const float* a_mean, const float* b_mean, float* gx, float* ggamma /*nullable*/,
                             float* gbeta /*nullable*/, float* amax, int N, int HW, int C, void* stream);
+/* ... reading an fp16 x (half storage, see smsut_conv2d_f16_hs_supported); amax nullable; C % 4 == 0 */
+int smsut_in_apply_bwd_hs(const float* gz, const void* x16, const float* mean, const float* rstd, const float* gamma,
+                          const float* a_mean, const float* b_mean, float* gx, float* ggamma /*nullable*/,
+                          float* gbeta /*nullable*/, float* amax /*nullable*/, int N, int HW, int C, void* stream);
 /* residual tail of BasicBlock (blocks.py:60-79): out = act(IN(y2) + (IN(s) | s)), forward and backward in one pass each */
 int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
                       const float* ms /*nullable: identity*/, const float* rs, const float* gs, const float* bs, float* out,
@@ -317,6 +338,15 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
                       const float* rs, const float* gs_, const float* bs /*nullable*/, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
                       float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, int N, int HW, int C,
                       float slope, void* stream);
+/* half storage: y2 and s are fp16 [N,HW,C]; conv shortcut with both betas (ms, b2, bs non-null); C % 4 == 0; amax nullable */
+int smsut_restail_fwd_hs(const void* y2_16, const float* m2, const float* r2, const float* g2, const float* b2, const void* s16,
+                         const float* ms, const float* rs, const float* gs, const float* bs, float* out, int N, int HW, int C,
+                         float slope, void* stream);
+int smsut_restail_bwd_hs(const float* gout, const float* out, const void* y2_16, const float* m2, const float* r2,
+                         const float* g2, const float* b2, const void* s16, const float* ms, const float* rs, const float* gs_,
+                         const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2,
+                         float* gb2, float* ggs, float* gbs, float* workspace, float* amax /*nullable*/, int N, int HW, int C,
+                         float slope, void* stream);
 /* ... that also hands over max|gy2| in amax[0 .. B) and max|gs| in amax[B .. 2B), B = smsut_amax_blocks(N, HW, C) */
 int smsut_restail_bwd_amax(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
                            const float* g2, const float* b2 /*nullable*/, const float* s, const float* ms /*nullable*/,

@@ -21,11 +21,15 @@ SIGNATURES: Dict[str, str] = {
     "smsut_in_chunks": "iii",
     "smsut_instnorm_fwd": "ppppppp iii ff i s",
     "smsut_instnorm_fwd_partials": "ppppppp iiii ff i s",
+    "smsut_instnorm_fwd_partials_hs": "ppppppp iiii ff i s",
     "smsut_in_finalize_fwd": "p i pp iii f s",
     "smsut_in_finalize_fwd2": "p i pp p i pp iii f s",
     "smsut_in_finalize_bwd": "p i pp iii s",
     "smsut_in_apply_bwd": "pppppppp pp iii s",
     "smsut_restail_fwd": "pppppppppp p iii f s",
+    "smsut_restail_fwd_hs": "pppppppppp p iii f s",
+    "smsut_restail_bwd_hs": "pppppppppppp pp ppp pppp pp iii f s",
+    "smsut_in_apply_bwd_hs": "pppppppp pp p iii s",
     "smsut_restail_bwd": "pppppppppppp pp ppp pppp p iii f s",
     "smsut_restail_bwd_amax": "pppppppppppp pp ppp pppp pp iii f s",
     "smsut_in_apply_bwd_amax": "pppppppp pp p iii s",
@@ -102,6 +106,10 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_fwd_mfma_stats_cat_f16": "ppppp iiiii s",
     "smsut_conv2d_fwd_mfma_split_f16": "ppppp iiiiiii s",
     "smsut_conv2d_dgrad_mfma_bwdstats_f16": "pppppppppp f iiiii s",
+    "smsut_conv2d_dgrad_mfma_bwdstats_f16_hs": "pppppppppp f iiiii s",
+    "smsut_conv2d_f16_hs_supported": "iiiiii",
+    "smsut_conv2d_fwd_mfma_stats_f16_hs": "ppppp iiiii s",
+    "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": "pppppppp iiiii s",
     "smsut_conv2d_wgrad_f16_supported": "iiiii",
     "smsut_conv2d_wgrad_f16_ws": "iiiii",
     "smsut_conv2d_wgrad_f16": "pp i pppp iiiii s",
@@ -186,7 +194,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_conv2d_flat_wgrad_supported", "smsut_conv2d_mfma_tiles", "smsut_conv2d_mfma_persistent", "smsut_conv1x1_supported",
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",
                          "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_fwd_sc_f16_supported", "smsut_conv2d_dgrad_sc_supported",
-                         "smsut_conv2d_dgrad_sc_f16_supported", "smsut_conv2d_wgrad_sc_f16_supported",
+                         "smsut_conv2d_dgrad_sc_f16_supported", "smsut_conv2d_wgrad_sc_f16_supported", "smsut_conv2d_f16_hs_supported",
                          "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported",
                          "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
 

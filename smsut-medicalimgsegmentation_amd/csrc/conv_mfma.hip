@@ -357,7 +357,7 @@ struct ScRef { const float* w; float* y; float* stats; };   // SC: the block's 1
 constexpr int SPIXW = 20;
 
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false>
+          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false, bool O16 = false>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WINO ? 2 : 1, WINO ? 2 : 8)))
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
@@ -400,6 +400,11 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // in the data-gradient (SC2) the chunks of the second reduction half (the shortcut's gradient) run ONLY those four sets,
   // against the 1x1 weights, and the result is added after the output transform.
   static_assert(!WINO || (KS == 3 && TH == 16 && !F16 && !K8 && !N8), "Winograd form: 3x3, 16-row items, fp32");
+  // O16 (r04, config 5): the result tensor(s) -- y, and sc.y of the fused shortcut -- are stored as fp16 (y points at _Float16
+  // [N,H,W,Ndim]): the block-internal raw conv outputs of a BasicBlock cross HBM at half the bytes.  InstanceNorm partials come
+  // from the fp32 accumulators, before the rounding.  Forward statistics forms with fp16 operands.
+  // With BST (the data-gradient that masks by the block's first InstanceNorm): bst.y1 is such an fp16 tensor; the result stays fp32.
+  static_assert(!O16 || (F16 && !ACC && !INAFF && (STATS != BST)), "fp16 storage: forward statistics forms / BST data-gradient, fp16 operands");
   constexpr int SPX = WINO ? SPIXW : SPIX;            // pixel stride of the staged fp32 input tile
   constexpr int NPOS = WINO ? 16 : KS * KS;           // weight blocks held in LDS (Winograd positions | taps)
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
@@ -657,7 +662,10 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       for (int j = 0; j < NR; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (nok) yb[o_lane + pxo(i, r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
+          if constexpr (O16 && !BST) {
+            reinterpret_cast<_Float16*>(yo)[(((size_t)en * H + ety * TH) * W + etx * TW) * os + oc0 + o_lane + pxo(i, r) * os + j * 16] =
+                (_Float16)pacc[i][j][r];
+          } else if (nok) yb[o_lane + pxo(i, r) * os + j * 16] = pacc[i][j][r] + (ACC ? pold[i][j][r] : 0.f);
     if constexpr (SC) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
@@ -677,7 +685,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) ys[o_lane + pxo(i, r) * Ndim + j * 16] = pacs[i][j][r];
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (O16)
+              reinterpret_cast<_Float16*>(sc.y)[(((size_t)en * H + ety * TH) * W + etx * TW) * Ndim + co0 + o_lane + pxo(i, r) * Ndim + j * 16] =
+                  (_Float16)pacs[i][j][r];
+            else ys[o_lane + pxo(i, r) * Ndim + j * 16] = pacs[i][j][r];
+          }
     }
   };
   // ACC: the values the outputs of item (n_, ty_, tx_) hold now (loaded one region before they are added and stored)
@@ -697,7 +710,12 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
 #pragma unroll
         for (int j = 0; j < NR; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pold[i][j][r] = nok ? yb[o_lane + pxo(i, r) * os + j * 16] : 0.f;
+          for (int r = 0; r < 4; ++r) {
+            if constexpr (BST && O16)
+              pold[i][j][r] = (float)reinterpret_cast<const _Float16*>(bst.y1)[(((size_t)n_ * H + ty_ * TH) * W + tx_ * TW) * os + oc0 + o_lane +
+                                                                              pxo(i, r) * os + j * 16];
+            else pold[i][j][r] = nok ? yb[o_lane + pxo(i, r) * os + j * 16] : 0.f;
+          }
     }
   };
   auto stats_out = [&](int par) {                     // after the barrier that completes red[par]
@@ -1767,7 +1785,7 @@ template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false, bo
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
                  float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
-                 bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr) {
+                 bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr, bool o16 = false) {
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH, WINO>();
   // fused 1x1 shortcut (SC): its weight block and a second statistics scratch
   constexpr size_t sh_sc = sh + (size_t)(16 * NCH * 16 * NTN + 2 * 4 * 16 * NTN * 2 + 8) * sizeof(float);
@@ -1789,6 +1807,8 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (sc && !sc2 && (KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || !sc->w || !sc->y || !sc->stats ||
                      (K8 && x2) || (f16 && (K8 || WINO))))
     return -1;                                                                  // fused shortcut: forward statistics forms
+  if (o16 && !bst && (!f16 || !stats || aff || y2 || transposed || K8 || N8 || WINO || KS != 3)) return -1;   // fp16 result storage
+  if (o16 && bst && (!f16 || !stats || aff || y2 || x2 || sc || (transposed & 2) || K8 || N8 || WINO || KS != 3)) return -1;  // fp16 y1 of the BST form
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = N8 ? 1 : Ndim / (16 * NTN);
   static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
@@ -1865,15 +1885,16 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     } else if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (f16) {                                   // fp16 operands (config 5; r04): direct form, plain or virtual-cat input
         if constexpr (!WINO) {
+#define SC16_GO(DU, O)                                                                                                        \
+  conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, DU, false, true, false, true, false, false, false, O><<<grid, TPB, sh_sc, st>>>( \
+      x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc)
           if (x2) {
-            if constexpr (NCH % 2 == 0)
-              conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, true, false, true><<<grid, TPB, sh_sc, st>>>(
-                  x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc);
+            if constexpr (NCH % 2 == 0) { if (o16) SC16_GO(true, true); else SC16_GO(true, false); }
             else return -1;
           } else {
-            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, true><<<grid, TPB, sh_sc, st>>>(
-                x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+            if (o16) SC16_GO(false, true); else SC16_GO(false, false);
           }
+#undef SC16_GO
         } else return -1;
       } else if (x2) {
         if constexpr (NCH % 2 == 0)
@@ -1887,8 +1908,24 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     } else return -1;
   } else if (aff) {
     P_GO(true, false, false, false, true);
+  } else if (o16 && !bst) {                       // fp16 operands, fp16 result storage: plain or virtual-cat forward statistics form
+    if constexpr (!K8 && !WINO && KS == 3) {
+      if (x2) {
+        if constexpr (NCH % 2 == 0)
+          conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
+              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr);
+        else return -1;
+      } else
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr);
+    } else return -1;
   } else if (x2) {
     if constexpr (NCH % 2 == 0) P_GO(true, false, false, true, false);
+    else return -1;
+  } else if (bst && o16) {
+    if constexpr (!K8 && !WINO && KS == 3)
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, true, false, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
+          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, nullptr, 0, nullptr, affv, gsc);
     else return -1;
   } else if (bst) {
     if (!stats || (transposed & 2)) return -1;
@@ -1930,8 +1967,8 @@ inline bool fwd_any_eligible(int N, int H, int W, int Kdim, int Ndim, bool f16) 
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
-                        const ScRef* sc = nullptr, const float* wu = nullptr) {
-#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc
+                        const ScRef* sc = nullptr, const float* wu = nullptr, bool o16 = false) {
+#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc, o16
   // (the fused shortcut data-gradient at 64 reduction channels stays on the direct resident-weight form: 107 us vs 142 us at
   //  16 x 128^2 (32 + 32) -> 64 -- its second-half chunks are a run-time branch inside the staging parts, r03 notes)
   const bool sc2_64 = sc && (transposed & 1) && Kdim == 64 && fwd_p_eligible(N, H, W, Kdim, Ndim);
@@ -2576,6 +2613,48 @@ int smsut_conv2d_dgrad_mfma_sc(const float* gy, const float* gs, const float* w,
   const ScRef sc{wsc, nullptr, nullptr};
   const int rc = select_fwd_p(gy, w, gxa, N, H, W, 2 * Cout, Cin, 1, (hipStream_t)stream, nullptr, nullptr, nullptr, gxb, gxb ? split : 0,
                               gs, nullptr, false, nullptr, &sc);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// fp16 RESULT STORAGE (config 5, r04): the same passes, the raw conv outputs y (and ysc) stored as fp16 [N,H,W,Ndim] -- block-internal
+// tensors of a BasicBlock (its consumers: smsut_restail_*_hs).  Persistent-kernel shapes, Kdim in {16, 32, 64}; xb nullable
+// (virtual cat); InstanceNorm partials as in the fp32-storage forms (tiles with f16 = 1).  SMSUT_F16_STORE=0 switches it off.
+int smsut_conv2d_f16_hs_supported(int N, int H, int W, int Kdim, int Ndim, int cat) {
+  static const bool on = [] { const char* e = getenv("SMSUT_F16_STORE"); return !e || atoi(e) != 0; }();
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  return !(cat && Kdim % 32 != 0);
+}
+int smsut_conv2d_fwd_mfma_stats_f16_hs(const float* x, const float* xb, const float* w, void* y16, float* stats, int N, int H, int W,
+                                       int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(x && w && y16 && stats && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, xb != nullptr));
+  const int rc = select_fwd_p(x, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb,
+                              nullptr, true, nullptr, nullptr, nullptr, true);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats_sc_f16_hs(const float* x, const float* xb, const float* w, const float* wsc, void* y16, void* ysc16,
+                                          float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(x && w && wsc && y16 && ysc16 && stats && stats_sc && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, xb != nullptr) &&
+                smsut_conv2d_fwd_sc_f16_supported(N, H, W, Kdim, Ndim, xb != nullptr));
+  const ScRef sc{wsc, (float*)ysc16, stats_sc};
+  const int rc = select_fwd_p(x, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb,
+                              nullptr, true, nullptr, &sc, nullptr, true);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// conv2's data-gradient with the IN1 / LeakyReLU mask and backward statistics (smsut_conv2d_dgrad_mfma_bwdstats_f16) reading an fp16 y1
+int smsut_conv2d_dgrad_mfma_bwdstats_f16_hs(const float* gy, const float* w, float* gz, float* stats, const void* y1_16,
+                                            const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                            const float* gsc, float slope, int N, int H, int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(gy && w && gz && stats && y1_16 && mean && rstd && gamma && beta && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, 0));
+  const BstRef b{(const float*)y1_16, mean, rstd, gamma, beta, slope};
+  const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, (hipStream_t)stream, stats, nullptr, &b, nullptr, 0, nullptr,
+                              nullptr, true, gsc, nullptr, nullptr, true);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

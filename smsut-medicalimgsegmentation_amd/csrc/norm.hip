@@ -313,7 +313,22 @@ __device__ __forceinline__ void img_walk(int HW, int CV, LoadP&& load_params, Bo
   }
 }
 
-template <int VEC>
+// HS ("half storage", config 5): the raw conv outputs y1, y2 and s of a BasicBlock live in HBM as fp16 (written by the conv epilogues,
+// smsut_conv2d_fwd_mfma_stats*_f16_hs); the x / y2 / s pointers of the HS kernel variants then point at _Float16 data.  Arithmetic
+// stays fp32.
+typedef _Float16 hs4 __attribute__((ext_vector_type(4)));
+template <int VEC, bool HS>
+__device__ __forceinline__ void ld_act(const float* base, size_t off, float* v) {       // off in ELEMENTS
+  if constexpr (HS) {
+    const _Float16* h = reinterpret_cast<const _Float16*>(base) + off;
+    if constexpr (VEC == 4) { const hs4 t = *(const hs4*)h; v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3]; }
+    else v[0] = (float)h[0];
+  } else {
+    if constexpr (VEC == 4) *(float4*)v = *(const float4*)(base + off); else v[0] = base[off];
+  }
+}
+
+template <int VEC, bool HS = false>
 __global__ void __launch_bounds__(TPB)
 in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
@@ -328,7 +343,7 @@ in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const 
     },
     [&](int64_t i, const Prm& p) {
       float v[VEC];
-      if constexpr (VEC == 4) *(float4*)v = *(const float4*)(x + i * 4); else v[0] = x[i];
+      ld_act<VEC, HS>(x, (size_t)i * VEC, v);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float r = in_affine(v[j], p.mu[j], p.rs[j], p.gm[j], p.bt[j]);
@@ -356,7 +371,7 @@ __device__ __forceinline__ void amax_emit(float m, float* slots) {
   __syncthreads();
 }
 
-template <int VEC>
+template <int VEC, bool HS = false>
 __global__ void __launch_bounds__(TPB)
 in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
@@ -384,12 +399,8 @@ in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const fl
     },
     [&](int64_t i, const Prm& p) {
       float g[VEC], xv[VEC];
-      if constexpr (VEC == 4) {
-        *(float4*)g = *(const float4*)(gy + i * 4);
-        *(float4*)xv = *(const float4*)(x + i * 4);
-      } else {
-        g[0] = gy[i]; xv[0] = x[i];
-      }
+      if constexpr (VEC == 4) *(float4*)g = *(const float4*)(gy + i * 4); else g[0] = gy[i];
+      ld_act<VEC, HS>(x, (size_t)i * VEC, xv);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float r = p.rs[j], gm = p.gm[j];
@@ -470,7 +481,7 @@ struct TailRef {
   const float* s;  const float* ms; const float* rs; const float* gs; const float* bs;   // ms == null: s is the identity
 };
 
-template <int VEC>
+template <int VEC, bool HS = false>
 __global__ void __launch_bounds__(TPB)
 restail_fwd(TailRef t, float* __restrict__ out, int HW, int C, float slope) {
   struct Prm { float m2[VEC], r2[VEC], g2[VEC], b2[VEC], ms[VEC], rs[VEC], gs[VEC], bs[VEC]; };
@@ -484,8 +495,7 @@ restail_fwd(TailRef t, float* __restrict__ out, int HW, int C, float slope) {
     },
     [&](int64_t i, const Prm& p) {
       float a[VEC], b[VEC];
-      if constexpr (VEC == 4) { *(float4*)a = *(const float4*)(t.y2 + i * 4); *(float4*)b = *(const float4*)(t.s + i * 4); }
-      else { a[0] = t.y2[i]; b[0] = t.s[i]; }
+      ld_act<VEC, HS>(t.y2, (size_t)i * VEC, a); ld_act<VEC, HS>(t.s, (size_t)i * VEC, b);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float u = in_affine(a[j], p.m2[j], p.r2[j], p.g2[j], p.b2[j]);
@@ -497,7 +507,7 @@ restail_fwd(TailRef t, float* __restrict__ out, int HW, int C, float slope) {
 }
 
 // partial [N][chunks][C][3] = {sum gz, sum gz*y2hat, sum gz*shat}
-template <int VEC, bool REMASK>
+template <int VEC, bool REMASK, bool HS = false>
 __global__ void __launch_bounds__(TPB)       // (a 128-VGPR cap spills here: 244 B scratch and +30 % time)
 restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
                     int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}) {
@@ -539,13 +549,12 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
         if constexpr (VEC == 4) {
           *(float4*)g = *(const float4*)(gout + off);
           if (!remask) *(float4*)o = *(const float4*)(out + off);
-          *(float4*)y = *(const float4*)(t.y2 + off);
-          if (t.ms) *(float4*)sv = *(const float4*)(t.s + off);
         } else {
-          g[0] = gout[off]; y[0] = t.y2[off];
+          g[0] = gout[off];
           if (!remask) o[0] = out[off];
-          if (t.ms) sv[0] = t.s[off];
         }
+        ld_act<VEC, HS>(t.y2, off, y);
+        if (t.ms) ld_act<VEC, HS>(t.s, off, sv);
       };
       auto accum = [&](const float* g, const float* o, const float* y, const float* sv) {
 #pragma unroll
@@ -626,7 +635,7 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
   }
 }
 
-template <int VEC, bool REMASK>
+template <int VEC, bool REMASK, bool HS = false>
 __global__ void __launch_bounds__(TPB)
 restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
                   const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
@@ -657,13 +666,12 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
       if constexpr (VEC == 4) {
         *(float4*)g = *(const float4*)(gout + i * 4);
         if (!remask) *(float4*)o = *(const float4*)(out + i * 4);
-        *(float4*)y = *(const float4*)(t.y2 + i * 4);
-        if (t.ms) *(float4*)sv = *(const float4*)(t.s + i * 4);
       } else {
-        g[0] = gout[i]; y[0] = t.y2[i];
+        g[0] = gout[i];
         if (!remask) o[0] = out[i];
-        if (t.ms) sv[0] = t.s[i];
       }
+      ld_act<VEC, HS>(t.y2, (size_t)i * VEC, y);
+      if (t.ms) ld_act<VEC, HS>(t.s, (size_t)i * VEC, sv);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
         const float pre = remask ? in_affine(y[j], p.m2[j], p.r2[j], p.g2[j], p.be2[j]) + in_affine(sv[j], p.msv[j], p.rsv[j], p.gsv[j], p.bes[j])
@@ -741,20 +749,35 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
 
 // Same as smsut_instnorm_fwd when the {sum, sum^2} partials [N][chunks][C][2] were already produced by the conv
 // epilogue (smsut_conv2d_fwd_mfma_stats): finalise + normalise/activate only.
-int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-                                float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
-                                float slope, int has_act, void* stream) {
+static int instnorm_fwd_partials_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                        float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                        float slope, int has_act, void* stream, bool hs) {
   SMSUT_REQUIRE(x && gamma && beta && y && mean && rstd && partials && chunks > 0 && N > 0 && HW > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
   in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(partials, chunks, C, HW, eps, mean, rstd, nullptr);
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
-  if (C % 4 == 0)
+  if (hs)
+    in_apply_fwd<4, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
+  else if (C % 4 == 0)
     in_apply_fwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
   else
     in_apply_fwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                float slope, int has_act, void* stream) {
+  return instnorm_fwd_partials_launch(x, gamma, beta, y, mean, rstd, partials, chunks, N, HW, C, eps, slope, has_act, stream, false);
+}
+// "half storage" (config 5): x is fp16 [N,HW,C] (the raw conv output a conv epilogue stored), y stays fp32; C % 4 == 0
+int smsut_instnorm_fwd_partials_hs(const void* x16, const float* gamma, const float* beta, float* y, float* mean,
+                                   float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                   float slope, int has_act, void* stream) {
+  SMSUT_REQUIRE(C % 4 == 0);
+  return instnorm_fwd_partials_launch((const float*)x16, gamma, beta, y, mean, rstd, partials, chunks, N, HW, C, eps, slope, has_act,
+                                      stream, true);
 }
 
 // beta == null: no activation; otherwise the LeakyReLU mask is recomputed from x (sign of the normalised
@@ -851,13 +874,16 @@ int smsut_in_finalize_bwd(const float* partials, int chunks, float* a_mean, floa
 // (nullable) are the affine gradients sum_n HW*b, sum_n HW*a.
 static int in_apply_bwd_launch(const float* gz, const float* x, const float* mean, const float* rstd, const float* gamma,
                                const float* a_mean, const float* b_mean, float* gx, float* ggamma, float* gbeta, float* amax, int N,
-                               int HW, int C, void* stream) {
+                               int HW, int C, void* stream, bool hs = false) {
   SMSUT_REQUIRE(gz && x && mean && rstd && gamma && a_mean && b_mean && gx && N > 0 && HW > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
   float* gg = (ggamma && gbeta) ? ggamma : nullptr;
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
-  if (C % 4 == 0)
+  if (hs)
+    in_apply_bwd<4, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C,
+                                                                      0.f, N, gg, gbeta, amax);
+  else if (C % 4 == 0)
     in_apply_bwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, 0.f,
                                                         N, gg, gbeta, amax);
   else
@@ -884,20 +910,40 @@ int smsut_in_apply_bwd_amax(const float* gz, const float* x, const float* mean, 
   SMSUT_REQUIRE(amax);
   return in_apply_bwd_launch(gz, x, mean, rstd, gamma, a_mean, b_mean, gx, ggamma, gbeta, amax, N, HW, C, stream);
 }
+// "half storage" (config 5): x is fp16 [N,HW,C]; amax nullable; C % 4 == 0
+int smsut_in_apply_bwd_hs(const float* gz, const void* x16, const float* mean, const float* rstd, const float* gamma,
+                          const float* a_mean, const float* b_mean, float* gx, float* ggamma, float* gbeta, float* amax, int N,
+                          int HW, int C, void* stream) {
+  SMSUT_REQUIRE(C % 4 == 0);
+  return in_apply_bwd_launch(gz, (const float*)x16, mean, rstd, gamma, a_mean, b_mean, gx, ggamma, gbeta, amax, N, HW, C, stream, true);
+}
 
 // out = act(IN(y2) + (IN(s) | s)); ms == null: s is added as it is (identity shortcut).
-int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
-                      const float* ms, const float* rs, const float* gs, const float* bs, float* out, int N, int HW, int C,
-                      float slope, void* stream) {
+static int restail_fwd_launch(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
+                              const float* ms, const float* rs, const float* gs, const float* bs, float* out, bool hs, int N, int HW,
+                              int C, float slope, void* stream) {
   SMSUT_REQUIRE(y2 && m2 && r2 && g2 && b2 && s && out && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs && bs)));
   TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs, bs};
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
   hipStream_t st = (hipStream_t)stream;
-  if (C % 4 == 0) restail_fwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(t, out, HW, C, slope);
+  if (hs) restail_fwd<4, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(t, out, HW, C, slope);
+  else if (C % 4 == 0) restail_fwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(t, out, HW, C, slope);
   else restail_fwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(t, out, HW, C, slope);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const float* g2, const float* b2, const float* s,
+                      const float* ms, const float* rs, const float* gs, const float* bs, float* out, int N, int HW, int C,
+                      float slope, void* stream) {
+  return restail_fwd_launch(y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, false, N, HW, C, slope, stream);
+}
+// "half storage" (config 5): y2 and s are fp16 [N,HW,C] (conv shortcut: ms != null), C % 4 == 0; everything else as above
+int smsut_restail_fwd_hs(const void* y2, const float* m2, const float* r2, const float* g2, const float* b2, const void* s,
+                         const float* ms, const float* rs, const float* gs, const float* bs, float* out, int N, int HW, int C,
+                         float slope, void* stream) {
+  SMSUT_REQUIRE(ms && C % 4 == 0);
+  return restail_fwd_launch((const float*)y2, m2, r2, g2, b2, (const float*)s, ms, rs, gs, bs, out, true, N, HW, C, slope, stream);
 }
 
 // Backward of the tail.  workspace: float[N * smsut_in_chunks(N,HW,C) * C * 3]; a/b2/bs: [N,C] scratch outputs;
@@ -908,7 +954,8 @@ int smsut_restail_fwd(const float* y2, const float* m2, const float* r2, const f
 static int restail_bwd_launch(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
                               const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
                               const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
-                              float* gbs, float* workspace, float* amax, int N, int HW, int C, float slope, void* stream) {
+                              float* gbs, float* workspace, float* amax, int N, int HW, int C, float slope, void* stream,
+                              bool hs = false) {
   SMSUT_REQUIRE(gout && out && y2 && m2 && r2 && g2 && s && gy2 && gs && a_mean && b2_mean && bs_mean && gg2 && gb2 &&
                 workspace && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs_ && ggs && gbs)));
   TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs_, bs};
@@ -919,7 +966,10 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
   const bool remask = ms && b2 && bs;
   const FinOut fin = (chunks == 1 && fin_emit_on()) ? FinOut{a_mean, b2_mean, bs_mean, 0.f} : FinOut{};
 #define TAIL_PARTIAL(V, R) restail_bwd_partial<V, R><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin)
-  if (C % 4 == 0) { if (remask) TAIL_PARTIAL(4, true); else TAIL_PARTIAL(4, false); }
+  if (hs) {
+    SMSUT_REQUIRE(remask && C % 4 == 0);
+    restail_bwd_partial<4, true, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin);
+  } else if (C % 4 == 0) { if (remask) TAIL_PARTIAL(4, true); else TAIL_PARTIAL(4, false); }
   else { if (remask) TAIL_PARTIAL(1, true); else TAIL_PARTIAL(1, false); }
 #undef TAIL_PARTIAL
   if (!fin.o0) in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
@@ -929,7 +979,10 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
 #define TAIL_APPLY(V, R)                                                                                                \
   restail_bwd_apply<V, R><<<img_grid((int64_t)HW * (C / V), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, HW, C, \
                                                               slope, N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr, amax)
-  if (C % 4 == 0) { if (remask) TAIL_APPLY(4, true); else TAIL_APPLY(4, false); }
+  if (hs)
+    restail_bwd_apply<4, true, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, HW, C,
+                                                                                 slope, N, gg2, gb2, ggs, gbs, amax);
+  else if (C % 4 == 0) { if (remask) TAIL_APPLY(4, true); else TAIL_APPLY(4, false); }
   else { if (remask) TAIL_APPLY(1, true); else TAIL_APPLY(1, false); }
 #undef TAIL_APPLY
   SMSUT_LAUNCH_CHECK();
@@ -950,6 +1003,16 @@ int smsut_restail_bwd_amax(const float* gout, const float* out, const float* y2,
   SMSUT_REQUIRE(amax);
   return restail_bwd_launch(gout, out, y2, m2, r2, g2, b2, s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean, bs_mean, gg2, gb2, ggs, gbs,
                             workspace, amax, N, HW, C, slope, stream);
+}
+// "half storage" (config 5): y2 and s are fp16 [N,HW,C]; two-IN tail with both betas (the mask is recomputed, `out` is not read),
+// C % 4 == 0; amax nullable (see smsut_restail_bwd_amax)
+int smsut_restail_bwd_hs(const float* gout, const float* out, const void* y2, const float* m2, const float* r2,
+                         const float* g2, const float* b2, const void* s, const float* ms, const float* rs,
+                         const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
+                         float* gbs, float* workspace, float* amax, int N, int HW, int C, float slope, void* stream) {
+  SMSUT_REQUIRE(ms && b2 && bs && C % 4 == 0);
+  return restail_bwd_launch(gout, out, (const float*)y2, m2, r2, g2, b2, (const float*)s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean,
+                            bs_mean, gg2, gb2, ggs, gbs, workspace, amax, N, HW, C, slope, stream, true);
 }
 
 }  // extern "C"

@@ -102,8 +102,8 @@ def nhwc(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def new_act(n, c, h, w, like: torch.Tensor) -> torch.Tensor:
-    return torch.empty_strided((n, c, h, w), (h * w * c, 1, w * c, c), dtype=torch.float32, device=like.device)
+def new_act(n, c, h, w, like: torch.Tensor, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty_strided((n, c, h, w), (h * w * c, 1, w * c, c), dtype=dtype, device=like.device)
 
 
 def hwio_strides(o, i, kh, kw):
@@ -779,6 +779,7 @@ SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-aft
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
 REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
+F16_STORE = bool(int(_os.environ.get("SMSUT_F16_STORE", "1")))           # fp16 operands: block-internal y1 / y2 / s stored as fp16
 AMAX_HANDOVER = bool(int(_os.environ.get("SMSUT_AMAX_HANDOVER", "1")))    # fp16 operands: gradient maxima from the producing kernels
 
 
@@ -837,23 +838,34 @@ class BasicBlockFn(Function):
         ctx.f16 = (f16a, f16)
         t3 = H.call("smsut_conv2d_mfma_tiles", n, h, w, ci, co, 3, int(f16a))    # tile shape depends on (N, H, W, Cin, Cout, dtype)
         t3b = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3, int(f16))
-        y1 = new_act(n, co, h, w, x)
         p1 = _ws(n * t3 * co * 2, x)
         # conv1 and the 1x1 shortcut read the same block input: one pass (the shortcut is conv1's centre tap with its own weights)
         fused_sc = has_sc and bool(H.call("smsut_conv2d_fwd_sc_f16_supported" if f16a else "smsut_conv2d_fwd_sc_supported",
                                           n, h, w, ci, co, 1 if virtual else 0))
+        # fp16 operands: the block-internal raw conv outputs y1, y2, s never leave the block -- stored as fp16 (half the HBM bytes
+        # of every pass over them: conv epilogues, IN apply, both tail passes, the BST mask read), arithmetic on them in fp32
+        hs = (F16_STORE and f16a and f16 and fused_sc and FUSED_BWD_STATS and REMASK_TAIL
+              and bool(H.call("smsut_conv2d_f16_hs_supported", n, h, w, ci, co, 1 if virtual else 0))
+              and bool(H.call("smsut_conv2d_f16_hs_supported", n, h, w, co, co, 0)))
+        ctx.hs = hs
+        act_dt = torch.float16 if hs else torch.float32
+        y1 = new_act(n, co, h, w, x, act_dt)
         if fused_sc:
-            s = new_act(n, co, h, w, x)
+            s = new_act(n, co, h, w, x, act_dt)
             ps, t1 = _ws(n * t3 * co * 2, x), t3
-            _conv3("smsut_conv2d_fwd_mfma_stats_sc_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_sc", w1, 0, xa if virtual else x,
-                   xb if virtual else None, w1, ws, y1, s, p1, ps, n, h, w, ci, co, st)
+            if hs:
+                H.call("smsut_conv2d_fwd_mfma_stats_sc_f16_hs", xa if virtual else x, xb if virtual else None, w1, ws, y1, s, p1, ps,
+                       n, h, w, ci, co, st)
+            else:
+                _conv3("smsut_conv2d_fwd_mfma_stats_sc_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_sc", w1, 0, xa if virtual else x,
+                       xb if virtual else None, w1, ws, y1, s, p1, ps, n, h, w, ci, co, st)
         elif virtual:
             _conv3("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_cat", w1, 0, xa, xb, w1, y1, p1, n, h, w,
                    ci, co, st)
         else:
             _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16a else "smsut_conv2d_fwd_mfma_stats", w1, 0, x, w1, y1, p1, n, h, w, ci, co, 3, st)
         m1, r1 = stat(co)
-        y2 = new_act(n, co, h, w, x)
+        y2 = new_act(n, co, h, w, x, act_dt)
         p2 = _ws(n * t3b * co * 2, x)
         inaff = (INAFF_CONV2 and not f16 and co % INAFF_MIN_CO == 0
                  and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, 0)))
@@ -865,8 +877,12 @@ class BasicBlockFn(Function):
             _conv3("smsut_conv2d_fwd_mfma_stats_inaff", w2, 0, y1, w2, y2, p2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
         else:
             a1 = new_act(n, co, h, w, x)
-            H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
-            _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w2, 0, a1, w2, y2, p2, n, h, w, co, co, 3, st)
+            if hs:
+                H.call("smsut_instnorm_fwd_partials_hs", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
+                H.call("smsut_conv2d_fwd_mfma_stats_f16_hs", a1, None, w2, y2, p2, n, h, w, co, co, st)
+            else:
+                H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
+                _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w2, 0, a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
         if fused_sc:
             ms, rs = stat(co)                                # both sets are due now: ONE launch of the latency-bound finalize
@@ -893,7 +909,7 @@ class BasicBlockFn(Function):
         else:
             s, ms, rs = x, None, None
         out = new_act(n, co, h, w, x)
-        H.call("smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, co, slope, st)
+        H.call("smsut_restail_fwd_hs" if hs else "smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, co, slope, st)
         ctx.has_sc = has_sc
         ctx.slope = slope
         if virtual:
@@ -944,7 +960,11 @@ class BasicBlockFn(Function):
         # [gy2 | gs_t | gy1], nb each), the scales of the gradient operands come from those slots instead of a pass over each tensor
         nb = H.call("smsut_amax_blocks", n, hw, co) if (f16 or f16a) and AMAX_HANDOVER else 0
         amax = torch.empty(3 * nb, dtype=torch.float32, device=dev) if nb else None
-        if amax is not None:
+        hs = ctx.hs
+        if hs:
+            H.call("smsut_restail_bwd_hs", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
+                   ggs, gbs, _ws(n * chunks * co * 3, x), amax, n, hw, co, slope, st)
+        elif amax is not None:
             H.call("smsut_restail_bwd_amax", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
                    ggs, gbs, _ws(n * chunks * co * 3, x), amax, n, hw, co, slope, st)
         else:
@@ -962,12 +982,18 @@ class BasicBlockFn(Function):
             # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
             tb = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3, int(f16))
             pb = _ws(n * tb * co * 2, x)
-            if f16:
+            if hs:
+                H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16_hs", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, sc2, slope, n, h, w, co, co, st)
+            elif f16:
                 H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, sc2, slope, n, h, w, co, co, st)
             else:
                 _conv3("smsut_conv2d_dgrad_mfma_bwdstats", w2, 1, gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
             H.call("smsut_in_finalize_bwd", pb, tb, a1m, b1m, n, hw, co, st)
-            if amax is not None and f16a:
+            if hs:
+                H.call("smsut_in_apply_bwd_hs", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, amax[2 * nb:] if amax is not None else None,
+                       n, hw, co, st)
+                amax1 = amax is not None
+            elif amax is not None and f16a:
                 H.call("smsut_in_apply_bwd_amax", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, amax[2 * nb:], n, hw, co, st)
                 amax1 = True
             else:

@@ -55,6 +55,10 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_dgrad_mfma_bwdstats_f16": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
     "smsut_conv2d_dgrad_mfma_sc_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 10, "mfma"),
+    # ... with fp16 storage of the block-internal raw conv outputs ("_hs")
+    "smsut_conv2d_fwd_mfma_stats_f16_hs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 10, "mfma"),
+    "smsut_conv2d_dgrad_mfma_bwdstats_f16_hs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_sc_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 10, "mfma"),
     "smsut_conv1x1_fwd": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "mfma"),
     "smsut_conv1x1_wgrad": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "mfma"),
@@ -98,6 +102,7 @@ def _base(name: str) -> str:
     if name.endswith("_pre"):
         return name[:-4]
     return name[:-5] if name.endswith("_amax") else name
+
 
 
 def _ints(name: str, conv_args) -> List[int]:
@@ -171,6 +176,14 @@ _BYTES: Dict[str, Callable[[List[int]], float]] = {
     "smsut_avgpool2_fwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 1.25,
     "smsut_avgpool2_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 1.25,
     "smsut_add_act": lambda a: 4.0 * a[0] * 3,
+    # half storage (config 5): the fp16 tensors count 2 bytes per element
+    "smsut_conv2d_fwd_mfma_stats_f16_hs": lambda a: a[0] * a[1] * a[2] * (4.0 * a[3] + 2.0 * a[4]),
+    "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": lambda a: a[0] * a[1] * a[2] * (4.0 * a[3] + 2.0 * 2 * a[4]),
+    "smsut_conv2d_dgrad_mfma_bwdstats_f16_hs": lambda a: a[0] * a[1] * a[2] * (4.0 * a[3] + 4.0 * a[4] + 2.0 * a[4]),
+    "smsut_restail_fwd_hs": lambda a: a[0] * a[1] * a[2] * (2.0 * 2 + 4.0),
+    "smsut_restail_bwd_hs": lambda a: a[0] * a[1] * a[2] * (4.0 * 3 + 2.0 * 2),
+    "smsut_in_apply_bwd_hs": lambda a: a[0] * a[1] * a[2] * (4.0 * 2 + 2.0),
+    "smsut_instnorm_fwd_partials_hs": lambda a: a[1] * a[2] * a[3] * (2.0 + 4.0),
     "smsut_act_bwd": lambda a: 4.0 * a[0] * 3,
     "smsut_tanh_fwd": lambda a: 4.0 * a[0] * 2,
     "smsut_tanh_bwd": lambda a: 4.0 * a[0] * 3,

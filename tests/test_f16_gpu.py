@@ -344,7 +344,9 @@ def test_gradient_scales_from_producer_maxima_are_the_absmax_pass(ops, monkeypat
     rec = profiling.record_step(lambda: res.update(r=_block(ops, x, ws_, gout, "f16")))
     o1, g1 = res["r"]
     names = [r[0] for r in rec]
-    assert "smsut_restail_bwd_amax" in names and "smsut_in_apply_bwd_amax" in names and "smsut_absmax_scale" not in names
+    tail = "smsut_restail_bwd_hs" if "smsut_restail_bwd_hs" in names else "smsut_restail_bwd_amax"      # (half storage where it applies)
+    assert tail in names and ("smsut_in_apply_bwd_hs" in names or "smsut_in_apply_bwd_amax" in names)
+    assert "smsut_absmax_finish" in names and "smsut_absmax_scale" not in names and "smsut_absmax_scale2" not in names
     monkeypatch.setattr(ops, "AMAX_HANDOVER", False)
     rec = profiling.record_step(lambda: res.update(r=_block(ops, x, ws_, gout, "f16")))
     o0, g0 = res["r"]
@@ -352,3 +354,108 @@ def test_gradient_scales_from_producer_maxima_are_the_absmax_pass(ops, monkeypat
     assert torch.equal(o0, o1)
     for a, b in zip(g1, g0):
         assert torch.equal(a, b)
+
+
+# ---- fp16 STORAGE of the block-internal raw conv outputs (y1, y2, s): "_hs" entry points ------------------------------------
+def _hs_shapes():
+    return [(4, 128, 16, 32, 0), (12, 128, 32, 16, 1), (2, 256, 16, 16, 0), (8, 64, 64, 64, 0)]
+
+
+@pytest.mark.parametrize("n,h,ci,co,cat", _hs_shapes())
+def test_half_storage_conv_epilogues_round_the_fp32_result(ops, n, h, ci, co, cat):
+    """``smsut_conv2d_fwd_mfma_stats_f16_hs`` / ``_sc_f16_hs`` store EXACTLY the fp16 rounding of what the fp32-storage entry
+    points store (same kernel, same accumulators; round-to-nearest-even at the store); InstanceNorm partials are bit-identical
+    (taken from the fp32 accumulators)."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_conv2d_f16_hs_supported", n, h, h, ci, co, cat) == 1
+    g = torch.Generator(device="cpu").manual_seed(17)
+    x = torch.randn(n, h, h, ci, generator=g).cuda()
+    w3 = (torch.randn(9 * ci * co, generator=g) / np.sqrt(9 * ci)).cuda()
+    w1 = (torch.randn(ci * co, generator=g) / np.sqrt(ci)).cuda()
+    tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, ci, co, 3, 1)
+    xa, xb = (x[..., :ci // 2].contiguous(), x[..., ci // 2:].contiguous()) if cat else (x, None)
+    y0, s0 = torch.empty(n, h, h, co, device="cuda"), torch.empty(n, h, h, co, device="cuda")
+    p0, q0 = torch.zeros(n * tiles * co * 2, device="cuda"), torch.zeros(n * tiles * co * 2, device="cuda")
+    H.call("smsut_conv2d_fwd_mfma_stats_sc_f16", xa, xb, w3, w1, y0, s0, p0, q0, n, h, h, ci, co, st)
+    yh = torch.full((n, h, h, co), float("nan"), device="cuda", dtype=torch.float16)
+    sh = torch.full_like(yh, float("nan"))
+    p1, q1 = torch.zeros_like(p0), torch.zeros_like(p0)
+    H.call("smsut_conv2d_fwd_mfma_stats_sc_f16_hs", xa, xb, w3, w1, yh, sh, p1, q1, n, h, h, ci, co, st)
+    assert torch.equal(yh, y0.half()) and torch.equal(sh, s0.half()) and torch.equal(p1, p0) and torch.equal(q1, q0)
+    yh2 = torch.full_like(yh, float("nan"))
+    p2 = torch.zeros_like(p0)
+    H.call("smsut_conv2d_fwd_mfma_stats_f16_hs", xa, xb, w3, yh2, p2, n, h, h, ci, co, st)
+    assert torch.equal(yh2, yh) and torch.equal(p2, p0)
+
+
+@pytest.mark.parametrize("n,h,c", [(4, 128, 32), (2, 256, 16), (8, 64, 64)])
+def test_half_storage_readers_equal_the_fp32_readers_on_the_same_values(ops, n, h, c):
+    """Every kernel that READS a block-internal tensor in half storage (IN apply forward / backward, both residual-tail passes,
+    the BST data-gradient's mask read) computes in fp32 from the fp16 values: BIT-IDENTICAL to the fp32-storage entry point fed
+    the same values widened to fp32."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    hw = h * h
+    g = torch.Generator(device="cpu").manual_seed(19)
+    R = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).cuda()
+    y1h, y2h, sh_ = R(n, h, h, c).half(), R(n, h, h, c).half(), R(n, h, h, c).half()
+    y1f, y2f, sf = y1h.float(), y2h.float(), sh_.float()
+    gam = [1 + 0.1 * R(c) for _ in range(3)]
+    bet = [0.1 * R(c) for _ in range(3)]
+    st_ = lambda: (R(n, c, sc=0.1), (1 + 0.1 * R(n, c)).abs())
+    (m1, r1), (m2, r2), (ms, rs) = st_(), st_(), st_()
+    E = lambda *sh: torch.full(sh, float("nan"), device="cuda")
+    # IN apply forward (statistics from partials of one chunk)
+    part = torch.stack([y1f.sum((1, 2)), (y1f * y1f).sum((1, 2))], -1).reshape(n, 1, c, 2).contiguous()
+    outs = []
+    for name, src in (("smsut_instnorm_fwd_partials", y1f), ("smsut_instnorm_fwd_partials_hs", y1h)):
+        a, mm, rr = E(n, h, h, c), E(n, c), E(n, c)
+        H.call(name, src, gam[0], bet[0], a, mm, rr, part, 1, n, hw, c, 1e-5, 0.01, 1, st)
+        outs.append((a, mm, rr))
+    assert all(torch.equal(p, q) for p, q in zip(*outs))
+    # residual tail forward
+    outs = []
+    for name, a, b in (("smsut_restail_fwd", y2f, sf), ("smsut_restail_fwd_hs", y2h, sh_)):
+        o = E(n, h, h, c)
+        H.call(name, a, m2, r2, gam[1], bet[1], b, ms, rs, gam[2], bet[2], o, n, hw, c, 0.01, st)
+        outs.append(o)
+    assert torch.equal(*outs)
+    out = outs[0]
+    # residual tail backward (+ the maxima hand-over)
+    gout = R(n, h, h, c, sc=1e-7)
+    chunks = H.call("smsut_in_chunks", n, hw, c)
+    nb = H.call("smsut_amax_blocks", n, hw, c)
+    res = []
+    for hs in (False, True):
+        gy2, gs_t = E(n, h, h, c), E(n, h, h, c)
+        vecs = [E(n, c) for _ in range(3)] + [E(c) for _ in range(4)]
+        amax = E(2 * nb)
+        args = [gout, out, y2h if hs else y2f, m2, r2, gam[1], bet[1], sh_ if hs else sf, ms, rs, gam[2], bet[2], gy2, gs_t, *vecs,
+                torch.empty(n * chunks * c * 3, device="cuda"), amax, n, hw, c, 0.01, st]
+        H.call("smsut_restail_bwd_hs" if hs else "smsut_restail_bwd_amax", *args)
+        res.append([gy2, gs_t, *vecs, amax])
+    assert all(torch.equal(p, q) for p, q in zip(*res))
+    assert float(res[0][-1][:nb].max()) == float(res[0][0].abs().max()) and float(res[0][-1][nb:].max()) == float(res[0][1].abs().max())
+    # IN apply backward
+    gz, am, bm = R(n, h, h, c, sc=1e-7), R(n, c, sc=1e-9), R(n, c, sc=1e-9)
+    res = []
+    for hs in (False, True):
+        gx, gg, gb, amax = E(n, h, h, c), E(c), E(c), E(nb)
+        H.call("smsut_in_apply_bwd_hs" if hs else "smsut_in_apply_bwd_amax", gz, y1h if hs else y1f, m1, r1, gam[0], am, bm, gx, gg, gb, amax,
+               n, hw, c, st)
+        res.append([gx, gg, gb, amax])
+    assert all(torch.equal(p, q) for p, q in zip(*res))
+    # conv2's data-gradient with the IN1 / LeakyReLU mask and backward partials
+    if H.call("smsut_conv2d_f16_hs_supported", n, h, h, c, c, 0):
+        w = (R(9 * c * c) / np.sqrt(9 * c))
+        sc = torch.empty(2, device="cuda")
+        H.call("smsut_absmax_scale", gout, gout.numel(), sc, torch.empty(1024, device="cuda"), st)
+        tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3, 1)
+        res = []
+        for hs in (False, True):
+            gz2, pb = E(n, h, h, c), torch.zeros(n * tiles * c * 2, device="cuda")
+            H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16_hs" if hs else "smsut_conv2d_dgrad_mfma_bwdstats_f16", gout, w, gz2, pb,
+                   y1h if hs else y1f, m1, r1, gam[0], bet[0], sc, 0.01, n, h, h, c, c, st)
+            res.append([gz2, pb])
+        assert all(torch.equal(p, q) for p, q in zip(*res))
