@@ -203,6 +203,9 @@ int smsut_conv2d_fwd_mfma_split_f16(const float* x, const float* w, float* ya, f
 int smsut_conv2d_f16_hs_supported(int N, int H, int W, int Kdim, int Ndim, int cat);
 int smsut_conv2d_fwd_mfma_stats_f16_hs(const float* x, const float* xb /*nullable*/, const float* w, void* y16, float* stats, int N,
                                        int H, int W, int Kdim, int Ndim, void* stream);
+/* ... whose input is fp16 too (conv2 of the block reading the a1 that smsut_instnorm_fwd_partials_hs2 stored): same operand bits */
+int smsut_conv2d_fwd_mfma_stats_f16_hsx(const void* x16, const float* w, void* y16, float* stats, int N, int H, int W, int Kdim,
+                                        int Ndim, void* stream);
 int smsut_conv2d_fwd_mfma_stats_sc_f16_hs(const float* x, const float* xb /*nullable*/, const float* w, const float* wsc, void* y16,
                                           void* ysc16, float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim,
                                           void* stream);
@@ -226,6 +229,9 @@ int smsut_conv2d_wgrad_f16_supported(int N, int H, int W, int Cin, int Cout);
 int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout);
 int smsut_conv2d_wgrad_f16(const float* x, const float* x2 /*nullable*/, int ca, const float* gy, float* gw, float* workspace,
                            const float* gsc /*nullable*/, int N, int H, int W, int Cin, int Cout, void* stream);
+/* ... with x stored as fp16 (half storage: conv2's weight gradient reads the activated a1): same operand bits, same result */
+int smsut_conv2d_wgrad_f16_xh(const void* x16, const float* gy, float* gw, float* workspace, const float* gsc /*nullable*/, int N,
+                              int H, int W, int Cin, int Cout, void* stream);
 /* ... plus the 1x1 shortcut's weight gradient in the same pass (fp16 twin of smsut_conv2d_wgrad_mfma_sc): gw10 [10][Cin][Cout],
  * rows 0..8 the 3x3 taps, row 9 the shortcut; gsc from smsut_absmax_scale2(gy, gs) */
 int smsut_conv2d_wgrad_sc_f16_supported(int N, int H, int W, int Cin, int Cout);
@@ -307,6 +313,10 @@ int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float*
 int smsut_instnorm_fwd_partials_hs(const void* x16, const float* gamma, const float* beta, float* y, float* mean,
                                    float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
                                    float slope, int has_act, void* stream);
+/* ... and y stored as fp16 as well (consumers: smsut_conv2d_fwd_mfma_stats_f16_hsx, smsut_conv2d_wgrad_f16_xh) */
+int smsut_instnorm_fwd_partials_hs2(const void* x16, const float* gamma, const float* beta, void* y16, float* mean,
+                                    float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                    float slope, int has_act, void* stream);
 int smsut_in_finalize_fwd(const float* partials, int chunks, float* mean, float* rstd, int N, int HW, int C, float eps,
                           void* stream);
 /* the same for TWO partial sets of one (N, HW, C) in one launch (conv2's and the shortcut's statistics of a BasicBlock,

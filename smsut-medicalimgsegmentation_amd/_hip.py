@@ -22,6 +22,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_instnorm_fwd": "ppppppp iii ff i s",
     "smsut_instnorm_fwd_partials": "ppppppp iiii ff i s",
     "smsut_instnorm_fwd_partials_hs": "ppppppp iiii ff i s",
+    "smsut_instnorm_fwd_partials_hs2": "ppppppp iiii ff i s",
     "smsut_in_finalize_fwd": "p i pp iii f s",
     "smsut_in_finalize_fwd2": "p i pp p i pp iii f s",
     "smsut_in_finalize_bwd": "p i pp iii s",
@@ -109,6 +110,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_dgrad_mfma_bwdstats_f16_hs": "pppppppppp f iiiii s",
     "smsut_conv2d_f16_hs_supported": "iiiiii",
     "smsut_conv2d_fwd_mfma_stats_f16_hs": "ppppp iiiii s",
+    "smsut_conv2d_fwd_mfma_stats_f16_hsx": "pppp iiiii s",
+    "smsut_conv2d_wgrad_f16_xh": "ppppp iiiii s",
     "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": "pppppppp iiiii s",
     "smsut_conv2d_wgrad_f16_supported": "iiiii",
     "smsut_conv2d_wgrad_f16_ws": "iiiii",

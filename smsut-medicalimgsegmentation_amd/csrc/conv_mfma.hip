@@ -357,7 +357,7 @@ struct ScRef { const float* w; float* y; float* stats; };   // SC: the block's 1
 constexpr int SPIXW = 20;
 
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false, bool O16 = false>
+          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false, bool O16 = false, bool I16 = false>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WINO ? 2 : 1, WINO ? 2 : 8)))
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
@@ -405,6 +405,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // from the fp32 accumulators, before the rounding.  Forward statistics forms with fp16 operands.
   // With BST (the data-gradient that masks by the block's first InstanceNorm): bst.y1 is such an fp16 tensor; the result stays fp32.
   static_assert(!O16 || (F16 && !ACC && !INAFF && (STATS != BST)), "fp16 storage: forward statistics forms / BST data-gradient, fp16 operands");
+  // I16: the INPUT x is such an fp16 tensor (conv2 of a BasicBlock reading the activated a1 another kernel stored as fp16): the
+  // staging copies 8-byte units instead of converting 16-byte ones -- the operand bits are those the fp32-input form rounds to.
+  static_assert(!I16 || (F16 && STATS && !BST && !DUAL && !INAFF && !SC), "fp16 input: plain forward statistics form, fp16 operands");
   constexpr int SPX = WINO ? SPIXW : SPIX;            // pixel stride of the staged fp32 input tile
   constexpr int NPOS = WINO ? 16 : KS * KS;           // weight blocks held in LDS (Winograd positions | taps)
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
@@ -526,7 +529,8 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // ---- per-thread staging descriptors (tile-independent): element offset relative to the tile's first halo pixel,
   //      LDS destination, and which image borders the unit falls outside of (bit 0 top, 1 bottom, 2 left, 3 right)
   int u_off[NI], u_lds[NI], u_flag[NI];
-  float4 rin[NI];
+  float4 rin[I16 ? 1 : NI];
+  [[maybe_unused]] h4 rinh[I16 ? NI : 1];
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int u = tid + i * TPB;
@@ -555,10 +559,19 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     const int cl = DUAL ? c % (NCH / 2 > 0 ? NCH / 2 : 1) : c;                          // chunk inside its source tensor
     const int base = (((pn * H + pty * TH - PAD) * W) + ptx * TW - PAD) * KST + cl * 16;   // may be "negative": only
     const float* xb = ((DUAL && c >= NCH / 2) ? x2 : x) + base;                          // used with in-image offsets
+    if constexpr (I16) {
+      const _Float16* xh = reinterpret_cast<const _Float16*>(x) + base;
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-      zero[i] = (u_flag[i] & pflags) != 0;
-      rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : u_off[i]));
+      for (int i = 0; i < NI; ++i) {
+        zero[i] = (u_flag[i] & pflags) != 0;
+        rinh[i] = *(const h4*)(xh + (zero[i] ? safe_off : u_off[i]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        zero[i] = (u_flag[i] & pflags) != 0;
+        rin[i] = *(const float4*)(xb + (zero[i] ? safe_off : u_off[i]));
+      }
     }
     if (INAFF) {                                     // every unit of a thread carries the channel quad tid & 3
       const int ch = c * 16 + 4 * (tid & 3);
@@ -572,9 +585,14 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
     if (++tx_ == tiles_x) { tx_ = 0; if (++ty_ == tiles_y) { ty_ = 0; ++n_; } }
   };
   auto publish = [&]() {
+    if constexpr (I16) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i) *(h4*)(in_h + u_lds[i]) = zero[i] ? (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f} : rinh[i];
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-      float4 v = rin[i];
+      float4 v = rin[I16 ? 0 : i];
       if (INAFF) {
         v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
         v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
@@ -1443,13 +1461,15 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
 // SC (r04, config 5): the weight gradient of the block's 1x1 shortcut in the same pass (network/blocks.py:66-80; the fp32 twin is
 // conv_mfma_wgrad_ts<.., SC>): a TENTH tap row -- x at the centre-tap offset against the shortcut's gradient gs, staged beside gy
 // with the same scale gsc (smsut_absmax_scale2) -- so the slab is [10][Cin][Cout], row 9 = the 1x1 weights' gradient.
-template <int CIT, int COT, bool DUAL, bool SC = false>
+// XH (r04): x is an fp16 tensor (the activated a1 of a BasicBlock in half storage) -- copied into the staging planes as it is.
+template <int CIT, int COT, bool DUAL, bool SC = false, bool XH = false>
 __global__ void __launch_bounds__(TPB)
 conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H, int W,
                int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, const float* __restrict__ x2, int ca,
                const float* __restrict__ gsc, const float* __restrict__ gsh = nullptr) {
   constexpr int KS = 3, KK = 9, PAD = 1;
   constexpr int KR = SC ? 10 : 9;                          // tap rows of the slab
+  static_assert(!XH || (!DUAL && !SC), "fp16 x: conv2's weight gradient (plain form)");
   constexpr bool TS = (CIT == 2 && COT == 2);
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int NPX = IH * IW, NPG = WTH * TW;              // pixels of the haloed x tile / of the gy tile
@@ -1481,7 +1501,8 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
   constexpr int UIN = NPX * (CI_T / 4), NIN = (UIN + TPB - 1) / TPB;
   constexpr int UGY = NPG * (CO_T / 4), NGY = UGY / TPB;
   static_assert(UGY % TPB == 0, "gy tile units divide evenly");
-  f32x4 rin[NIN], rgy[NGY];
+  f32x4 rin[XH ? 1 : NIN], rgy[NGY];
+  [[maybe_unused]] h4 rinh[XH ? NIN : 1];
   [[maybe_unused]] f32x4 rgs[SC ? NGY : 1];
   int in_off[NIN], in_lds[NIN], in_flag[NIN], gy_off[NGY], gy_lds[NGY];
   const CatSrc xsrc = DUAL ? cat_src(x, x2, Cin, ca, ci0 + 4 * (tid % (CI_T / 4))) : CatSrc{x, Cin, 0};
@@ -1511,10 +1532,19 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
     const int flags = (pty == 0 ? 1 : 0) | (pty == tiles_y - 1 ? 2 : 0) | (ptx == 0 ? 4 : 0) | (ptx == tiles_x - 1 ? 8 : 0);
     const float* xb = xsrc.p + (((pn * H + pty * WTH - PAD) * W) + ptx * TW - PAD) * xsrc.stride + ci0 - xsrc.coff;
     const float* gb = gy + (((pn * H + pty * WTH) * W) + ptx * TW) * Cout + co0;
+    if constexpr (XH) {
+      const _Float16* xh = reinterpret_cast<const _Float16*>(xsrc.p) + (xb - xsrc.p);
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) {
-      zero[i] = (in_flag[i] & flags) != 0;
-      rin[i] = *(const f32x4*)(xb + (zero[i] ? safe_off : in_off[i]));
+      for (int i = 0; i < NIN; ++i) {
+        zero[i] = (in_flag[i] & flags) != 0;
+        rinh[i] = *(const h4*)(xh + (zero[i] ? safe_off : in_off[i]));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) {
+        zero[i] = (in_flag[i] & flags) != 0;
+        rin[i] = *(const f32x4*)(xb + (zero[i] ? safe_off : in_off[i]));
+      }
     }
 #pragma unroll
     for (int i = 0; i < NGY; ++i) rgy[i] = *(const f32x4*)(gb + gy_off[i]);
@@ -1534,10 +1564,16 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
   if (t_begin < t_end) prefetch();
   for (int t = t_begin; t < t_end; ++t) {
     __syncthreads();
+    if constexpr (XH) {
 #pragma unroll
-    for (int i = 0; i < NIN; ++i) {
-      const f32x4 v = zero[i] ? (f32x4){0.f, 0.f, 0.f, 0.f} : rin[i];
-      *(h4*)(x_h + in_lds[i]) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+      for (int i = 0; i < NIN; ++i)
+        *(h4*)(x_h + in_lds[i]) = zero[i] ? (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f} : rinh[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIN; ++i) {
+        const f32x4 v = zero[i] ? (f32x4){0.f, 0.f, 0.f, 0.f} : rin[i];
+        *(h4*)(x_h + in_lds[i]) = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+      }
     }
 #pragma unroll
     for (int i = 0; i < NGY; ++i) {
@@ -1785,7 +1821,8 @@ template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false, bo
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
                  float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
-                 bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr, bool o16 = false) {
+                 bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr, int hs = 0) {
+  const bool o16 = (hs & 1) != 0, i16 = (hs & 2) != 0;   // half storage: bit 0 = the result (or the BST y1) is fp16, bit 1 = the input is
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH, WINO>();
   // fused 1x1 shortcut (SC): its weight block and a second statistics scratch
   constexpr size_t sh_sc = sh + (size_t)(16 * NCH * 16 * NTN + 2 * 4 * 16 * NTN * 2 + 8) * sizeof(float);
@@ -1807,6 +1844,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (sc && !sc2 && (KS != 3 || sh_sc > 64 * 1024 || !stats || bst || y2 || aff || transposed || !sc->w || !sc->y || !sc->stats ||
                      (K8 && x2) || (f16 && (K8 || WINO))))
     return -1;                                                                  // fused shortcut: forward statistics forms
+  if (i16 && (!o16 || bst || x2 || sc)) return -1;
   if (o16 && !bst && (!f16 || !stats || aff || y2 || transposed || K8 || N8 || WINO || KS != 3)) return -1;   // fp16 result storage
   if (o16 && bst && (!f16 || !stats || aff || y2 || x2 || sc || (transposed & 2) || K8 || N8 || WINO || KS != 3)) return -1;  // fp16 y1 of the BST form
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
@@ -1915,7 +1953,10 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
           conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
               x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr);
         else return -1;
-      } else
+      } else if (i16)
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, false, false, false, false, true, true><<<grid, TPB, sh, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr);
+      else
         conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
             x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr);
     } else return -1;
@@ -1967,8 +2008,8 @@ inline bool fwd_any_eligible(int N, int H, int W, int Kdim, int Ndim, bool f16) 
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
-                        const ScRef* sc = nullptr, const float* wu = nullptr, bool o16 = false) {
-#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc, o16
+                        const ScRef* sc = nullptr, const float* wu = nullptr, int hs = 0) {
+#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc, hs
   // (the fused shortcut data-gradient at 64 reduction channels stays on the direct resident-weight form: 107 us vs 142 us at
   //  16 x 128^2 (32 + 32) -> 64 -- its second-half chunks are a run-time branch inside the staging parts, r03 notes)
   const bool sc2_64 = sc && (transposed & 1) && Kdim == 64 && fwd_p_eligible(N, H, W, Kdim, Ndim);
@@ -2630,7 +2671,18 @@ int smsut_conv2d_fwd_mfma_stats_f16_hs(const float* x, const float* xb, const fl
                                        int Kdim, int Ndim, void* stream) {
   SMSUT_REQUIRE(x && w && y16 && stats && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, xb != nullptr));
   const int rc = select_fwd_p(x, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb,
-                              nullptr, true, nullptr, nullptr, nullptr, true);
+                              nullptr, true, nullptr, nullptr, nullptr, 1);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+// ... whose INPUT is fp16 as well (conv2 of the block reading the activated a1 that smsut_instnorm_fwd_partials_hs2 stored as fp16):
+// the operands are the bits the fp32-input form rounds a1 to -- same result, 2 bytes per element less to read
+int smsut_conv2d_fwd_mfma_stats_f16_hsx(const void* x16, const float* w, void* y16, float* stats, int N, int H, int W, int Kdim,
+                                        int Ndim, void* stream) {
+  SMSUT_REQUIRE(x16 && w && y16 && stats && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, 0));
+  const int rc = select_fwd_p((const float*)x16, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr,
+                              nullptr, 0, nullptr, nullptr, true, nullptr, nullptr, nullptr, 3);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
@@ -2641,7 +2693,7 @@ int smsut_conv2d_fwd_mfma_stats_sc_f16_hs(const float* x, const float* xb, const
                 smsut_conv2d_fwd_sc_f16_supported(N, H, W, Kdim, Ndim, xb != nullptr));
   const ScRef sc{wsc, (float*)ysc16, stats_sc};
   const int rc = select_fwd_p(x, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb,
-                              nullptr, true, nullptr, &sc, nullptr, true);
+                              nullptr, true, nullptr, &sc, nullptr, 1);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
@@ -2654,7 +2706,7 @@ int smsut_conv2d_dgrad_mfma_bwdstats_f16_hs(const float* gy, const float* w, flo
   SMSUT_REQUIRE(gy && w && gz && stats && y1_16 && mean && rstd && gamma && beta && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, 0));
   const BstRef b{(const float*)y1_16, mean, rstd, gamma, beta, slope};
   const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, (hipStream_t)stream, stats, nullptr, &b, nullptr, 0, nullptr,
-                              nullptr, true, gsc, nullptr, nullptr, true);
+                              nullptr, true, gsc, nullptr, nullptr, 1);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
@@ -3091,7 +3143,8 @@ int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout) {
 // x2 (nullable): x is the virtual cat([x, x2]) with ca channels in x (ca % 16 == 0).  gs != null: the fused-shortcut form (slab of
 // 10 tap rows, see conv_f16_wgrad<.., SC>).
 static void launch_wgrad_f16(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* workspace,
-                             const float* gsc, int N, int H, int W, int Cin, int Cout, const WgradPlan& p, hipStream_t st) {
+                             const float* gsc, int N, int H, int W, int Cin, int Cout, const WgradPlan& p, hipStream_t st,
+                             bool xh = false) {
   constexpr int NPX = (WTH + 2) * (TW + 2), NPG = WTH * TW;
 #define F16_WGRAD(CI, CO, SCF)                                                                                              \
   do {                                                                                                                      \
@@ -3111,8 +3164,23 @@ static void launch_wgrad_f16(const float* x, const float* x2, int ca, const floa
     else if (p.cot == 2) F16_WGRAD(1, 2, SCF);                \
     else F16_WGRAD(1, 1, SCF);                                \
   } while (0)
-  if (gs) F16_WGRAD_FORMS(true);
+#define F16_WGRAD_XH(CI, CO)                                                                                                \
+  do {                                                                                                                      \
+    constexpr size_t stage = (size_t)((CI * NPX + CO * NPG) * 16 + 8) * sizeof(_Float16);                                   \
+    constexpr size_t red = (CI == 2 && CO == 2) ? 0 : (size_t)9 * CI * CO * 64 * 4 * sizeof(float);                         \
+    constexpr size_t sh = stage > red ? stage : red;                                                                        \
+    dim3 grid(p.splits, Cin / (16 * CI), Cout / (16 * CO));                                                                 \
+    conv_f16_wgrad<CI, CO, false, false, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x,       \
+                                                                     p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, nullptr); \
+  } while (0)
+  if (xh) {
+    if (p.cit == 2 && p.cot == 2) F16_WGRAD_XH(2, 2);
+    else if (p.cit == 2) F16_WGRAD_XH(2, 1);
+    else if (p.cot == 2) F16_WGRAD_XH(1, 2);
+    else F16_WGRAD_XH(1, 1);
+  } else if (gs) F16_WGRAD_FORMS(true);
   else F16_WGRAD_FORMS(false);
+#undef F16_WGRAD_XH
 #undef F16_WGRAD_FORMS
 #undef F16_WGRAD
 }
@@ -3123,6 +3191,17 @@ int smsut_conv2d_wgrad_f16(const float* x, const float* x2, int ca, const float*
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
   launch_wgrad_f16(x, x2, ca, gy, nullptr, workspace, gsc, N, H, W, Cin, Cout, p, st);
+  launch_sum_splits(workspace, gw, 9 * Cin * Cout, p.splits, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+// ... with x stored as fp16 [N,H,W,Cin] (half storage: conv2's weight gradient of a BasicBlock reads the activated a1): same bits
+int smsut_conv2d_wgrad_f16_xh(const void* x16, const float* gy, float* gw, float* workspace, const float* gsc, int N, int H, int W,
+                              int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(x16 && gy && gw && workspace && smsut_conv2d_wgrad_f16_supported(N, H, W, Cin, Cout));
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
+  launch_wgrad_f16((const float*)x16, nullptr, 0, gy, nullptr, workspace, gsc, N, H, W, Cin, Cout, p, st, true);
   launch_sum_splits(workspace, gw, 9 * Cin * Cout, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

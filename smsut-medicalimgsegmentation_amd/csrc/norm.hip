@@ -328,7 +328,7 @@ __device__ __forceinline__ void ld_act(const float* base, size_t off, float* v) 
   }
 }
 
-template <int VEC, bool HS = false>
+template <int VEC, bool HS = false, bool YH = false>       // YH: y is stored as fp16 too
 __global__ void __launch_bounds__(TPB)
 in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
@@ -349,7 +349,10 @@ in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const 
         const float r = in_affine(v[j], p.mu[j], p.rs[j], p.gm[j], p.bt[j]);
         v[j] = has_act ? lrelu_f(r, slope) : r;
       }
-      if constexpr (VEC == 4) *(float4*)(y + i * 4) = *(float4*)v; else y[i] = v[0];
+      if constexpr (YH) {
+        static_assert(!YH || VEC == 4, "fp16 output: whole channel quads");
+        *(hs4*)(reinterpret_cast<_Float16*>(y) + i * 4) = (hs4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+      } else if constexpr (VEC == 4) *(float4*)(y + i * 4) = *(float4*)v; else y[i] = v[0];
     });
 }
 
@@ -751,13 +754,15 @@ int smsut_instnorm_fwd(const float* x, const float* gamma, const float* beta, fl
 // epilogue (smsut_conv2d_fwd_mfma_stats): finalise + normalise/activate only.
 static int instnorm_fwd_partials_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                         float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
-                                        float slope, int has_act, void* stream, bool hs) {
+                                        float slope, int has_act, void* stream, int hs) {
   SMSUT_REQUIRE(x && gamma && beta && y && mean && rstd && partials && chunks > 0 && N > 0 && HW > 0 && C > 0);
   hipStream_t st = (hipStream_t)stream;
   in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(partials, chunks, C, HW, eps, mean, rstd, nullptr);
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
-  if (hs)
+  if (hs == 2)
+    in_apply_fwd<4, true, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
+  else if (hs)
     in_apply_fwd<4, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
   else if (C % 4 == 0)
     in_apply_fwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, HW, C, slope, has_act);
@@ -769,7 +774,7 @@ static int instnorm_fwd_partials_launch(const float* x, const float* gamma, cons
 int smsut_instnorm_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                                 float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
                                 float slope, int has_act, void* stream) {
-  return instnorm_fwd_partials_launch(x, gamma, beta, y, mean, rstd, partials, chunks, N, HW, C, eps, slope, has_act, stream, false);
+  return instnorm_fwd_partials_launch(x, gamma, beta, y, mean, rstd, partials, chunks, N, HW, C, eps, slope, has_act, stream, 0);
 }
 // "half storage" (config 5): x is fp16 [N,HW,C] (the raw conv output a conv epilogue stored), y stays fp32; C % 4 == 0
 int smsut_instnorm_fwd_partials_hs(const void* x16, const float* gamma, const float* beta, float* y, float* mean,
@@ -777,7 +782,15 @@ int smsut_instnorm_fwd_partials_hs(const void* x16, const float* gamma, const fl
                                    float slope, int has_act, void* stream) {
   SMSUT_REQUIRE(C % 4 == 0);
   return instnorm_fwd_partials_launch((const float*)x16, gamma, beta, y, mean, rstd, partials, chunks, N, HW, C, eps, slope, has_act,
-                                      stream, true);
+                                      stream, 1);
+}
+// ... and y stored as fp16 too (read by smsut_conv2d_fwd_mfma_stats_f16_hsx / smsut_conv2d_wgrad_f16_xh, which round to fp16 anyway)
+int smsut_instnorm_fwd_partials_hs2(const void* x16, const float* gamma, const float* beta, void* y16, float* mean,
+                                    float* rstd, const float* partials, int chunks, int N, int HW, int C, float eps,
+                                    float slope, int has_act, void* stream) {
+  SMSUT_REQUIRE(C % 4 == 0);
+  return instnorm_fwd_partials_launch((const float*)x16, gamma, beta, (float*)y16, mean, rstd, partials, chunks, N, HW, C, eps, slope,
+                                      has_act, stream, 2);
 }
 
 // beta == null: no activation; otherwise the LeakyReLU mask is recomputed from x (sign of the normalised

@@ -876,10 +876,11 @@ class BasicBlockFn(Function):
             H.call("smsut_in_finalize_fwd", p1, t3, m1, r1, n, hw, co, IN_EPS, st)
             _conv3("smsut_conv2d_fwd_mfma_stats_inaff", w2, 0, y1, w2, y2, p2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
         else:
-            a1 = new_act(n, co, h, w, x)
+            a1 = new_act(n, co, h, w, x, act_dt)
             if hs:
-                H.call("smsut_instnorm_fwd_partials_hs", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
-                H.call("smsut_conv2d_fwd_mfma_stats_f16_hs", a1, None, w2, y2, p2, n, h, w, co, co, st)
+                # (a1 as fp16 changes nothing downstream: conv2 and its weight gradient round their x operand to fp16 anyway)
+                H.call("smsut_instnorm_fwd_partials_hs2", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
+                H.call("smsut_conv2d_fwd_mfma_stats_f16_hsx", a1, w2, y2, p2, n, h, w, co, co, st)
             else:
                 H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
                 _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w2, 0, a1, w2, y2, p2, n, h, w, co, co, 3, st)
@@ -1008,7 +1009,10 @@ class BasicBlockFn(Function):
         gw2 = new_weight(co, co, 3, 3, device=dev)
         f16w2 = f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, co, co))
         f16w1 = f16a and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, ci, co))
-        if f16w2:
+        if hs:
+            H.call("smsut_conv2d_wgrad_f16_xh", a1, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x), sc2,
+                   n, h, w, co, co, st)
+        elif f16w2:
             H.call("smsut_conv2d_wgrad_f16", a1, None, 0, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x),
                    sc2, n, h, w, co, co, st)
         else:

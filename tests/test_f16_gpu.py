@@ -414,6 +414,27 @@ def test_half_storage_readers_equal_the_fp32_readers_on_the_same_values(ops, n, 
         H.call(name, src, gam[0], bet[0], a, mm, rr, part, 1, n, hw, c, 1e-5, 0.01, 1, st)
         outs.append((a, mm, rr))
     assert all(torch.equal(p, q) for p, q in zip(*outs))
+    a1f = outs[0][0]
+    a1h = torch.full((n, h, h, c), float("nan"), device="cuda", dtype=torch.float16)
+    H.call("smsut_instnorm_fwd_partials_hs2", y1h, gam[0], bet[0], a1h, E(n, c), E(n, c), part, 1, n, hw, c, 1e-5, 0.01, 1, st)
+    assert torch.equal(a1h, a1f.half())                     # the activated tensor, rounded at the store
+    if H.call("smsut_conv2d_f16_hs_supported", n, h, h, c, c, 0):
+        # conv2 forward and its weight gradient read that fp16 a1: the operand bits the fp32-input forms round to -> same results
+        w = (R(9 * c * c) / np.sqrt(9 * c))
+        tiles = H.call("smsut_conv2d_mfma_tiles", n, h, h, c, c, 3, 1)
+        ya, yb = (torch.full((n, h, h, c), float("nan"), device="cuda", dtype=torch.float16) for _ in range(2))
+        pa, pb_ = (torch.zeros(n * tiles * c * 2, device="cuda") for _ in range(2))
+        H.call("smsut_conv2d_fwd_mfma_stats_f16_hs", a1f, None, w, ya, pa, n, h, h, c, c, st)
+        H.call("smsut_conv2d_fwd_mfma_stats_f16_hsx", a1h, w, yb, pb_, n, h, h, c, c, st)
+        assert torch.equal(ya, yb) and torch.equal(pa, pb_)
+        gy = R(n, h, h, c, sc=1e-7)
+        sc = torch.empty(2, device="cuda")
+        H.call("smsut_absmax_scale", gy, gy.numel(), sc, torch.empty(1024, device="cuda"), st)
+        wsz = H.call("smsut_conv2d_wgrad_f16_ws", n, h, h, c, c)
+        ga, gb_ = E(9 * c * c), E(9 * c * c)
+        H.call("smsut_conv2d_wgrad_f16", a1f, None, 0, gy, ga, torch.empty(wsz, device="cuda"), sc, n, h, h, c, c, st)
+        H.call("smsut_conv2d_wgrad_f16_xh", a1h, gy, gb_, torch.empty(wsz, device="cuda"), sc, n, h, h, c, c, st)
+        assert torch.equal(ga, gb_)
     # residual tail forward
     outs = []
     for name, a, b in (("smsut_restail_fwd", y2f, sf), ("smsut_restail_fwd_hs", y2h, sh_)):
