@@ -199,7 +199,8 @@ int smsut_conv2d_fwd_mfma_split_f16(const float* x, const float* w, float* ya, f
                                     int split, int N, int H, int W, int Kdim, int Ndim, int transposed, void* stream);
 /* fp16 STORAGE of a BasicBlock's internal raw conv outputs y1, y2, s (config 5, "_hs" = half storage): the conv epilogues store
  * fp16 [N,H,W,Ndim] (InstanceNorm partials still from the fp32 accumulators), the consumers below and in the InstanceNorm section
- * read fp16 and compute in fp32.  Persistent-kernel shapes, Kdim in {16, 32, 64}; xb nullable (virtual cat). */
+ * read fp16 and compute in fp32.  Persistent-kernel shapes, Kdim in {16, 32, 64}; xb nullable (virtual cat).  Kdim == 8 (first
+ * block after the stem): the fused-shortcut entry only, on fp32 operands (the 8-channel form has no fp16 twin), same storage. */
 int smsut_conv2d_f16_hs_supported(int N, int H, int W, int Kdim, int Ndim, int cat);
 int smsut_conv2d_fwd_mfma_stats_f16_hs(const float* x, const float* xb /*nullable*/, const float* w, void* y16, float* stats, int N,
                                        int H, int W, int Kdim, int Ndim, void* stream);

@@ -404,7 +404,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // [N,H,W,Ndim]): the block-internal raw conv outputs of a BasicBlock cross HBM at half the bytes.  InstanceNorm partials come
   // from the fp32 accumulators, before the rounding.  Forward statistics forms with fp16 operands.
   // With BST (the data-gradient that masks by the block's first InstanceNorm): bst.y1 is such an fp16 tensor; the result stays fp32.
-  static_assert(!O16 || (F16 && !ACC && !INAFF && (STATS != BST)), "fp16 storage: forward statistics forms / BST data-gradient, fp16 operands");
+  // (K8 + SC: the first block after the stem, 8 -> 16 -- fp32 operands, its two results stored as fp16 like the other blocks'.)
+  static_assert(!O16 || ((F16 || (K8 && SC)) && !ACC && !INAFF && (STATS != BST)),
+                "fp16 storage: forward statistics forms / BST data-gradient, fp16 operands (or the 8-channel fused-shortcut form)");
   // I16: the INPUT x is such an fp16 tensor (conv2 of a BasicBlock reading the activated a1 another kernel stored as fp16): the
   // staging copies 8-byte units instead of converting 16-byte ones -- the operand bits are those the fp32-input form rounds to.
   static_assert(!I16 || (F16 && STATS && !BST && !DUAL && !INAFF && !SC), "fp16 input: plain forward statistics form, fp16 operands");
@@ -1845,7 +1847,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
                      (K8 && x2) || (f16 && (K8 || WINO))))
     return -1;                                                                  // fused shortcut: forward statistics forms
   if (i16 && (!o16 || bst || x2 || sc)) return -1;
-  if (o16 && !bst && (!f16 || !stats || aff || y2 || transposed || K8 || N8 || WINO || KS != 3)) return -1;   // fp16 result storage
+  if (o16 && !bst && (!(f16 || (K8 && sc)) || !stats || aff || y2 || transposed || (K8 && !sc) || N8 || WINO || KS != 3)) return -1;   // fp16 result storage
   if (o16 && bst && (!f16 || !stats || aff || y2 || x2 || sc || (transposed & 2) || K8 || N8 || WINO || KS != 3)) return -1;  // fp16 y1 of the BST form
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = N8 ? 1 : Ndim / (16 * NTN);
@@ -1918,8 +1920,12 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     } else return -1;
   } else if (sc) {
     if constexpr (K8 && KS == 3 && sh_sc <= 64 * 1024) {
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true><<<grid, TPB, sh_sc, st>>>(
-          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+      if (o16)
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+      else
+        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true><<<grid, TPB, sh_sc, st>>>(
+            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
     } else if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (f16) {                                   // fp16 operands (config 5; r04): direct form, plain or virtual-cat input
         if constexpr (!WINO) {
@@ -2662,14 +2668,17 @@ int smsut_conv2d_dgrad_mfma_sc(const float* gy, const float* gs, const float* w,
 // fp16 RESULT STORAGE (config 5, r04): the same passes, the raw conv outputs y (and ysc) stored as fp16 [N,H,W,Ndim] -- block-internal
 // tensors of a BasicBlock (its consumers: smsut_restail_*_hs).  Persistent-kernel shapes, Kdim in {16, 32, 64}; xb nullable
 // (virtual cat); InstanceNorm partials as in the fp32-storage forms (tiles with f16 = 1).  SMSUT_F16_STORE=0 switches it off.
+// Kdim == 8 (the first block after the stem): the fused-shortcut form only, fp32 operands (no fp16 twin), same fp16 storage.
 int smsut_conv2d_f16_hs_supported(int N, int H, int W, int Kdim, int Ndim, int cat) {
   static const bool on = [] { const char* e = getenv("SMSUT_F16_STORE"); return !e || atoi(e) != 0; }();
-  if (!on || N <= 0 || H <= 0 || W <= 0 || !(Kdim == 16 || Kdim == 32 || Kdim == 64) || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  if (!on || N <= 0 || H <= 0 || W <= 0 || !fwd_p_eligible(N, H, W, Kdim, Ndim)) return 0;
+  if (Kdim == 8) return !cat && smsut_conv2d_fwd_sc_supported(N, H, W, Kdim, Ndim, 0);
+  if (!(Kdim == 16 || Kdim == 32 || Kdim == 64)) return 0;
   return !(cat && Kdim % 32 != 0);
 }
 int smsut_conv2d_fwd_mfma_stats_f16_hs(const float* x, const float* xb, const float* w, void* y16, float* stats, int N, int H, int W,
                                        int Kdim, int Ndim, void* stream) {
-  SMSUT_REQUIRE(x && w && y16 && stats && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, xb != nullptr));
+  SMSUT_REQUIRE(x && w && y16 && stats && Kdim != 8 && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, xb != nullptr));
   const int rc = select_fwd_p(x, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb,
                               nullptr, true, nullptr, nullptr, nullptr, 1);
   SMSUT_REQUIRE(rc == 0);
@@ -2690,10 +2699,10 @@ int smsut_conv2d_fwd_mfma_stats_f16_hsx(const void* x16, const float* w, void* y
 int smsut_conv2d_fwd_mfma_stats_sc_f16_hs(const float* x, const float* xb, const float* w, const float* wsc, void* y16, void* ysc16,
                                           float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
   SMSUT_REQUIRE(x && w && wsc && y16 && ysc16 && stats && stats_sc && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, xb != nullptr) &&
-                smsut_conv2d_fwd_sc_f16_supported(N, H, W, Kdim, Ndim, xb != nullptr));
+                (Kdim == 8 || smsut_conv2d_fwd_sc_f16_supported(N, H, W, Kdim, Ndim, xb != nullptr)));
   const ScRef sc{wsc, (float*)ysc16, stats_sc};
   const int rc = select_fwd_p(x, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb,
-                              nullptr, true, nullptr, &sc, nullptr, 1);
+                              nullptr, Kdim != 8, nullptr, &sc, nullptr, 1);
   SMSUT_REQUIRE(rc == 0);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

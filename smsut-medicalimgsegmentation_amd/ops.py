@@ -844,7 +844,8 @@ class BasicBlockFn(Function):
                                           n, h, w, ci, co, 1 if virtual else 0))
         # fp16 operands: the block-internal raw conv outputs y1, y2, s never leave the block -- stored as fp16 (half the HBM bytes
         # of every pass over them: conv epilogues, IN apply, both tail passes, the BST mask read), arithmetic on them in fp32
-        hs = (F16_STORE and f16a and f16 and fused_sc and FUSED_BWD_STATS and REMASK_TAIL
+        # (the 8 -> 16 first block: conv1 stays on fp32 operands -- the 8-channel form has no fp16 twin -- and stores fp16 all the same)
+        hs = (F16_STORE and (f16a or ci == 8) and f16 and fused_sc and FUSED_BWD_STATS and REMASK_TAIL
               and bool(H.call("smsut_conv2d_f16_hs_supported", n, h, w, ci, co, 1 if virtual else 0))
               and bool(H.call("smsut_conv2d_f16_hs_supported", n, h, w, co, co, 0)))
         ctx.hs = hs
