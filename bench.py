@@ -138,7 +138,8 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
     cat([up, skip]) [B,16+16,256,256] -> 16 ch, conv1 + the block's 1x1 shortcut): the persistent resident-weight kernel with the
     InstanceNorm-statistics epilogue, the virtual-cat input and -- fp32 -- the FUSED SHORTCUT (``smsut_conv2d_fwd_mfma_stats_sc``,
     ops.py BasicBlockFn.forward; r03's line timed the ``_stats_cat`` form, which the fp32 step has not launched since the shortcut
-    fusion); fp16 operands (config 5) keep ``_stats_cat_f16``, which that mode does launch.  Since r03 the fp32 form is Winograd
+    fusion); fp16 operands (config 5): ``smsut_conv2d_fwd_mfma_stats_sc_f16_hs`` -- fused shortcut, both results stored as fp16 -- the
+    form that mode launches since r04 (r03 timed ``_stats_cat_f16``).  Since r03 the fp32 form is Winograd
     F(2x2,3x3) (16 products per 2x2 output tile instead of 36; the fused 1x1 runs on the raw pixels).  ``achieved`` is ALGORITHMIC FLOPs
     (2 N H W Cin Cout (9 + 1)) / launch time; ``executed_mfma_*`` is what the matrix pipes did.  Returns the roofline dict."""
     from smsut_amd import ops, _hip as H
@@ -155,28 +156,41 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
     st = torch.cuda.current_stream()
 
     sc = not f16 and bool(H.call("smsut_conv2d_fwd_sc_supported", batch, h, h, cin, cout, 1))
-    if sc:
+    hs = f16 and bool(H.call("smsut_conv2d_f16_hs_supported", batch, h, h, cin, cout, 1)) and bool(
+        H.call("smsut_conv2d_fwd_sc_f16_supported", batch, h, h, cin, cout, 1))
+    if sc or hs:
         wsc = ops.new_weight(cout, cin, 1, 1, device=dev)
         wsc.copy_(torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5)
-        s_out = ops.new_act(batch, cout, h, h, xa)
+        s_out = ops.new_act(batch, cout, h, h, xa, torch.float16 if hs else torch.float32)
         part_s = torch.empty_like(part)
+    if hs:
+        y = ops.new_act(batch, cout, h, h, xa, torch.float16)
 
     def launch():
-        if sc:
+        if hs:
+            H.call("smsut_conv2d_fwd_mfma_stats_sc_f16_hs", xa, xb, w, wsc, y, s_out, part, part_s, batch, h, h, cin, cout, st.cuda_stream)
+        elif sc:
             H.call("smsut_conv2d_fwd_mfma_stats_sc", xa, xb, w, wsc, y, s_out, part, part_s, batch, h, h, cin, cout, st.cuda_stream)
         else:
             H.call("smsut_conv2d_fwd_mfma_stats_cat_f16" if f16 else "smsut_conv2d_fwd_mfma_stats_cat", xa, xb, w, y, part, batch, h, h,
                    cin, cout, st.cuda_stream)
     ms = _events(st, launch)
-    fl = conv_flops(batch, h, h, cin, cout, 3) * (10.0 / 9.0 if sc else 1.0)
+    fl = conv_flops(batch, h, h, cin, cout, 3) * (10.0 / 9.0 if (sc or hs) else 1.0)
     achieved = fl / (ms * 1e-3) / 1e12
     byts = 4.0 * batch * h * h * (cin + cout * (2 if sc else 1))
+    if hs:                                             # fp32 input (the block input), two fp16 results
+        byts = float(batch) * h * h * (4 * cin + 2 * 2 * cout)
     if f16:
         # fp16 operands: 36 FLOP/B against a ridge of 2500 / 8 ~ 310 FLOP/B -> the kernel is HBM-bound
         gbs = byts / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel": "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,F16> via smsut_conv2d_fwd_mfma_stats_cat_f16",
-                "kernel_kind": "mfma f16 operands", "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3, IN-statistics epilogue, virtual cat",
+                "traffic": None,
+                "kernel": ("conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,F16,SC,O16> via smsut_conv2d_fwd_mfma_stats_sc_f16_hs" if hs else
+                           "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,F16> via smsut_conv2d_fwd_mfma_stats_cat_f16"),
+                "entry_point": "smsut_conv2d_fwd_mfma_stats_sc_f16_hs" if hs else "smsut_conv2d_fwd_mfma_stats_cat_f16",
+                "kernel_kind": "mfma f16 operands",
+                "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3" + (" + 1x1 shortcut, both results stored as fp16" if hs else "") +
+                         ", IN-statistics epilogue(s), virtual cat",
                 "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
                 "algorithmic_gbytes_per_launch": round(byts / 1e9, 4), "tflops": round(achieved, 2),
                 "frac_of_fp16_mfma_peak": round(achieved / FP16_MFMA_PEAK_TFLOPS, 4),
@@ -268,8 +282,9 @@ def time_unet_step(dev, rank, B=32, warmup=10, steps=30):
 
 def time_config5(dev, rank, B=16, warmup=10, steps=30, size=512):
     """BASELINE config 5 on one GPU, in the same run (a driver-visible number): the uganConsis iteration at
-    512x512 with the fp16-operand MFMA conv path (fp32 tensors in HBM, fp32 accumulators / InstanceNorm statistics / losses /
-    optimizers), 8 + 8 slices, consistency branch on -- with its own roofline entry: at fp16 operands the
+    512x512 with the fp16-operand MFMA conv path (block-internal raw conv outputs y1 / y2 / s and the activated a1 stored as fp16
+    since r04, every other tensor fp32; fp32 accumulators / InstanceNorm statistics / losses / optimizers),
+    8 + 8 slices, consistency branch on -- with its own roofline entry: at fp16 operands the
     3x3 convs are HBM-bound (36 FLOP/B against a ridge of ~310), so the bound is HBM GB/s."""
     import types as _t
     from smsut_amd import config as cfg, ops
@@ -299,8 +314,9 @@ def time_config5(dev, rank, B=16, warmup=10, steps=30, size=512):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         scal = [round(float(v), 5) for v in last.tolist()]
-        out = {"config": f"uganConsisTrainer iteration, {B // 2} + {B // 2} slices 1x{size}x{size}, fp16-operand MFMA conv path, fp32 "
-                         f"accumulators / IN / losses (BASELINE config 5, one GPU)", "dtype": "f16 conv operands, f32 accumulate / IN / losses",
+        out = {"config": f"uganConsisTrainer iteration, {B // 2} + {B // 2} slices 1x{size}x{size}, fp16-operand MFMA conv path, fp16 storage of the block-internal "
+                         f"tensors, fp32 accumulators / IN / losses (BASELINE config 5, one GPU)",
+               "dtype": "f16 conv operands + block-internal storage, f32 accumulate / IN / losses",
                "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 3), "slices_per_s": round(B / dt, 1),
                "last_step_scalars": scal, "finite": all(v == v and abs(v) != float("inf") for v in scal),
                "graph": tr.graph_report(), "roofline": measure_dominant_conv(dev, B, size, True)}
@@ -582,7 +598,7 @@ def main():
     value = B * world * args.steps / dt
     out = {"metric": metric, "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "f16 conv operands, f32 accumulate / IN / losses",
+           "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "f16 conv operands + block-internal storage, f32 accumulate / IN / losses",
            "data": "synthetic",
            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
                       "parallelism": f"dp{world}", "weights": "random init (reference initialisers)"},

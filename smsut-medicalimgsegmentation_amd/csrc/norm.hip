@@ -374,8 +374,8 @@ __device__ __forceinline__ void amax_emit(float m, float* slots) {
   __syncthreads();
 }
 
-template <int VEC, bool HS = false>
-__global__ void __launch_bounds__(TPB)
+template <int VEC, bool HS = false, bool AMAX = false>      // AMAX: hand max|gx| over (amax non-null); compile-time, so that the
+__global__ void __launch_bounds__(TPB)                       // fp32 path's instantiation carries nothing of it
 in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
              const float* __restrict__ am, const float* __restrict__ bm, float* __restrict__ gx,
@@ -410,11 +410,11 @@ in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const fl
         const float gz = beta ? g[j] * lrelu_mask(in_affine(xv[j], p.mu[j], r, gm, p.bt[j]), slope) : g[j];
         const float xh = (xv[j] - p.mu[j]) * r;
         g[j] = gm * r * (gz - p.av[j] - xh * p.bv[j]);
-        mx = fmaxf(mx, fabsf(g[j]));
+        if constexpr (AMAX) mx = fmaxf(mx, fabsf(g[j]));
       }
       if constexpr (VEC == 4) *(float4*)(gx + i * 4) = *(float4*)g; else gx[i] = g[0];
     });
-  if (amax) amax_emit(mx, amax);
+  if constexpr (AMAX) amax_emit(mx, amax);
 }
 
 template <int VEC>
@@ -638,7 +638,7 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
   }
 }
 
-template <int VEC, bool REMASK, bool HS = false>
+template <int VEC, bool REMASK, bool HS = false, bool AMAX = false>
 __global__ void __launch_bounds__(TPB)
 restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
                   const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
@@ -683,12 +683,12 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
         const float a = p.av[j];
         o1[j] = p.g2[j] * p.r2[j] * (gz - a - ((y[j] - p.m2[j]) * p.r2[j]) * p.b2v[j]);
         o2[j] = t.ms ? p.gsv[j] * p.rsv[j] * (gz - a - ((sv[j] - p.msv[j]) * p.rsv[j]) * p.bsv[j]) : gz;
-        mx1 = fmaxf(mx1, fabsf(o1[j])); mx2 = fmaxf(mx2, fabsf(o2[j]));
+        if constexpr (AMAX) { mx1 = fmaxf(mx1, fabsf(o1[j])); mx2 = fmaxf(mx2, fabsf(o2[j])); }
       }
       if constexpr (VEC == 4) { *(float4*)(gy2 + i * 4) = *(float4*)o1; *(float4*)(gs + i * 4) = *(float4*)o2; }
       else { gy2[i] = o1[0]; gs[i] = o2[0]; }
     });
-  if (amax) { amax_emit(mx1, amax); amax_emit(mx2, amax + gridDim.x * gridDim.y); }
+  if constexpr (AMAX) { amax_emit(mx1, amax); amax_emit(mx2, amax + gridDim.x * gridDim.y); }
 }
 
 inline bool fin_emit_on() {                         // SMSUT_IN_ONE_CHUNK=0: always launch in_moments_final (A/B switch)
@@ -893,15 +893,13 @@ static int in_apply_bwd_launch(const float* gz, const float* x, const float* mea
   float* gg = (ggamma && gbeta) ? ggamma : nullptr;
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
-  if (hs)
-    in_apply_bwd<4, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C,
-                                                                      0.f, N, gg, gbeta, amax);
-  else if (C % 4 == 0)
-    in_apply_bwd<4><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, 0.f,
-                                                        N, gg, gbeta, amax);
-  else
-    in_apply_bwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, 0.f,
-                                                    N, gg, gbeta, amax);
+#define IN_APPLY_BWD(V, HSF, AM)                                                                                           \
+  in_apply_bwd<V, HSF, AM><<<img_grid((int64_t)HW * (C / V), N), TPB, 0, st>>>(gz, x, nullptr, mean, rstd, gamma, a_mean, b_mean, gx, \
+                                                                               HW, C, 0.f, N, gg, gbeta, amax)
+  if (hs) { if (amax) IN_APPLY_BWD(4, true, true); else IN_APPLY_BWD(4, true, false); }
+  else if (C % 4 == 0) { if (amax) IN_APPLY_BWD(4, false, true); else IN_APPLY_BWD(4, false, false); }
+  else { if (amax) IN_APPLY_BWD(1, false, true); else IN_APPLY_BWD(1, false, false); }
+#undef IN_APPLY_BWD
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
@@ -989,14 +987,15 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
   // the affine gradients (and the copy gbs = gb2) are written by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
-#define TAIL_APPLY(V, R)                                                                                                \
-  restail_bwd_apply<V, R><<<img_grid((int64_t)HW * (C / V), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, HW, C, \
-                                                              slope, N, gg2, gb2, ms ? ggs : nullptr, ms ? gbs : nullptr, amax)
-  if (hs)
-    restail_bwd_apply<4, true, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, HW, C,
-                                                                                 slope, N, gg2, gb2, ggs, gbs, amax);
-  else if (C % 4 == 0) { if (remask) TAIL_APPLY(4, true); else TAIL_APPLY(4, false); }
-  else { if (remask) TAIL_APPLY(1, true); else TAIL_APPLY(1, false); }
+#define TAIL_APPLY(V, R, HSF, AM)                                                                                       \
+  restail_bwd_apply<V, R, HSF, AM><<<img_grid((int64_t)HW * (C / V), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, gs, \
+                                                                               HW, C, slope, N, gg2, gb2, ms ? ggs : nullptr,  \
+                                                                               ms ? gbs : nullptr, amax)
+#define TAIL_APPLY_AM(V, R, HSF) do { if (amax) TAIL_APPLY(V, R, HSF, true); else TAIL_APPLY(V, R, HSF, false); } while (0)
+  if (hs) TAIL_APPLY_AM(4, true, true);
+  else if (C % 4 == 0) { if (remask) TAIL_APPLY_AM(4, true, false); else TAIL_APPLY_AM(4, false, false); }
+  else { if (remask) TAIL_APPLY_AM(1, true, false); else TAIL_APPLY_AM(1, false, false); }
+#undef TAIL_APPLY_AM
 #undef TAIL_APPLY
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
