@@ -207,6 +207,10 @@ int smsut_conv2d_fwd_mfma_stats_f16_hs(const float* x, const float* xb /*nullabl
 /* ... whose input is fp16 too (conv2 of the block reading the a1 that smsut_instnorm_fwd_partials_hs2 stored): same operand bits */
 int smsut_conv2d_fwd_mfma_stats_f16_hsx(const void* x16, const float* w, void* y16, float* stats, int N, int H, int W, int Kdim,
                                         int Ndim, void* stream);
+/* ... reading the RAW fp16 conv1 output and applying lrelu(IN(.)) while staging (half-storage twin of ..._stats_inaff) */
+int smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx(const void* y1_16, const float* w, void* y16, float* stats, const float* mean,
+                                              const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
+                                              int W, int Kdim, int Ndim, void* stream);
 int smsut_conv2d_fwd_mfma_stats_sc_f16_hs(const float* x, const float* xb /*nullable*/, const float* w, const float* wsc, void* y16,
                                           void* ysc16, float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim,
                                           void* stream);
@@ -233,6 +237,10 @@ int smsut_conv2d_wgrad_f16(const float* x, const float* x2 /*nullable*/, int ca,
 /* ... with x stored as fp16 (half storage: conv2's weight gradient reads the activated a1): same operand bits, same result */
 int smsut_conv2d_wgrad_f16_xh(const void* x16, const float* gy, float* gw, float* workspace, const float* gsc /*nullable*/, int N,
                               int H, int W, int Cin, int Cout, void* stream);
+/* ... with x the RAW fp16 conv1 output, lrelu(IN(.)) applied while staging (half-storage twin of smsut_conv2d_wgrad_mfma_inaff) */
+int smsut_conv2d_wgrad_f16_xh_inaff(const void* y1_16, const float* gy, float* gw, float* workspace, const float* gsc /*nullable*/,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, int N,
+                                    int H, int W, int Cin, int Cout, void* stream);
 /* ... plus the 1x1 shortcut's weight gradient in the same pass (fp16 twin of smsut_conv2d_wgrad_mfma_sc): gw10 [10][Cin][Cout],
  * rows 0..8 the 3x3 taps, row 9 the shortcut; gsc from smsut_absmax_scale2(gy, gs) */
 int smsut_conv2d_wgrad_sc_f16_supported(int N, int H, int W, int Cin, int Cout);

@@ -405,11 +405,13 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   // from the fp32 accumulators, before the rounding.  Forward statistics forms with fp16 operands.
   // With BST (the data-gradient that masks by the block's first InstanceNorm): bst.y1 is such an fp16 tensor; the result stays fp32.
   // (K8 + SC: the first block after the stem, 8 -> 16 -- fp32 operands, its two results stored as fp16 like the other blocks'.)
-  static_assert(!O16 || ((F16 || (K8 && SC)) && !ACC && !INAFF && (STATS != BST)),
+  static_assert(!O16 || ((F16 || (K8 && SC)) && !ACC && (!INAFF || I16) && (STATS != BST)),
                 "fp16 storage: forward statistics forms / BST data-gradient, fp16 operands (or the 8-channel fused-shortcut form)");
   // I16: the INPUT x is such an fp16 tensor (conv2 of a BasicBlock reading the activated a1 another kernel stored as fp16): the
   // staging copies 8-byte units instead of converting 16-byte ones -- the operand bits are those the fp32-input form rounds to.
-  static_assert(!I16 || (F16 && STATS && !BST && !DUAL && !INAFF && !SC), "fp16 input: plain forward statistics form, fp16 operands");
+  // I16 + INAFF: the fp16 input is the RAW conv1 output y1; it is widened, normalised + activated (fp32, as smsut_instnorm_fwd_partials_hs2
+  // does) and rounded back while staged -- the a1 tensor and the pass that wrote it disappear, the operand bits stay the same.
+  static_assert(!I16 || (F16 && STATS && !BST && !DUAL && !SC), "fp16 input: plain / input-side-IN forward statistics form, fp16 operands");
   constexpr int SPX = WINO ? SPIXW : SPIX;            // pixel stride of the staged fp32 input tile
   constexpr int NPOS = WINO ? 16 : KS * KS;           // weight blocks held in LDS (Winograd positions | taps)
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
@@ -589,7 +591,16 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   auto publish = [&]() {
     if constexpr (I16) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) *(h4*)(in_h + u_lds[i]) = zero[i] ? (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f} : rinh[i];
+      for (int i = 0; i < NI; ++i) {
+        h4 hv = rinh[i];
+        if constexpr (INAFF) {
+          float4 v = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+          v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+          v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
+          hv = to_h4(v);
+        }
+        *(h4*)(in_h + u_lds[i]) = zero[i] ? (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f} : hv;
+      }
       return;
     }
 #pragma unroll
@@ -1464,14 +1475,17 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
 // conv_mfma_wgrad_ts<.., SC>): a TENTH tap row -- x at the centre-tap offset against the shortcut's gradient gs, staged beside gy
 // with the same scale gsc (smsut_absmax_scale2) -- so the slab is [10][Cin][Cout], row 9 = the 1x1 weights' gradient.
 // XH (r04): x is an fp16 tensor (the activated a1 of a BasicBlock in half storage) -- copied into the staging planes as it is.
-template <int CIT, int COT, bool DUAL, bool SC = false, bool XH = false>
+// INAFF (with XH): x is the RAW fp16 conv1 output; lrelu(IN(.)) is applied while staging (as conv_mfma_fwd_p<.., INAFF, .., I16>).
+template <int CIT, int COT, bool DUAL, bool SC = false, bool XH = false, bool INAFF = false>
 __global__ void __launch_bounds__(TPB)
 conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H, int W,
                int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, const float* __restrict__ x2, int ca,
-               const float* __restrict__ gsc, const float* __restrict__ gsh = nullptr) {
+               const float* __restrict__ gsc, const float* __restrict__ gsh = nullptr, AffRef aff = AffRef{}) {
   constexpr int KS = 3, KK = 9, PAD = 1;
   constexpr int KR = SC ? 10 : 9;                          // tap rows of the slab
   static_assert(!XH || (!DUAL && !SC), "fp16 x: conv2's weight gradient (plain form)");
+  static_assert(!INAFF || XH, "input-side IN: the half-storage form");
+  [[maybe_unused]] float4 a_m, a_r, a_g, a_b;              // INAFF: statistics of (image, this thread's channel quad), affine pair
   constexpr bool TS = (CIT == 2 && COT == 2);
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
   constexpr int NPX = IH * IW, NPG = WTH * TW;              // pixels of the haloed x tile / of the gy tile
@@ -1541,6 +1555,13 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
         zero[i] = (in_flag[i] & flags) != 0;
         rinh[i] = *(const h4*)(xh + (zero[i] ? safe_off : in_off[i]));
       }
+      if constexpr (INAFF) {                           // every unit of a thread carries the channel quad tid % (CI_T / 4)
+        const int ch = ci0 + 4 * (tid % (CI_T / 4));
+        a_m = *(const float4*)(aff.mean + (size_t)pn * Cin + ch);
+        a_r = *(const float4*)(aff.rstd + (size_t)pn * Cin + ch);
+        a_g = *(const float4*)(aff.gamma + ch);
+        a_b = *(const float4*)(aff.beta + ch);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < NIN; ++i) {
@@ -1568,8 +1589,16 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
     __syncthreads();
     if constexpr (XH) {
 #pragma unroll
-      for (int i = 0; i < NIN; ++i)
-        *(h4*)(x_h + in_lds[i]) = zero[i] ? (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f} : rinh[i];
+      for (int i = 0; i < NIN; ++i) {
+        h4 hv = rinh[i];
+        if constexpr (INAFF) {
+          float4 v = make_float4((float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]);
+          v.x = aff1(v.x, a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v.y = aff1(v.y, a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
+          v.z = aff1(v.z, a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v.w = aff1(v.w, a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
+          hv = to_h4(v);
+        }
+        *(h4*)(x_h + in_lds[i]) = zero[i] ? (h4){(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f} : hv;
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < NIN; ++i) {
@@ -1847,7 +1876,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
                      (K8 && x2) || (f16 && (K8 || WINO))))
     return -1;                                                                  // fused shortcut: forward statistics forms
   if (i16 && (!o16 || bst || x2 || sc)) return -1;
-  if (o16 && !bst && (!(f16 || (K8 && sc)) || !stats || aff || y2 || transposed || (K8 && !sc) || N8 || WINO || KS != 3)) return -1;   // fp16 result storage
+  if (o16 && !bst && (!(f16 || (K8 && sc)) || !stats || (aff && !i16) || y2 || transposed || (K8 && !sc) || N8 || WINO || KS != 3)) return -1;   // fp16 result storage
   if (o16 && bst && (!f16 || !stats || aff || y2 || x2 || sc || (transposed & 2) || K8 || N8 || WINO || KS != 3)) return -1;  // fp16 y1 of the BST form
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = N8 ? 1 : Ndim / (16 * NTN);
@@ -1950,6 +1979,11 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
             x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
       }
     } else return -1;
+  } else if (aff && i16) {                        // fp16 y1 in, normalised while staged, fp16 y2 out (half-storage conv2)
+    if constexpr (!K8 && !WINO && KS == 3)
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, true, true, false, false, false, false, false, true, true><<<grid, TPB, sh, st>>>(
+          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr);
+    else return -1;
   } else if (aff) {
     P_GO(true, false, false, false, true);
   } else if (o16 && !bst) {                       // fp16 operands, fp16 result storage: plain or virtual-cat forward statistics form
@@ -2696,6 +2730,19 @@ int smsut_conv2d_fwd_mfma_stats_f16_hsx(const void* x16, const float* w, void* y
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
+// ... reading the RAW fp16 conv1 output y1 and applying lrelu(IN(.)) while staging (mean / rstd [N,Kdim], gamma / beta [Kdim]): the
+// half-storage twin of smsut_conv2d_fwd_mfma_stats_inaff -- the activated a1 is never built
+int smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx(const void* y1_16, const float* w, void* y16, float* stats, const float* mean,
+                                              const float* rstd, const float* gamma, const float* beta, float slope, int N, int H,
+                                              int W, int Kdim, int Ndim, void* stream) {
+  SMSUT_REQUIRE(y1_16 && w && y16 && stats && mean && rstd && gamma && beta && Kdim != 8 && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, 0));
+  const AffRef a{mean, rstd, gamma, beta, slope};
+  const int rc = select_fwd_p((const float*)y1_16, w, (float*)y16, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr,
+                              nullptr, 0, nullptr, &a, true, nullptr, nullptr, nullptr, 3);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
 int smsut_conv2d_fwd_mfma_stats_sc_f16_hs(const float* x, const float* xb, const float* w, const float* wsc, void* y16, void* ysc16,
                                           float* stats, float* stats_sc, int N, int H, int W, int Kdim, int Ndim, void* stream) {
   SMSUT_REQUIRE(x && w && wsc && y16 && ysc16 && stats && stats_sc && smsut_conv2d_f16_hs_supported(N, H, W, Kdim, Ndim, xb != nullptr) &&
@@ -3153,7 +3200,7 @@ int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout) {
 // 10 tap rows, see conv_f16_wgrad<.., SC>).
 static void launch_wgrad_f16(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* workspace,
                              const float* gsc, int N, int H, int W, int Cin, int Cout, const WgradPlan& p, hipStream_t st,
-                             bool xh = false) {
+                             bool xh = false, const AffRef* aff = nullptr) {
   constexpr int NPX = (WTH + 2) * (TW + 2), NPG = WTH * TW;
 #define F16_WGRAD(CI, CO, SCF)                                                                                              \
   do {                                                                                                                      \
@@ -3179,8 +3226,13 @@ static void launch_wgrad_f16(const float* x, const float* x2, int ca, const floa
     constexpr size_t red = (CI == 2 && CO == 2) ? 0 : (size_t)9 * CI * CO * 64 * 4 * sizeof(float);                         \
     constexpr size_t sh = stage > red ? stage : red;                                                                        \
     dim3 grid(p.splits, Cin / (16 * CI), Cout / (16 * CO));                                                                 \
-    conv_f16_wgrad<CI, CO, false, false, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x,       \
-                                                                     p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, nullptr); \
+    if (aff)                                                                                                                \
+      conv_f16_wgrad<CI, CO, false, false, true, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, \
+                                                                             p.tiles_y, p.tiles_per_split, nullptr, 0, gsc,  \
+                                                                             nullptr, *aff);                               \
+    else                                                                                                                    \
+      conv_f16_wgrad<CI, CO, false, false, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x,     \
+                                                                       p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, nullptr); \
   } while (0)
   if (xh) {
     if (p.cit == 2 && p.cot == 2) F16_WGRAD_XH(2, 2);
@@ -3211,6 +3263,19 @@ int smsut_conv2d_wgrad_f16_xh(const void* x16, const float* gy, float* gw, float
   hipStream_t st = (hipStream_t)stream;
   const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
   launch_wgrad_f16((const float*)x16, nullptr, 0, gy, nullptr, workspace, gsc, N, H, W, Cin, Cout, p, st, true);
+  launch_sum_splits(workspace, gw, 9 * Cin * Cout, p.splits, st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+// ... with x the RAW fp16 conv1 output, lrelu(IN(.)) applied while staging (half-storage twin of smsut_conv2d_wgrad_mfma_inaff)
+int smsut_conv2d_wgrad_f16_xh_inaff(const void* y1_16, const float* gy, float* gw, float* workspace, const float* gsc,
+                                    const float* mean, const float* rstd, const float* gamma, const float* beta, float slope, int N,
+                                    int H, int W, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(y1_16 && gy && gw && workspace && mean && rstd && gamma && beta && smsut_conv2d_wgrad_f16_supported(N, H, W, Cin, Cout));
+  hipStream_t st = (hipStream_t)stream;
+  const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
+  const AffRef a{mean, rstd, gamma, beta, slope};
+  launch_wgrad_f16((const float*)y1_16, nullptr, 0, gy, nullptr, workspace, gsc, N, H, W, Cin, Cout, p, st, true, &a);
   launch_sum_splits(workspace, gw, 9 * Cin * Cout, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;

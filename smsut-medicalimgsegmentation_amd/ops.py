@@ -779,6 +779,7 @@ SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-aft
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
 REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
+HS_INAFF = bool(int(_os.environ.get("SMSUT_HS_INAFF", "1")))              # half storage: conv2 / its weight gradient normalise y1 while staging
 F16_STORE = bool(int(_os.environ.get("SMSUT_F16_STORE", "1")))           # fp16 operands: block-internal y1 / y2 / s stored as fp16
 AMAX_HANDOVER = bool(int(_os.environ.get("SMSUT_AMAX_HANDOVER", "1")))    # fp16 operands: gradient maxima from the producing kernels
 
@@ -877,12 +878,19 @@ class BasicBlockFn(Function):
             H.call("smsut_in_finalize_fwd", p1, t3, m1, r1, n, hw, co, IN_EPS, st)
             _conv3("smsut_conv2d_fwd_mfma_stats_inaff", w2, 0, y1, w2, y2, p2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
         else:
-            a1 = new_act(n, co, h, w, x, act_dt)
-            if hs:
+            if hs and HS_INAFF:
+                # conv2 (and later its weight gradient) widen the raw fp16 y1, normalise + activate and round it while staging: the
+                # operand bits smsut_instnorm_fwd_partials_hs2 would have stored -- a1 and the pass that writes it disappear
+                a1 = None
+                H.call("smsut_in_finalize_fwd", p1, t3, m1, r1, n, hw, co, IN_EPS, st)
+                H.call("smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx", y1, w2, y2, p2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+            elif hs:
                 # (a1 as fp16 changes nothing downstream: conv2 and its weight gradient round their x operand to fp16 anyway)
+                a1 = new_act(n, co, h, w, x, act_dt)
                 H.call("smsut_instnorm_fwd_partials_hs2", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
                 H.call("smsut_conv2d_fwd_mfma_stats_f16_hsx", a1, w2, y2, p2, n, h, w, co, co, st)
             else:
+                a1 = new_act(n, co, h, w, x)
                 H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
                 _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w2, 0, a1, w2, y2, p2, n, h, w, co, co, 3, st)
         m2, r2 = stat(co)
@@ -1010,7 +1018,10 @@ class BasicBlockFn(Function):
         gw2 = new_weight(co, co, 3, 3, device=dev)
         f16w2 = f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, co, co))
         f16w1 = f16a and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, ci, co))
-        if hs:
+        if hs and a1 is None:
+            H.call("smsut_conv2d_wgrad_f16_xh_inaff", y1, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x), sc2,
+                   m1, r1, g1, b1, slope, n, h, w, co, co, st)
+        elif hs:
             H.call("smsut_conv2d_wgrad_f16_xh", a1, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x), sc2,
                    n, h, w, co, co, st)
         elif f16w2:

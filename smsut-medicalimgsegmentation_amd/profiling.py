@@ -60,6 +60,8 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 10, "mfma"),
     "smsut_conv2d_fwd_mfma_stats_f16_hsx": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_f16_xh": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_wgrad_f16_xh_inaff": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
+    "smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_dgrad_mfma_bwdstats_f16_hs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_sc_f16": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 10, "mfma"),
     "smsut_conv1x1_fwd": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3], "mfma"),
@@ -189,6 +191,8 @@ _BYTES: Dict[str, Callable[[List[int]], float]] = {
     "smsut_instnorm_fwd_partials_hs2": lambda a: a[1] * a[2] * a[3] * (2.0 + 2.0),
     "smsut_conv2d_fwd_mfma_stats_f16_hsx": lambda a: a[0] * a[1] * a[2] * (2.0 * a[3] + 2.0 * a[4]),
     "smsut_conv2d_wgrad_f16_xh": lambda a: a[0] * a[1] * a[2] * (2.0 * a[3] + 4.0 * a[4]),
+    "smsut_conv2d_wgrad_f16_xh_inaff": lambda a: a[0] * a[1] * a[2] * (2.0 * a[3] + 4.0 * a[4]),
+    "smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx": lambda a: a[0] * a[1] * a[2] * (2.0 * a[3] + 2.0 * a[4]),
     "smsut_act_bwd": lambda a: 4.0 * a[0] * 3,
     "smsut_tanh_fwd": lambda a: 4.0 * a[0] * 2,
     "smsut_tanh_bwd": lambda a: 4.0 * a[0] * 3,

@@ -438,6 +438,14 @@ def test_half_storage_readers_equal_the_fp32_readers_on_the_same_values(ops, n, 
         H.call("smsut_conv2d_wgrad_f16", a1f, None, 0, gy, ga, torch.empty(wsz, device="cuda"), sc, n, h, h, c, c, st)
         H.call("smsut_conv2d_wgrad_f16_xh", a1h, gy, gb_, torch.empty(wsz, device="cuda"), sc, n, h, h, c, c, st)
         assert torch.equal(ga, gb_)
+        # ... or read the RAW fp16 y1 and normalise + activate it while staging (a1 never built): the same operand bits again
+        mm, rr = outs[0][1], outs[0][2]
+        yc, pc, gc = torch.full_like(ya, float("nan")), torch.zeros_like(pa), E(9 * c * c)
+        H.call("smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx", y1h, w, yc, pc, mm, rr, gam[0], bet[0], 0.01, n, h, h, c, c, st)
+        assert torch.equal(yc, ya) and torch.equal(pc, pa)
+        H.call("smsut_conv2d_wgrad_f16_xh_inaff", y1h, gy, gc, torch.empty(wsz, device="cuda"), sc, mm, rr, gam[0], bet[0], 0.01,
+               n, h, h, c, c, st)
+        assert torch.equal(gc, ga)
     # residual tail forward
     outs = []
     for name, a, b in (("smsut_restail_fwd", y2f, sf), ("smsut_restail_fwd_hs", y2h, sh_)):
