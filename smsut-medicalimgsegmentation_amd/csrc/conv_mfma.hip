@@ -2075,7 +2075,8 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
   if (use_wino && !f16 && H % 16 == 0 && (Kdim == 16 || Kdim == 32))
     return Kdim == 16 ? launch_fwd_p<3, 16, 1, 1, false, false, true>(PARGS) : launch_fwd_p<3, 16, 1, 2, false, false, true>(PARGS);
   if (Kdim == 16 && H % 16 == 0) return launch_fwd_p<3, 16, 1, 1>(PARGS);
-  // fp16 operands are HBM-bound: 16-row items re-read 1.27x their input as halo instead of 1.41x (tuning hook SMSUT_F16_TH16)
+  // (tuning hook SMSUT_F16_TH16, off: 16-row items re-read 1.27x their input as halo instead of 1.41x, but the halo rows are L2 hits
+  //  under the XCD-aware item map -- config 5 measured 52.77 ms off, 52.80 with 1 (Ndim 16 only), 53.59 with 2 (every Kdim-32 shape))
   static const int f16_th16 = [] { const char* e = getenv("SMSUT_F16_TH16"); return e ? atoi(e) : 0; }();
   if (f16 && f16_th16 && Kdim == 32 && H % 16 == 0 && (f16_th16 > 1 || Ndim % 32 != 0)) return launch_fwd_p<3, 16, 1, 2>(PARGS);
   if (Kdim == 32 && Ndim % 32 == 0 && !(y2 && split % 32 != 0)) return launch_fwd_p<3, 8, 2, 2>(PARGS);   // (32-channel slabs must not straddle a split)
