@@ -112,6 +112,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_fwd_mfma_stats_f16_hs": "ppppp iiiii s",
     "smsut_conv2d_fwd_mfma_stats_f16_hsx": "pppp iiiii s",
     "smsut_conv2d_wgrad_f16_xh": "ppppp iiiii s",
+    "smsut_conv2d_wgrad_f16x3": "pp i ppppp pppp f iiiii s",
     "smsut_conv2d_wgrad_f16_xh_inaff": "ppppp pppp f iiiii s",
     "smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx": "pppp pppp f iiiii s",
     "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": "pppppppp iiiii s",

@@ -1,0 +1,114 @@
+"""Opt-in "split fp16" 3x3 weight gradient (``smsut_conv2d_wgrad_f16x3``, ``SMSUT_WGRAD_X3=1`` / ``ops.WGRAD_X3``): fp32 tensors,
+every operand element staged as hi = fp16(v), lo = fp16((v - hi) 2^11), a product = three fp16 MFMAs with fp32 accumulate.
+The claim it ships under (profiles/r04_split_fp16.md): NOT a reduced-precision path -- its result is at
+least as close to fp64 as the fp32 MFMA kernel's on the same inputs.  The fp32 MFMA kernels stay the default."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import l2_rel
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, g):
+    n, h, _, ci = x.shape
+    co = g.shape[-1]
+    xp = torch.nn.functional.pad(x.double(), (0, 0, 1, 1, 1, 1))
+    out = torch.zeros(3, 3, ci, co, dtype=torch.float64, device=x.device)
+    for a in range(3):
+        for b in range(3):
+            out[a, b] = xp[:, a:a + h, b:b + h, :].reshape(-1, ci).t() @ g.double().reshape(-1, co)
+    return out
+
+
+@pytest.mark.parametrize("n,h,ci,co,form", [(8, 128, 16, 16, "plain"), (8, 64, 32, 32, "inaff"), (4, 64, 64, 32, "cat"), (8, 64, 32, 64, "sc"),
+                                            (4, 128, 32, 16, "cat+sc"), (3, 32, 16, 48, "plain"), (2, 32, 128, 128, "inaff")])
+def test_split_fp16_weight_gradient_is_at_least_as_close_to_fp64_as_the_fp32_kernel(n, h, ci, co, form):
+    import smsut_amd  # noqa: F401
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    assert H.call("smsut_conv2d_wgrad_f16_supported", n, h, h, ci, co) == 1
+    g = torch.Generator(device="cpu").manual_seed(23)
+    R = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).cuda()
+    E = lambda k: torch.full((k,), float("nan"), device="cuda")
+    x, gy, gs = R(n, h, h, ci), R(n, h, h, co, sc=2e-7), R(n, h, h, co, sc=5e-7)
+    sc = torch.empty(2, device="cuda")
+    cat, fsc, inaff = "cat" in form, "sc" in form, form == "inaff"
+    if fsc:
+        H.call("smsut_absmax_scale2", gy, gy.numel(), gs, gs.numel(), sc, torch.empty(1024, device="cuda"), st)
+    else:
+        H.call("smsut_absmax_scale", gy, gy.numel(), sc, torch.empty(1024, device="cuda"), st)
+    xa, xb, ca = (x[..., :ci // 2].contiguous(), x[..., ci // 2:].contiguous(), ci // 2) if cat else (x, None, 0)
+    aff = (None,) * 4
+    xin = x
+    if inaff:                                               # x is a raw conv output, the operand is lrelu(IN(x))
+        mean, rstd = R(n, ci, sc=0.1), (1 + 0.1 * R(n, ci)).abs()
+        gam, bet = 1 + 0.1 * R(ci), 0.1 * R(ci)
+        aff = (mean, rstd, gam, bet)
+        z = (x.double() - mean.double()[:, None, None]) * rstd.double()[:, None, None] * gam.double() + bet.double()
+        xin = torch.where(z > 0, z, 0.01 * z)
+    rows = 10 if fsc else 9
+    got = E(rows * ci * co)
+    wsz = H.call("smsut_conv2d_wgrad_sc_f16_ws" if fsc else "smsut_conv2d_wgrad_f16_ws", n, h, h, ci, co)
+    H.call("smsut_conv2d_wgrad_f16x3", xa, xb, ca, gy, gs if fsc else None, got, torch.empty(wsz, device="cuda"), sc, *aff, 0.01,
+           n, h, h, ci, co, st)
+    ref = _ref(xin, gy)
+    e3 = l2_rel(got[:9 * ci * co].view(3, 3, ci, co).double().cpu().numpy(), ref.cpu().numpy())
+    # the fp32 MFMA kernel of the same form on the same inputs
+    f32 = E(rows * ci * co)
+    if fsc:
+        H.call("smsut_conv2d_wgrad_mfma_sc", xa, xb, ca, gy, gs, f32, torch.empty(H.call("smsut_conv2d_wgrad_sc_ws", n, h, h, ci, co), device="cuda"),
+               n, h, h, ci, co, st)
+    else:
+        ws32 = torch.empty(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, h, ci, co, 3), device="cuda")
+        if inaff:
+            H.call("smsut_conv2d_wgrad_mfma_inaff", x, gy, f32, ws32, *aff, 0.01, n, h, h, ci, co, st)
+        elif cat:
+            H.call("smsut_conv2d_wgrad_mfma_cat", xa, xb, ca, gy, f32, ws32, n, h, h, ci, co, 3, st)
+        else:
+            H.call("smsut_conv2d_wgrad_mfma", x, gy, f32, ws32, n, h, h, ci, co, 3, st)
+    e32 = l2_rel(f32[:9 * ci * co].view(3, 3, ci, co).double().cpu().numpy(), ref.cpu().numpy())
+    assert e3 < 4e-7 and e3 <= 1.1 * e32, (e3, e32)          # (measured 1.7e-7 .. 2.5e-7 against 2.9e-7 .. 4.5e-7)
+    if fsc:
+        r1 = (xin.double().reshape(-1, ci).t() @ gs.double().reshape(-1, co)).cpu().numpy()
+        assert l2_rel(got[9 * ci * co:].view(ci, co).double().cpu().numpy(), r1) < 4e-7
+
+
+def test_opt_in_switch_changes_only_the_weight_gradients(monkeypatch):
+    """``ops.WGRAD_X3``: a fused BasicBlock's forward output, input gradient and affine gradients stay BIT-IDENTICAL (those kernels
+    do not change; the gradient-maximum hand-over only adds outputs), the three weight gradients move by fp32-rounding amounts."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd import ops, profiling
+    n, h, ci, co = 8, 128, 16, 32
+    g = torch.Generator(device="cpu").manual_seed(29)
+    R = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc).cuda()
+    x = R(n, ci, h, h).contiguous(memory_format=torch.channels_last)
+
+    def W(o, i, k):
+        w = ops.new_weight(o, i, k, k, device="cuda")
+        w.copy_(R(o, i, k, k) / np.sqrt(k * k * i))
+        return w
+    ws_ = [W(co, ci, 3), 1 + 0.1 * R(co), 0.1 * R(co), W(co, co, 3), 1 + 0.1 * R(co), 0.1 * R(co), W(co, ci, 1), 1 + 0.1 * R(co), 0.1 * R(co)]
+    gout = R(n, co, h, h, sc=1e-6).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        leaves = [x.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in ws_]
+        res = {}
+        rec = profiling.record_step(lambda: res.update(o=ops.basic_block(*leaves, 0.01)))
+        res["o"].backward(gout)
+        return res["o"].detach(), [t.grad for t in leaves]
+    o0, g0 = run()
+    monkeypatch.setattr(ops, "WGRAD_X3", True)
+    names = []
+    orig = ops.H.call
+    monkeypatch.setattr(ops.H, "call", lambda name, *a: (names.append(name), orig(name, *a))[1])
+    o1, g1 = run()
+    assert names.count("smsut_conv2d_wgrad_f16x3") == 2 and "smsut_conv2d_wgrad_mfma_sc" not in names
+    assert torch.equal(o0, o1)
+    weights = {1, 4, 7}                                      # conv1, conv2, shortcut weights in the leaf order
+    for k, (a, b) in enumerate(zip(g0, g1)):
+        if k in weights:
+            assert not torch.equal(a, b) and l2_rel(b.cpu().numpy(), a.cpu().numpy()) < 2e-6
+        else:
+            assert torch.equal(a, b), k
