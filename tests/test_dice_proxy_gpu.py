@@ -45,3 +45,22 @@ def test_trained_dice_through_the_ugan_consis_trainer_matches_oracle():
         assert r["prediction_agreement"] > 0.97, r
     mean_delta = sum(r["delta_mean_dice_pt"] for r in runs) / len(runs)
     assert abs(mean_delta) <= 0.5, (mean_delta, [r["delta_mean_dice_pt"] for r in runs])
+
+
+def test_trained_dice_with_fp16_operands_and_half_storage_matches_oracle():
+    """BASELINE config 5's arithmetic on the same claim: the HIP ``UnetTrainer`` with fp16 conv operands and fp16 storage of the
+    block-internal tensors (``ops.set_conv_dtype("f16")``; 128x128 slices, batch 16, so that the top levels run the persistent
+    half-storage kernels) against the fp32 CPU oracle, same schedule, same batches: validation Dice within north_star's 0.5 pt."""
+    from smsut_amd import ops, profiling
+    prev = ops.conv_dtype()
+    ops.set_conv_dtype("f16")
+    try:
+        res = dice_proxy.run(steps=300, size=128, batch=16, n_train=16, n_val=4, log=lambda *a: None)
+    finally:
+        ops.set_conv_dtype(prev)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    json.dump(res, open(os.path.join(out, "dice_proxy_f16_test.json"), "w"), indent=1)
+    assert res["dice_mean_oracle"] > 0.90 and res["dice_mean_hip"] > 0.90, res
+    assert abs(res["delta_mean_dice_pt"]) <= 0.5, res
+    assert res["prediction_agreement"] > 0.98, res
