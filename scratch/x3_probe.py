@@ -29,8 +29,8 @@ for (n, h, ci, co) in [(16, 256, 16, 16), (16, 128, 32, 32), (16, 64, 64, 64), (
     f32 = lambda: H.call("smsut_conv2d_wgrad_mfma", x, gy, g32, ws32, n, h, h, ci, co, 3, st)
     g16 = torch.empty(9 * ci * co, device="cuda"); ws16 = torch.empty(H.call("smsut_conv2d_wgrad_f16_ws", n, h, h, ci, co), device="cuda")
     f16 = lambda: H.call("smsut_conv2d_wgrad_f16", x, None, 0, gy, g16, ws16, sc, n, h, h, ci, co, st)
-    gx3 = torch.empty(9 * ci * co, device="cuda")
-    fx3 = lambda: H.call("smsut_conv2d_wgrad_f16x3", x, None, 0, gy, None, gx3, ws16, sc, n, h, h, ci, co, st)
+    gx3 = torch.empty(9 * ci * co, device="cuda"); wsx = torch.empty(H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, h, ci, co, 0), device="cuda")
+    fx3 = lambda: H.call("smsut_conv2d_wgrad_f16x3", x, None, 0, gy, None, gx3, wsx, sc, None, None, None, None, 0.01, n, h, h, ci, co, st)
     res = []
     for name, fn, buf in (("fp32", f32, g32), ("f16", f16, g16), ("x3", fx3, gx3)):
         t = timeit(fn)

@@ -3350,6 +3350,17 @@ int smsut_conv2d_wgrad_f16(const float* x, const float* x2, int ca, const float*
 // "split fp16" (conv_f16_wgrad<.., X3>): fp32 tensors, every operand element as two fp16 numbers, three MFMAs per product -- fp32-level
 // results (~22 bits per operand) on the fp16 matrix pipes.  gs nullable: non-null = the fused-shortcut form, gw holds 10 tap rows.
 // gsc as for the fp16-operand forms (absmax scale of gy, or of [gy | gs]).  Workspace: smsut_conv2d_wgrad_f16_ws / _sc_f16_ws.
+// workspace floats of smsut_conv2d_wgrad_f16x3 for any of its forms (sc = 1: 10 tap rows)
+int64_t smsut_conv2d_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout, int sc) {
+  int64_t splits = plan_wgrad_f16(N, H, W, Cin, Cout).splits;
+  for (int aff = 0; aff < 2; ++aff)
+    for (int cat = 0; cat < 2; ++cat) {
+      if (aff && (cat || sc)) continue;
+      const int r = smsut_wgrad_rr_splits(N, H, W, Cin, Cout, cat ? (const float*)1 : nullptr, cat ? Cin / 2 : 0, aff != 0, sc != 0, true);
+      if (r > splits) splits = r;
+    }
+  return splits * (sc ? 10 : 9) * Cin * Cout;
+}
 // mean .. beta nullable together: x is the raw conv1 output, lrelu(IN(.)) applied while staging (not with x2 / gs).
 int smsut_conv2d_wgrad_f16x3(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* gw, float* workspace,
                              const float* gsc, const float* mean, const float* rstd, const float* gamma, const float* beta,
@@ -3358,6 +3369,15 @@ int smsut_conv2d_wgrad_f16x3(const float* x, const float* x2, int ca, const floa
   SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0));
   SMSUT_REQUIRE((!mean && !rstd && !gamma && !beta) || (mean && rstd && gamma && beta && !x2 && !gs));
   hipStream_t st = (hipStream_t)stream;
+  // the register-row kernel on split operands where it covers the shape (conv_wgrad_rr.hip, wgrad_rr<.., X3>), else the LDS-staged one
+  static const bool rr_x3 = [] { const char* e = getenv("SMSUT_RR_X3"); return !e || atoi(e) != 0; }();
+  const RrAff ra{mean, rstd, gamma, beta, slope};
+  if (rr_x3 && smsut_wgrad_rr_launch(x, x2, ca, gy, gs, workspace, N, H, W, Cin, Cout, mean ? &ra : nullptr, st, gsc) == 0) {
+    launch_sum_splits(workspace, gw, (gs ? 10 : 9) * Cin * Cout,
+                      smsut_wgrad_rr_splits(N, H, W, Cin, Cout, x2, ca, mean != nullptr, gs != nullptr, true), st);
+    SMSUT_LAUNCH_CHECK();
+    return SMSUT_OK;
+  }
   const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
   const AffRef a{mean, rstd, gamma, beta, slope};
   launch_wgrad_f16(x, x2, ca, gy, gs, workspace, gsc, N, H, W, Cin, Cout, p, st, false, mean ? &a : nullptr, true);

@@ -1036,7 +1036,7 @@ class BasicBlockFn(Function):
         elif x3w2:
             aff = (m1, r1, g1, b1) if ctx.inaff else (None, None, None, None)
             H.call("smsut_conv2d_wgrad_f16x3", y1 if ctx.inaff else a1, None, 0, gy2, None, gw2,
-                   _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x), sc2, *aff, slope, n, h, w, co, co, st)
+                   _ws(H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, w, co, co, 0), x), sc2, *aff, slope, n, h, w, co, co, st)
         else:
             wws2 = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x)
             if ctx.inaff:
@@ -1069,7 +1069,7 @@ class BasicBlockFn(Function):
             gws = torch.as_strided(g10, (co, ci, 1, 1), hwio_strides(co, ci, 1, 1), 9 * ci * co)
             if fused_wsc_x3:
                 H.call("smsut_conv2d_wgrad_f16x3", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
-                       g10, _ws(H.call("smsut_conv2d_wgrad_sc_f16_ws", n, h, w, ci, co), x), sc1, None, None, None, None, slope,
+                       g10, _ws(H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, w, ci, co, 1), x), sc1, None, None, None, None, slope,
                        n, h, w, ci, co, st)
             elif fused_wsc16:
                 H.call("smsut_conv2d_wgrad_sc_f16", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
@@ -1083,7 +1083,7 @@ class BasicBlockFn(Function):
             pass
         elif x3w1:
             H.call("smsut_conv2d_wgrad_f16x3", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, None, gw1,
-                   _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, ci, co), x), sc1, None, None, None, None, slope, n, h, w, ci, co, st)
+                   _ws(H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, w, ci, co, 0), x), sc1, None, None, None, None, slope, n, h, w, ci, co, st)
         elif f16w1:
             wws = _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, ci, co), x)
             if ctx.virtual:

@@ -50,7 +50,7 @@ def test_split_fp16_weight_gradient_is_at_least_as_close_to_fp64_as_the_fp32_ker
         xin = torch.where(z > 0, z, 0.01 * z)
     rows = 10 if fsc else 9
     got = E(rows * ci * co)
-    wsz = H.call("smsut_conv2d_wgrad_sc_f16_ws" if fsc else "smsut_conv2d_wgrad_f16_ws", n, h, h, ci, co)
+    wsz = H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, h, ci, co, int(fsc))
     H.call("smsut_conv2d_wgrad_f16x3", xa, xb, ca, gy, gs if fsc else None, got, torch.empty(wsz, device="cuda"), sc, *aff, 0.01,
            n, h, h, ci, co, st)
     ref = _ref(xin, gy)
