@@ -491,3 +491,30 @@ def test_half_storage_readers_equal_the_fp32_readers_on_the_same_values(ops, n, 
                    y1h if hs else y1f, m1, r1, gam[0], bet[0], sc, 0.01, n, h, h, c, c, st)
             res.append([gz2, pb])
         assert all(torch.equal(p, q) for p, q in zip(*res))
+
+
+def test_gradient_scale_entry_points_edge_cases(ops):
+    """``smsut_absmax_scale`` / ``_scale2`` / ``smsut_absmax_finish``: the scale is the power of two that puts the maximum into
+    [2^13, 2^14]; an all-zero operand and a non-finite maximum give the neutral pair {1, 1}; ``_scale2`` is the scale of the larger of
+    two tensors; ``_finish`` over per-workgroup maxima is the scale of their maximum."""
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    ws = torch.empty(1024, device="cuda")
+    out = torch.empty(2, device="cuda")
+
+    def scale(t):
+        H.call("smsut_absmax_scale", t, t.numel(), out, ws, st)
+        return out.tolist()
+    x = torch.randn(100003, device="cuda") * 3e-7                         # (odd length: the scalar tail path)
+    s, si = scale(x)
+    m = float(x.abs().max())
+    assert 2.0 ** 13 <= m * s <= 2.0 ** 14 and s * si == 1.0 and np.log2(s) == round(np.log2(s))
+    assert scale(torch.zeros(4096, device="cuda")) == [1.0, 1.0]
+    bad = x.clone(); bad[17] = float("inf")
+    assert scale(bad) == [1.0, 1.0]
+    y = torch.randn(4096, device="cuda") * 5e-5
+    H.call("smsut_absmax_scale2", x[:100000], 100000, y, y.numel(), out, ws, st)
+    assert out.tolist() == scale(y)                                       # y holds the larger maximum
+    slots = torch.tensor([0.0, 3e-7, 1.25e-6, 0.0, 9e-7], device="cuda")
+    H.call("smsut_absmax_finish", slots, slots.numel(), out, st)
+    assert out.tolist() == scale(torch.full((4,), 1.25e-6, device="cuda"))
