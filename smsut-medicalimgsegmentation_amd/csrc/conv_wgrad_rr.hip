@@ -39,16 +39,9 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 mfma16h(h4 a, h4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
 }
-#ifndef RR_X3_ABL
-#define RR_X3_ABL 0     // ablation builds only (scratch/x3_rr_abl.sh; results wrong by construction): 1 = no residual arithmetic, 2 = hi hi pass only
-#endif
 __device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
   hi = (_Float16)v;
-#if RR_X3_ABL & 1
-  lo = hi;
-#else
   lo = (_Float16)((v - (float)hi) * 2048.f);
-#endif
 }
 // order fence for the software pipeline: the empty volatile asm keeps the (read-only, otherwise freely movable) buffer loads on
 // their side at the IR / DAG level, sched_barrier does the same for the machine scheduler
@@ -286,7 +279,7 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
           }
           // three passes over the tiles (hi hi | hi lo | lo hi): the two MFMAs on one cross-term accumulator are NT tiles apart
 #pragma unroll
-          for (int pass = 0; pass < ((RR_X3_ABL & 2) ? 1 : 3); ++pass)
+          for (int pass = 0; pass < 3; ++pass)
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
