@@ -157,14 +157,15 @@ def test_f16_generic_conv_family_first_order_only(ops):
 
 
 def test_f16_unet_512_vs_fp32_oracle(ops):
-    """U-Net(1,5,16) at 512x512 (config 5's slice size), fp16 conv operands, vs the fp32 CPU oracle: logits within 2e-2 of
-    the logit range (~40 stacked convs, each 2^-11 per operand), Dice+CE loss within 5e-3.
+    """U-Net(1,5,16) at 512x512 (config 5's slice size), fp16 conv operands + fp16 storage of the block-internal tensors, vs the fp32
+    CPU oracle: logits within 1e-2 of the logit range (~40 stacked convs, each 2^-11 per operand; measured 4.3e-3 with half storage,
+    2.2e-3 without -- scratch/f16_unet512_vals.py), Dice+CE loss within 1e-4 (measured 3e-6).
 
     Parameter gradients: the network is not smooth (4 MaxPools, 18 LeakyReLUs), so a forward perturbation of relative size d
     flips a fraction ~d of the argmax / sign decisions and moves the gradient by ~sqrt(d) in l2 terms.  SURVEY.md section 9
     measured that law on the reference itself: fp32 vs fp64 (d ~ 1e-7) -> median 1.4e-3, worst 6.5e-3.  fp16 operands are
-    d ~ 5e-4, i.e. sqrt(5000) ~ 70x that: ~0.1.  Bars: median < 0.12, worst < 0.2, and the direction is kept -- cosine
-    similarity of the full gradient vector > 0.985."""
+    d ~ 5e-4, i.e. sqrt(5000) ~ 70x that: ~0.1.  Bars: median < 0.12, worst < 0.2 (measured 0.110 / 0.169 with half storage, 0.092 /
+    0.162 without), and the direction is kept -- cosine similarity of the full gradient vector > 0.995 (measured 0.9991)."""
     from smsut_amd.network.unet import UNet
     from smsut_amd.misc.loss import DiceAndCrossEntropyLoss
     torch.set_num_threads(16)
@@ -183,21 +184,22 @@ def test_f16_unet_512_vs_fp32_oracle(ops):
     loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y.cuda())
     loss.backward()
     e = rel_err(out.detach().cpu().numpy(), ref.detach().numpy())
-    assert 1e-5 < e < 2e-2, e                                          # (> 1e-5: the fp16 kernels really ran)
-    assert abs(loss.item() - ref_loss.item()) < 5e-3 * abs(ref_loss.item())
+    assert 1e-5 < e < 1e-2, e                                          # (> 1e-5: the fp16 kernels really ran)
+    assert abs(loss.item() - ref_loss.item()) < 1e-4 * abs(ref_loss.item())
     errs = {k: l2_rel(p.grad.cpu().numpy(), leaf[k].grad.numpy()) for k, p in net.named_parameters()}
     worst = max(errs.items(), key=lambda kv: kv[1])
     assert float(np.median(list(errs.values()))) < 0.12 and worst[1] < 0.2, (float(np.median(list(errs.values()))), worst)
     ga = torch.cat([p.grad.detach().cpu().double().reshape(-1) for _, p in net.named_parameters()])
     gb = torch.cat([leaf[k].grad.double().reshape(-1) for k, _ in net.named_parameters()])
     cos = float(torch.dot(ga, gb) / (ga.norm() * gb.norm()))
-    assert cos > 0.985, cos
+    assert cos > 0.995, cos
 
 
 def test_f16_ugan_consis_iteration_512_vs_fp32_oracle(ops):
     """One uganConsis iteration at config 5's size (512x512, 1 labeled + 1 unlabeled slice, the 7-stage discriminator of
-    ugan.py:205-215) with fp16 conv operands vs the fp32 CPU oracle, optimizers at lr 0: segmentor-side scalars at 1e-2,
-    everything else (through the tanh translator and D) at 5e-2."""
+    ugan.py:205-215) with fp16 conv operands and half storage vs the fp32 CPU oracle, optimizers at lr 0: segmentor-side scalars at
+    1e-3 (measured <= 8.3e-5, scratch/f16_iter512_vals.py), everything else (through the tanh translator and D) at 1.5e-2 (measured
+    <= 5.0e-3: G_cls), the gradient penalty at 2e-2 (7.2e-3).  (r03's bars were 1e-2 / 5e-2 / 5e-2.)"""
     from smsut_amd import config as cfg
     from smsut_amd.trainer.uganConsisTrainer import UGANConsisTrainer, SCALARS
     old = (cfg.input_size, cfg.batch_size)
@@ -224,11 +226,11 @@ def test_f16_ugan_consis_iteration_512_vs_fp32_oracle(ops):
         rep = dict(zip(SCALARS, zip(got, ref)))
         assert np.isfinite(got).all(), rep
         seg = [SCALARS.index(k) for k in ("G_seg", "G_semi", "G_rec")]
-        assert np.allclose(got[seg], ref[seg], rtol=1e-2, atol=1e-4), rep
+        assert np.allclose(got[seg], ref[seg], rtol=1e-3, atol=1e-4), rep
         rest = [i for i in range(10) if i not in seg and SCALARS[i] != "D_gp"]
-        assert np.allclose(got[rest], ref[rest], rtol=5e-2, atol=2e-3), rep
+        assert np.allclose(got[rest], ref[rest], rtol=1.5e-2, atol=2e-3), rep
         i_gp = SCALARS.index("D_gp")                                   # the x_hat pass keeps fp32 operands; x_fake itself is f16-made
-        assert abs(got[i_gp] - ref[i_gp]) <= 5e-2 * abs(ref[i_gp]), rep
+        assert abs(got[i_gp] - ref[i_gp]) <= 2e-2 * abs(ref[i_gp]), rep
     finally:
         cfg.input_size, cfg.batch_size = old
 
