@@ -13,6 +13,9 @@ rocprofv3 --kernel-trace --stats $common -d $out/${tag}_ugan -- python3 bench.py
 tail -1 $out/${tag}_ugan.log | cut -c1-160
 rocprofv3 --kernel-trace --stats $common -d $out/${tag}_unet -- python3 bench.py --workload unet --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-unet-step > $out/${tag}_unet.log 2>&1
 tail -1 $out/${tag}_unet.log | cut -c1-160
+rm -rf $out/${tag}_c5
+rocprofv3 --kernel-trace --stats $common -d $out/${tag}_c5 -- python3 bench.py --dtype f16 --size 512 --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-unet-step --no-config5 > $out/${tag}_c5.log 2>&1
+tail -1 $out/${tag}_c5.log | cut -c1-160
 rocprofv3 --kernel-trace --stats $common -d $out/${tag}_roof -- python3 bench.py --roofline-only > $out/${tag}_roof.log 2>&1
 tail -1 $out/${tag}_roof.log | cut -c1-400
 rocprofv3 --pmc FETCH_SIZE --kernel-trace $common -d $out/${tag}_pmc_fetch -- python3 bench.py --roofline-only > $out/${tag}_pmc_fetch.log 2>&1

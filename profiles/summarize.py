@@ -64,7 +64,9 @@ def pmc_rows(path, counter):
 
 md = [f"# {tag}: rocprofv3 summaries", "",
       "Commands: `profiles/collect.sh` (rocprofv3 --kernel-trace --stats; PMC in separate passes).", ""]
-for wl in ("ugan", "unet"):
+for wl in ("ugan", "unet", "c5"):
+    if wl == "c5" and not glob.glob(os.path.join(OUT, f"{tag}_c5", "**", "*_kernel_stats.csv"), recursive=True):
+        continue                                    # (config-5 pass: collected since r04)
     src = one(f"{tag}_{wl}/**/*_kernel_stats.csv")
     shutil.copy(src, os.path.join(PROF, f"{tag}_{wl}_kernel_stats.csv"))
     try:
@@ -75,7 +77,8 @@ for wl in ("ugan", "unet"):
                      "D(x_fake) -- no longer overlaps the generator's backward; the un-profiled number is the driver's BENCH line / README)")
     except (ValueError, IndexError):
         head = "(bench line unreadable)"
-    md += [f"## {wl} workload", "", head, "", stats_table(src, STEPS), ""]
+    title = "config 5 (uganConsis iteration at 512x512, fp16 operands + half storage)" if wl == "c5" else f"{wl} workload"
+    md += [f"## {title}", "", head, "", stats_table(src, STEPS), ""]
 
 src = one(f"{tag}_roof/**/*_kernel_stats.csv")
 shutil.copy(src, os.path.join(PROF, f"{tag}_roofline_kernel_stats.csv"))
