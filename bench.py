@@ -251,6 +251,7 @@ def time_unet_step(dev, rank, B=32, warmup=10, steps=30, profile=True):
     from smsut_amd.misc.synthetic import SyntheticSliceLoader
     old_bs = cfg.batch_size
     cfg.batch_size = B
+    torch.manual_seed(20202)                             # (the same initial weights for every call: the legs' losses are comparable)
     try:
         tr = UnetTrainer("train", _t.SimpleNamespace(fold=0, expr_name=None, write_env=False))
         tr.net.train()
