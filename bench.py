@@ -28,6 +28,7 @@ import types
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -530,15 +531,21 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     copies0 = ops.layout_copies()
+    # per-step spread: one event per step on the stream every step ends on (recording an event is not a sync; the clock of the
+    # headline stays the host's, around the whole region)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
     last = None
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         last = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -599,7 +606,10 @@ def main():
     ms = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     out = {"metric": metric, "value": round(value, 3), "unit": "slices/s", "n_gpus": world, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "warmup": args.warmup, "ms_per_step": round(ms, 3),
+           "ms_per_step_min": round(min(per_step), 3), "ms_per_step_max": round(max(per_step), 3),
+           "ms_per_step_std": round(float(np.std(per_step)), 3), "ms_per_step_median": round(float(np.median(per_step)), 3),
+           "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32" if args.dtype == "f32" else "f16 conv operands + block-internal storage, f32 accumulate / IN / losses",
            "data": "synthetic",
            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,

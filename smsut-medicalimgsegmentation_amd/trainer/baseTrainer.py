@@ -5,7 +5,8 @@ last-batch padding, Dice matrix, checkpoint save/load with the reference's file 
 MI355X-first differences (all opt-in or invisible to a caller of the reference API):
   * one process per GPU: ``LOCAL_RANK`` selects the device and, when ``WORLD_SIZE > 1``, gradients are averaged
     with one flat RCCL all-reduce per network (``parallel.GradAllReducer``) instead of ``nn.DataParallel``;
-  * loaders default to the synthetic slice source (the PNG pipeline is outside the hot-path scope);
+  * the mains call ``fit('inTurn')`` / ``test('inTurn', ...)`` as the reference's do; ``get_loaders`` hands out the real PNG
+    loaders when ``config.base_root`` holds a processed dataset and the synthetic slice source (same batch contract) otherwise;
   * TensorBoard / code snapshot / medpy are optional extras that are skipped when not installed.
 """
 import abc
@@ -217,6 +218,11 @@ class BaseTrainer(abc.ABC):
                                                            rank=self.rank if phase != "test" else 0,
                                                            world=self.world if phase != "test" else 1)
             return mk("train", self.fold, cfg.data_aug), mk("val", self.fold, cfg.data_aug), mk("test", 0, None)
+        if loader_type != "synthetic" and not self.__dict__.get("_told_synthetic"):
+            # the reference's mains ask for 'inTurn' (uganConsisTrainer.py:320-332); with no dataset configured this is what they get
+            self._told_synthetic = True
+            self.info("loader %r: config.base_root %r is not a processed PNG dataset -- using the synthetic slice source "
+                      "(same batch contract)" % (loader_type, cfg.base_root))
         n = getattr(self.args, "iters_per_epoch", None) or cfg.num_iter_per_epoch
         mk = lambda labeled, nb: SyntheticSliceLoader(cfg.batch_size, n_batches=nb, device=self.device,
                                                       labeled=labeled, rank=self.rank)

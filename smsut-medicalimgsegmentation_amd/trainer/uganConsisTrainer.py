@@ -577,13 +577,13 @@ def main(argv=None):
     seed_all()
     trainer = UGANConsisTrainer(args.phase, args)
     if args.phase == "train":
-        trainer.fit("synthetic")
+        trainer.fit("inTurn")
     elif args.phase == "test":
         trainer.load_model(args.model_id, args.which_ckpt)
-        trainer.test("synthetic", pjoin(trainer.expr_root, args.model_id))
+        trainer.test("inTurn", pjoin(trainer.expr_root, args.model_id))
     elif args.phase == "pseudo":
         trainer.load_model(args.model_id, args.which_ckpt)
-        trainer.saving_pseudo("synthetic", pjoin(trainer.expr_root, args.model_id))
+        trainer.saving_pseudo("inTurn", pjoin(trainer.expr_root, args.model_id))
 
 
 if __name__ == "__main__":

@@ -114,10 +114,10 @@ def main(argv=None):
     seed_all()
     t = UnetTrainer(args.phase, args)
     if args.phase == "train":
-        t.fit("synthetic")
+        t.fit("inTurn")
     else:
         t.load_model(args.model_id, args.which_ckpt)
-        t.test("synthetic", t.expr_root + "/" + args.model_id)
+        t.test("inTurn", t.expr_root + "/" + args.model_id)
 
 
 if __name__ == "__main__":

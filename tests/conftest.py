@@ -28,6 +28,18 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def elem_rel_err(a, b, floor=1e-2):
+    """ELEMENT-WISE relative error: max over the elements with |b| > floor * max|b| of |a-b| / |b| -- the stricter companion of
+    ``rel_err`` (which divides every difference by the tensor's maximum).  Elements below the floor are values that cancel to
+    near zero, where a relative figure measures the reference's own round-off, not the path under test."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    keep = np.abs(b) > floor * max(np.abs(b).max(), 1e-30)
+    if not keep.any():
+        return 0.0
+    return float((np.abs(a - b)[keep] / np.abs(b)[keep]).max())
+
+
 def l2_rel(a, b):
     a = np.asarray(a, dtype=np.float64).ravel()
     b = np.asarray(b, dtype=np.float64).ravel()

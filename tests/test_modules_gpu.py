@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, l2_rel
+from conftest import rel_err, elem_rel_err, l2_rel
 from oracle import recipe, smsut_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -68,7 +68,11 @@ def test_unet_256_full_size(pkg, golden):
     x = recipe.synth_images((1, 1, 256, 256), seed + 1).cuda()
     y = recipe.synth_labels(1, 256, 256, 5, seed + 2).cuda()
     out = net(x)
-    assert rel_err(out[:, :, ::8, ::8].detach().cpu().numpy(), g["logits_s8"]) < TOL
+    got_s8 = out[:, :, ::8, ::8].detach().cpu().numpy()
+    e_max, e_elem = rel_err(got_s8, g["logits_s8"]), elem_rel_err(got_s8, g["logits_s8"])
+    print(f"unet_256 logits: max-norm rel {e_max:.2e}, element-wise rel over |ref| > 1e-2 max|ref| {e_elem:.2e}")
+    assert e_max < TOL
+    assert e_elem < TOL, e_elem                    # north_star's 1e-3, element by element (not only against the tensor maximum)
     loss = DiceAndCrossEntropyLoss(0.5, 0.5, batch_dice=True)(out, y)
     assert abs(loss.item() - float(g["loss"])) < TOL * float(g["loss"])
     loss.backward()
