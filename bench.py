@@ -694,18 +694,6 @@ def main():
             out["roofline"]["in_step_record"] = bool(prof.get("has_call", {}).get("dominant"))
     if world == 1 and args.workload == "ugan" and not args.no_unet_step and args.dtype == "f32" and args.size == 256:
         out["unet_step"] = time_unet_step(dev, rank)
-        # the opt-in weight-gradient arithmetic (off in every number above), so that the record shows what it would change
-        from smsut_amd import ops as _ops
-        _ops.WGRAD_X3 = True
-        try:
-            alt = time_unet_step(dev, rank, profile=False)              # (same steps and batches as the default leg: the losses are comparable)
-        finally:
-            _ops.WGRAD_X3 = False
-        out["optional_split_fp16_wgrad"] = {
-            "what": "SMSUT_WGRAD_X3=1: 3x3 weight gradients as three fp16 MFMAs per product on hi / lo operand pairs, fp32 accumulate "
-                    "(measured closer to fp64 than the fp32 MFMA kernels: profiles/r04_split_fp16.md, tests/test_split_fp16_gpu.py); "
-                    "OFF by default and in every other figure of this line",
-            "unet_step_ms": alt["ms_per_step"], "unet_step_ms_default": out["unet_step"]["ms_per_step"], "last_loss": alt["last_loss"]}
         if not args.no_config5:
             out["config5"] = time_config5(dev, rank)
     if world == 1 and not args.no_cpu_baseline and args.size == 256:

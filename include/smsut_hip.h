@@ -234,15 +234,6 @@ int smsut_conv2d_wgrad_f16_supported(int N, int H, int W, int Cin, int Cout);
 int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout);
 int smsut_conv2d_wgrad_f16(const float* x, const float* x2 /*nullable*/, int ca, const float* gy, float* gw, float* workspace,
                            const float* gsc /*nullable*/, int N, int H, int W, int Cin, int Cout, void* stream);
-/* "split fp16" weight gradient (opt-in, SMSUT_WGRAD_X3=1; the fp32 MFMA kernels stay the default): fp32 tensors; every operand
- * element is staged as hi = fp16(v), lo = fp16((v - hi) 2^11) and a product is three fp16 MFMAs (hi hi + 2^-11 (hi lo + lo hi)),
- * fp32 accumulate: 23 bits per operand, measured closer to fp64 than the fp32 MFMA kernels (profiles/r04_split_fp16.md).
- * gs nullable (non-null: fused shortcut, gw10 layout).  gsc required (gradient range). */
-int64_t smsut_conv2d_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout, int sc);
-int smsut_conv2d_wgrad_f16x3(const float* x, const float* x2 /*nullable*/, int ca, const float* gy, const float* gs /*nullable*/,
-                             float* gw, float* workspace, const float* gsc, const float* mean /*nullable group: input-side IN*/,
-                             const float* rstd, const float* gamma, const float* beta, float slope, int N, int H, int W, int Cin,
-                             int Cout, void* stream);
 /* ... with x stored as fp16 (half storage: conv2's weight gradient reads the activated a1): same operand bits, same result */
 int smsut_conv2d_wgrad_f16_xh(const void* x16, const float* gy, float* gw, float* workspace, const float* gsc /*nullable*/, int N,
                               int H, int W, int Cin, int Cout, void* stream);

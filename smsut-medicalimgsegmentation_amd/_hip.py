@@ -112,8 +112,6 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_fwd_mfma_stats_f16_hs": "ppppp iiiii s",
     "smsut_conv2d_fwd_mfma_stats_f16_hsx": "pppp iiiii s",
     "smsut_conv2d_wgrad_f16_xh": "ppppp iiiii s",
-    "smsut_conv2d_wgrad_f16x3": "pp i ppppp pppp f iiiii s",
-    "smsut_conv2d_wgrad_f16x3_ws": "iiiiii",
     "smsut_conv2d_wgrad_f16_xh_inaff": "ppppp pppp f iiiii s",
     "smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx": "pppp pppp f iiiii s",
     "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": "pppppppp iiiii s",
@@ -193,7 +191,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_patchnce_fwd": "pppp iii f s",
     "smsut_patchnce_bwd": "pppp iii f s",
 }
-_RET_I64 = {"smsut_wino_image_floats", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_conv2d_wgrad_f16x3_ws", "smsut_conv2d_wgrad_sc_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
+_RET_I64 = {"smsut_wino_image_floats", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_conv2d_wgrad_sc_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws",
             "smsut_conv1x1_thin_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_amax_blocks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",

@@ -1476,13 +1476,7 @@ conv_mfma_wgrad_ts(const float* __restrict__ x, const float* __restrict__ gy, fl
 // with the same scale gsc (smsut_absmax_scale2) -- so the slab is [10][Cin][Cout], row 9 = the 1x1 weights' gradient.
 // XH (r04): x is an fp16 tensor (the activated a1 of a BasicBlock in half storage) -- copied into the staging planes as it is.
 // INAFF (with XH): x is the RAW fp16 conv1 output; lrelu(IN(.)) is applied while staging (as conv_mfma_fwd_p<.., INAFF, .., I16>).
-// X3 (r04, "split fp16"): fp32-LEVEL products on the fp16 matrix pipes.  Every operand element v is staged as TWO fp16 numbers,
-// hi = fp16(v) and lo = fp16((v - hi) * 2^11) -- v = hi + lo 2^-11 up to 2^-22 |v| (the residual is exact in fp32, its fp16 rounding
-// keeps 11 more bits; the 2^11 keeps lo in the normal range wherever hi is) -- and a product a b is three MFMAs: a_hi b_hi into the
-// main accumulator, a_hi b_lo + a_lo b_hi into a second one that enters with 2^-11 at the end; the dropped a_lo b_lo term is 2^-22 of
-// the product.  fp16 x fp16 products are exact in the fp32 accumulate, so the result carries ~22 bits per operand where the
-// fp32 MFMA carries 24 -- at 3 x 1/16 of its cycles per product.  Opt-in (ops.set_conv_dtype("f16x3")); the fp32 MFMA path stays the default.
-template <int CIT, int COT, bool DUAL, bool SC = false, bool XH = false, bool INAFF = false, bool X3 = false>
+template <int CIT, int COT, bool DUAL, bool SC = false, bool XH = false, bool INAFF = false>
 __global__ void __launch_bounds__(TPB)
 conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ part, int N, int H, int W,
                int Cin, int Cout, int tiles_x, int tiles_y, int tiles_per_split, const float* __restrict__ x2, int ca,
@@ -1490,8 +1484,7 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
   constexpr int KS = 3, KK = 9, PAD = 1;
   constexpr int KR = SC ? 10 : 9;                          // tap rows of the slab
   static_assert(!XH || (!DUAL && !SC), "fp16 x: conv2's weight gradient (plain form)");
-  static_assert(!INAFF || ((XH || X3) && !DUAL && !SC), "input-side IN: the half-storage form or the split-fp16 form, plain input");
-  static_assert(!X3 || !XH, "split fp16: fp32 tensors");
+  static_assert(!INAFF || (XH && !DUAL && !SC), "input-side IN: the half-storage form, plain input");
   [[maybe_unused]] float4 a_m, a_r, a_g, a_b;              // INAFF: statistics of (image, this thread's channel quad), affine pair
   constexpr bool TS = (CIT == 2 && COT == 2);
   constexpr int IH = WTH + KS - 1, IW = TW + KS - 1;
@@ -1502,7 +1495,6 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
   _Float16* x_h = reinterpret_cast<_Float16*>(smem);       // [CIT][NPX][16]
   _Float16* g_h = x_h + CIT * NPX * 16;                    // [COT][NPG][16]
   [[maybe_unused]] _Float16* s_h = g_h + COT * NPG * 16;   // SC: [COT][NPG][16], the shortcut's gradient
-  constexpr int PLANES = (CIT * NPX + (SC ? 2 : 1) * COT * NPG) * 16 + 8;   // halves of the hi images (+ dummy slot); X3: the lo images follow
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lm = lane & 15, kq = lane >> 4;
@@ -1515,28 +1507,10 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
   const float gs = gsc ? gsc[0] : 1.f, gi = gsc ? gsc[1] : 1.f;
 
   f32x4 acc[NACC];
-  [[maybe_unused]] f32x4 accx[X3 ? NACC : 1];              // X3: the cross terms a_hi b_lo + a_lo b_hi (x 2^11)
 #pragma unroll
   for (int k = 0; k < NACC; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < (X3 ? NACC : 1); ++k) accx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  auto split_store = [&](_Float16* dst, f32x4 v) __attribute__((always_inline)) {          // hi at dst, X3: lo at dst + PLANES
-    const h4 hi = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-    *(h4*)dst = hi;
-    if constexpr (X3) {
-      const f32x4 r = (v - (f32x4){(float)hi[0], (float)hi[1], (float)hi[2], (float)hi[3]}) * 2048.f;
-      *(h4*)(dst + PLANES) = (h4){(_Float16)r[0], (_Float16)r[1], (_Float16)r[2], (_Float16)r[3]};
-    }
-  };
-  // acc (+ accx) += a b for one fragment pair; lo fragments are read PLANES halves behind the hi ones
-  auto mma = [&](int k, const _Float16* ap, const _Float16* bp, auto&& rd) __attribute__((always_inline)) {
-    const h4 a = rd(ap), b = rd(bp);
-    acc[k] = mfma16h(a, b, acc[k]);
-    if constexpr (X3) {
-      const h4 al = rd(ap + PLANES), bl = rd(bp + PLANES);
-      accx[k] = mfma16h(a, bl, accx[k]);
-      accx[k] = mfma16h(al, b, accx[k]);
-    }
+  auto split_store = [&](_Float16* dst, f32x4 v) __attribute__((always_inline)) {
+    *(h4*)dst = (h4){(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
   };
 
   // transposed-read lane address inside a 16-channel plane: group kq takes pixels 4kq .. 4kq+3 of the row segment, lane
@@ -1632,10 +1606,6 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
 #pragma unroll
       for (int i = 0; i < NIN; ++i) {
         f32x4 v = rin[i];
-        if constexpr (INAFF) {                         // (X3 on fp32 tensors: x is the raw conv1 output)
-          v[0] = aff1(v[0], a_m.x, a_r.x, a_g.x, a_b.x, aff.slope); v[1] = aff1(v[1], a_m.y, a_r.y, a_g.y, a_b.y, aff.slope);
-          v[2] = aff1(v[2], a_m.z, a_r.z, a_g.z, a_b.z, aff.slope); v[3] = aff1(v[3], a_m.w, a_r.w, a_g.w, a_b.w, aff.slope);
-        }
         split_store(x_h + in_lds[i], zero[i] ? (f32x4){0.f, 0.f, 0.f, 0.f} : v);
       }
     }
@@ -1651,16 +1621,6 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
       const int jt = wave & 1;
 #pragma unroll
       for (int r = 0; r < WTH; ++r) {
-        if constexpr (X3) {
-          const _Float16* bp = g_h + (jt * NPG + r * TW) * 16;
-#pragma unroll
-          for (int k = 0; k < 9; ++k) {
-            const int ti = (wave + 4 * k) >> 1;
-            const int tap = ti >> 1, i = ti & 1;
-            mma(k, x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16, bp, tr_read);
-          }
-          if constexpr (SC) mma(9, x_h + ((wave >> 1) * NPX + (r + 1) * IW + 1) * 16, s_h + (jt * NPG + r * TW) * 16, tr_read);
-        } else {
         const h4 b = tr_read(g_h + (jt * NPG + r * TW) * 16);
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
@@ -1674,29 +1634,11 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
           const h4 a = tr_read(x_h + ((wave >> 1) * NPX + (r + 1) * IW + 1) * 16);
           acc[9] = mfma16h(a, bs, acc[9]);
         }
-        }
       }
     } else {
 #pragma unroll
       for (int rr = 0; rr < WTH / 4; ++rr) {
         const int r = wave * (WTH / 4) + rr;
-        if constexpr (X3) {
-#pragma unroll
-          for (int tap = 0; tap < KK; ++tap)
-#pragma unroll
-            for (int i = 0; i < CIT; ++i)
-#pragma unroll
-              for (int j = 0; j < COT; ++j)
-                mma((tap * CIT + i) * COT + j, x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16, g_h + (j * NPG + r * TW) * 16, tr_read);
-          if constexpr (SC) {
-#pragma unroll
-            for (int i = 0; i < CIT; ++i)
-#pragma unroll
-              for (int j = 0; j < COT; ++j)
-                mma((9 * CIT + i) * COT + j, x_h + (i * NPX + (r + 1) * IW + 1) * 16, s_h + (j * NPG + r * TW) * 16, tr_read);
-          }
-          continue;
-        }
         h4 b[COT];
 #pragma unroll
         for (int j = 0; j < COT; ++j) b[j] = tr_read(g_h + (j * NPG + r * TW) * 16);
@@ -1721,10 +1663,6 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
         }
       }
     }
-  }
-  if constexpr (X3) {
-#pragma unroll
-    for (int k = 0; k < NACC; ++k) acc[k] += accx[k] * (1.f / 2048.f);
   }
   // ---- store: acc[.][r] is (ci = tile*16 + 4*kq + r, co = tile*16 + lm)
   if constexpr (TS) {
@@ -3263,7 +3201,7 @@ int64_t smsut_conv2d_wgrad_f16_ws(int N, int H, int W, int Cin, int Cout) {
 // 10 tap rows, see conv_f16_wgrad<.., SC>).
 static void launch_wgrad_f16(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* workspace,
                              const float* gsc, int N, int H, int W, int Cin, int Cout, const WgradPlan& p, hipStream_t st,
-                             bool xh = false, const AffRef* aff = nullptr, bool x3 = false) {
+                             bool xh = false, const AffRef* aff = nullptr) {
   constexpr int NPX = (WTH + 2) * (TW + 2), NPG = WTH * TW;
 #define F16_WGRAD(CI, CO, SCF)                                                                                              \
   do {                                                                                                                      \
@@ -3297,41 +3235,13 @@ static void launch_wgrad_f16(const float* x, const float* x2, int ca, const floa
       conv_f16_wgrad<CI, CO, false, false, true><<<grid, TPB, sh, st>>>(x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x,     \
                                                                        p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, nullptr); \
   } while (0)
-#define F16_WGRAD_X3(CI, CO, SCF)                                                                                           \
-  do {                                                                                                                      \
-    constexpr size_t stage = 2 * (size_t)((CI * NPX + (SCF ? 2 : 1) * CO * NPG) * 16 + 8) * sizeof(_Float16);               \
-    constexpr size_t red = (CI == 2 && CO == 2) ? 0 : (size_t)(SCF ? 10 : 9) * CI * CO * 64 * 4 * sizeof(float);             \
-    constexpr size_t sh = stage > red ? stage : red;                                                                        \
-    dim3 grid(p.splits, Cin / (16 * CI), Cout / (16 * CO));                                                                 \
-    if (x2) conv_f16_wgrad<CI, CO, true, SCF, false, false, true><<<grid, TPB, sh, st>>>(                                    \
-        x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_per_split, x2, ca, gsc, gs);                   \
-    else if constexpr (!SCF) {                                                                                              \
-      if (aff) conv_f16_wgrad<CI, CO, false, false, false, true, true><<<grid, TPB, sh, st>>>(                               \
-          x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, nullptr, *aff);  \
-      else conv_f16_wgrad<CI, CO, false, false, false, false, true><<<grid, TPB, sh, st>>>(                                  \
-          x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, nullptr);        \
-    } else conv_f16_wgrad<CI, CO, false, SCF, false, false, true><<<grid, TPB, sh, st>>>(                                    \
-        x, gy, workspace, N, H, W, Cin, Cout, p.tiles_x, p.tiles_y, p.tiles_per_split, nullptr, 0, gsc, gs);               \
-  } while (0)
-#define F16_WGRAD_X3_FORMS(SCF)                                  \
-  do {                                                           \
-    if (p.cit == 2 && p.cot == 2) F16_WGRAD_X3(2, 2, SCF);       \
-    else if (p.cit == 2) F16_WGRAD_X3(2, 1, SCF);                \
-    else if (p.cot == 2) F16_WGRAD_X3(1, 2, SCF);                \
-    else F16_WGRAD_X3(1, 1, SCF);                                \
-  } while (0)
-  if (x3) {
-    if (gs) F16_WGRAD_X3_FORMS(true);
-    else F16_WGRAD_X3_FORMS(false);
-  } else if (xh) {
+  if (xh) {
     if (p.cit == 2 && p.cot == 2) F16_WGRAD_XH(2, 2);
     else if (p.cit == 2) F16_WGRAD_XH(2, 1);
     else if (p.cot == 2) F16_WGRAD_XH(1, 2);
     else F16_WGRAD_XH(1, 1);
   } else if (gs) F16_WGRAD_FORMS(true);
   else F16_WGRAD_FORMS(false);
-#undef F16_WGRAD_X3_FORMS
-#undef F16_WGRAD_X3
 #undef F16_WGRAD_XH
 #undef F16_WGRAD_FORMS
 #undef F16_WGRAD
@@ -3344,44 +3254,6 @@ int smsut_conv2d_wgrad_f16(const float* x, const float* x2, int ca, const float*
   const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
   launch_wgrad_f16(x, x2, ca, gy, nullptr, workspace, gsc, N, H, W, Cin, Cout, p, st);
   launch_sum_splits(workspace, gw, 9 * Cin * Cout, p.splits, st);
-  SMSUT_LAUNCH_CHECK();
-  return SMSUT_OK;
-}
-// "split fp16" (conv_f16_wgrad<.., X3>): fp32 tensors, every operand element as two fp16 numbers, three MFMAs per product -- fp32-level
-// results (~22 bits per operand) on the fp16 matrix pipes.  gs nullable: non-null = the fused-shortcut form, gw holds 10 tap rows.
-// gsc as for the fp16-operand forms (absmax scale of gy, or of [gy | gs]).  Workspace: smsut_conv2d_wgrad_f16_ws / _sc_f16_ws.
-// workspace floats of smsut_conv2d_wgrad_f16x3 for any of its forms (sc = 1: 10 tap rows)
-int64_t smsut_conv2d_wgrad_f16x3_ws(int N, int H, int W, int Cin, int Cout, int sc) {
-  int64_t splits = plan_wgrad_f16(N, H, W, Cin, Cout).splits;
-  for (int aff = 0; aff < 2; ++aff)
-    for (int cat = 0; cat < 2; ++cat) {
-      if (aff && (cat || sc)) continue;
-      const int r = smsut_wgrad_rr_splits(N, H, W, Cin, Cout, cat ? (const float*)1 : nullptr, cat ? Cin / 2 : 0, aff != 0, sc != 0, true);
-      if (r > splits) splits = r;
-    }
-  return splits * (sc ? 10 : 9) * Cin * Cout;
-}
-// mean .. beta nullable together: x is the raw conv1 output, lrelu(IN(.)) applied while staging (not with x2 / gs).
-int smsut_conv2d_wgrad_f16x3(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* gw, float* workspace,
-                             const float* gsc, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                             float slope, int N, int H, int W, int Cin, int Cout, void* stream) {
-  SMSUT_REQUIRE(x && gy && gw && workspace && gsc && smsut_conv2d_wgrad_f16_supported(N, H, W, Cin, Cout));
-  SMSUT_REQUIRE(!x2 || (ca > 0 && ca < Cin && ca % 16 == 0));
-  SMSUT_REQUIRE((!mean && !rstd && !gamma && !beta) || (mean && rstd && gamma && beta && !x2 && !gs));
-  hipStream_t st = (hipStream_t)stream;
-  // the register-row kernel on split operands where it covers the shape (conv_wgrad_rr.hip, wgrad_rr<.., X3>), else the LDS-staged one
-  static const bool rr_x3 = [] { const char* e = getenv("SMSUT_RR_X3"); return !e || atoi(e) != 0; }();
-  const RrAff ra{mean, rstd, gamma, beta, slope};
-  if (rr_x3 && smsut_wgrad_rr_launch(x, x2, ca, gy, gs, workspace, N, H, W, Cin, Cout, mean ? &ra : nullptr, st, gsc) == 0) {
-    launch_sum_splits(workspace, gw, (gs ? 10 : 9) * Cin * Cout,
-                      smsut_wgrad_rr_splits(N, H, W, Cin, Cout, x2, ca, mean != nullptr, gs != nullptr, true), st);
-    SMSUT_LAUNCH_CHECK();
-    return SMSUT_OK;
-  }
-  const WgradPlan p = plan_wgrad_f16(N, H, W, Cin, Cout);
-  const AffRef a{mean, rstd, gamma, beta, slope};
-  launch_wgrad_f16(x, x2, ca, gy, gs, workspace, gsc, N, H, W, Cin, Cout, p, st, false, mean ? &a : nullptr, true);
-  launch_sum_splits(workspace, gw, (gs ? 10 : 9) * Cin * Cout, p.splits, st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

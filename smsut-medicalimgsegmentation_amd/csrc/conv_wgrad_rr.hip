@@ -30,19 +30,6 @@ constexpr int TPB = 256;
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
-// X3 ("split fp16", opt-in -- see conv_f16_wgrad<.., X3> in conv_mfma.hip for the arithmetic): lane (lm, kq) of
-// v_mfma_f32_16x16x16_f16 supplies FOUR consecutive k -- exactly the four pixels 4kq .. 4kq+3 this kernel's lane already holds for
-// its four fp32 MFMAs -- so one fp16 MFMA replaces four fp32 ones and a product on split operands is 3 instead of 4 matrix
-// instructions at 1/4 (or less) of the cycles each.
-typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 mfma16h(h4 a, h4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
-}
-__device__ __forceinline__ void split2(float v, _Float16& hi, _Float16& lo) {
-  hi = (_Float16)v;
-  lo = (_Float16)((v - (float)hi) * 2048.f);
-}
 // order fence for the software pipeline: the empty volatile asm keeps the (read-only, otherwise freely movable) buffer loads on
 // their side at the IR / DAG level, sched_barrier does the same for the machine scheduler
 #define FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -69,7 +56,6 @@ struct RrArgs {
   int groups_per_split;                         // groups of WS wave-units a workgroup walks
   int total_wu;                                 // N * (H / RC) * (W / 16)
   RrAff aff;
-  const float* gsc;                             // X3: {s, 1/s}, the power-of-two scale of the gradient operand(s)
 #ifdef SMSUT_STAMPS                             // diagnostic build only (scratch/rr_clock.py): per-workgroup cycle / real-time stamps
   unsigned long long* dbg;                      // [workgroups][4]: s_memtime, s_memrealtime at the start and at the end of wave 0
 #endif
@@ -84,7 +70,7 @@ struct RrArgs {
 #ifndef RR_OCC4
 #define RR_OCC4 1       // workgroups per CU the 32 x 32-per-wave form must allow (2 = at most 256 registers)
 #endif
-template <int CIW, int COW, int WI, int WJ, int R, int D, bool DUAL, bool INAFF, bool SC, bool X3 = false>
+template <int CIW, int COW, int WI, int WJ, int R, int D, bool DUAL, bool INAFF, bool SC>
 __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgrad_rr(const RrArgs a) {
   static_assert(WI * WJ == 1 || WI * WJ == 2 || WI * WJ == 4, "sub-slabs per workgroup");
   static_assert(R >= D + 3, "ring: three live rows + D in flight");
@@ -117,12 +103,6 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
 #pragma unroll
     for (int k = 0; k < NTS; ++k) acs[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  [[maybe_unused]] f32x4 accx[X3 ? NT : 1], acsx[(X3 && SC) ? NTS : 1];     // X3: cross terms hi lo + lo hi (x 2^11)
-#pragma unroll
-  for (int k = 0; k < (X3 ? NT : 1); ++k) accx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < ((X3 && SC) ? NTS : 1); ++k) acsx[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  [[maybe_unused]] const float gsx = (X3 && a.gsc) ? a.gsc[0] : 1.f, gix = (X3 && a.gsc) ? a.gsc[1] : 1.f;
 
   // per ci tile: source tensor, its channel stride, the tile's first channel inside it (uniform)
   const float* xs[CIW];
@@ -140,8 +120,6 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
   float xr[R][CIW][6];
   float gr[G][COW][4];
   [[maybe_unused]] float sr[SC ? G : 1][COW][4];
-  // X3: the live rows as packed fp16 pairs -- pair k = pixels (k, k+1) of the lane's six; a tap offset d reads pairs d and d + 2
-  [[maybe_unused]] h2 xh[X3 ? R : 1][CIW][5], xl[X3 ? R : 1][CIW][5];
 
   for (int g = 0; g < a.groups_per_split; ++g) {
     const int wu = uni((int)((blockIdx.x * a.groups_per_split + g) * WS + strip));
@@ -220,16 +198,6 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
           const bool z = rowz || (e == 0 && lz) || (e == 5 && rz);
           xr[slot][i][e] = z ? 0.f : v;
         }
-      if constexpr (X3) {
-#pragma unroll
-        for (int i = 0; i < CIW; ++i) {
-          _Float16 hi[6], lo[6];
-#pragma unroll
-          for (int e = 0; e < 6; ++e) split2(xr[slot][i][e], hi[e], lo[e]);
-#pragma unroll
-          for (int k = 0; k < 5; ++k) { xh[slot][i][k] = (h2){hi[k], hi[k + 1]}; xl[slot][i][k] = (h2){lo[k], lo[k + 1]}; }
-        }
-      }
     };
 
     // prologue, in the order of the loop's own requests: rows 0, 1, then (x row 2 + d, gy row d) for d < D
@@ -258,52 +226,8 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
 #endif
 #if !RR_SPREAD
         FENCE();                                                    // (the scheduler would sink the loads to their uses)
-#else
-        if constexpr (X3) FENCE();
 #endif
         fix_x((s + 2) % R, t + 2);
-        if constexpr (X3) {
-          h4 ghi[COW], glo[COW];
-          [[maybe_unused]] h4 shi[SC ? COW : 1], slo[SC ? COW : 1];
-#pragma unroll
-          for (int j = 0; j < COW; ++j) {
-            _Float16 hi[4], lo[4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) split2(gr[s % G][j][ks] * gsx, hi[ks], lo[ks]);
-            ghi[j] = (h4){hi[0], hi[1], hi[2], hi[3]}; glo[j] = (h4){lo[0], lo[1], lo[2], lo[3]};
-            if constexpr (SC) {
-#pragma unroll
-              for (int ks = 0; ks < 4; ++ks) split2(sr[s % G][j][ks] * gsx, hi[ks], lo[ks]);
-              shi[j] = (h4){hi[0], hi[1], hi[2], hi[3]}; slo[j] = (h4){lo[0], lo[1], lo[2], lo[3]};
-            }
-          }
-          // three passes over the tiles (hi hi | hi lo | lo hi): the two MFMAs on one cross-term accumulator are NT tiles apart
-#pragma unroll
-          for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-              for (int i = 0; i < CIW; ++i) {
-                const int slot = (s + tap / 3) % R, d = tap % 3;
-                const h4 av = pass == 2 ? __builtin_shufflevector(xl[slot][i][d], xl[slot][i][d + 2], 0, 1, 2, 3)
-                                        : __builtin_shufflevector(xh[slot][i][d], xh[slot][i][d + 2], 0, 1, 2, 3);
-#pragma unroll
-                for (int j = 0; j < COW; ++j) {
-                  const int k = (tap * CIW + i) * COW + j;
-                  if (pass == 0) acc[k] = mfma16h(av, ghi[j], acc[k]);
-                  else accx[k] = mfma16h(av, pass == 1 ? glo[j] : ghi[j], accx[k]);
-                }
-                if constexpr (SC) {
-                  if (tap == 4) {
-#pragma unroll
-                    for (int j = 0; j < COW; ++j) {
-                      if (pass == 0) acs[i * COW + j] = mfma16h(av, shi[j], acs[i * COW + j]);
-                      else acsx[i * COW + j] = mfma16h(av, pass == 1 ? slo[j] : shi[j], acsx[i * COW + j]);
-                    }
-                  }
-                }
-              }
-        } else {
         // taps of rows t, t+1 first: the row that is fixed up in this step (t+2) feeds the last third of the MFMAs only
 #pragma unroll
         for (int half = 0; half < 2; ++half)
@@ -327,11 +251,10 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
               }
             }
           }
-        }
 #if RR_SPREAD
         // issue order inside the step (one scheduling region): the step's loads and the fix-up VALU spread under the MFMAs of
         // rows t, t+1 instead of a burst in front of them (one wave per SIMD has nobody else to fill the matrix pipe meanwhile)
-        if constexpr (!X3) {
+        {
           constexpr int NLD = 6 * CIW + 4 * COW * (SC ? 2 : 1);
 #pragma unroll
           for (int q = 0; q < NLD; ++q) {
@@ -353,14 +276,6 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
     a.dbg[wg_lin * 4 + 3] = __builtin_amdgcn_s_memrealtime();
   }
 #endif
-  if constexpr (X3) {                                             // fold the cross terms, undo the gradient scale
-#pragma unroll
-    for (int k = 0; k < NT; ++k) acc[k] = (acc[k] + accx[k] * (1.f / 2048.f)) * gix;
-    if constexpr (SC) {
-#pragma unroll
-      for (int k = 0; k < NTS; ++k) acs[k] = (acs[k] + acsx[k] * (1.f / 2048.f)) * gix;
-    }
-  }
   // ---- epilogue: the WS strip waves of each sub-slab combine in a fixed order -- (w0 + w2) + (w1 + w3) for WS = 4, w0 + w1 for
   // WS = 2 -- and ALL 256 threads store the slab as 16-byte rows (one wave storing 36 tiles dword by dword was ~4 us of tail).
   constexpr int NTA = NT + NTS;
@@ -440,23 +355,20 @@ struct RrPlan {
 
 int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
-RrPlan plan_rr(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, bool aff, bool sc, bool x3 = false) {
+RrPlan plan_rr(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, bool aff, bool sc) {
   RrPlan p{};
   static const int on = env_int("SMSUT_WGRAD_RR", 1);
   if (!on || N <= 0 || H < 4 || W < 16 || (W % 16) || (H % 4) || (Cin % 16) || (Cout % 16)) return p;
   if ((int64_t)H * W * (Cin > Cout ? Cin : Cout) >= (1ll << 29)) return p;       // byte offsets inside an image are 32-bit
   if (x2 && (ca <= 0 || ca >= Cin || (ca % 16))) return p;
-  static const int v32 = env_int("SMSUT_RR_V32", 4);                            // variant for the 32 x 32 slabs: 4, 5 or 6
+  // variant for the 32 x 32 slabs: 4, 5 or 6 (tuning hook; anything else falls back to 4, so that eligible() never promises a
+  // plan launch() has no kernel for -- ADVICE r04)
+  static const int v32 = [] { const int v = env_int("SMSUT_RR_V32", 4); return (v == 4 || v == 5 || v == 6) ? v : 4; }();
   if (Cin == 16 && Cout == 16) { p.variant = 1; p.slab_ci = 16; p.slab_co = 16; p.ws = 4; }
   else if (Cin == 32 && Cout == 16) { p.variant = 2; p.slab_ci = 32; p.slab_co = 16; p.ws = 4; }
   else if (Cin == 16 && Cout == 32) { p.variant = 3; p.slab_ci = 16; p.slab_co = 32; p.ws = 4; }
   else if (Cin % 32 == 0 && Cout % 32 == 0) {
-    // split fp16 on 32 x 32 slabs: 32 x 32 per wave spills (twice the accumulators) and the 32 x 16 / two-sub-slab form measured
-    // SLOWER than the LDS-staged split kernel (42-44 vs 33-37 us at 16 x 128^2 32 -> 32 .. 16^2 256 -> 256) -> not covered here
-    // (tuning hook SMSUT_RR_X3_V32 = 6 to try it); the 16- / 32 x 16-channel slabs are where this kernel wins (32 vs 38, 64 vs 79 us)
-    static const int v32x = env_int("SMSUT_RR_X3_V32", 0);
-    if (x3 && v32x == 0) return RrPlan{};
-    const int v = x3 ? v32x : v32;
+    const int v = v32;
     p.variant = v; p.slab_ci = 32; p.slab_co = 32; p.ws = v == 4 ? 4 : (v == 5 ? 1 : 2);
   } else return p;
   if (aff && x2) return RrPlan{};
@@ -502,7 +414,7 @@ int launch_v(const RrArgs& a, const RrPlan& p, hipStream_t st) {
   dim3 grid(p.splits, a.Cin / p.slab_ci, a.Cout / p.slab_co);
 #define RR_GO(DUAL, INAFF, SC)                                                                                          \
   do {                                                                                                                  \
-    auto kfn = a.gsc ? wgrad_rr<CIW, COW, WI, WJ, R, D, DUAL, INAFF, SC, true> : wgrad_rr<CIW, COW, WI, WJ, R, D, DUAL, INAFF, SC>; \
+    auto kfn = wgrad_rr<CIW, COW, WI, WJ, R, D, DUAL, INAFF, SC>;                                                     \
     if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
     kfn<<<grid, TPB, sh, st>>>(a);                                                                                      \
     return 0;                                                                                                           \
@@ -521,24 +433,23 @@ static unsigned long long* g_rr_dbg = nullptr;
 extern "C" void smsut_dbg_rr_stamps(unsigned long long* p) { g_rr_dbg = p; }
 #endif
 
-bool smsut_wgrad_rr_eligible(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, bool aff, bool sc, bool x3) {
-  return plan_rr(N, H, W, Cin, Cout, x2, ca, aff, sc, x3).variant != 0;
+bool smsut_wgrad_rr_eligible(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, bool aff, bool sc) {
+  return plan_rr(N, H, W, Cin, Cout, x2, ca, aff, sc).variant != 0;
 }
-int smsut_wgrad_rr_splits(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, bool aff, bool sc, bool x3) {
-  const RrPlan p = plan_rr(N, H, W, Cin, Cout, x2, ca, aff, sc, x3);
+int smsut_wgrad_rr_splits(int N, int H, int W, int Cin, int Cout, const float* x2, int ca, bool aff, bool sc) {
+  const RrPlan p = plan_rr(N, H, W, Cin, Cout, x2, ca, aff, sc);
   return p.variant ? p.splits : 0;
 }
 
 int smsut_wgrad_rr_launch(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* part, int N, int H,
-                          int W, int Cin, int Cout, const RrAff* aff, hipStream_t st, const float* gsc_x3) {
-  const RrPlan p = plan_rr(N, H, W, Cin, Cout, x2, ca, aff != nullptr, gs != nullptr, gsc_x3 != nullptr);
+                          int W, int Cin, int Cout, const RrAff* aff, hipStream_t st) {
+  const RrPlan p = plan_rr(N, H, W, Cin, Cout, x2, ca, aff != nullptr, gs != nullptr);
   if (!p.variant) return -1;
   RrArgs a{};
   a.x = x; a.x2 = x2; a.ca = ca; a.gy = gy; a.gs = gs; a.part = part;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.RC = p.RC; a.groups_per_split = p.groups_per_split; a.total_wu = p.total_wu;
   if (aff) a.aff = *aff;
-  a.gsc = gsc_x3;
 #ifdef SMSUT_STAMPS
   a.dbg = g_rr_dbg;
 #endif

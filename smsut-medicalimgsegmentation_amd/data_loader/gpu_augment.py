@@ -118,20 +118,48 @@ class GpuJointAugment:
         return angs, crops, (torch.stack(ctrl) if any_el else None), out_hw
 
     def __call__(self, img, msk=None, params=None):
-        """img [N,1,H,W] on the [0, 1] scale (zeros = black outside the image), msk [N,H,W] int64 or None."""
+        """img [N,1,H,W] on the [0, 1] scale (zeros = black outside the image), msk [N,H,W] int64 or None.
+
+        The resampling path is chosen PER SLICE (a slice's pixels must not depend on what its batchmates drew):
+          * a slice that did not draw the elastic deformation: rotation and crop + resize composed into ONE bilinear pass -- the form
+            ``tests/golden/augment_pil.npz`` pins against PIL's two 8-bit steps (``tests/test_augment_pil_cpu.py``: within 1.5 grey
+            levels mean of rotate -> 8-bit -> resized_crop, externalTransforms.py:45-66);
+          * a slice that did: the reference's three steps -- rotate, round to the 8-bit grid PIL hands on, elastic deformation
+            (order 0), crop + resize."""
         n, _, H_, W_ = img.shape
         angs, crops, ctrl, (Ho, Wo) = params if params is not None else self.draw(n, (H_, W_))
-        if ctrl is None:                                     # rotation and crop composed: one resampling pass
-            aff = torch.tensor([affine_for(a, c, (H_, W_), (Ho, Wo)) for a, c in zip(angs, crops)], dtype=torch.float32)
-            return warp_joint(img, msk, aff, None, Ho, Wo)
-        # the reference's three steps (a slice without the deformation carries zero displacements: an exact copy in step 2)
-        full = (0, 0, H_, W_)
-        rot = torch.tensor([affine_for(a, full, (H_, W_), (H_, W_)) for a in angs], dtype=torch.float32)
-        img, msk = warp_joint(img, msk, rot, None, H_, W_)
-        img = torch.round(img * 255.0) / 255.0               # PIL hands an 8-bit image on (F.rotate -> Image)
-        img, msk = elastic_deform(img, msk, ctrl)
-        crop = torch.tensor([affine_for(0.0, c, (H_, W_), (Ho, Wo)) for c in crops], dtype=torch.float32)
-        return warp_joint(img, msk, crop, None, Ho, Wo)
+
+        def composed(im, mk, idx):
+            aff = torch.tensor([affine_for(angs[i], crops[i], (H_, W_), (Ho, Wo)) for i in idx], dtype=torch.float32)
+            return warp_joint(im, mk, aff, None, Ho, Wo)
+
+        def three_steps(im, mk, idx, ct):
+            full = (0, 0, H_, W_)
+            rot = torch.tensor([affine_for(angs[i], full, (H_, W_), (H_, W_)) for i in idx], dtype=torch.float32)
+            im, mk = warp_joint(im, mk, rot, None, H_, W_)
+            im = torch.round(im * 255.0) / 255.0             # PIL hands an 8-bit image on (F.rotate -> Image)
+            im, mk = elastic_deform(im, mk, ct)
+            crop = torch.tensor([affine_for(0.0, crops[i], (H_, W_), (Ho, Wo)) for i in idx], dtype=torch.float32)
+            return warp_joint(im, mk, crop, None, Ho, Wo)
+
+        if ctrl is None:                                     # nobody drew the deformation
+            return composed(img, msk, range(n))
+        drew = ctrl.flatten(1).abs().sum(1) > 0              # (a drawn grid of exact zeros has probability 0 and IS the identity)
+        ie = [i for i in range(n) if bool(drew[i])]
+        ip = [i for i in range(n) if not bool(drew[i])]
+        if not ip:
+            return three_steps(img, msk, ie, ctrl)
+        oimg = torch.empty(n, 1, Ho, Wo, dtype=torch.float32, device=img.device)
+        omsk = torch.empty(n, Ho, Wo, dtype=torch.int64, device=img.device) if msk is not None else None
+        for idx, fn in ((ip, lambda im, mk: composed(im, mk, ip)), (ie, lambda im, mk: three_steps(im, mk, ie, ctrl[ie]))):
+            if not idx:
+                continue
+            sel = torch.tensor(idx, device=img.device)
+            a, b = fn(img.index_select(0, sel), msk.index_select(0, sel) if msk is not None else None)
+            oimg.index_copy_(0, sel, a)
+            if omsk is not None:
+                omsk.index_copy_(0, sel, b)
+        return oimg, omsk
 
 
 def elastic_deform(img, msk, ctrl):

@@ -101,9 +101,12 @@ class ScalarFetcher:
     ITERATION LATER (``push`` returns the previous item, whose copy has long finished); ``flush`` returns the last one.  Same values,
     same order -- the meter / log just see them one iteration late, and the device never waits for the host."""
 
-    def __init__(self, numel: int, device):
+    def __init__(self, numel: int, device, check_finite: bool = True):
+        """``check_finite``: a NaN / Inf among the fetched scalars raises ``FloatingPointError`` naming the item's tag -- one
+        iteration after it happened, but it happens: the kernels' own maxima (fmaxf) pass over NaNs silently."""
         import torch
         self._torch = torch
+        self._check = check_finite
         self._bufs = [torch.empty(numel, dtype=torch.float32).pin_memory() if torch.device(device).type == "cuda"
                       else torch.empty(numel, dtype=torch.float32) for _ in range(2)]
         self._events = [None, None]
@@ -114,7 +117,10 @@ class ScalarFetcher:
     def _take(self, slot):
         if self._events[slot] is not None:
             self._events[slot].synchronize()
-        return self._bufs[slot].tolist(), self._tags[slot]
+        vals = self._bufs[slot].tolist()
+        if self._check and not all(v == v and abs(v) != float("inf") for v in vals):
+            raise FloatingPointError(f"non-finite training scalars {vals} at {self._tags[slot]!r}")
+        return vals, self._tags[slot]
 
     def push(self, scalars, tag=None):
         """Enqueue the device -> host copy of ``scalars`` (1-D float tensor); returns ``(values, tag)`` of the PREVIOUS push or None."""

@@ -222,18 +222,26 @@ class _WinoForm:
         self._entries = [((w.data_ptr(), e[1]), base + 4 * o) for w, e, o in zip(self.weights, ent, offs)]
 
     def enter(self):
+        """Returns the previous bindings of this form's keys (what ``exit`` restores: a nested scope over the same module hands the
+        OUTER scope's images back instead of dropping them -- ADVICE r04)."""
         if self.n == 0:
-            return
+            return ()
         # ALWAYS re-made on entry (one launch for all tensors of the form): a weight's ``_version`` is no witness of its
         # contents -- the fused optimizers (torch.optim.SGD / Adam(fused=True), what the trainers use) update in place without
         # moving it, and so does anything that writes through ``.data``
         H.call("smsut_wino_prepare", *self._addr, self.n, _s())
+        prev = tuple((key, _WINO_ACTIVE.get(key)) for key, _ in self._entries)
         for key, addr in self._entries:
             _WINO_ACTIVE[key] = addr
+        return prev
 
-    def exit(self):
-        for key, _ in (self._entries if self.n else ()):
-            _WINO_ACTIVE.pop(key, None)
+    @staticmethod
+    def exit(prev):
+        for key, addr in prev:
+            if addr is None:
+                _WINO_ACTIVE.pop(key, None)
+            else:
+                _WINO_ACTIVE[key] = addr
 
 
 class _WinoSet:
@@ -289,13 +297,14 @@ def wino_prepared(*modules: torch.nn.Module, forms: str = "fb"):
                 active.append(ws.forms[0])
             if "b" in forms:
                 active.append(ws.forms[1])
-    for f in active:
-        f.enter()
+    entered = []                                             # (form, previous bindings), in entry order
     try:
+        for f in active:                                     # inside the try: a failing enter() leaves no binding of an earlier form behind
+            entered.append((f, f.enter()))
         yield
     finally:
-        for f in active:
-            f.exit()
+        for f, prev in reversed(entered):
+            f.exit(prev)
 
 
 def _grad_scale(t: torch.Tensor) -> torch.Tensor:
@@ -779,10 +788,6 @@ SPLIT_DGRAD = bool(int(_os.environ.get("SMSUT_SPLIT_DGRAD", "1")))   # block-aft
 THIN_1X1 = bool(int(_os.environ.get("SMSUT_THIN_1X1", "1")))         # streaming dgrad / wgrad of the <= 8-channel 1x1 heads
 REMASK_TAIL = bool(int(_os.environ.get("SMSUT_REMASK_TAIL", "1")))   # two-IN tail backward: mask from y2, s instead of reading out
 FUSED_BWD_STATS = bool(int(_os.environ.get("SMSUT_FUSED_BWD_STATS", "1")))     # IN-backward statistics in the dgrad epilogue
-# opt-in: 3x3 WEIGHT GRADIENTS of the fp32 path as split-fp16 MFMA triples (every operand element hi + lo 2^-11 in two fp16 numbers,
-# hi hi + 2^-11 (hi lo + lo hi), fp32 accumulate; conv_f16_wgrad<.., X3>): measured CLOSER to fp64 than the fp32 MFMA kernels
-# (profiles/r04_split_fp16.md) at 0.7x their time.  Off by default: the headline path stays on fp32 MFMA arithmetic.
-WGRAD_X3 = bool(int(_os.environ.get("SMSUT_WGRAD_X3", "0")))
 HS_INAFF = bool(int(_os.environ.get("SMSUT_HS_INAFF", "1")))              # half storage: conv2 / its weight gradient normalise y1 while staging
 F16_STORE = bool(int(_os.environ.get("SMSUT_F16_STORE", "1")))           # fp16 operands: block-internal y1 / y2 / s stored as fp16
 AMAX_HANDOVER = bool(int(_os.environ.get("SMSUT_AMAX_HANDOVER", "1")))    # fp16 operands: gradient maxima from the producing kernels
@@ -972,9 +977,7 @@ class BasicBlockFn(Function):
         f16a, f16 = ctx.f16                                  # fp16 operands for conv1 / conv2 and their gradients
         # fp16 operands: the kernels that write gy2 / gs_t / gy1 hand their absolute maxima over (one slot per workgroup:
         # [gy2 | gs_t | gy1], nb each), the scales of the gradient operands come from those slots instead of a pass over each tensor
-        x3w2 = WGRAD_X3 and not f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, co, co))
-        x3w1 = WGRAD_X3 and not f16a and ci % 16 == 0 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, ci, co))
-        nb = H.call("smsut_amax_blocks", n, hw, co) if (f16 or f16a or x3w2 or x3w1) and AMAX_HANDOVER else 0
+        nb = H.call("smsut_amax_blocks", n, hw, co) if (f16 or f16a) and AMAX_HANDOVER else 0
         amax = torch.empty(3 * nb, dtype=torch.float32, device=dev) if nb else None
         hs = ctx.hs
         if hs:
@@ -992,7 +995,7 @@ class BasicBlockFn(Function):
         ga1 = new_act(n, co, h, w, x)
         gy1 = new_act(n, co, h, w, x)
         a1m, b1m, gg1, gb1 = vec(n, co), vec(n, co), vec(co), vec(co)
-        sc2 = (_grad_scale_from(amax[:nb]) if amax is not None else _grad_scale(gy2)) if (f16 or x3w2) else None   # serves conv2's data- and weight-gradient
+        sc2 = (_grad_scale_from(amax[:nb]) if amax is not None else _grad_scale(gy2)) if f16 else None   # serves conv2's data- and weight-gradient
         amax1 = False                                        # amax[2] = max |gy1| written
         if FUSED_BWD_STATS and H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, int(f16)):
             # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
@@ -1009,7 +1012,7 @@ class BasicBlockFn(Function):
                 H.call("smsut_in_apply_bwd_hs", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, amax[2 * nb:] if amax is not None else None,
                        n, hw, co, st)
                 amax1 = amax is not None
-            elif amax is not None and (f16a or x3w1):
+            elif amax is not None and f16a:
                 H.call("smsut_in_apply_bwd_amax", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, amax[2 * nb:], n, hw, co, st)
                 amax1 = True
             else:
@@ -1033,10 +1036,6 @@ class BasicBlockFn(Function):
         elif f16w2:
             H.call("smsut_conv2d_wgrad_f16", a1, None, 0, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x),
                    sc2, n, h, w, co, co, st)
-        elif x3w2:
-            aff = (m1, r1, g1, b1) if ctx.inaff else (None, None, None, None)
-            H.call("smsut_conv2d_wgrad_f16x3", y1 if ctx.inaff else a1, None, 0, gy2, None, gw2,
-                   _ws(H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, w, co, co, 0), x), sc2, *aff, slope, n, h, w, co, co, st)
         else:
             wws2 = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x)
             if ctx.inaff:
@@ -1049,29 +1048,19 @@ class BasicBlockFn(Function):
         fused_dsc16 = (ctx.has_sc and f16a and (ctx.needs_input_grad[0] or ctx.needs_input_grad[11] or ctx.needs_input_grad[12])
                        and bool(H.call("smsut_conv2d_dgrad_sc_f16_supported", n, h, w, co, ci, split_c)))
         # fp16 operands: the fused-shortcut kernels read [gy1 | gs_t] as ONE operand -> one scale over both tensors
-        fused_wsc_x3 = x3w1 and ctx.has_sc
-        if x3w1:
-            if fused_wsc_x3:
-                sc1 = _grad_scale_from(amax[nb:]) if amax1 else _grad_scale2(gy1, gs_t)
-            else:
-                sc1 = _grad_scale_from(amax[2 * nb:]) if amax1 else _grad_scale(gy1)
-        elif not f16a:
+        if not f16a:
             sc1 = None
         elif fused_wsc16 or fused_dsc16:
             sc1 = _grad_scale_from(amax[nb:]) if amax1 else _grad_scale2(gy1, gs_t)
         else:
             sc1 = _grad_scale_from(amax[2 * nb:]) if amax1 else _grad_scale(gy1)
-        fused_wsc = fused_wsc16 or fused_wsc_x3 or (ctx.has_sc and not f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_supported", n, h, w, ci, co)))
+        fused_wsc = fused_wsc16 or (ctx.has_sc and not f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_supported", n, h, w, ci, co)))
         if fused_wsc:
             # both weight gradients in one pass over x: rows 0..8 = conv1's taps, row 9 = the 1x1 shortcut's
             g10 = torch.empty(10 * ci * co, dtype=torch.float32, device=dev)
             gw1 = torch.as_strided(g10, (co, ci, 3, 3), hwio_strides(co, ci, 3, 3))
             gws = torch.as_strided(g10, (co, ci, 1, 1), hwio_strides(co, ci, 1, 1), 9 * ci * co)
-            if fused_wsc_x3:
-                H.call("smsut_conv2d_wgrad_f16x3", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
-                       g10, _ws(H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, w, ci, co, 1), x), sc1, None, None, None, None, slope,
-                       n, h, w, ci, co, st)
-            elif fused_wsc16:
+            if fused_wsc16:
                 H.call("smsut_conv2d_wgrad_sc_f16", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
                        g10, _ws(H.call("smsut_conv2d_wgrad_sc_f16_ws", n, h, w, ci, co), x), sc1, n, h, w, ci, co, st)
             else:
@@ -1081,9 +1070,6 @@ class BasicBlockFn(Function):
             gw1 = new_weight(co, ci, 3, 3, device=dev)
         if fused_wsc:
             pass
-        elif x3w1:
-            H.call("smsut_conv2d_wgrad_f16x3", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, None, gw1,
-                   _ws(H.call("smsut_conv2d_wgrad_f16x3_ws", n, h, w, ci, co, 0), x), sc1, None, None, None, None, slope, n, h, w, ci, co, st)
         elif f16w1:
             wws = _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, ci, co), x)
             if ctx.virtual:

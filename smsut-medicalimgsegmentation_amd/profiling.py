@@ -60,7 +60,6 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_fwd_mfma_stats_sc_f16_hs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 10, "mfma"),
     "smsut_conv2d_fwd_mfma_stats_f16_hsx": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_f16_xh": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
-    "smsut_conv2d_wgrad_f16x3": (lambda a: 2.0 * a[1] * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
     "smsut_conv2d_wgrad_f16_xh_inaff": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_fwd_mfma_stats_inaff_f16_hsx": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_dgrad_mfma_bwdstats_f16_hs": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),

@@ -510,26 +510,29 @@ class UGANConsisTrainer(UGANShp0Trainer):
         tic = time.time()
         from ..misc.utils import ScalarFetcher
         fetch = ScalarFetcher(len(SCALARS), self.device)
-        for i in range(self.n_critic * cfg.num_iter_per_epoch):
-            try:
-                x1, y_real, mo1, _ = next(lb_itr)
-            except StopIteration:
-                lb_itr = iter(lb_loader); x1, y_real, mo1, _ = next(lb_itr)
-            try:
-                x2, _, mo2, _ = next(ul_itr)
-            except StopIteration:
-                ul_itr = iter(ul_loader); x2, _, mo2, _ = next(ul_itr)
-            x_real = torch.cat([x1.to(self.device, non_blocking=True), x2.to(self.device, non_blocking=True)], 0)
-            modal_org = torch.cat([mo1, mo2], 0)
-            scal = self.train_iteration(x_real, y_real.to(self.device, non_blocking=True), modal_org)
-            # the iteration's ten scalars travel to pinned host memory without a sync and are consumed ONE ITERATION LATER
-            # (misc.utils.ScalarFetcher): same values in the same order for the meter and the log, no device stall
-            done = fetch.push(scal, (i, self.iter, int(mo1[0])))
+        try:
+            for i in range(self.n_critic * cfg.num_iter_per_epoch):
+                try:
+                    x1, y_real, mo1, _ = next(lb_itr)
+                except StopIteration:
+                    lb_itr = iter(lb_loader); x1, y_real, mo1, _ = next(lb_itr)
+                try:
+                    x2, _, mo2, _ = next(ul_itr)
+                except StopIteration:
+                    ul_itr = iter(ul_loader); x2, _, mo2, _ = next(ul_itr)
+                x_real = torch.cat([x1.to(self.device, non_blocking=True), x2.to(self.device, non_blocking=True)], 0)
+                modal_org = torch.cat([mo1, mo2], 0)
+                scal = self.train_iteration(x_real, y_real.to(self.device, non_blocking=True), modal_org)
+                # the iteration's ten scalars travel to pinned host memory without a sync and are consumed ONE ITERATION LATER
+                # (misc.utils.ScalarFetcher): same values in the same order for the meter and the log, no device stall
+                done = fetch.push(scal, (i, self.iter, int(mo1[0])))
+                if done is not None:
+                    tic = self._consume_scalars(done, meter, tic)
+        finally:
+            # also on the way out of an exception: the last finished iteration's scalars still reach the meter / the log
+            done = fetch.flush()
             if done is not None:
-                tic = self._consume_scalars(done, meter, tic)
-        done = fetch.flush()
-        if done is not None:
-            self._consume_scalars(done, meter, tic)
+                self._consume_scalars(done, meter, tic)
 
     def _consume_scalars(self, done, meter, tic):
         vals, (i, it, modality) = done
@@ -537,7 +540,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
             v, n = meter.collect_loss_by(vals[SCALARS.index("G_seg")], modality, cfg.batch_size)
             meter.accumulate(v, n)
         if (i + 1) % (self.n_critic * self.log_step) == 0:
-            self.info("Iter: %d/%d(%d), elapsed: %.2fs, " % (i, cfg.num_iter_per_epoch, it, time.time() - tic)
+            # (host time between two log lines: the host runs up to one iteration ahead of the device, so this is the enqueue
+            #  rate, equal to the device rate once the launch queue is full)
+            self.info("Iter: %d/%d(%d), elapsed (host): %.2fs, " % (i, cfg.num_iter_per_epoch, it, time.time() - tic)
                       + " ".join("%s: %.4f," % kv for kv in zip(SCALARS, vals)))
             tic = time.time()
         return tic

@@ -88,19 +88,21 @@ class UnetTrainer(BaseTrainer):
         fetch = ScalarFetcher(1, self.device)                # (the loss reaches the meter one iteration late: no device stall)
 
         def consume(done):
-            if done is not None:
+            if done is not None and meter is not None:
                 (val,), (modality, bsz) = done
                 v, n = meter.collect_loss_by(val, modality, bsz)
                 meter.accumulate(v, n)
-        for _ in range(cfg.num_iter_per_epoch):
-            try:
-                img, msk, mdl, _ = next(it)
-            except StopIteration:
-                it = iter(lb_loader)
-                img, msk, mdl, _ = next(it)
-            loss = self.train_step(img.to(self.device, non_blocking=True), msk.to(self.device, non_blocking=True))
-            consume(fetch.push(loss.reshape(1), (int(mdl[0]), img.size(0))))
-        consume(fetch.flush())
+        try:
+            for _ in range(cfg.num_iter_per_epoch):
+                try:
+                    img, msk, mdl, _ = next(it)
+                except StopIteration:
+                    it = iter(lb_loader)
+                    img, msk, mdl, _ = next(it)
+                loss = self.train_step(img.to(self.device, non_blocking=True), msk.to(self.device, non_blocking=True))
+                consume(fetch.push(loss.reshape(1), (int(mdl[0]), img.size(0))))
+        finally:
+            consume(fetch.flush())                           # (also when the loop raised: the last finished step still counts)
 
 
 def main(argv=None):

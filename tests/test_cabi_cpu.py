@@ -130,17 +130,6 @@ def test_weight_gradient_workspace_covers_every_kernel_plan():
                 assert need <= 64 * (1 << 20), (n, h, w, ci, co, need)          # bounded slabs (sum_splits re-reads them)
                 if lib.smsut_conv2d_wgrad_sc_supported(n, h, w, ci, co):
                     assert lib.smsut_conv2d_wgrad_sc_ws(n, h, w, ci, co) >= 10 * ci * co
-    # the opt-in split-fp16 entry chooses between two kernels with their own split plans: its workspace covers both, every form
-    lib.smsut_conv2d_wgrad_f16x3_ws.restype = ctypes.c_int64
-    lib.smsut_conv2d_wgrad_f16_ws.restype = ctypes.c_int64
-    lib.smsut_conv2d_wgrad_sc_f16_ws.restype = ctypes.c_int64
-    for n in (2, 16, 32):
-        for h in (256, 128, 32):
-            for (ci, co) in ((16, 16), (32, 16), (16, 32), (32, 32), (64, 128)):
-                if lib.smsut_conv2d_wgrad_f16_supported(n, h, h, ci, co):
-                    assert lib.smsut_conv2d_wgrad_f16x3_ws(n, h, h, ci, co, 0) >= lib.smsut_conv2d_wgrad_f16_ws(n, h, h, ci, co)
-                    assert lib.smsut_conv2d_wgrad_f16x3_ws(n, h, h, ci, co, 1) >= lib.smsut_conv2d_wgrad_sc_f16_ws(n, h, h, ci, co)
-                    assert lib.smsut_conv2d_wgrad_f16x3_ws(n, h, h, ci, co, 1) <= 80 * (1 << 20)
     assert lib.smsut_amax_blocks(16, 65536, 16) > 0 and lib.smsut_amax_blocks(0, 65536, 16) == 0
     assert lib.smsut_conv2d_wgrad_sc_supported(16, 256, 256, 32, 16) == 1            # r04: the register-row kernel carries the extra tile
     assert lib.smsut_conv2d_wgrad_sc_supported(16, 128, 128, 16, 32) == 1

@@ -111,8 +111,9 @@ def test_elastic_deform_kernel_matches_the_restated_elasticdeform():
 
 
 def test_augmenter_runs_the_reference_steps_when_the_deformation_is_drawn():
-    """GpuJointAugment: no slice drew the deformation -> ONE composed rotate + crop pass; one did -> rotate, 8-bit rounding,
-    elastic (order 0), crop + resize, as baseLoader.py:92-98 orders them -- checked against the oracle's passes on the same draws."""
+    """GpuJointAugment, PER SLICE: a slice that did not draw the deformation -> ONE composed rotate + crop pass; one that
+    did -> rotate, 8-bit rounding, elastic (order 0), crop + resize, as baseLoader.py:92-98 orders them -- checked against the oracle's
+    passes on the same draws; and a slice's pixels do not depend on what its batchmates drew."""
     import smsut_amd  # noqa: F401
     from smsut_amd import config as cfg
     from smsut_amd.data_loader import gpu_augment as ga
@@ -130,17 +131,24 @@ def test_augmenter_runs_the_reference_steps_when_the_deformation_is_drawn():
         xi, yi = aug(x, y, params=(angs, crops, ctrl, out_hw))
         assert tuple(xi.shape) == (4, 1, 48, 48) and tuple(yi.shape) == (4, 48, 48)
         assert float(xi.min()) >= 0.0 and float(xi.max()) <= 1.0 + 1e-6
-        seen.add(ctrl is not None)
-        if ctrl is None:
-            aff = np.array([ga.affine_for(a, c, (64, 64), (48, 48)) for a, c in zip(angs, crops)], dtype=np.float32)
-            ri, rm = AO.warp_joint(img, msk, aff, None, 48, 48)
-        else:
-            rot = np.array([ga.affine_for(a, (0, 0, 64, 64), (64, 64), (64, 64)) for a in angs], dtype=np.float32)
-            ri, rm = AO.warp_joint(img, msk, rot, None, 64, 64)
-            ri = np.round(ri * 255.0) / 255.0
-            ri, rm, _ = AO.elastic_deform_grid(ri, rm, ctrl.numpy())
-            crop = np.array([ga.affine_for(0.0, c, (64, 64), (48, 48)) for c in crops], dtype=np.float32)
-            ri, rm = AO.warp_joint(ri.astype(np.float32), rm, crop, None, 48, 48)
         gi, gm = xi[:, 0].cpu().numpy(), yi.cpu().numpy()
-        assert np.mean(np.abs(gi - ri) > 2e-2) < 1e-2 and np.mean(gm != rm) < 1e-2, (np.abs(gi - ri).max(), np.mean(gm != rm))
+        for k in range(4):
+            drew = ctrl is not None and float(ctrl[k].abs().sum()) > 0
+            seen.add(drew)
+            ik, mk = img[k:k + 1], msk[k:k + 1]
+            if not drew:
+                aff = np.array([ga.affine_for(angs[k], crops[k], (64, 64), (48, 48))], dtype=np.float32)
+                ri, rm = AO.warp_joint(ik, mk, aff, None, 48, 48)
+            else:
+                rot = np.array([ga.affine_for(angs[k], (0, 0, 64, 64), (64, 64), (64, 64))], dtype=np.float32)
+                ri, rm = AO.warp_joint(ik, mk, rot, None, 64, 64)
+                ri = np.round(ri * 255.0) / 255.0
+                ri, rm, _ = AO.elastic_deform_grid(ri, rm, ctrl[k:k + 1].numpy())
+                crop = np.array([ga.affine_for(0.0, crops[k], (64, 64), (48, 48))], dtype=np.float32)
+                ri, rm = AO.warp_joint(ri.astype(np.float32), rm, crop, None, 48, 48)
+            assert np.mean(np.abs(gi[k] - ri[0]) > 2e-2) < 1e-2 and np.mean(gm[k] != rm[0]) < 1e-2, \
+                (trial, k, drew, np.abs(gi[k] - ri[0]).max(), np.mean(gm[k] != rm[0]))
+            # the same slice alone, with the same draws: bit-identical to what it got inside the batch
+            one = aug(x[k:k + 1], y[k:k + 1], params=([angs[k]], [crops[k]], ctrl[k:k + 1] if drew else None, out_hw))
+            assert torch.equal(one[0][0], xi[k]) and torch.equal(one[1][0], yi[k]), (trial, k, drew)
     assert seen == {True, False}                                   # both branches were exercised

@@ -3,6 +3,7 @@ weight-memory layouts, drop-in module aliases, synthetic loader contract, Meter,
 import io
 
 import numpy as np
+import pytest
 import torch
 
 import smsut_amd
@@ -173,6 +174,54 @@ def test_wino_prepared_scope_is_inert_without_device_weights():
     with ops.wino_prepared(twin, blk, forms="f"):
         pass
     assert set(blk.state_dict()) == keys and set(twin.state_dict()) == keys
+
+
+def test_wino_prepared_scope_unwinds_on_failure_and_nests(monkeypatch):
+    """(1) a form whose ``enter`` raises must not leave the bindings of the forms entered before it behind (a stale image
+    would be used silently after the next optimizer step); (2) a nested scope over the same module restores the OUTER scope's
+    bindings on exit instead of dropping them.  Host logic: CPU stand-ins for the forms (no library call)."""
+    import types
+    import smsut_amd  # noqa: F401
+    from smsut_amd import ops
+
+    class Form:
+        def __init__(self, keys, addr, fail=False):
+            self.n, self._entries, self.fail = len(keys), [(k, addr) for k in keys], fail
+
+        def enter(self):
+            if self.fail:
+                raise RuntimeError("smsut_wino_prepare failed")
+            prev = tuple((k, ops._WINO_ACTIVE.get(k)) for k, _ in self._entries)
+            for k, a in self._entries:
+                ops._WINO_ACTIVE[k] = a
+            return prev
+
+        exit = staticmethod(ops._WinoForm.exit)
+
+    class Mod(torch.nn.Module):
+        pass
+
+    def module(forms):
+        m = Mod()
+        ws = types.SimpleNamespace(forms=forms, stale_layout=lambda mod: False)
+        m.__dict__["_smsut_wino_set"] = ws
+        return m
+    monkeypatch.setattr(ops, "WINO_PREPARED", True)
+    monkeypatch.setattr(ops, "CONV_F16", False)
+    assert not ops._WINO_ACTIVE
+    good = module((Form([(1, 0), (2, 0)], 100), Form([(1, 1)], 200)))
+    bad = module((Form([(3, 0)], 300), Form([(3, 1)], 400, fail=True)))
+    with pytest.raises(RuntimeError, match="smsut_wino_prepare failed"):
+        with ops.wino_prepared(good, bad):
+            raise AssertionError("the scope body must not run")
+    assert ops._WINO_ACTIVE == {}
+    inner = module((Form([(1, 0)], 111), Form([], 0)))
+    with ops.wino_prepared(good):
+        assert ops._WINO_ACTIVE == {(1, 0): 100, (2, 0): 100, (1, 1): 200}
+        with ops.wino_prepared(inner, forms="f"):
+            assert ops._WINO_ACTIVE[(1, 0)] == 111
+        assert ops._WINO_ACTIVE == {(1, 0): 100, (2, 0): 100, (1, 1): 200}       # the outer images are back
+    assert ops._WINO_ACTIVE == {}
 
 
 def test_graphed_phases_hold_no_cycle_and_close_frees_them(monkeypatch):
