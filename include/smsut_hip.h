@@ -166,6 +166,20 @@ int smsut_conv2d_wgrad_mfma_sc(const float* xa, const float* xb /*nullable*/, in
                                float* gw10, float* workspace, int N, int H, int W, int Cin, int Cout, void* stream);
 int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace,
                                 int N, int H, int W, int Cin, int Cout, int KS, void* stream);
+/* PAIRED 3x3 weight gradient: gw = wgrad(set A) + wgrad(set B) in ONE launch, for two image sets that went through the same conv
+ * (the reference differentiates every generator layer twice per iteration: G(x_real) and the cycle pass G(x_fake),
+ * trainer/uganConsisTrainer.py:152,159,179 -- autograd sums the two weight gradients; here they are summed in the kernel's
+ * accumulators).  Forms as the single-set entry points, present in both sets or in neither: x2 (virtual cat, ca channels in x),
+ * mean / rstd [N, Cin] (x is the raw conv output, lrelu(IN(.)) applied in flight; gamma, beta, slope of the shared layer), gs (fused
+ * 1x1 shortcut: gw holds 10 rows).  cat / aff / sc in the queries: 0 / 1 for those forms.  workspace: _ws floats. */
+int smsut_conv2d_wgrad_pair_supported(int NA, int NB, int H, int W, int Cin, int Cout, int cat, int aff, int sc);
+int64_t smsut_conv2d_wgrad_pair_ws(int NA, int NB, int H, int W, int Cin, int Cout, int cat, int aff, int sc);
+int smsut_conv2d_wgrad_pair(const float* xA, const float* x2A /*nullable*/, const float* gyA, const float* gsA /*nullable*/,
+                            const float* meanA /*nullable*/, const float* rstdA /*nullable*/, int NA, const float* xB,
+                            const float* x2B /*nullable*/, const float* gyB, const float* gsB /*nullable*/,
+                            const float* meanB /*nullable*/, const float* rstdB /*nullable*/, int NB, int ca,
+                            const float* gamma /*nullable*/, const float* beta /*nullable*/, float slope, float* gw, float* workspace,
+                            int H, int W, int Cin, int Cout, void* stream);
 int smsut_conv1x1_fwd_cat(const float* xa, const float* xb, int ca, const float* w, float* y, float* stats /*nullable*/,
                           int N, int HW, int Kdim, int Ndim, void* stream);
 int smsut_conv1x1_wgrad_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace, int N,

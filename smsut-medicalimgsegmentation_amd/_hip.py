@@ -95,6 +95,9 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_wgrad_sc_ws": "iiiii",
     "smsut_conv2d_wgrad_mfma_sc": "pp i pppp iiiii s",
     "smsut_conv2d_wgrad_mfma_cat": "pp i ppp iiiiii s",
+    "smsut_conv2d_wgrad_pair_supported": "iiiiiiiii",
+    "smsut_conv2d_wgrad_pair_ws": "iiiiiiiii",
+    "smsut_conv2d_wgrad_pair": "pppppp i pppppp i i pp f pp iiii s",
     # 4x4 s1 p1 (networks.NLayerDiscriminator)
     "smsut_conv2d_k4_supported": "ii",
     "smsut_conv2d_k4_fwd": "ppp iiiii i s",
@@ -191,7 +194,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_patchnce_fwd": "pppp iii f s",
     "smsut_patchnce_bwd": "pppp iii f s",
 }
-_RET_I64 = {"smsut_wino_image_floats", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_conv2d_wgrad_sc_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
+_RET_I64 = {"smsut_wino_image_floats", "smsut_conv2d_wgrad_pair_ws", "smsut_convT2x2_wgrad_ps_ws", "smsut_conv2d_wgrad_sc_ws", "smsut_conv2d_k4_wgrad_ws", "smsut_conv2d_wgrad_f16_ws", "smsut_conv2d_wgrad_sc_f16_ws", "smsut_absmax_scale_ws", "smsut_conv2d_wgrad_generic_ws", "smsut_colsum_ws", "smsut_dicece_ws", "smsut_sum_ws",
             "smsut_conv2d_wgrad_mfma_ws", "smsut_convT2x2_wgrad_mfma_ws", "smsut_conv2d_flat_wgrad_ws", "smsut_conv1x1_wgrad_ws",
             "smsut_conv1x1_thin_wgrad_ws"}
 _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supported", "smsut_conv2d_wgrad_f16_supported", "smsut_in_chunks", "smsut_amax_blocks", "smsut_conv2d_mfma_supported", "smsut_conv2d_wgrad_mfma_supported",

@@ -1835,14 +1835,17 @@ constexpr size_t fwd_p_lds() {
 }
 
 
-// dynamic LDS above the 64 KB default needs the per-kernel opt-in once (gfx950: 160 KB per workgroup)
+// resident workgroups per CU of ONE kernel instantiation at the dynamic LDS size it is launched with (which is a function of its
+// template arguments, so one query per instantiation; magic static: safe under concurrent host threads)
 template <auto Kern>
-inline void allow_big_lds(size_t bytes) {
-  static bool done = false;
-  if (!done && bytes > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    done = true;
-  }
+inline int p_occupancy(size_t lds) {
+  static const int occ = [lds] {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)Kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    int o = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, Kern, TPB, lds) != hipSuccess || o < 1) o = 1;
+    return o;
+  }();
+  return occ;
 }
 
 template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false, bool WINO = false>
@@ -1877,24 +1880,24 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   if (o16 && bst && (!f16 || !stats || aff || y2 || x2 || sc || (transposed & 2) || K8 || N8 || WINO || KS != 3)) return -1;  // fp16 y1 of the BST form
   if (tiles_out) { *tiles_out = tiles_img; return 0; }
   const int nz = N8 ? 1 : Ndim / (16 * NTN);
-  static int occ = 0;                                   // resident workgroups per CU (registers / LDS), per instantiation
-  if (occ == 0) {
-    int o = 0;
-    allow_big_lds<conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, false, false, false, WINO>>(sh);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &o, conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, false, false, false, WINO>, TPB, sh) !=
-            hipSuccess ||
-        o < 1)
-      o = 1;
-    occ = o;
-  }
-  // (tuning hook: SMSUT_P_WGS_PER_CU overrides the resident-workgroup count the grid is sized for)
+  // The persistent grid is sized for ONE resident round of the kernel instantiation ACTUALLY launched, at its own dynamic LDS size
+  // (P_K below; ADVICE r04: one occupancy figure -- the fp32 statistics form's -- used to serve every form of this template, whatever
+  // its registers and LDS: fused shortcut, fp16 operands, half storage).  Tuning hook: SMSUT_P_WGS_PER_CU overrides the count.
   static const int occ_env = [] { const char* e = getenv("SMSUT_P_WGS_PER_CU"); return e ? atoi(e) : 0; }();
-  const int64_t slots = (int64_t)device_cus() * (occ_env > 0 ? occ_env : occ);
   const int64_t items = (int64_t)N * tiles_img;
-  int ipw = (int)((items * nz + slots - 1) / slots);   // one resident round: each workgroup walks ipw consecutive items
-  if (ipw < 1) ipw = 1;
-  dim3 grid((unsigned)((items + ipw - 1) / ipw), nz);
+  int ipw = 1;
+  dim3 grid(1, nz);
+  auto size_grid = [&](int occ) {
+    const int64_t slots = (int64_t)device_cus() * (occ_env > 0 ? occ_env : occ);
+    ipw = (int)((items * nz + slots - 1) / slots);        // one resident round: each workgroup walks ipw consecutive items
+    if (ipw < 1) ipw = 1;
+    grid.x = (unsigned)((items + ipw - 1) / ipw);
+  };
+#define P_K(SH, ARGS, ...)                                  \
+  do {                                                      \
+    size_grid(p_occupancy<__VA_ARGS__>(SH));                \
+    __VA_ARGS__<<<grid, TPB, SH, st>>> ARGS;                \
+  } while (0)
   const int tr = transposed & 1;
   const BstRef bstv = bst ? *bst : BstRef{};
   const AffRef affv = aff ? *aff : AffRef{};
@@ -1903,32 +1906,27 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   do {                                                                                                                       \
     if constexpr (K8) {                                                                                                      \
       if constexpr (!BS && !DU && !IA)                                                                                       \
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, false, false, false, false, true><<<grid, TPB, sh, st>>>(                  \
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                 \
+        P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr), conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, false, false, false, false, true>);                 \
     } else if constexpr (WINO) {                                                                                             \
-      allow_big_lds<conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false, false, false, false, false, true>>(sh);      \
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(  \
-          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
+      P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr), conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false, false, false, false, false, true>);                   \
     } else if (f16)                                                                                                          \
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, true><<<grid, TPB, sh, st>>>(                                     \
-          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, gsc);                       \
+      P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, gsc), conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, true>);                       \
     else                                                                                                                     \
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false><<<grid, TPB, sh, st>>>(                                    \
-          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr);                   \
+      P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr), conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false>);                   \
   } while (0)
   if constexpr (N8) {                           // 8 result channels: data-gradient forms only (checked above)
     if constexpr (NTN == 1 && !K8 && KS == 3) {
       if (sc2) {
         if constexpr (NCH % 2 == 0)
-          conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, true><<<grid, TPB, sh, st>>>(
-              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, x2, affv, nullptr, *sc);
+          P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, x2, affv, nullptr, *sc),
+              conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, true>);
         else return -1;
       } else if (transposed & 2)
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, false, true, false, false, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, nullptr, affv, nullptr);
+        P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, nullptr, affv, nullptr),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, false, true, false, false, false, false, false, false, false, true>);
       else
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, false, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, nullptr, affv, nullptr);
+        P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, nullptr, 0, nullptr, affv, nullptr),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, false, false, false, false, false, false, true>);
       return 0;
     } else return -1;
   } else if (sc2) {
@@ -1937,27 +1935,27 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     if constexpr (!K8 && KS == 3 && NCH % 2 == 0) {
       if (f16) {
         if constexpr (!WINO)
-          conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, true, false, false, true><<<grid, TPB, sh, st>>>(
-              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, gsc, *sc);
+          P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, gsc, *sc),
+              conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, true, false, false, true>);
         else return -1;
       } else
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, false, WINO><<<grid, TPB, sh, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc);
+        P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 1, nullptr, bstv, y2, split, x2, affv, nullptr, *sc),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, false, true, false, false, false, false, true, false, WINO>);
     } else return -1;
   } else if (sc) {
     if constexpr (K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (o16)
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true, false, false, false, true><<<grid, TPB, sh_sc, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+        P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true, false, false, false, true>);
       else
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true><<<grid, TPB, sh_sc, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+        P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true>);
     } else if constexpr (!K8 && KS == 3 && sh_sc <= 64 * 1024) {
       if (f16) {                                   // fp16 operands (config 5; r04): direct form, plain or virtual-cat input
         if constexpr (!WINO) {
 #define SC16_GO(DU, O)                                                                                                        \
-  conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, DU, false, true, false, true, false, false, false, O><<<grid, TPB, sh_sc, st>>>( \
-      x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc)
+  P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc),           \
+      conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, DU, false, true, false, true, false, false, false, O>)
           if (x2) {
             if constexpr (NCH % 2 == 0) { if (o16) SC16_GO(true, true); else SC16_GO(true, false); }
             else return -1;
@@ -1968,18 +1966,18 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
         } else return -1;
       } else if (x2) {
         if constexpr (NCH % 2 == 0)
-          conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true, false, false, WINO><<<grid, TPB, sh_sc, st>>>(
-              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc);
+          P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc),
+              conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true, false, false, WINO>);
         else return -1;
       } else {
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true, false, false, WINO><<<grid, TPB, sh_sc, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc);
+        P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true, false, false, WINO>);
       }
     } else return -1;
   } else if (aff && i16) {                        // fp16 y1 in, normalised while staged, fp16 y2 out (half-storage conv2)
     if constexpr (!K8 && !WINO && KS == 3)
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, true, true, false, false, false, false, false, true, true><<<grid, TPB, sh, st>>>(
-          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr);
+      P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr),
+          conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, true, true, false, false, false, false, false, true, true>);
     else return -1;
   } else if (aff) {
     P_GO(true, false, false, false, true);
@@ -1987,23 +1985,23 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
     if constexpr (!K8 && !WINO && KS == 3) {
       if (x2) {
         if constexpr (NCH % 2 == 0)
-          conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
-              x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr);
+          P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr),
+              conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, true, false, false, false, false, false, true>);
         else return -1;
       } else if (i16)
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, false, false, false, false, true, true><<<grid, TPB, sh, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr);
+        P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, false, false, false, false, true, true>);
       else
-        conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
-            x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr);
+        P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, true, false, false, false, false, false, true>);
     } else return -1;
   } else if (x2) {
     if constexpr (NCH % 2 == 0) P_GO(true, false, false, true, false);
     else return -1;
   } else if (bst && o16) {
     if constexpr (!K8 && !WINO && KS == 3)
-      conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, true, false, false, true, false, false, false, false, false, true><<<grid, TPB, sh, st>>>(
-          x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, nullptr, 0, nullptr, affv, gsc);
+      P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, nullptr, 0, nullptr, affv, gsc),
+          conv_mfma_fwd_p<KS, TH, NTN, NCH, false, false, true, false, false, true, false, false, false, false, false, true>);
     else return -1;
   } else if (bst) {
     if (!stats || (transposed & 2)) return -1;
@@ -2014,6 +2012,7 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   } else if (stats) P_GO(true, false, false, false, false);
   else P_GO(false, false, false, false, false);
 #undef P_GO
+#undef P_K
   return 0;
   }
 }
@@ -3124,6 +3123,44 @@ int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const 
                                 int N, int H, int W, int Cin, int Cout, int KS, void* stream) {
   SMSUT_REQUIRE(xb);
   return wgrad_mfma_launch(xa, gy, gw, workspace, N, H, W, Cin, Cout, KS, stream, xb, ca);
+}
+
+// PAIRED 3x3 weight gradient (r05): gw = wgrad(set A) + wgrad(set B) in ONE launch of the register-row kernel, for two image sets
+// that went through the SAME conv -- the two generator passes of a uganConsis iteration (G(x_real), G(x_fake); reference
+// uganConsisTrainer.py:152,159) differentiate every layer twice with 16 slices each; paired, a layer's weight gradient is one launch
+// over 32 slices (the fixed part of a launch -- prologue, first-row latency, combine, slab store, the split-slab sum -- is paid once
+// and the split plan is the 32-slice one).  Form flags as the single-set entry points: x2 (virtual cat, ca channels in x), mean /
+// rstd (x is the RAW conv output, lrelu(IN(.)) applied in flight: gamma, beta, slope shared -- same layer), gs (fused 1x1 shortcut,
+// gw holds 10 rows); each present in BOTH sets or in neither.
+int smsut_conv2d_wgrad_pair_supported(int NA, int NB, int H, int W, int Cin, int Cout, int cat, int aff, int sc) {
+  static const bool on = [] { const char* e = getenv("SMSUT_WGRAD_PAIR"); return !e || atoi(e) != 0; }();
+  if (!on || NA <= 0 || NB <= 0 || (cat && aff) || (aff && sc)) return 0;
+  if (sc && !smsut_conv2d_wgrad_sc_supported(NA + NB, H, W, Cin, Cout)) return 0;
+  return smsut_wgrad_rr_eligible(NA + NB, H, W, Cin, Cout, cat ? (const float*)1 : nullptr, cat ? Cin / 2 : 0, aff != 0, sc != 0) ? 1 : 0;
+}
+int64_t smsut_conv2d_wgrad_pair_ws(int NA, int NB, int H, int W, int Cin, int Cout, int cat, int aff, int sc) {
+  return (int64_t)smsut_wgrad_rr_splits(NA + NB, H, W, Cin, Cout, cat ? (const float*)1 : nullptr, cat ? Cin / 2 : 0, aff != 0, sc != 0) *
+         (sc ? 10 : 9) * Cin * Cout;
+}
+int smsut_conv2d_wgrad_pair(const float* xA, const float* x2A, const float* gyA, const float* gsA, const float* meanA,
+                            const float* rstdA, int NA, const float* xB, const float* x2B, const float* gyB, const float* gsB,
+                            const float* meanB, const float* rstdB, int NB, int ca, const float* gamma, const float* beta, float slope,
+                            float* gw, float* workspace, int H, int W, int Cin, int Cout, void* stream) {
+  SMSUT_REQUIRE(xA && gyA && xB && gyB && gw && workspace);
+  SMSUT_REQUIRE((x2A != nullptr) == (x2B != nullptr) && (gsA != nullptr) == (gsB != nullptr));
+  const bool aff = meanA != nullptr;
+  SMSUT_REQUIRE(aff == (rstdA != nullptr) && aff == (meanB != nullptr) && aff == (rstdB != nullptr) && (!aff || (gamma && beta)));
+  SMSUT_REQUIRE(smsut_conv2d_wgrad_pair_supported(NA, NB, H, W, Cin, Cout, x2A != nullptr, aff, gsA != nullptr));
+  SMSUT_REQUIRE(!x2A || (ca > 0 && ca < Cin && ca % 16 == 0));
+  hipStream_t st = (hipStream_t)stream;
+  const RrAff ra{meanA, rstdA, gamma, beta, slope};
+  const RrSetB sb{xB, x2B, gyB, gsB, meanB, rstdB, NB};
+  if (smsut_wgrad_rr_launch(xA, x2A, x2A ? ca : 0, gyA, gsA, workspace, NA + NB, H, W, Cin, Cout, aff ? &ra : nullptr, st, &sb) != 0)
+    return SMSUT_EINVAL;
+  launch_sum_splits(workspace, gw, (gsA ? 10 : 9) * Cin * Cout,
+                    smsut_wgrad_rr_splits(NA + NB, H, W, Cin, Cout, x2A, x2A ? ca : 0, aff, gsA != nullptr), st);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
 }
 
 // ---- fp16-operand entry points (BASELINE config 5; see the block comment above mfma16h) -----------------------------------

@@ -56,6 +56,10 @@ struct RrArgs {
   int groups_per_split;                         // groups of WS wave-units a workgroup walks
   int total_wu;                                 // N * (H / RC) * (W / 16)
   RrAff aff;
+  // PAIRED launch (smsut_conv2d_wgrad_pair): images n >= N1 belong to a SECOND set of tensors that went through the same conv
+  // (another forward pass of the same layer) -- one launch, one slab set, both sets summed in the accumulators.  N1 == N: one set.
+  int N1;
+  const float* xB; const float* x2B; const float* gyB; const float* gsB; const float* meanB; const float* rstdB;
 #ifdef SMSUT_STAMPS                             // diagnostic build only (scratch/rr_clock.py): per-workgroup cycle / real-time stamps
   unsigned long long* dbg;                      // [workgroups][4]: s_memtime, s_memrealtime at the start and at the end of wave 0
 #endif
@@ -104,16 +108,17 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
     for (int k = 0; k < NTS; ++k) acs[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  // per ci tile: source tensor, its channel stride, the tile's first channel inside it (uniform)
-  const float* xs[CIW];
+  // per ci tile: which source tensor (first / second part of a virtual cat), its channel stride, the tile's first channel inside
+  // it (uniform; the tensors themselves are picked per wave-unit: a paired launch has two sets)
+  bool second[CIW];
   int cs[CIW], cf[CIW];
 #pragma unroll
   for (int i = 0; i < CIW; ++i) {
     const int c = ci0 + 16 * i;
     if (DUAL && a.x2) {
-      if (c < a.ca) { xs[i] = a.x; cs[i] = a.ca; cf[i] = c; }
-      else { xs[i] = a.x2; cs[i] = Cin - a.ca; cf[i] = c - a.ca; }
-    } else { xs[i] = a.x; cs[i] = Cin; cf[i] = c; }
+      if (c < a.ca) { second[i] = false; cs[i] = a.ca; cf[i] = c; }
+      else { second[i] = true; cs[i] = Cin - a.ca; cf[i] = c - a.ca; }
+    } else { second[i] = false; cs[i] = Cin; cf[i] = c; }
   }
 
   constexpr int G = (R % (D + 1) == 0) ? D + 1 : R;        // gy ring: the row in use + D in flight
@@ -124,8 +129,14 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
   for (int g = 0; g < a.groups_per_split; ++g) {
     const int wu = uni((int)((blockIdx.x * a.groups_per_split + g) * WS + strip));
     if (wu >= a.total_wu) break;                                   // (uniform per wave; the combine below is outside the loop)
-    const int xsn = wu % NXS, ycn = (wu / NXS) % NYC, n = wu / (NXS * NYC);
+    const int xsn = wu % NXS, ycn = (wu / NXS) % NYC, nall = wu / (NXS * NYC);
     const int x0 = xsn << 4, y0 = ycn * RC;
+    const bool setb = nall >= a.N1;                                // (uniform) second image set of a paired launch
+    const int n = setb ? nall - a.N1 : nall;
+    const float* const px = setb ? a.xB : a.x;
+    const float* const px2 = setb ? a.x2B : a.x2;
+    const float* const pgy = setb ? a.gyB : a.gy;
+    const float* const pgs = setb ? a.gsB : a.gs;
     const bool lz = (x0 == 0) && kq == 0, rz = (x0 + 16 == W) && kq == 3;
     // Buffer descriptors of this image (wave-uniform inputs, so every load is ONE buffer_load_dword with the row in the scalar
     // offset); lane byte offsets inside a row of the source / of gy, the two edge pixels clamped into the row.
@@ -133,11 +144,11 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
     int rowb[DUAL ? CIW : 1];                                      // bytes per image row of the source
 #pragma unroll
     for (int i = 0; i < (DUAL ? CIW : 1); ++i) {
-      sx[i] = make_rsrc(xs[i] + (size_t)n * H * W * cs[i], H * W * cs[i] * 4);
+      sx[i] = make_rsrc((second[i] ? px2 : px) + (size_t)n * H * W * cs[i], H * W * cs[i] * 4);
       rowb[i] = uni(W * cs[i] * 4);
     }
-    const rsrc_t sg = make_rsrc(a.gy + (size_t)n * H * W * Cout, H * W * Cout * 4);
-    [[maybe_unused]] const rsrc_t ss = make_rsrc(SC ? a.gs + (size_t)n * H * W * Cout : a.gy, H * W * Cout * 4);
+    const rsrc_t sg = make_rsrc(pgy + (size_t)n * H * W * Cout, H * W * Cout * 4);
+    [[maybe_unused]] const rsrc_t ss = make_rsrc(SC ? pgs + (size_t)n * H * W * Cout : pgy, H * W * Cout * 4);
     const int rowg = uni(W * Cout * 4);
     int vx[DUAL ? CIW : 1][6], vg[4];
 #pragma unroll
@@ -152,10 +163,12 @@ __global__ void __launch_bounds__(TPB, (CIW == 2 && COW == 2) ? RR_OCC4 : 1) wgr
     for (int ks = 0; ks < 4; ++ks) vg[ks] = ((x0 + 4 * kq + ks) * Cout + co0 + lm) * 4;
     [[maybe_unused]] float am[CIW], ar[CIW], ag[CIW], ab[CIW];
     if constexpr (INAFF) {
+      const float* const pm = setb ? a.meanB : a.aff.mean;
+      const float* const pr = setb ? a.rstdB : a.aff.rstd;
 #pragma unroll
       for (int i = 0; i < CIW; ++i) {
         const int c = ci0 + 16 * i + lm;
-        am[i] = a.aff.mean[(size_t)n * Cin + c]; ar[i] = a.aff.rstd[(size_t)n * Cin + c];
+        am[i] = pm[(size_t)n * Cin + c]; ar[i] = pr[(size_t)n * Cin + c];
         ag[i] = a.aff.gamma[c]; ab[i] = a.aff.beta[c];
       }
     }
@@ -442,14 +455,22 @@ int smsut_wgrad_rr_splits(int N, int H, int W, int Cin, int Cout, const float* x
 }
 
 int smsut_wgrad_rr_launch(const float* x, const float* x2, int ca, const float* gy, const float* gs, float* part, int N, int H,
-                          int W, int Cin, int Cout, const RrAff* aff, hipStream_t st) {
+                          int W, int Cin, int Cout, const RrAff* aff, hipStream_t st, const RrSetB* b) {
   const RrPlan p = plan_rr(N, H, W, Cin, Cout, x2, ca, aff != nullptr, gs != nullptr);
   if (!p.variant) return -1;
+  if (b && (b->n <= 0 || b->n >= N || !b->x || !b->gy || (x2 != nullptr) != (b->x2 != nullptr) || (gs != nullptr) != (b->gs != nullptr) ||
+            (aff != nullptr) != (b->mean != nullptr && b->rstd != nullptr)))
+    return -1;
   RrArgs a{};
   a.x = x; a.x2 = x2; a.ca = ca; a.gy = gy; a.gs = gs; a.part = part;
   a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.RC = p.RC; a.groups_per_split = p.groups_per_split; a.total_wu = p.total_wu;
   if (aff) a.aff = *aff;
+  a.N1 = N;
+  if (b) {
+    a.N1 = N - b->n;
+    a.xB = b->x; a.x2B = b->x2; a.gyB = b->gy; a.gsB = b->gs; a.meanB = b->mean; a.rstdB = b->rstd;
+  }
 #ifdef SMSUT_STAMPS
   a.dbg = g_rr_dbg;
 #endif
