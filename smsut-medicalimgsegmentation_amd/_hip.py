@@ -203,7 +203,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_conv1x1_tiles", "smsut_conv1x1_thin_supported", "smsut_conv2d_mfma_split_supported", "smsut_conv2d_mfma_cat_supported",
                          "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_fwd_sc_f16_supported", "smsut_conv2d_dgrad_sc_supported",
                          "smsut_conv2d_dgrad_sc_f16_supported", "smsut_conv2d_wgrad_sc_f16_supported", "smsut_conv2d_f16_hs_supported",
-                         "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported",
+                         "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported", "smsut_conv2d_wgrad_pair_supported",
                          "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,

@@ -89,3 +89,128 @@ __device__ __forceinline__ CatSrc cat_src(const float* x, const float* x2, int C
   if (!x2) return CatSrc{x, Ctot, 0};
   return c < ca ? CatSrc{x, ca, 0} : CatSrc{x2, Ctot - ca, ca};
 }
+
+// ---- in-launch InstanceNorm finalize by the last-arriving workgroup (r05) -----------------------------------------------------
+// A statistics-producing conv kernel leaves per-tile partials {sum, sum of squares} (or the backward pair) and a SEPARATE launch
+// (in_moments_final, norm.hip: 4.7 us at the dependent-launch floor, ~220 of them per uganConsis iteration) used to combine
+// them per (image, channel).  With a FinRef the workgroup whose partials complete an image runs that same fixed-order fp64
+// combine itself, at the end of the producing kernel:
+//   * partials are stored WRITE-THROUGH (8-byte sc1 stores: they leave the XCD's L2 at once, no release fence -- r02's variant
+//     of this, `__threadfence()` in every workgroup, wrote back whole L2s and cost 15-27 % of the step);
+//   * the storing wave drains (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane adds the workgroup's tile count
+//     to the image's ticket (agent-scope atomic; the eight XCD L2s do not see each other's plain stores);
+//   * the workgroup whose add completes the image -- told by the value the add returned -- reads every partial of the image with
+//     sc1 loads (they bypass this CU's L1, which may hold stale lines of the buffer) after a barrier the adding lane joins,
+//     combines in the order in_moments_final uses (bit-identical results) and resets the ticket to 0 for the next launch.
+// (MI355X_MICROARCH.md "inter-workgroup visibility", valid form: one agent-scope add per storing workgroup, last arriver loads
+// sc1.)  tickets: int [N], ZERO on entry, zero again on exit; null = no in-launch finalize (plain stores, separate launch).
+struct FinRef {
+  int* tickets;
+  float* o0; float* o1;          // [N][C]: (mean, rstd) of the forward statistics | (mean gz, mean gz * xhat) of the backward pair
+  float* s0; float* s1;          // fused shortcut: the second statistics set's (mean, rstd); null otherwise
+  float eps;
+};
+
+typedef unsigned long long smsut_u64;
+__device__ __forceinline__ void st_sc1_f2(float* p, float a, float b) {      // 8-byte write-through store
+  const smsut_u64 bits = ((smsut_u64)__float_as_uint(b) << 32) | (smsut_u64)__float_as_uint(a);
+  __hip_atomic_store((smsut_u64*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void ld_sc1_f2(const float* p, float& a, float& b) {
+  const smsut_u64 bits = __hip_atomic_load((const smsut_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  a = __uint_as_float((unsigned)bits); b = __uint_as_float((unsigned)(bits >> 32));
+}
+
+// Combine one image's partials part[chunks][C][2] -> o0[C], o1[C].  FWD: (mean, rstd = 1/sqrt(var + eps)); else the two means.
+// Whole workgroup (256 threads), sm: >= 256 * 2 doubles of LDS nobody else uses any more.  Summation order = in_moments_final_body
+// (norm.hip): per channel, chunk lanes l = 0..15 each add rows l, l+16, ... in fp64, then the 16 lane sums in lane order -- with
+// <= 16 chunks that is the plain sum in chunk order, done by ONE thread per channel without a barrier.
+template <bool FWD>
+__device__ __forceinline__ void fin_image(const float* part, int chunks, int C, int HW, float eps, float* o0, float* o1, double* sm) {
+  const double inv = 1.0 / (double)HW;
+  auto emit = [&](int c, double t0, double t1) {
+    if (FWD) {
+      const double m = t0 * inv;
+      double var = t1 * inv - m * m;
+      if (var < 0.0) var = 0.0;
+      o0[c] = (float)m;
+      o1[c] = (float)(1.0 / sqrt(var + (double)eps));
+    } else {
+      o0[c] = (float)(t0 * inv);
+      o1[c] = (float)(t1 * inv);
+    }
+  };
+  if (chunks <= 16) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float a[16], b[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) ld_sc1_f2(part + ((size_t)(u < chunks ? u : 0) * C + c) * 2, a[u], b[u]);
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { t0 += (u < chunks) ? (double)a[u] : 0.0; t1 += (u < chunks) ? (double)b[u] : 0.0; }
+      emit(c, t0, t1);
+    }
+    return;
+  }
+  const int col = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  for (int cb = 0; cb < C; cb += 16) {                       // (uniform: barriers inside)
+    const int c = cb + col;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C) {
+      constexpr int U = 16;
+      for (int ch = cl; ch < chunks; ch += U * 16) {
+        float a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = ch + u * 16;
+          ld_sc1_f2(part + ((size_t)(r < chunks ? r : ch) * C + c) * 2, a[u], b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          s0 += (ch + u * 16 < chunks) ? (double)a[u] : 0.0;
+          s1 += (ch + u * 16 < chunks) ? (double)b[u] : 0.0;
+        }
+      }
+    }
+    sm[threadIdx.x * 2] = s0; sm[threadIdx.x * 2 + 1] = s1;
+    __syncthreads();
+    if (cl == 0 && c < C) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int l = 0; l < 16; ++l) { t0 += sm[(l * 16 + col) * 2]; t1 += sm[(l * 16 + col) * 2 + 1]; }
+      emit(c, t0, t1);
+    }
+    __syncthreads();
+  }
+}
+
+// End of a statistics-producing persistent kernel: this workgroup produced the partials of items [item0, item1) (item = image *
+// tiles_img + tile) for its channel group; `units_per_image` = tiles_img * (channel groups of the grid).  stats / stats2: the
+// partial buffers [N][tiles_img][C][2] (stats2 with fin.s0: the fused shortcut's).  Called by ALL threads, after the last partial
+// store; `flag`: one int of LDS, sm as fin_image.
+template <bool FWD>
+__device__ __forceinline__ void fin_tail(const FinRef& fin, const float* stats, const float* stats2, int item0, int item1, int tiles_img,
+                                         int units_per_image, int C, int HW, int* flag, double* sm) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its write-through partial stores have left
+  __syncthreads();
+  const int n0 = item0 / tiles_img, n1 = (item1 - 1) / tiles_img;
+  for (int n = n0; n <= n1; ++n) {                           // (uniform)
+    const int lo = max(item0, n * tiles_img), hi = min(item1, (n + 1) * tiles_img);
+    if (threadIdx.x == 0) {
+      const int k = hi - lo;
+      const int t = __hip_atomic_fetch_add(fin.tickets + n, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (t + k == units_per_image) ? 1 : 0;
+    }
+    __syncthreads();                                         // the adding lane joins: its add has returned
+    const bool last = *flag != 0;
+    __syncthreads();                                         // (flag is rewritten for the next image)
+    if (last) {
+      fin_image<FWD>(stats + (size_t)n * tiles_img * C * 2, tiles_img, C, HW, fin.eps, fin.o0 + (size_t)n * C, fin.o1 + (size_t)n * C, sm);
+      if (FWD && fin.s0) {
+        __syncthreads();
+        fin_image<true>(stats2 + (size_t)n * tiles_img * C * 2, tiles_img, C, HW, fin.eps, fin.s0 + (size_t)n * C, fin.s1 + (size_t)n * C, sm);
+      }
+      if (threadIdx.x == 0) __hip_atomic_store(fin.tickets + n, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+    }
+  }
+}

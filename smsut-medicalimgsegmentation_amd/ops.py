@@ -800,6 +800,93 @@ def basic_block_fusable(x, w1, ws):
             and (ws is not None or ci == co))
 
 
+# ------------------------------------------------------------------------------------------- paired weight gradients
+# A uganConsis iteration runs the generator twice with the same weights -- G(x_real) and the cycle pass G(x_fake) (reference
+# trainer/uganConsisTrainer.py:152,159) -- and differentiates both passes in one G-step (:179), so every 3x3 layer has its weight
+# gradient computed TWICE over 16 slices, and autograd adds the two.  At 16 slices the fixed part of a weight-gradient launch
+# (prologue, first-row latency, cross-strip combine, slab store, the split-slab sum behind it) is a third of its time.  Inside
+# ``pair_wgrads()`` scopes the fused blocks' backward therefore PAIRS the two passes: the node that runs first parks its operands
+# (``_PAIR_STASH``, keyed by the weight's storage -- the cycle pass runs on parameter aliases of the same storage) and returns no
+# weight gradient; the node of the other pass launches ONE ``smsut_conv2d_wgrad_pair`` over both image sets and returns the sum.
+# Same products, summed in the kernel's accumulators instead of by a separate add; deterministic (autograd's order is).
+# ``SMSUT_WGRAD_PAIR=0`` (read by the library: ``smsut_conv2d_wgrad_pair_supported`` then says no) keeps two launches.
+_PAIR_FWD = False
+_PAIR_STASH = {}
+
+
+@contextlib.contextmanager
+def pair_wgrads():
+    """Forward scope: fused blocks run inside take part in weight-gradient pairing.  The caller guarantees that every weight used
+    inside such scopes is used an EVEN number of times before ``pair_assert_empty()`` (the trainer: both generator passes)."""
+    global _PAIR_FWD
+    prev, _PAIR_FWD = _PAIR_FWD, True
+    try:
+        yield
+    finally:
+        _PAIR_FWD = prev
+
+
+def pair_reset():
+    """Forget parked operands (start of an iteration: an iteration that died half-way must not pair with the next one)."""
+    _PAIR_STASH.clear()
+
+
+def pair_flush():
+    """End of the iteration's LAST backward (inside that phase, so that a captured phase holds these launches too): operand sets
+    still parked have no partner in this iteration -- e.g. the cycle pass' segmentation branch gets no gradient before the
+    consistency term switches on (reference uganConsisTrainer.py:165: iter >= 1000), so the G(x_real) nodes of that branch wait in
+    vain -- and are computed alone, as they would have been without pairing, and handed to their weight's ``.grad``."""
+    if not _PAIR_STASH:
+        return 0
+    n = 0
+    for key in list(_PAIR_STASH):
+        for mine, single, deliver in _PAIR_STASH.pop(key):
+            deliver(single(mine))
+            n += 1
+    return n
+
+
+def pair_assert_empty():
+    """After ``pair_flush()``: nothing may be parked across iterations."""
+    if _PAIR_STASH:
+        n = sum(len(v) for v in _PAIR_STASH.values())
+        _PAIR_STASH.clear()
+        raise RuntimeError(f"ops.pair_wgrads: {n} parked weight-gradient operand set(s) were never computed (pair_flush() missing "
+                           "at the end of the iteration's last backward)")
+
+
+def _add_grad(p, g):
+    """What autograd's AccumulateGrad does for a leaf, for a gradient that arrives outside the engine (``pair_flush``)."""
+    if p.grad is None:
+        p.grad = g
+    else:
+        p.grad = p.grad + g
+
+
+def _pair_wgrad(key, mine, ca, gamma, beta, slope, rows, h, w, ci, co, single, deliver):
+    """Park ``mine`` = (x, x2, gy, gs, mean, rstd, n) under ``key`` and return None, or -- when the other pass is parked there --
+    launch the paired weight gradient over both sets and return gw [rows][ci][co] (flat).  ``single(set)``: the one-set launch
+    (flat result; used when the library refuses the pair at the partner's batch size, and by ``pair_flush`` for a set that never
+    met a partner, whose result goes to ``deliver``)."""
+    lst = _PAIR_STASH.get(key)
+    if not lst:
+        _PAIR_STASH.setdefault(key, []).append((mine, single, deliver))
+        return None
+    other = lst.pop()[0]
+    if not lst:
+        del _PAIR_STASH[key]
+    xa, x2a, gya, gsa, ma, ra, na = mine
+    xb, x2b, gyb, gsb, mb, rb, nb = other
+    cat, aff, sc = int(x2a is not None), int(ma is not None), int(gsa is not None)
+    if not H.call("smsut_conv2d_wgrad_pair_supported", na, nb, h, w, ci, co, cat, aff, sc):
+        return single(mine) + single(other)
+    gw = torch.empty(rows * ci * co, dtype=torch.float32, device=xa.device)
+    ws = _ws(H.call("smsut_conv2d_wgrad_pair_ws", na, nb, h, w, ci, co, cat, aff, sc), xa)
+    H.call("smsut_conv2d_wgrad_pair", xa, x2a, gya, gsa, ma, ra, na, xb, x2b, gyb, gsb, mb, rb, nb, ca, gamma if aff else None,
+           beta if aff else None, float(slope), gw, ws, h, w, ci, co, _s())
+    return gw
+
+
 class BasicBlockFn(Function):
     """out = act(IN(conv3x3(act(IN(conv3x3(x))))) + IN(conv1x1(x)) | x)   (network/blocks.py:53-80).
 
@@ -816,6 +903,7 @@ class BasicBlockFn(Function):
         # block-input gradient straight into the two parts (split-output data-gradients) instead of returning d/dx
         # x None (with xa, xb): the cat is never materialised -- conv1, the shortcut and their weight gradients read the two
         # parts in place (virtual-cat entry points; chunk order and arithmetic of the materialised cat: same bits)
+        leaves = (w1, w2, ws)                        # (as passed: the tensors autograd accumulates into)
         ctx.cat_split = (xa.shape[1], xb.shape[1]) if xa is not None else None
         virtual = x is None
         ctx.virtual = virtual
@@ -931,6 +1019,8 @@ class BasicBlockFn(Function):
         H.call("smsut_restail_fwd_hs" if hs else "smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, co, slope, st)
         ctx.has_sc = has_sc
         ctx.slope = slope
+        ctx.pair = _PAIR_FWD and not CONV_F16
+        ctx.pair_w = leaves if ctx.pair else None      # the leaves a parked set's gradient goes to if it never meets a partner
         if virtual:
             ctx.save_for_backward(xa, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs, xb)
         elif has_sc:
@@ -1024,9 +1114,9 @@ class BasicBlockFn(Function):
                 _conv3("smsut_conv2d_fwd_mfma", w2, 1, gy2, w2, ga1, n, h, w, co, co, 3, 1, st)
             H.call("smsut_instnorm_bwd", ga1, y1, b1, m1, r1, g1, gy1, a1m, b1m, gg1, gb1, _ws(n * chunks * co * 3, x),
                    n, hw, co, slope, st)
-        gw2 = new_weight(co, co, 3, 3, device=dev)
         f16w2 = f16 and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, co, co))
         f16w1 = f16a and bool(H.call("smsut_conv2d_wgrad_f16_supported", n, h, w, ci, co))
+        gw2 = new_weight(co, co, 3, 3, device=dev) if (hs or f16w2) else None
         if hs and a1 is None:
             H.call("smsut_conv2d_wgrad_f16_xh_inaff", y1, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x), sc2,
                    m1, r1, g1, b1, slope, n, h, w, co, co, st)
@@ -1037,11 +1127,25 @@ class BasicBlockFn(Function):
             H.call("smsut_conv2d_wgrad_f16", a1, None, 0, gy2, gw2, _ws(H.call("smsut_conv2d_wgrad_f16_ws", n, h, w, co, co), x),
                    sc2, n, h, w, co, co, st)
         else:
-            wws2 = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, co, co, 3), x)
-            if ctx.inaff:
-                H.call("smsut_conv2d_wgrad_mfma_inaff", y1, gy2, gw2, wws2, m1, r1, g1, b1, slope, n, h, w, co, co, st)
+            def single2(t):                               # -> flat [9][co][co]
+                g = torch.empty(9 * co * co, dtype=torch.float32, device=dev)
+                wws2 = _ws(H.call("smsut_conv2d_wgrad_mfma_ws", t[6], h, w, co, co, 3), t[0])
+                if t[4] is not None:
+                    H.call("smsut_conv2d_wgrad_mfma_inaff", t[0], t[2], g, wws2, t[4], t[5], g1, b1, slope, t[6], h, w, co, co, _s())
+                else:
+                    H.call("smsut_conv2d_wgrad_mfma", t[0], t[2], g, wws2, t[6], h, w, co, co, 3, _s())
+                return g
+            as_w2 = lambda g: torch.as_strided(g, (co, co, 3, 3), hwio_strides(co, co, 3, 3))     # noqa: E731
+            mine2 = (y1, None, gy2, None, m1, r1, n) if ctx.inaff else (a1, None, gy2, None, None, None, n)
+            if ctx.pair and H.call("smsut_conv2d_wgrad_pair_supported", n, n, h, w, co, co, 0, int(ctx.inaff), 0):
+                # the other generator pass through this layer is (or will be) parked under the weight's storage: one launch for both
+                leaf2 = ctx.pair_w[1]
+                gw2 = _pair_wgrad(("w2", w2.data_ptr()), mine2, 0, g1, b1, slope, 9, h, w, co, co, single2,
+                                  lambda g: _add_grad(leaf2, as_w2(g)))
+                if gw2 is not None:
+                    gw2 = as_w2(gw2)
             else:
-                H.call("smsut_conv2d_wgrad_mfma", a1, gy2, gw2, wws2, n, h, w, co, co, 3, st)
+                gw2 = as_w2(single2(mine2))
         # ---- conv1 and the shortcut
         split_c = ctx.cat_split[0] if ctx.cat_split is not None else 0
         fused_wsc16 = ctx.has_sc and f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_f16_supported", n, h, w, ci, co))
@@ -1057,15 +1161,33 @@ class BasicBlockFn(Function):
         fused_wsc = fused_wsc16 or (ctx.has_sc and not f16w1 and bool(H.call("smsut_conv2d_wgrad_sc_supported", n, h, w, ci, co)))
         if fused_wsc:
             # both weight gradients in one pass over x: rows 0..8 = conv1's taps, row 9 = the 1x1 shortcut's
-            g10 = torch.empty(10 * ci * co, dtype=torch.float32, device=dev)
-            gw1 = torch.as_strided(g10, (co, ci, 3, 3), hwio_strides(co, ci, 3, 3))
-            gws = torch.as_strided(g10, (co, ci, 1, 1), hwio_strides(co, ci, 1, 1), 9 * ci * co)
             if fused_wsc16:
+                g10 = torch.empty(10 * ci * co, dtype=torch.float32, device=dev)
+                gw1 = torch.as_strided(g10, (co, ci, 3, 3), hwio_strides(co, ci, 3, 3))
+                gws = torch.as_strided(g10, (co, ci, 1, 1), hwio_strides(co, ci, 1, 1), 9 * ci * co)
                 H.call("smsut_conv2d_wgrad_sc_f16", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1, gs_t,
                        g10, _ws(H.call("smsut_conv2d_wgrad_sc_f16_ws", n, h, w, ci, co), x), sc1, n, h, w, ci, co, st)
             else:
-                H.call("smsut_conv2d_wgrad_mfma_sc", x, xb_part if ctx.virtual else None, x.shape[1] if ctx.virtual else 0, gy1,
-                       gs_t, g10, _ws(H.call("smsut_conv2d_wgrad_sc_ws", n, h, w, ci, co), x), n, h, w, ci, co, st)
+                ca1 = x.shape[1] if ctx.virtual else 0
+
+                def single1(t):                           # -> flat [10][ci][co]
+                    g = torch.empty(10 * ci * co, dtype=torch.float32, device=dev)
+                    H.call("smsut_conv2d_wgrad_mfma_sc", t[0], t[1], ca1, t[2], t[3], g,
+                           _ws(H.call("smsut_conv2d_wgrad_sc_ws", t[6], h, w, ci, co), t[0]), t[6], h, w, ci, co, _s())
+                    return g
+                as_w1 = lambda g: torch.as_strided(g, (co, ci, 3, 3), hwio_strides(co, ci, 3, 3))                     # noqa: E731
+                as_ws = lambda g: torch.as_strided(g, (co, ci, 1, 1), hwio_strides(co, ci, 1, 1), 9 * ci * co)        # noqa: E731
+                mine1 = (x, xb_part if ctx.virtual else None, gy1, gs_t, None, None, n)
+                if ctx.pair and H.call("smsut_conv2d_wgrad_pair_supported", n, n, h, w, ci, co, int(ctx.virtual), 0, 1):
+                    leaf1, leafs = ctx.pair_w[0], ctx.pair_w[2]
+                    g10 = _pair_wgrad(("w1", w1.data_ptr()), mine1, ca1, None, None, slope, 10, h, w, ci, co, single1,
+                                      lambda g: (_add_grad(leaf1, as_w1(g)), _add_grad(leafs, as_ws(g))))
+                else:
+                    g10 = single1(mine1)
+                if g10 is None:                              # parked: the other pass returns the sum (or pair_flush delivers it)
+                    gw1 = gws = None
+                else:
+                    gw1, gws = as_w1(g10), as_ws(g10)
         else:
             gw1 = new_weight(co, ci, 3, 3, device=dev)
         if fused_wsc:

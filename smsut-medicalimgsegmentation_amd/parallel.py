@@ -53,10 +53,22 @@ def _flat_memory(t: torch.Tensor) -> torch.Tensor:
 
 
 class GradAllReducer:
-    """Averages the gradients of ``params`` across ranks with one flat all-reduce.
+    """Averages the gradients of ``params`` across ranks with one flat all-reduce (reference: ``nn.DataParallel``'s gradient
+    reduction, /root/reference/trainer/uganShp0Trainer.py:66-68).
 
-    ``reduce()`` is called after ``backward()`` and before ``optimizer.step()``.  Parameters whose ``.grad``
-    is None on this rank contribute zeros (keeps the collective shape identical on every rank)."""
+    ``reduce()`` (= ``finish(begin())``) is called after ``backward()`` and before ``optimizer.step()``.  Parameters whose
+    ``.grad`` is None on this rank contribute zeros (keeps the collective shape identical on every rank).
+
+    Cost model (r05; what is left per network and step: ONE pack kernel + ONE collective):
+      * pack: one batched ``torch.cat`` of the gradients' memory into the flat bucket (the gradients are autograd's / the captured
+        graphs' own tensors -- their addresses are not ours to choose);
+      * the collective averages where the backend can (``ReduceOp.AVG``: RCCL), else SUM + one scale;
+      * NO unpack: after the collective ``p.grad`` is re-pointed to a view of the bucket (the parameter's strides, no copy) and the
+        optimizer reads the averaged gradients in place.  The tensors the backward wrote (``_src``) are remembered: under
+        hipGraph replay the next iteration writes the SAME tensors again while ``p.grad`` still names our view -- ``begin()``
+        then packs from the remembered ones; whoever re-points ``p.grad`` in between (an eager step, a graph re-installing its
+        bindings) is simply seen as the new source.
+      * the per-parameter view lists are built once, not every step (175 + 46 tensors: ~1 ms of host time per iteration)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -64,57 +76,85 @@ class GradAllReducer:
         self.world = dist.get_world_size(group) if (group is not None and dist.is_initialized()) else 1
         self.numel = sum(p.numel() for p in self.params)
         self._flat: Optional[torch.Tensor] = None
+        self._views: List[torch.Tensor] = []          # per parameter: the bucket's slice with the parameter's shape / strides
+        self._chunks: List[torch.Tensor] = []         # ... and as a 1-D slice (memory order)
+        self._src: List[Optional[torch.Tensor]] = []  # the gradient tensors last packed (what the backward writes)
+        self._src_flat: List[Optional[torch.Tensor]] = []
+        self._avg = None
+
+    def _bucket(self, dev):
+        if self._flat is None or self._flat.device != dev:
+            self._flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
+            self._views, self._chunks, off = [], [], 0
+            for p in self.params:
+                n = p.numel()
+                self._chunks.append(self._flat[off:off + n])
+                self._views.append(self._flat.as_strided(p.size(), p.stride(), off))
+                off += n
+            self._src = [None] * len(self.params)
+            self._src_flat = [None] * len(self.params)
+        return self._flat
+
+    def _can_avg(self) -> bool:
+        if self._avg is None:
+            try:
+                self._avg = dist.get_backend(self.group) == "nccl"        # (gloo has no ReduceOp.AVG)
+            except Exception:
+                self._avg = False
+        return self._avg
 
     def reduce(self):
-        """Synchronous form: pack, all-reduce, average, unpack."""
+        """Synchronous form: pack, all-reduce (average), re-point the gradients."""
         self.finish(self.begin())
 
     def begin(self):
         """Pack the gradients and START the all-reduce (``async_op=True``: RCCL runs it on its own stream behind the work
-        already queued on the current one).  Whatever the caller launches next overlaps with it; ``finish`` waits, averages and
-        unpacks.  Returns a handle (None when there is nothing to reduce)."""
+        already queued on the current one).  Whatever the caller launches next overlaps with it; ``finish`` waits and hands the
+        averaged gradients to the parameters.  Returns a handle (None when there is nothing to reduce)."""
         if self.world <= 1 and not (force_dist() and self.group is not None):
             return None
         from . import graphs
         graphs.assert_no_capture("GradAllReducer.begin (gradient all-reduce)")
-        dev = self.params[0].device
-        if self._flat is None or self._flat.device != dev:
-            self._flat = torch.empty(self.numel, dtype=torch.float32, device=dev)
-        flat = self._flat
-        if all(p.grad is not None for p in self.params):
+        flat = self._bucket(self.params[0].device)
+        missing = False
+        for i, p in enumerate(self.params):
+            g = p.grad
+            if g is self._views[i]:                   # still our view from the last step: the backward wrote the remembered tensor
+                continue
+            self._src[i] = g
+            self._src_flat[i] = None if g is None else _flat_memory(g)
+        for i, p in enumerate(self.params):
+            if self._src[i] is None:
+                missing = True
+            elif self._src[i].shape != p.shape or self._src[i].stride() != p.stride():
+                # a gradient in another memory order than its parameter (never produced by this package's ops): pack a converted copy
+                c = torch.empty_like(p)
+                c.copy_(self._src[i])
+                self._src_flat[i] = _flat_memory(c)
+        if not missing:
             # one batched concat (two launches for 175 tensors): 26 us for the generator's 12.6 MB, 75 us as a multi-tensor copy
-            torch.cat([_flat_memory(p.grad) for p in self.params], out=flat)
+            torch.cat(self._src_flat, out=flat)
         else:
-            off = 0
             views, srcs = [], []
-            for p in self.params:
-                n = p.numel()
-                if p.grad is None:
-                    flat[off:off + n].zero_()
+            for i in range(len(self.params)):
+                if self._src[i] is None:
+                    self._chunks[i].zero_()
                 else:
-                    views.append(flat[off:off + n])
-                    srcs.append(_flat_memory(p.grad))
-                off += n
+                    views.append(self._chunks[i])
+                    srcs.append(self._src_flat[i])
             if views:
                 torch._foreach_copy_(views, srcs)
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        op = dist.ReduceOp.AVG if self._can_avg() else dist.ReduceOp.SUM
+        return dist.all_reduce(flat, op=op, group=self.group, async_op=True)
 
     def finish(self, work):
         if work is None:
             return
         work.wait()                                  # the current stream now waits for the collective
-        flat = self._flat
-        flat.mul_(1.0 / self.world)
-        off = 0
-        dsts, chunks = [], []
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = torch.empty_like(p)       # preserves the parameter's (permuted) strides
-            dsts.append(_flat_memory(p.grad))
-            chunks.append(flat[off:off + n])
-            off += n
-        torch._foreach_copy_(dsts, chunks)
+        if not self._can_avg():
+            self._flat.mul_(1.0 / self.world)
+        for p, v in zip(self.params, self._views):
+            p.grad = v                               # no unpack copy: the optimizer reads the bucket through the parameter's strides
 
 
 def broadcast_parameters(module: torch.nn.Module, group=None, src: int = 0):

@@ -125,8 +125,17 @@ def executed_factor(name: str, conv_args) -> float:
     return ent[1]
 
 
+def _pair_dims(conv_args):
+    """smsut_conv2d_wgrad_pair (two image sets of one layer in one launch): (images, H, W, Cin, Cout, tap rows)."""
+    na, nb, _ca, h, w, cin, cout = [a for c, a in zip(H.SIGNATURES["smsut_conv2d_wgrad_pair"].replace(" ", ""), conv_args) if c == "i"]
+    return na + nb, h, w, cin, cout, (10 if conv_args[3] is not None else 9)          # (conv_args[3] = gsA: fused shortcut row)
+
+
 def conv_flops_of(name: str, conv_args) -> float:
     """Algorithmic FLOPs of one recorded call (0 for non-conv entry points)."""
+    if name == "smsut_conv2d_wgrad_pair":
+        n, h, w, cin, cout, rows = _pair_dims(conv_args)
+        return 2.0 * n * h * w * cin * cout * rows
     ent = _CONV_FLOPS.get(_base(name))
     if ent is None:
         return 0.0
@@ -200,6 +209,9 @@ _BYTES: Dict[str, Callable[[List[int]], float]] = {
 
 
 def bytes_of(name: str, conv_args) -> float:
+    if name == "smsut_conv2d_wgrad_pair":
+        n, h, w, cin, cout, rows = _pair_dims(conv_args)
+        return _cv(n, h, w, cin, cout * (2 if rows == 10 else 1))
     ent = _BYTES.get(_base(name))
     return float(ent(_ints(name, conv_args))) if ent else 0.0
 
@@ -278,7 +290,7 @@ def summarize(rows: List[Row], peak_tflops: float) -> dict:
     DEFINES (what the contract's ``achieved`` is made of); ``*_executed`` count the products the MFMA pipes actually run (Winograd
     forms: 16 / 36 of them) -- the figure to hold against the 157.3 TFLOP/s the pipes can do."""
     conv = [r for r in rows if r.flops > 0]
-    mfma = [r for r in conv if _CONV_FLOPS[_base(r.name)][1] == "mfma"]
+    mfma = [r for r in conv if r.name == "smsut_conv2d_wgrad_pair" or _CONV_FLOPS[_base(r.name)][1] == "mfma"]
     t_all = sum(r.total_us for r in rows)
     t_conv = sum(r.total_us for r in conv)
     f_conv = sum(r.flops * r.calls for r in conv)

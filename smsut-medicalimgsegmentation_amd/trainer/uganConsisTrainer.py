@@ -130,7 +130,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
     #   G2   D(x_fake) through the UPDATED frozen D, both DiceCE values from the global statistics, g_loss.backward()
     def _g1_phase(self, x_real, vec_ot, ids, y_real):
         """G(x_real -> x_fake) with the autograd graph retained for the G-step; returns (x_fake detached, seg statistics)."""
-        with ops.wino_prepared(self.net, forms="f"):        # (scopes: the weights move in the optimizer steps only)
+        # (scopes: the weights move in the optimizer steps only; pair_wgrads: this pass and the cycle pass of phase G2gen go through
+        #  every generator layer with the same weights -- their 3x3 weight gradients are computed by ONE launch per layer, ops.py)
+        with ops.wino_prepared(self.net, forms="f"), ops.pair_wgrads():
             if self._g_split:
                 y_fake, x_fake, feat_x = self.net._trunk(x_real, vec_ot)          # feat_x: the raw bottleneck features t_e5
             else:
@@ -202,7 +204,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
             xd, td = x_fake.detach().requires_grad_(True), feat_x.detach().requires_grad_(True)
             feat_x, _ = self.net.netF([td], patch_ids=[ids])
             cut, x_fake = (xd, td), xd
-        with ops.wino_prepared(self.net, forms="f"):
+        with ops.wino_prepared(self.net, forms="f"), ops.pair_wgrads():
             y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
                                                                  {"sample_ids": [ids]})
         g_rec = ops.l1_mean(x_real, x_rec)
@@ -271,6 +273,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         xd, td = self._g2[4]
         with ops.wino_prepared(self.net, forms="b"):
             torch.autograd.backward([x_fake, t_e5], [xd.grad + self._gx_d, td.grad])
+            ops.pair_flush()                     # sets parked without a partner (consistency term off): computed alone, here
         self._g1 = self._g2 = self._gx_d = None
         main, extra = [], []
         for name, p in self.net.named_parameters():
@@ -324,6 +327,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         g_loss = g_fake + self.lambda_rec * g_rec + self.lambda_cls * g_cls + self.lambda_seg * g_seg \
             + lambda_semi * g_semi + 1.0 * g_nce
         g_loss.backward()
+        ops.pair_flush()                         # sets parked without a partner (consistency term off): computed alone, here
         self._g1 = self._g2 = None
         main, extra = [], []
         for name, p in self.net.named_parameters():
@@ -374,6 +378,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         """One iteration; returns a float32 device tensor with the 10 scalars in ``SCALARS`` order."""
         lambda_semi = self.lambda_semi * self.sigmoid_rampup(self.epoch, cfg.max_epoch)       # :74
         self._geom = (tuple(x_real.shape), tuple(y_real.shape))
+        ops.pair_reset()                       # (paired weight gradients: nothing parked by an iteration that died half-way survives)
         if mj is None:
             mj = random.randint(0, cfg.n_modal - 1)                                           # :114
         # modality ids go to the device through a pinned staging buffer (a pageable .to(device) would make the host
@@ -492,6 +497,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
                 p.requires_grad_(True)
         if self._probe:
             self._finite_probe("G2", [("g_scalars", g_scal)] + [("grad " + k, p.grad) for k, p in self.net.named_parameters()])
+        ops.pair_assert_empty()                # every parked operand set of the cycle pass met its G(x_real) partner
         self.g_reducer.reduce()
         self.optimizer.step()
         if self._probe:

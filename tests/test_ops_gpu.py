@@ -398,6 +398,78 @@ def test_fused_basic_block_vs_torch(ops, n, h, ci, co):
             assert rel_err(got.grad.cpu().numpy(), ref.grad.numpy()) < 5e-3, tuple(ref.shape)
 
 
+@pytest.mark.parametrize("n,h,ci,co", [(8, 128, 16, 32), (4, 64, 32, 64), (8, 32, 64, 128), (2, 32, 16, 16), (8, 128, 8, 16)])
+def test_paired_weight_gradients_of_two_passes_through_one_block(ops, n, h, ci, co):
+    """``ops.pair_wgrads()``: two passes through ONE fused BasicBlock (the generator's G(x_real) and cycle pass, reference
+    uganConsisTrainer.py:152,159) with the second pass on parameter ALIASES, as the trainer runs it.  Paired: the pass whose
+    backward runs first parks its operands and returns no weight gradient, the other returns the sum from one launch --
+    main.grad + alias.grad must equal the unpaired sum (fp32 rounding of the accumulation order only); every other gradient (inputs,
+    affine parameters) is bit-identical; a pass WITHOUT a partner is computed alone by ``pair_flush()`` and lands on its own leaf."""
+    if not ops.FUSED_BLOCK:
+        pytest.skip("SMSUT_FUSED_BLOCK=0 in the environment")
+    slope = 0.01
+    has_sc = ci != co
+    mk = lambda t: to_hwio(ops, t)                                                                              # noqa: E731
+    w1, w2 = mk(rnd(co, ci, 3, 3, seed=2) / np.sqrt(9 * ci)), mk(rnd(co, co, 3, 3, seed=3) / np.sqrt(9 * co))
+    ws = mk(rnd(co, ci, 1, 1, seed=11) / np.sqrt(ci)) if has_sc else None
+    aff = [dev(1 + 0.1 * rnd(co, seed=4 + k)) if k % 2 == 0 else dev(0.1 * rnd(co, seed=4 + k)) for k in range(6)]
+    xs = [dev(rnd(n, ci, h, h, seed=20 + k)) for k in range(2)]
+    gos = [dev(rnd(n, co, h, h, seed=30 + k)) for k in range(2)]
+
+    def run(paired, passes=(0, 1)):
+        main = [None if t is None else (to_hwio(ops, t) if t.dim() == 4 else t.detach().clone()).requires_grad_(True)
+                for t in (w1, w2, ws, *aff)]
+        alias = [None if t is None else t.detach().requires_grad_(True) for t in main]          # same storage, own .grad
+        xin = [x.clone().requires_grad_(True) for x in xs]
+        outs = []
+        ops.pair_reset()
+        for k in passes:
+            P = main if k == 0 else alias
+            ctxm = ops.pair_wgrads() if paired else contextlib.nullcontext()
+            with ctxm:
+                outs.append(ops.basic_block(xin[k], P[0], P[3], P[4], P[1], P[5], P[6], P[2], P[7] if has_sc else None,
+                                            P[8] if has_sc else None, slope))
+        for k, o in zip(reversed(passes), reversed(outs)):           # the later pass' backward runs first, as in the trainer
+            o.backward(gos[k])
+        flushed = ops.pair_flush()
+        ops.pair_assert_empty()
+        tot = []
+        for m, a in zip(main, alias):
+            if m is None:
+                tot.append(None)
+                continue
+            g = [t.grad for t in (m, a) if t.grad is not None]
+            tot.append(sum(g[1:], g[0]) if g else None)
+        return tot, [x.grad for x in xin], flushed, main, alias
+
+    import contextlib
+    ref, ref_gx, _, _, _ = run(False)
+    got, got_gx, flushed, main, alias = run(True)
+    pairable = ci % 16 == 0 and has_sc           # (8-channel first block / identity shortcut: conv1 keeps its own kernels, conv2 pairs)
+    assert flushed == 0
+    # the weights that paired: the parked pass returned nothing, the other carries the sum
+    if pairable:
+        assert alias[0].grad is None or main[0].grad is None
+    assert alias[1].grad is None or main[1].grad is None
+    from conftest import l2_rel
+    for k, (g, r) in enumerate(zip(got, ref)):
+        if r is None:
+            continue
+        if k < 3:
+            assert l2_rel(g.cpu().numpy(), r.cpu().numpy()) < 2e-6, k           # accumulation order only
+        else:
+            assert torch.equal(g, r), k                                         # affine gradients: untouched kernels
+    for g, r in zip(got_gx, ref_gx):
+        assert torch.equal(g, r)
+    # one pass only: nothing to pair with -> pair_flush computes it alone, onto the pass' own leaves, bit-identical to unpaired
+    ref1, _, _, _, _ = run(False, passes=(0,))
+    got1, _, flushed1, main1, _ = run(True, passes=(0,))
+    assert flushed1 == (2 if pairable else 1)
+    for k, (g, r) in enumerate(zip(got1, ref1)):
+        if r is not None:
+            assert torch.equal(g, r), k
+
+
 @pytest.mark.parametrize("n,h,ca,cb,co", [(8, 128, 16, 16, 16), (16, 64, 32, 32, 32), (32, 32, 64, 64, 64),      # split-output kernels
                                           (2, 32, 16, 16, 16), (4, 64, 32, 32, 32), (2, 16, 128, 128, 128)])    # contiguous + split copy
 def test_block_after_concat_split_gradients(ops, n, h, ca, cb, co):

@@ -31,12 +31,24 @@ def _worker(rank, world, port, q):
     # ---- 1. flat all-reduce over permuted-stride parameters, one tensor without a gradient on rank 1
     p1 = torch.nn.Parameter(ops.new_weight(4, 3, 3, 3)); p2 = torch.nn.Parameter(torch.zeros(5)); p3 = torch.nn.Parameter(torch.zeros(2, 2))
     g1 = ops.new_weight(4, 3, 3, 3); g1.copy_(torch.arange(108.).reshape(4, 3, 3, 3) * (rank + 1)); p1.grad = g1
-    p2.grad = torch.full((5,), float(rank))
-    p3.grad = torch.ones(2, 2) if rank == 0 else None
+    g2 = torch.full((5,), float(rank)); p2.grad = g2
+    g3 = torch.ones(2, 2) if rank == 0 else None; p3.grad = g3
     red = parallel.GradAllReducer([p1, p2, p3], group)
     red.reduce()
     ok = torch.allclose(p1.grad, torch.arange(108.).reshape(4, 3, 3, 3) * 1.5) and p1.grad.stride() == p1.stride()
     ok = ok and torch.allclose(p2.grad, torch.full((5,), 0.5)) and torch.allclose(p3.grad, torch.full((2, 2), 0.5))
+    # ... no unpack copy: the gradients ARE views of the flat bucket now, and the backward's own tensors are untouched
+    ok = ok and all(p.grad.untyped_storage().data_ptr() == red._flat.untyped_storage().data_ptr() for p in (p1, p2, p3))
+    ok = ok and torch.equal(g2, torch.full((5,), float(rank)))
+    # a second step as under hipGraph replay: the backward REWRITES the same gradient tensors while p.grad still names the bucket
+    g1.mul_(2.0); g2.add_(10.0)
+    red.reduce()
+    ok = ok and torch.allclose(p1.grad, torch.arange(108.).reshape(4, 3, 3, 3) * 3.0) and torch.allclose(p2.grad, torch.full((5,), 10.5))
+    ok = ok and torch.allclose(p3.grad, torch.full((2, 2), 0.5))
+    # ... and a step that re-points .grad (an eager step, a graph re-installing its bindings): the new tensor is the source
+    p2.grad = torch.full((5,), 100.0 * (rank + 1))
+    red.reduce()
+    ok = ok and torch.allclose(p2.grad, torch.full((5,), 150.0)) and torch.allclose(p1.grad, torch.arange(108.).reshape(4, 3, 3, 3) * 3.0)
     # ---- 2. broadcast_parameters
     lin = torch.nn.Linear(3, 3)
     parallel.broadcast_parameters(lin, group)

@@ -96,6 +96,68 @@ def test_register_row_weight_gradient_forms(n, h, w, ci, co, form):
         assert torch.equal(gw, g9)                                  # virtual cat == materialised cat
 
 
+PAIR_SHAPES = [  # na, nb, h, w, ci, co
+    (3, 2, 64, 64, 16, 16), (1, 1, 32, 16, 16, 16), (2, 3, 40, 32, 32, 16), (2, 2, 24, 80, 16, 32), (1, 2, 32, 32, 32, 32),
+    (3, 1, 16, 48, 64, 32), (2, 2, 16, 16, 128, 64), (8, 8, 32, 32, 128, 128),
+]
+
+
+@pytest.mark.parametrize("na,nb,h,w,ci,co", PAIR_SHAPES)
+@pytest.mark.parametrize("form", ["plain", "cat", "inaff", "sc", "cat+sc"])
+def test_paired_weight_gradient_is_the_sum_of_the_two_sets(na, nb, h, w, ci, co, form):
+    """``smsut_conv2d_wgrad_pair``: ONE register-row launch over two image sets of the same layer (the two generator passes of a
+    uganConsis iteration; the reference's autograd sums the two weight gradients, trainer/uganConsisTrainer.py:152,159,179) ==
+    wgrad(A) + wgrad(B): against fp64 torch at the single-set bar, and against the two single-set calls."""
+    import smsut_amd  # noqa: F401
+    from smsut_amd import _hip as H
+    st = H.stream_ptr()
+    if "cat" in form and ci < 32:
+        pytest.skip("virtual cat needs two whole 16-channel halves")
+    cat, inaff, sc = "cat" in form, form == "inaff", "sc" in form
+    if not H.call("smsut_conv2d_wgrad_pair_supported", na, nb, h, w, ci, co, int(cat), int(inaff), int(sc)):
+        pytest.skip("shape not paired")
+    g = torch.Generator(device="cpu").manual_seed(na * 1000 + nb * 100 + h + ci)
+    ga, be, sl = (torch.rand(ci, generator=g) + 0.5).cuda(), (torch.randn(ci, generator=g) * 0.2).cuda(), 0.01
+    sets = []
+    for n in (na, nb):
+        x = torch.randn(n, h, w, ci, generator=g).cuda()
+        gy = torch.randn(n, h, w, co, generator=g).cuda()
+        gs = torch.randn(n, h, w, co, generator=g).cuda() if sc else None
+        m = (torch.randn(n, ci, generator=g) * 0.3).cuda() if inaff else None
+        r = (torch.rand(n, ci, generator=g) + 0.5).cuda() if inaff else None
+        sets.append((x, gy, gs, m, r))
+    want = sum(_ref(x, gy, gs, (m, r, ga, be, sl) if inaff else None) for x, gy, gs, m, r in sets)
+    rows = 10 if sc else 9
+    ca = ci // 2
+    parts = [((x[..., :ca].contiguous(), x[..., ca:].contiguous()) if cat else (x, None)) for x, *_ in sets]
+    gw = torch.full((rows, ci, co), float("nan"), device="cuda")
+    ws = torch.empty(H.call("smsut_conv2d_wgrad_pair_ws", na, nb, h, w, ci, co, int(cat), int(inaff), int(sc)), device="cuda")
+    (xa0, xa1), (xb0, xb1) = parts
+    H.call("smsut_conv2d_wgrad_pair", xa0, xa1, sets[0][1], sets[0][2], sets[0][3], sets[0][4], na,
+           xb0, xb1, sets[1][1], sets[1][2], sets[1][3], sets[1][4], nb, ca if cat else 0,
+           ga if inaff else None, be if inaff else None, sl, gw, ws, h, w, ci, co, st)
+    assert torch.isfinite(gw).all()
+    err = float((gw.double() - want).abs().max() / want.abs().max())
+    assert err < 3e-6, (form, err)
+    # ... and next to the two single-set calls (their sum differs from the paired accumulation by fp32 rounding only)
+    single = torch.zeros(rows, ci, co, device="cuda")
+    for (x, gy, gs, m, r), (p0, p1), n in zip(sets, parts, (na, nb)):
+        o = torch.empty(rows, ci, co, device="cuda")
+        if sc:
+            w1 = torch.empty(H.call("smsut_conv2d_wgrad_sc_ws", n, h, w, ci, co), device="cuda")
+            H.call("smsut_conv2d_wgrad_mfma_sc", p0, p1, ca if cat else 0, gy, gs, o, w1, n, h, w, ci, co, st)
+        else:
+            w1 = torch.empty(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), device="cuda")
+            if inaff:
+                H.call("smsut_conv2d_wgrad_mfma_inaff", x, gy, o, w1, m, r, ga, be, sl, n, h, w, ci, co, st)
+            elif cat:
+                H.call("smsut_conv2d_wgrad_mfma_cat", p0, p1, ca, gy, o, w1, n, h, w, ci, co, 3, st)
+            else:
+                H.call("smsut_conv2d_wgrad_mfma", x, gy, o, w1, n, h, w, ci, co, 3, st)
+        single += o
+    assert float((gw - single).abs().max() / single.abs().max()) < 2e-6
+
+
 def test_conv_form_query_matches_the_dispatch():
     """``smsut_conv2d_mfma_form`` (what bench.py / profiling.py use to count the products the matrix pipes execute): 1 = resident
     Winograd for 16 / 32 reduction channels on planes divisible by 16, 2 = streamed-weight Winograd from 64, 0 = direct (8-channel
