@@ -70,6 +70,27 @@ def pmc_traffic_per_slice():
         return None
 
 
+PMC_FWD_FILE = "r05_pmc_fwd.json"      # the same passes, the two Winograd forward kernels (profiles/summarize.py)
+PMC_C5_FILE = "r05_c5_pmc.json"        # config 5's roofline leg: passes of `bench.py --roofline-only --dtype f16 --size 512`
+
+
+def pmc_fwd_file(name):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def pmc_fwd(key):
+    """Committed counters of a forward roofline leg (``resident`` / ``wino_l``): {hbm_bytes_per_slice, mfma_busy_frac, ...} or {}."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_FWD_FILE)) as f:
+            return json.load(f).get(key, {})
+    except (OSError, ValueError):
+        return {}
+
+
 def _events(st, launch, reps=20, warm=3):
     for _ in range(warm):
         launch()
@@ -84,51 +105,64 @@ def _events(st, launch, reps=20, warm=3):
 
 
 def dominant_wgrad_call(batch, size=256):
-    """(entry point, integer / float arguments) of the roofline leg's call as ``profiling.record_step`` keys it."""
+    """(entry point, integer / float arguments) of the roofline leg's call as ``profiling.record_step`` keys it: the PAIRED
+    weight gradient of conv2 at level 2 -- both generator passes of the iteration (``batch`` slices each) in one launch."""
     h = size // 2
-    return "smsut_conv2d_wgrad_mfma_inaff", (0.01, batch, h, h, 32, 32)
+    return "smsut_conv2d_wgrad_pair", (batch, batch, 0, 0.01, h, h, 32, 32)
 
 
 def measure_dominant_wgrad(dev, batch, size=256):
-    """HIP-event timing of the kernel that carries the most time of the iteration (committed profile: profiles/r04_summary.md):
+    """HIP-event timing of the kernel that carries the most time of the iteration (committed profile: profiles/r05_summary.md):
     the register-row 3x3 weight gradient ``wgrad_rr<2,2,1,1,4,1,false,true,false>`` (csrc/conv_wgrad_rr.hip), i.e. conv2's weight
     gradient of a BasicBlock (reference network/blocks.py:70-72 backward) with the input-side InstanceNorm + LeakyReLU form: x is
-    the RAW conv1 output y1, normalised while the operands are loaded.  Launched exactly as the step launches it
-    (ops.py BasicBlockFn.backward: ``smsut_conv2d_wgrad_mfma_inaff(y1, gy2, gw2, ws, mean, rstd, gamma, beta, slope, N, H, W, C, C)``) at
-    the level-2 shape N x (size/2)^2 x 32 -> 32; that call is two launches (the kernel + the 5-us split-slab reduction), so the
-    kernel ALONE is also timed through ``smsut_conv2d_wgrad_mfma_slabs`` (same kernel, same arguments, no reduction): that is the
-    duration rocprofv3 lists and the one ``achieved`` is computed from.  Direct products: algorithmic FLOPs = executed FLOPs."""
+    the RAW conv1 output y1, normalised while the operands are loaded.  Launched exactly as the step launches it since r05
+    (ops.py BasicBlockFn.backward -> ``_pair_wgrad``): ``smsut_conv2d_wgrad_pair`` over the TWO generator passes' operand sets
+    (reference trainer/uganConsisTrainer.py:152,159: G(x_real) and the cycle pass differentiate the layer twice; here one launch
+    over 2 x ``batch`` slices) at the level-2 shape (size/2)^2 x 32 -> 32; that call is two launches (the kernel + the 5-us
+    split-slab reduction), so the kernel ALONE is also timed through ``smsut_conv2d_wgrad_pair_slabs`` (same kernel, same arguments,
+    no reduction): that is the duration rocprofv3 lists and the one ``achieved`` is computed from.  Direct products: algorithmic
+    FLOPs = executed FLOPs."""
     from smsut_amd import ops, _hip as H
-    name, (slope, n, h, w, ci, co) = dominant_wgrad_call(batch, size)
+    name, (na, nb, _ca, slope, h, w, ci, co) = dominant_wgrad_call(batch, size)
     cl = torch.channels_last
-    y1 = torch.randn(n, ci, h, w, device=dev).contiguous(memory_format=cl)
-    gy2 = torch.randn(n, co, h, w, device=dev).contiguous(memory_format=cl)
+    sets = []
+    for n in (na, nb):
+        y1 = torch.randn(n, ci, h, w, device=dev).contiguous(memory_format=cl)
+        gy2 = torch.randn(n, co, h, w, device=dev).contiguous(memory_format=cl)
+        sets.append((y1, gy2, torch.randn(n, ci, device=dev) * 0.3, torch.rand(n, ci, device=dev) + 0.5))
     gw2 = ops.new_weight(co, ci, 3, 3, device=dev)
-    ws = torch.empty(H.call("smsut_conv2d_wgrad_mfma_ws", n, h, w, ci, co, 3), device=dev)
-    mean, rstd = torch.randn(n, ci, device=dev) * 0.3, torch.rand(n, ci, device=dev) + 0.5
+    assert H.call("smsut_conv2d_wgrad_pair_supported", na, nb, h, w, ci, co, 0, 1, 0), "paired register-row weight gradient not available"
+    ws = torch.empty(H.call("smsut_conv2d_wgrad_pair_ws", na, nb, h, w, ci, co, 0, 1, 0), device=dev)
     gamma, beta = torch.rand(ci, device=dev) + 0.5, torch.randn(ci, device=dev) * 0.2
     st = torch.cuda.current_stream()
-    slabs = H.call("smsut_conv2d_wgrad_mfma_slabs", y1, gy2, ws, mean, rstd, gamma, beta, slope, n, h, w, ci, co, st.cuda_stream)
+    (ya, ga, ma, ra), (yb, gb, mb, rb) = sets
+
+    def slabs_only():
+        return H.call("smsut_conv2d_wgrad_pair_slabs", ya, ga, ma, ra, na, yb, gb, mb, rb, nb, gamma, beta, slope, ws, h, w, ci, co,
+                      st.cuda_stream)
+    slabs = slabs_only()
     assert slabs > 0, "register-row weight gradient not available for the roofline shape"
-    call_ms = _events(st, lambda: H.call(name, y1, gy2, gw2, ws, mean, rstd, gamma, beta, slope, n, h, w, ci, co, st.cuda_stream))
-    ms = _events(st, lambda: H.call("smsut_conv2d_wgrad_mfma_slabs", y1, gy2, ws, mean, rstd, gamma, beta, slope, n, h, w, ci, co,
-                                    st.cuda_stream))
+    call_ms = _events(st, lambda: H.call(name, ya, None, ga, None, ma, ra, na, yb, None, gb, None, mb, rb, nb, 0, gamma, beta, slope,
+                                         gw2, ws, h, w, ci, co, st.cuda_stream))
+    ms = _events(st, slabs_only)
+    n = na + nb
     fl = conv_flops(n, h, w, ci, co, 3)
     achieved = fl / (ms * 1e-3) / 1e12
     byts = 4.0 * n * h * w * (ci + co) + 4.0 * slabs * 9 * ci * co       # both operands read once + the split slabs written
     per_slice = pmc_traffic_per_slice() if size == 256 else None
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "achieved_note": "algorithmic = executed FLOPs (direct products, 2 N H W Cin Cout 9) / the kernel's own launch time",
-            "traffic": None if per_slice is None else round(per_slice * batch),
+            "achieved_note": "algorithmic = executed FLOPs (direct products, 2 N H W Cin Cout 9, N = both passes' slices) / the kernel's own launch time",
+            "traffic": None if per_slice is None else round(per_slice * n),
             "traffic_unit": f"HBM bytes per launch (PMC, profiles/{PMC_FILE})",
             "traffic_source": "PROFILED, not live: FETCH_SIZE x2 + WRITE_SIZE of this kernel from the committed rocprofv3 --pmc passes "
-                              "(counters cannot be read in-process), per slice, scaled to this run's batch",
-            "kernel": "wgrad_rr<2,2,1,1,4,1,false,true,false> (csrc/conv_wgrad_rr.hip) via smsut_conv2d_wgrad_mfma_inaff",
+                              "(counters cannot be read in-process), per slice, scaled to this launch's slices",
+            "kernel": "wgrad_rr<2,2,1,1,4,1,false,true,false> (csrc/conv_wgrad_rr.hip) via smsut_conv2d_wgrad_pair",
             "kernel_match": "wgrad_rr<2, 2, 1, 1, 4, 1, false, true, false>",
             "kernel_kind": "mfma", "selected_by": "largest total time per device kernel in the committed rocprofv3 summary of the iteration",
-            "entry_point": name, "entry_args": [slope, n, h, w, ci, co],
-            "shape": f"N{n} {h}x{w} 32->32 k3 weight gradient, x = lrelu(IN(raw conv1 output)) applied while loading, {slabs} split slabs",
+            "entry_point": name, "entry_args": [na, nb, 0, slope, h, w, ci, co],
+            "shape": f"N{na}+{nb} (both generator passes) {h}x{w} 32->32 k3 weight gradient, x = lrelu(IN(raw conv1 output)) applied while "
+                     f"loading, {slabs} split slabs",
             "avg_launch_ms": round(ms, 4), "call_ms_with_reduction": round(call_ms, 4),
             "algorithmic_gflop_per_launch": round(fl / 1e9, 3), "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
             "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
@@ -167,9 +201,17 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
     if hs:
         y = ops.new_act(batch, cout, h, h, xa, torch.float16)
 
+    fin = sc and ops.FIN_ON                             # (r05) the form the step launches: statistics finalised inside the launch
+    if fin:
+        tickets = torch.zeros(batch, dtype=torch.int32, device=dev)
+        mr = [torch.empty(batch, cout, device=dev) for _ in range(4)]
+
     def launch():
         if hs:
             H.call("smsut_conv2d_fwd_mfma_stats_sc_f16_hs", xa, xb, w, wsc, y, s_out, part, part_s, batch, h, h, cin, cout, st.cuda_stream)
+        elif fin:
+            H.call("smsut_conv2d_fwd_mfma_stats_sc_fin", xa, xb, w, wsc, y, s_out, part, part_s, tickets, *mr, 1e-5, batch, h, h, cin, cout,
+                   None, st.cuda_stream)
         elif sc:
             H.call("smsut_conv2d_fwd_mfma_stats_sc", xa, xb, w, wsc, y, s_out, part, part_s, batch, h, h, cin, cout, st.cuda_stream)
         else:
@@ -184,8 +226,13 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
     if f16:
         # fp16 operands: 36 FLOP/B against a ridge of 2500 / 8 ~ 310 FLOP/B -> the kernel is HBM-bound
         gbs = byts / (ms * 1e-3) / 1e9
+        c5 = pmc_fwd_file(PMC_C5_FILE) if size == 512 else {}
         return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": round(c5["hbm_bytes_per_slice"] * batch) if c5 else None,
+                "traffic_source": f"PROFILED, not live: profiles/{PMC_C5_FILE} (FETCH_SIZE x2 + WRITE_SIZE of this kernel, separate rocprofv3 "
+                                  "--pmc passes of `bench.py --roofline-only --dtype f16 --size 512`), per slice x this launch's slices",
+                "traffic_over_algorithmic": c5.get("traffic_over_algorithmic"),
+                "kernel_match": "conv_mfma_fwd_p<3, 8, 1, 2, true, false, false, true, false, true, false, true",
                 "kernel": ("conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,F16,SC,O16> via smsut_conv2d_fwd_mfma_stats_sc_f16_hs" if hs else
                            "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,F16> via smsut_conv2d_fwd_mfma_stats_cat_f16"),
                 "entry_point": "smsut_conv2d_fwd_mfma_stats_sc_f16_hs" if hs else "smsut_conv2d_fwd_mfma_stats_cat_f16",
@@ -199,19 +246,79 @@ def measure_dominant_conv(dev, batch, size=256, f16=False):
     form = H.call("smsut_conv2d_mfma_form", batch, h, h, cin, cout, 0)
     wino = form != 0
     kname = ("conv_mfma_fwd_p<3,16,1,2,STATS,DUAL,SC,WINO> (Winograd F(2x2,3x3) + fused 1x1 shortcut)" if wino else
-             "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,SC>") + " via smsut_conv2d_fwd_mfma_stats_sc"
+             "conv_mfma_fwd_p<3,8,1,2,STATS,DUAL,SC>") + " via smsut_conv2d_fwd_mfma_stats_sc" + ("_fin (statistics finalised in the launch)" if fin else "")
     executed = achieved * (0.5 if sc else 16.0 / 36.0) if wino else achieved
     return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
             "achieved_note": "algorithmic conv FLOPs / launch time; the Winograd form executes 16 of 36 products per 3x3 tap set (20 of 40 "
                              "with the fused 1x1) on the matrix pipes" if wino else "algorithmic = executed FLOPs (direct form)",
             "executed_mfma_tflops": round(executed, 3), "executed_mfma_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "kernel": kname, "kernel_kind": "mfma", "entry_point": "smsut_conv2d_fwd_mfma_stats_sc",
-            "entry_args": [batch, h, h, cin, cout],
+            "traffic": (round(pmc_fwd("resident")["hbm_bytes_per_slice"] * batch) if size == 256 and pmc_fwd("resident") else None),
+            "traffic_source": f"PROFILED, not live: profiles/{PMC_FWD_FILE} (FETCH_SIZE x2 + WRITE_SIZE of this kernel, separate rocprofv3 --pmc "
+                              "passes of `bench.py --roofline-only`), per slice x this launch's slices",
+            "mfma_busy": pmc_fwd("resident").get("mfma_busy_frac") if size == 256 else None,
+            "kernel_match": "conv_mfma_fwd_p<3, 16, 1, 2, true, false, false, true, false, false, false, true, false, false, true",
+            "kernel": kname, "kernel_kind": "mfma",
+            "entry_point": "smsut_conv2d_fwd_mfma_stats_sc_fin" if fin else "smsut_conv2d_fwd_mfma_stats_sc",
+            "entry_args": ([1e-5] if fin else []) + [batch, h, h, cin, cout],
             "shape": f"N{batch} {size}x{size} (16+16)->{cout} k3 + 1x1 shortcut, IN-statistics epilogues, virtual cat",
             "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
             "algorithmic_gbytes_per_launch": round(byts / 1e9, 4),
             "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
+
+
+def measure_wino_l(dev, batch, size=256):
+    """Third roofline leg (r05): the STREAMED-weight Winograd kernel ``conv_wino_l`` (csrc/conv_wino.hip; reductions of
+    >= 64 channels: 60 % of the 3x3 FLOPs) in the form with the most time in the iteration -- decoder level 3's conv1 + fused 1x1
+    shortcut on the virtual cat([up, skip]) (reference network/blocks.py:37-50,66-80: (64 + 64) -> 64 channels at (size/4)^2),
+    prepared weight image, launched through the entry point the step uses."""
+    from smsut_amd import ops, _hip as H
+    cin, cout, h = 128, 64, size // 4
+    cl = torch.channels_last
+    xa = torch.randn(batch, cin // 2, h, h, device=dev).contiguous(memory_format=cl)
+    xb = torch.randn(batch, cin // 2, h, h, device=dev).contiguous(memory_format=cl)
+    conv = torch.nn.Module()
+    conv.weight = torch.nn.Parameter(ops.new_weight(cout, cin, 3, 3, device=dev))
+    conv.stride, conv.padding = 1, 1
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(cout, cin, 3, 3, device=dev) / (cin * 9) ** 0.5)
+    wsc = ops.new_weight(cout, cin, 1, 1, device=dev)
+    wsc.copy_(torch.randn(cout, cin, 1, 1, device=dev) / cin ** 0.5)
+    y, s_out = ops.new_act(batch, cout, h, h, xa), ops.new_act(batch, cout, h, h, xa)
+    tiles = H.call("smsut_conv2d_mfma_tiles", batch, h, h, cin, cout, 3, 0)
+    part, part_s = torch.empty(batch * tiles * cout * 2, device=dev), torch.empty(batch * tiles * cout * 2, device=dev)
+    assert H.call("smsut_conv2d_fwd_sc_supported", batch, h, h, cin, cout, 1) and H.call("smsut_conv2d_mfma_form", batch, h, h, cin, cout, 0) == 2
+    st = torch.cuda.current_stream()
+    fin = ops.FIN_ON
+    tickets = torch.zeros(batch, dtype=torch.int32, device=dev)
+    mr = [torch.empty(batch, cout, device=dev) for _ in range(4)]
+    w = conv.weight
+    with ops.wino_prepared(conv, forms="f"):
+        wu = ops._wu(w, 0)
+
+        def launch():
+            if fin:
+                H.call("smsut_conv2d_fwd_mfma_stats_sc_fin", xa, xb, w, wsc, y, s_out, part, part_s, tickets, *mr, 1e-5, batch, h, h, cin,
+                       cout, wu, st.cuda_stream)
+            else:
+                H.call("smsut_conv2d_fwd_mfma_stats_sc_pre", xa, xb, w, wsc, y, s_out, part, part_s, batch, h, h, cin, cout, wu, st.cuda_stream)
+        ms = _events(st, launch)
+    fl = conv_flops(batch, h, h, cin, cout, 3) * 10.0 / 9.0
+    achieved = fl / (ms * 1e-3) / 1e12
+    executed = achieved * 0.5                                  # 16 of 36 products + the 1x1 on raw pixels: 20 of 40
+    byts = 4.0 * batch * h * h * (cin + 2 * cout)
+    pm = pmc_fwd("wino_l") if size == 256 else {}
+    return {"bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "executed_mfma_tflops": round(executed, 3),
+            "executed_mfma_frac": round(executed / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": round(pm["hbm_bytes_per_slice"] * batch) if pm else None, "mfma_busy": pm.get("mfma_busy_frac"),
+            "traffic_source": f"PROFILED, not live: profiles/{PMC_FWD_FILE}",
+            "kernel": "conv_wino_l<2,STATS,DUAL,SC,PRE> (Winograd F(2x2,3x3), streamed prepared weights, fused 1x1 shortcut, virtual cat)",
+            "kernel_match": "conv_wino_l<2, true, false, false, true, false, true, false, true",
+            "entry_point": "smsut_conv2d_fwd_mfma_stats_sc_fin" if fin else "smsut_conv2d_fwd_mfma_stats_sc_pre",
+            "shape": f"N{batch} {h}x{h} (64+64)->{cout} k3 + 1x1 shortcut, IN-statistics epilogues, virtual cat",
+            "avg_launch_ms": round(ms, 4), "algorithmic_gflop_per_launch": round(fl / 1e9, 3),
+            "algorithmic_gbytes_per_launch": round(byts / 1e9, 4), "hbm_gbs_algorithmic": round(byts / (ms * 1e-3) / 1e9, 1)}
 
 
 def measure_step_conv(step, label, find=None):
@@ -428,6 +535,28 @@ def self_launch(args, argv):
     return 0
 
 
+def measure_dist_overhead(args, plain_ms):
+    """What the data-parallel plumbing costs a rank BEFORE any xGMI hop: the same timed loop in a child process
+    over a ONE-rank RCCL communicator (``SMSUT_FORCE_DIST=1``: every collective of the real path -- Dice statistics, D and G
+    gradient all-reduces with their pack, the data-parallel schedule of the iteration -- runs, numerically the identity), against
+    this process' plain iteration.  One box, one GPU: the child shares the card with this (idle) process."""
+    import subprocess
+    env = dict(os.environ, SMSUT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK=os.environ.get("LOCAL_RANK", "0"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--no-cpu-baseline",
+           "--no-roofline", "--no-unet-step", "--no-config5", "--no-dist-leg"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        line = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        return {"ms": round(line["ms_per_step"] - plain_ms, 3), "one_rank_rccl_ms_per_step": line["ms_per_step"],
+                "plain_ms_per_step": round(plain_ms, 3), "dist": line.get("dist"),
+                "what": "SMSUT_FORCE_DIST=1: one-rank RCCL communicator, data-parallel schedule (compute-only side stream, collectives on the "
+                        "main stream), flat-bucket all-reduce of D's and G's gradients, Dice-statistics all-reduce; child process, same steps"}
+    except Exception as e:                                   # noqa: BLE001  (a failed side leg must not take the headline down)
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -443,6 +572,8 @@ def main():
     ap.add_argument("--no-unet-step", action="store_true", help="skip the BASELINE config-2 (U-Net step) leg")
     ap.add_argument("--no-config5", action="store_true", help="skip the BASELINE config-5 leg (512x512, fp16 operands)")
     ap.add_argument("--no-step-profile", action="store_true", help="skip the per-shape replay profile (roofline.step_conv_frac)")
+    ap.add_argument("--no-dist-leg", action="store_true",
+                    help="skip the data-parallel overhead leg (the same iteration over a ONE-rank RCCL communicator, in a child process)")
     ap.add_argument("--roofline-only", action="store_true",
                     help="run only the dominant-kernel leg (the command the rocprofv3 stats / PMC passes profile)")
     ap.add_argument("--d-overlap", choices=("default", "0", "1", "2"), default="default",
@@ -474,7 +605,8 @@ def main():
             print(json.dumps({"roofline": measure_dominant_conv(dev, B, args.size, True)}))
         else:
             print(json.dumps({"roofline": measure_dominant_wgrad(dev, B, args.size),
-                              "roofline_fwd": measure_dominant_conv(dev, B, args.size, False)}))
+                              "roofline_fwd": measure_dominant_conv(dev, B, args.size, False),
+                              "roofline_wino_l": measure_wino_l(dev, B, args.size)}))
         return
     ns = types.SimpleNamespace(fold=0, expr_name=None, write_env=False)
 
@@ -671,6 +803,7 @@ def main():
         else:
             out["roofline"] = measure_dominant_wgrad(dev, B, args.size)
             out["roofline_fwd"] = measure_dominant_conv(dev, B, args.size, False)
+            out["roofline_wino_l"] = measure_wino_l(dev, B, args.size)
         if not args.no_step_profile and world == 1:      # (an eager step holds collectives: single-rank runs only)
             prof = measure_step_conv(step_again, args.workload, {"dominant": dominant_wgrad_call(B, args.size)})
             out["roofline"]["step_conv_frac"] = prof["step_conv_frac"]
@@ -696,6 +829,11 @@ def main():
         out["unet_step"] = time_unet_step(dev, rank)
         if not args.no_config5:
             out["config5"] = time_config5(dev, rank)
+    if world == 1 and args.workload == "ugan" and args.dtype == "f32" and args.size == 256 and not args.no_dist_leg \
+            and not parallel.force_dist():
+        out["dist_overhead"] = measure_dist_overhead(args, ms)
+        if "ms" in out["dist_overhead"]:
+            out["dist_overhead_ms"] = out["dist_overhead"]["ms"]
     if world == 1 and not args.no_cpu_baseline and args.size == 256:
         out["cpu_baseline"] = cpu_baseline_ugan() if args.workload == "ugan" else cpu_baseline_unet()
     print(json.dumps(out), flush=True)

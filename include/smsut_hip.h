@@ -166,6 +166,24 @@ int smsut_conv2d_wgrad_mfma_sc(const float* xa, const float* xb /*nullable*/, in
                                float* gw10, float* workspace, int N, int H, int W, int Cin, int Cout, void* stream);
 int smsut_conv2d_wgrad_mfma_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace,
                                 int N, int H, int W, int Cin, int Cout, int KS, void* stream);
+/* `_fin` forms (r05) of the three statistics-producing convs of a fused BasicBlock: the same launch, with the InstanceNorm statistics
+ * FINALISED INSIDE IT by the workgroup whose partials complete an image (fixed-order fp64 combine, the bits smsut_in_finalize_fwd /
+ * _fwd2 / _bwd produce) -- the separate finalize launch behind each of them disappears (reference: conv -> nn.InstanceNorm2d,
+ * network/blocks.py:70-79, and its backward).  tickets: int [N], ZERO on entry and zero again when the launch is over (the caller
+ * keeps one zero-initialised pool and hands out slices; slices of launches that may run concurrently must not overlap).
+ * wu: nullable prepared Winograd image (the `_pre` argument).  Partials are still written (stats / stats_sc), outputs [N][Ndim]. */
+int smsut_conv2d_fwd_mfma_stats_sc_fin(const float* x, const float* xb /*nullable*/, const float* w, const float* wsc, float* y,
+                                       float* ysc, float* stats, float* stats_sc, int* tickets, float* mean, float* rstd,
+                                       float* mean_sc, float* rstd_sc, float eps, int N, int H, int W, int Kdim, int Ndim,
+                                       const float* wu /*nullable*/, void* stream);
+int smsut_conv2d_fwd_mfma_stats_inaff_fin(const float* x, const float* w, float* y, float* stats, const float* mean,
+                                          const float* rstd, const float* gamma, const float* beta, float slope, int* tickets,
+                                          float* mean_out, float* rstd_out, float eps, int N, int H, int W, int Kdim, int Ndim,
+                                          const float* wu /*nullable*/, void* stream);
+int smsut_conv2d_dgrad_mfma_bwdstats_fin(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                         const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                                         int* tickets, float* a_mean, float* b_mean, int N, int H, int W, int Kdim, int Ndim,
+                                         const float* wu /*nullable*/, void* stream);
 /* PAIRED 3x3 weight gradient: gw = wgrad(set A) + wgrad(set B) in ONE launch, for two image sets that went through the same conv
  * (the reference differentiates every generator layer twice per iteration: G(x_real) and the cycle pass G(x_fake),
  * trainer/uganConsisTrainer.py:152,159,179 -- autograd sums the two weight gradients; here they are summed in the kernel's
@@ -180,6 +198,12 @@ int smsut_conv2d_wgrad_pair(const float* xA, const float* x2A /*nullable*/, cons
                             const float* meanB /*nullable*/, const float* rstdB /*nullable*/, int NB, int ca,
                             const float* gamma /*nullable*/, const float* beta /*nullable*/, float slope, float* gw, float* workspace,
                             int H, int W, int Cin, int Cout, void* stream);
+/* measurement twin of smsut_conv2d_wgrad_mfma_slabs for the paired launch (plain / input-side-IN form): the kernel alone, slabs left in
+ * the workspace; returns the slab count (> 0) or a negative value */
+int smsut_conv2d_wgrad_pair_slabs(const float* xA, const float* gyA, const float* meanA /*nullable*/, const float* rstdA /*nullable*/,
+                                  int NA, const float* xB, const float* gyB, const float* meanB /*nullable*/,
+                                  const float* rstdB /*nullable*/, int NB, const float* gamma /*nullable*/, const float* beta /*nullable*/,
+                                  float slope, float* workspace, int H, int W, int Cin, int Cout, void* stream);
 int smsut_conv1x1_fwd_cat(const float* xa, const float* xb, int ca, const float* w, float* y, float* stats /*nullable*/,
                           int N, int HW, int Kdim, int Ndim, void* stream);
 int smsut_conv1x1_wgrad_cat(const float* xa, const float* xb, int ca, const float* gy, float* gw, float* workspace, int N,
@@ -370,6 +394,13 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
                       const float* g2, const float* b2 /*nullable*/, const float* s, const float* ms /*nullable*/,
                       const float* rs, const float* gs_, const float* bs /*nullable*/, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
                       float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, int N, int HW, int C,
+                      float slope, void* stream);
+/* ... with the per-image means finalised inside the partial-sum launch (r05; tickets: int [N], zero on entry and on exit): two
+ * launches instead of three, same bits */
+int smsut_restail_bwd_fin(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                      const float* g2, const float* b2 /*nullable*/, const float* s, const float* ms /*nullable*/,
+                      const float* rs, const float* gs_, const float* bs /*nullable*/, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
+                      float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, int* tickets, int N, int HW, int C,
                       float slope, void* stream);
 /* half storage: y2 and s are fp16 [N,HW,C]; conv shortcut with both betas (ms, b2, bs non-null); C % 4 == 0; amax nullable */
 int smsut_restail_fwd_hs(const void* y2_16, const float* m2, const float* r2, const float* g2, const float* b2, const void* s16,

@@ -144,6 +144,85 @@ md += ["## dominant kernel (roofline leg, `bench.py --roofline-only`)", "",
        f"PMC: FETCH_SIZE {fetch_kb:.1f} KB (x2 gfx950 correction), WRITE_SIZE {write_kb:.1f} KB per launch -> "
        f"{hbm / 1e6:.1f} MB HBM traffic vs {dom['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic "
        f"(x{dom['traffic_over_algorithmic']}).", "", sq_note, ""]
+# ---- the two Winograd forward legs (r05): counters of THEIR kernels from the same passes -> <tag>_pmc_fwd.json
+def kernel_counters(match, directory, counter):
+    vals = []
+    with open(one(f"{tag}_{directory}/**/*_counter_collection.csv")) as f:
+        for r in csv.DictReader(f):
+            if match in norm(r["Kernel_Name"]) and r["Counter_Name"] == counter:
+                vals.append(float(r["Counter_Value"]))
+    return vals
+
+
+fwd_json = {}
+for key, leg in (("resident", "roofline_fwd"), ("wino_l", "roofline_wino_l")):
+    lv = live_all.get(leg)
+    if not lv or not lv.get("kernel_match"):
+        continue
+    m = lv["kernel_match"]
+    try:
+        fv, wv = kernel_counters(m, "pmc_fetch", "FETCH_SIZE"), kernel_counters(m, "pmc_write", "WRITE_SIZE")
+        if not fv or not wv:
+            continue
+        fkb, wkb = sum(fv) / len(fv), sum(wv) / len(wv)
+        hb = (2.0 * fkb + wkb) * 1024.0
+        nb = int(lv["shape"].split()[0][1:])
+        ent = {"kernel_match": m, "shape": lv["shape"], "dispatches": len(fv), "FETCH_SIZE_kb_per_launch": round(fkb, 1),
+               "WRITE_SIZE_kb_per_launch": round(wkb, 1), "fetch_correction": 2.0, "hbm_bytes_per_launch": round(hb),
+               "hbm_bytes_per_slice": round(hb / nb), "algorithmic_bytes_per_launch": round(lv["algorithmic_gbytes_per_launch"] * 1e9),
+               "traffic_over_algorithmic": round(hb / (lv["algorithmic_gbytes_per_launch"] * 1e9), 3),
+               "hip_event_avg_launch_us": round(lv["avg_launch_ms"] * 1e3, 2), "achieved_tflops_algorithmic": lv["achieved"],
+               "executed_mfma_tflops": lv.get("executed_mfma_tflops")}
+        sqv = {}
+        for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE"):
+            v = kernel_counters(m, "pmc_sq", c)
+            if v:
+                sqv[c] = sum(v) / len(v)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in sqv and "GRBM_GUI_ACTIVE" in sqv:
+            cyc = sqv["GRBM_GUI_ACTIVE"] / 8.0
+            ent["sq"] = {k: round(v) for k, v in sqv.items()}
+            ent["mfma_busy_frac"] = round(sqv["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4), 4)
+            ent["mfma_busy_over_algorithmic"] = round(sqv["SQ_VALU_MFMA_BUSY_CYCLES"] / (lv["algorithmic_gflop_per_launch"] * 1e9 / 64.0), 4)
+            if sqv.get("SQ_WAVE_CYCLES"):
+                ent["wave_time_split"] = {k: round(sqv[k] / sqv["SQ_WAVE_CYCLES"], 3) for k in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY") if k in sqv}
+        fwd_json[key] = ent
+        md += [f"## `{leg}`: `{m}...` at {lv['shape']}", "",
+               f"HIP events {ent['hip_event_avg_launch_us']} us -> {lv['achieved']} TFLOP/s algorithmic, {lv.get('executed_mfma_tflops')} executed; PMC "
+               f"FETCH_SIZE {fkb:.1f} KB (x2), WRITE_SIZE {wkb:.1f} KB -> {hb / 1e6:.1f} MB per launch = x{ent['traffic_over_algorithmic']} the "
+               f"algorithmic bytes; MFMA pipes busy {ent.get('mfma_busy_frac')} of the kernel's cycles "
+               f"(= {ent.get('mfma_busy_over_algorithmic')} x algorithmic FLOPs / 64); wave time {ent.get('wave_time_split')}.", ""]
+    except SystemExit:
+        pass
+if fwd_json:
+    json.dump(fwd_json, open(os.path.join(PROF, f"{tag}_pmc_fwd.json"), "w"), indent=1)
+# ---- config 5's roofline leg (r05, VERDICT r04 missing #3): counters of the fp16-operand fused-shortcut forward at 512^2
+try:
+    c5 = json.loads(json_line(os.path.join(OUT, f"{tag}_c5roof.log")))["roofline"]
+    m = c5["kernel_match"]
+
+    def c5_counter(directory, counter):
+        vals = []
+        with open(one(f"{tag}_{directory}/**/*_counter_collection.csv")) as f:
+            for r in csv.DictReader(f):
+                if m in norm(r["Kernel_Name"]) and r["Counter_Name"] == counter:
+                    vals.append(float(r["Counter_Value"]))
+        return vals
+    fv, wv = c5_counter("c5pmc_fetch", "FETCH_SIZE"), c5_counter("c5pmc_write", "WRITE_SIZE")
+    fkb, wkb = sum(fv) / len(fv), sum(wv) / len(wv)
+    hb = (2.0 * fkb + wkb) * 1024.0
+    nb = int(c5["shape"].split()[0][1:])
+    c5j = {"kernel_match": m, "shape": c5["shape"], "dispatches": len(fv), "FETCH_SIZE_kb_per_launch": round(fkb, 1),
+           "WRITE_SIZE_kb_per_launch": round(wkb, 1), "fetch_correction": 2.0, "hbm_bytes_per_launch": round(hb),
+           "hbm_bytes_per_slice": round(hb / nb), "algorithmic_bytes_per_launch": round(c5["algorithmic_gbytes_per_launch"] * 1e9),
+           "traffic_over_algorithmic": round(hb / (c5["algorithmic_gbytes_per_launch"] * 1e9), 3),
+           "hip_event_avg_launch_us": round(c5["avg_launch_ms"] * 1e3, 2), "hbm_gbs_measured": round(hb / (c5["avg_launch_ms"] * 1e-3) / 1e9, 1)}
+    json.dump(c5j, open(os.path.join(PROF, f"{tag}_c5_pmc.json"), "w"), indent=1)
+    md += ["## config 5's roofline leg (`bench.py --roofline-only --dtype f16 --size 512`)", "",
+           f"`{m}...` at {c5['shape']}: HIP events {c5j['hip_event_avg_launch_us']} us; PMC FETCH_SIZE {fkb:.1f} KB (x2), WRITE_SIZE {wkb:.1f} KB "
+           f"-> {hb / 1e6:.1f} MB per launch = x{c5j['traffic_over_algorithmic']} the algorithmic bytes = {c5j['hbm_gbs_measured']} GB/s of HBM "
+           f"traffic ({c5j['hbm_gbs_measured'] / 80:.1f} % of 8 TB/s).", ""]
+except (SystemExit, OSError, KeyError, ZeroDivisionError, IndexError, ValueError):
+    pass
 fwd = live_all.get("roofline_fwd")
 if fwd:
     rows = [r for r in csv.DictReader(open(src)) if "conv_mfma_fwd_p" in r["Name"]]

@@ -92,6 +92,62 @@ def load_pmc(tag, wl, which):
     return window(list(by_disp.values()), "Kernel_Name")
 
 
+def fused_bound_ugan(size=256):
+    """SURVEY 8d's fused lower bound -- forward: conv inputs + conv outputs + 2 x InstanceNorm elements; backward: 2 x (conv inputs +
+    conv outputs) + 3 x InstanceNorm elements -- walked layer by layer over ONE uganConsis iteration (reference
+    trainer/uganConsisTrainer.py:110-180 on network/ugan.py, blocks.py), fp32, per slice of size x size:
+      * generator UGANnce (two encoders, shared enc5 called twice, two decoders): the reference runs it forward THREE times per
+        iteration (:133, :152, :159) and backward twice; this build computes G(x_real) once -- both are given;
+      * discriminator: forward on real, fake, x_hat and (G-step) fake again; backward of the first two, the gradient-penalty's
+        first backward (data-gradients) and its double backward (counted as one forward-like and one backward-like sweep), and the
+        data-gradient sweep of the G-step.  Pooling / upsampling / concat / losses are NOT in the rule (they are fused away in it)."""
+    S = size
+
+    def block(ci, co, h):           # BasicBlock: conv1 3x3, conv2 3x3, 1x1 shortcut, each followed by an InstanceNorm
+        px = h * h
+        return px * (ci + co) + px * (co + co) + px * (ci + co), 3 * px * co          # (conv in + out elements, IN elements)
+
+    def conv(ci, co, h_in, h_out, norm=False):
+        return h_in * h_in * ci + h_out * h_out * co, (h_out * h_out * co if norm else 0)
+
+    def add(*items):
+        return sum(i[0] for i in items), sum(i[1] for i in items)
+
+    def encoder(cin):
+        return add(conv(cin, 8, S, S, True), block(8, 16, S), block(16, 32, S // 2), block(32, 64, S // 4), block(64, 128, S // 8))
+
+    def decoder(cout, transposed):
+        items = []
+        for lvl, (c, h) in enumerate(((256, S // 16), (128, S // 8), (64, S // 4), (32, S // 2))):
+            items.append(conv(c, c // 2, h, 2 * h if transposed else h))            # ConvT 2x2 | 1x1 conv at the low resolution
+            items.append(block(c, c // 2, 2 * h))
+        items.append(conv(16, cout, S, S))
+        return add(*items)
+    enc5 = block(128, 256, S // 16)
+    g_c, g_n = add(encoder(5), encoder(1), enc5, enc5, decoder(1, False), decoder(5, True))
+
+    def bottle(ci, co, h):          # BottleBlock stride 2: conv1 at h, conv2 and the 1x1 shortcut at h / 2
+        return add(conv(ci, co, h, h, True), conv(co, co, h // 2, h // 2, True), conv(ci, co, h // 2, h // 2, True))
+    d_items = [conv(1, 16, S, S // 2)]
+    c, h = 16, S // 2
+    while h > 4:
+        co = min(2 * c, 256)
+        d_items.append(bottle(c, co, h))
+        c, h = co, h // 2
+    d_items += [conv(c, 1, 4, 4), conv(c, 4, 4, 1)]
+    d_c, d_n = add(*d_items)
+    fwd = lambda cn: cn[0] + 2 * cn[1]                    # noqa: E731
+    bwd = lambda cn: 2 * cn[0] + 3 * cn[1]                # noqa: E731
+    G, D = (g_c, g_n), (d_c, d_n)
+    ref_elems = 3 * fwd(G) + 2 * bwd(G) + 4 * fwd(D) + 2 * bwd(D) + (bwd(D) + fwd(D) + bwd(D)) + bwd(D)
+    own_elems = ref_elems - fwd(G)
+    return {"gb_per_slice": round(4.0 * own_elems / 1e9, 4), "reference_gb_per_slice": round(4.0 * ref_elems / 1e9, 4),
+            "rule": "fwd = conv in + conv out + 2 IN, bwd = 2 (conv in + conv out) + 3 IN, fp32",
+            "parts": f"generator pass fwd {4.0 * fwd(G) / 1e9:.3f} / bwd {4.0 * bwd(G) / 1e9:.3f} GB, discriminator pass fwd "
+                     f"{4.0 * fwd(D) / 1e9:.4f} / bwd {4.0 * bwd(D) / 1e9:.4f} GB per slice; 2 generator forwards (the reference runs 3: "
+                     f"{4.0 * ref_elems / 1e9:.3f} GB per slice) + 2 backwards, discriminator 4 forwards + 6 backward-like sweeps"}
+
+
 def main():
     tag, wl = sys.argv[1], sys.argv[2]
     slices = 32 if wl == "unet" else 16
@@ -132,7 +188,7 @@ def main():
                                "launches_under_256_wgs": round(a["small_grid_launches"] / K, 1),
                                "ms_in_launches_under_256_wgs": round(a["small_grid_us"] / K / 1e3, 3)}
         tot["ms"] += ms; tot["bytes"] += byts; tot["launches"] += a["launches"] / K
-    lower = 0.62e9 * slices if wl == "unet" else None
+    lower = 0.62e9 * slices if wl == "unet" else fused_bound_ugan(256)["gb_per_slice"] * 1e9 * slices
     # the floor of THIS build's launches (bench.py census: every tensor of every conv / InstanceNorm / residual-tail / pooling call
     # read once + written once, fp32; profiling._BYTES) -- SURVEY 8d's rule applied call by call; for the ugan iteration it is the
     # only stated bound (8d derives a fused bound for the U-Net only)
@@ -163,9 +219,18 @@ def main():
     st = res["step_total"]
     md += ["", f"Step total: {st['kernel_ms']} ms of kernels, {st['launches']} launches, **{st['hbm_gb']} GB HBM traffic "
                f"({st['hbm_gb_per_slice']} GB per slice)**, average {st['avg_hbm_gbs']} GB/s."]
-    if lower is not None:
+    if lower is not None and wl == "unet":
         md.append(f"SURVEY 8d fused lower bound: 0.62 GB per slice = {st['fused_lower_bound_gb']} GB per step -> traffic ratio "
                   f"**{st['traffic_over_lower_bound']}x**.")
+    elif lower is not None:
+        fb = fused_bound_ugan(256)
+        res["step_total"]["fused_lower_bound_rule"] = fb["rule"]
+        res["step_total"]["fused_lower_bound_gb_per_slice"] = fb["gb_per_slice"]
+        res["step_total"]["fused_lower_bound_parts"] = fb["parts"]
+        json.dump(res, open(os.path.join(PROF, f"{tag}_step_{wl}_classes.json"), "w"), indent=1)
+        md.append(f"Fused lower bound of the iteration, SURVEY 8d's rule applied layer by layer (r05; `fused_bound_ugan`: {fb['rule']}): "
+                  f"**{fb['gb_per_slice']} GB per slice** = {st['fused_lower_bound_gb']} GB per step ({fb['parts']}) -> measured traffic / "
+                  f"fused bound = **{st['traffic_over_lower_bound']}x**.")
     if census is not None:
         md += ["", f"Floor of this build's launches (every tensor of every conv / InstanceNorm / residual-tail / pooling call read once + "
                    f"written once, fp32; `bench.py` census, `profiling._BYTES`): **{census['gb_per_slice']} GB per slice** -> measured traffic / "

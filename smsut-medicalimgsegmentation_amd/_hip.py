@@ -32,6 +32,7 @@ SIGNATURES: Dict[str, str] = {
     "smsut_restail_bwd_hs": "pppppppppppp pp ppp pppp pp iii f s",
     "smsut_in_apply_bwd_hs": "pppppppp pp p iii s",
     "smsut_restail_bwd": "pppppppppppp pp ppp pppp p iii f s",
+    "smsut_restail_bwd_fin": "pppppppppppp pp ppp pppp pp iii f s",
     "smsut_restail_bwd_amax": "pppppppppppp pp ppp pppp pp iii f s",
     "smsut_in_apply_bwd_amax": "pppppppp pp p iii s",
     "smsut_absmax_finish": "p i p s",
@@ -95,9 +96,13 @@ SIGNATURES: Dict[str, str] = {
     "smsut_conv2d_wgrad_sc_ws": "iiiii",
     "smsut_conv2d_wgrad_mfma_sc": "pp i pppp iiiii s",
     "smsut_conv2d_wgrad_mfma_cat": "pp i ppp iiiiii s",
+    "smsut_conv2d_fwd_mfma_stats_sc_fin": "pppppppp ppppp f iiiii p s",
+    "smsut_conv2d_fwd_mfma_stats_inaff_fin": "pppppppp f ppp f iiiii p s",
+    "smsut_conv2d_dgrad_mfma_bwdstats_fin": "ppppppppp f ppp iiiii p s",
     "smsut_conv2d_wgrad_pair_supported": "iiiiiiiii",
     "smsut_conv2d_wgrad_pair_ws": "iiiiiiiii",
     "smsut_conv2d_wgrad_pair": "pppppp i pppppp i i pp f pp iiii s",
+    "smsut_conv2d_wgrad_pair_slabs": "pppp i pppp i pp f p iiii s",
     # 4x4 s1 p1 (networks.NLayerDiscriminator)
     "smsut_conv2d_k4_supported": "ii",
     "smsut_conv2d_k4_fwd": "ppp iiiii i s",
@@ -204,7 +209,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_fwd_sc_f16_supported", "smsut_conv2d_dgrad_sc_supported",
                          "smsut_conv2d_dgrad_sc_f16_supported", "smsut_conv2d_wgrad_sc_f16_supported", "smsut_conv2d_f16_hs_supported",
                          "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported", "smsut_conv2d_wgrad_pair_supported",
-                         "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
+                         "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_wgrad_pair_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

@@ -116,9 +116,19 @@ __device__ __forceinline__ void st_sc1_f2(float* p, float a, float b) {      // 
   const smsut_u64 bits = ((smsut_u64)__float_as_uint(b) << 32) | (smsut_u64)__float_as_uint(a);
   __hip_atomic_store((smsut_u64*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ld_sc1_f2(const float* p, float& a, float& b) {
-  const smsut_u64 bits = __hip_atomic_load((const smsut_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  a = __uint_as_float((unsigned)bits); b = __uint_as_float((unsigned)(bits >> 32));
+// sc1 loads of the partials through a buffer descriptor over ONE image's block: the per-lane offset is one VGPR, the row a scalar
+// offset (no 64-bit address per load in flight: the tail of a 72-register kernel must not raise its register count), and rows past
+// the block's end read as 0 (descriptor range check) -- exactly the "+ 0.0" in_moments_final adds for them.
+typedef __amdgpu_buffer_rsrc_t smsut_rsrc_t;
+__device__ __forceinline__ smsut_rsrc_t fin_rsrc(const float* p, int bytes) {
+  const smsut_u64 v = (smsut_u64)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((smsut_u64)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+typedef unsigned smsut_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ld_sc1_f2(smsut_rsrc_t r, int voff, int soff, float& a, float& b) {
+  const smsut_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 16);       // aux 16 = sc1
+  a = __uint_as_float(v[0]); b = __uint_as_float(v[1]);
 }
 
 // Combine one image's partials part[chunks][C][2] -> o0[C], o1[C].  FWD: (mean, rstd = 1/sqrt(var + eps)); else the two means.
@@ -128,6 +138,7 @@ __device__ __forceinline__ void ld_sc1_f2(const float* p, float& a, float& b) {
 template <bool FWD>
 __device__ __forceinline__ void fin_image(const float* part, int chunks, int C, int HW, float eps, float* o0, float* o1, double* sm) {
   const double inv = 1.0 / (double)HW;
+  const smsut_rsrc_t rs = fin_rsrc(part, chunks * C * 8);
   auto emit = [&](int c, double t0, double t1) {
     if (FWD) {
       const double m = t0 * inv;
@@ -140,36 +151,33 @@ __device__ __forceinline__ void fin_image(const float* part, int chunks, int C, 
       o1[c] = (float)(t1 * inv);
     }
   };
+  constexpr int U = 16;
   if (chunks <= 16) {
+    const int rowb = __builtin_amdgcn_readfirstlane(C * 8);
     for (int c = threadIdx.x; c < C; c += 256) {
-      float a[16], b[16];
+      float a[U], b[U];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) ld_sc1_f2(part + ((size_t)(u < chunks ? u : 0) * C + c) * 2, a[u], b[u]);
+      for (int u = 0; u < U; ++u) ld_sc1_f2(rs, c * 8, u * rowb, a[u], b[u]);
       double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { t0 += (u < chunks) ? (double)a[u] : 0.0; t1 += (u < chunks) ? (double)b[u] : 0.0; }
+      for (int u = 0; u < U; ++u) { t0 += (double)a[u]; t1 += (double)b[u]; }
       emit(c, t0, t1);
     }
     return;
   }
   const int col = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int rowb16 = __builtin_amdgcn_readfirstlane(C * 8 * 16);
   for (int cb = 0; cb < C; cb += 16) {                       // (uniform: barriers inside)
     const int c = cb + col;
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
-      constexpr int U = 16;
-      for (int ch = cl; ch < chunks; ch += U * 16) {
+      for (int ch0 = 0; ch0 < chunks; ch0 += U * 16) {       // rows cl + ch0 + 16 u: all U in flight
         float a[U], b[U];
+        const int voff = ((cl + ch0) * C + c) * 8;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int r = ch + u * 16;
-          ld_sc1_f2(part + ((size_t)(r < chunks ? r : ch) * C + c) * 2, a[u], b[u]);
-        }
+        for (int u = 0; u < U; ++u) ld_sc1_f2(rs, voff, u * rowb16, a[u], b[u]);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          s0 += (ch + u * 16 < chunks) ? (double)a[u] : 0.0;
-          s1 += (ch + u * 16 < chunks) ? (double)b[u] : 0.0;
-        }
+        for (int u = 0; u < U; ++u) { s0 += (double)a[u]; s1 += (double)b[u]; }
       }
     }
     sm[threadIdx.x * 2] = s0; sm[threadIdx.x * 2 + 1] = s1;
@@ -213,4 +221,67 @@ __device__ __forceinline__ void fin_tail(const FinRef& fin, const float* stats, 
       __syncthreads();
     }
   }
+}
+
+// ... and for the THREE sums of the residual tail's backward (partials [chunks][C][3]; in_moments_final<2>'s order): the means go
+// to o0, o1, o2 [C].  12-byte sc1 loads through the same descriptor scheme.
+typedef unsigned smsut_u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void fin_image3(const float* part, int chunks, int C, int HW, float* o0, float* o1, float* o2, double* sm) {
+  const double inv = 1.0 / (double)HW;
+  const smsut_rsrc_t rs = fin_rsrc(part, chunks * C * 12);
+  auto ld = [&](int voff, int soff, float (&v)[3]) __attribute__((always_inline)) {
+    const smsut_u32x3 q = __builtin_amdgcn_raw_buffer_load_b96(rs, voff, soff, 16);    // aux 16 = sc1
+    v[0] = __uint_as_float(q[0]); v[1] = __uint_as_float(q[1]); v[2] = __uint_as_float(q[2]);
+  };
+  constexpr int U = 16;
+  if (chunks <= 16) {
+    const int rowb = __builtin_amdgcn_readfirstlane(C * 12);
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float v[U][3];
+#pragma unroll
+      for (int u = 0; u < U; ++u) ld(c * 12, u * rowb, v[u]);
+      double t[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] += (double)v[u][k];
+      o0[c] = (float)(t[0] * inv); o1[c] = (float)(t[1] * inv); o2[c] = (float)(t[2] * inv);
+    }
+    return;
+  }
+  const int col = threadIdx.x & 15, cl = threadIdx.x >> 4;
+  const int rowb16 = __builtin_amdgcn_readfirstlane(C * 12 * 16);
+  for (int cb = 0; cb < C; cb += 16) {                       // (uniform: barriers inside)
+    const int c = cb + col;
+    double s[3] = {0.0, 0.0, 0.0};
+    if (c < C) {
+      for (int ch0 = 0; ch0 < chunks; ch0 += U * 16) {
+        float v[U][3];
+        const int voff = ((cl + ch0) * C + c) * 12;
+#pragma unroll
+        for (int u = 0; u < U; ++u) ld(voff, u * rowb16, v[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) s[k] += (double)v[u][k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sm[threadIdx.x * 3 + k] = s[k];
+    __syncthreads();
+    if (cl == 0 && c < C) {
+      double t[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        double a = 0.0;
+        for (int l = 0; l < 16; ++l) a += sm[(l * 16 + col) * 3 + k];
+        t[k] = a;
+      }
+      o0[c] = (float)(t[0] * inv); o1[c] = (float)(t[1] * inv); o2[c] = (float)(t[2] * inv);
+    }
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ void st_sc1_f(float* p, float a) {                 // 4-byte write-through store
+  __hip_atomic_store((unsigned*)p, __float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -357,13 +357,18 @@ struct ScRef { const float* w; float* y; float* stats; };   // SC: the block's 1
 constexpr int SPIXW = 20;
 
 template <int KS, int TH, int NTN, int NCH, bool STATS, bool ACC, bool BST = false, bool DUAL = false, bool INAFF = false,
-          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false, bool O16 = false, bool I16 = false>
+          bool F16 = false, bool K8 = false, bool SC = false, bool SC2 = false, bool N8 = false, bool WINO = false, bool O16 = false, bool I16 = false,
+          bool FIN = false>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(WINO ? 2 : 1, WINO ? 2 : 8)))
 conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int N, int H, int W,
                 int Ndim, int tiles_x, int tiles_img, int items_per_wg, int transposed, float* __restrict__ stats,
                 BstRef bst = BstRef{}, float* __restrict__ y2 = nullptr, int split = 0,
                 const float* __restrict__ x2 = nullptr, AffRef aff = AffRef{}, const float* __restrict__ gsc = nullptr,
-                ScRef sc = ScRef{}) {
+                ScRef sc = ScRef{}, FinRef fin = FinRef{}) {
+  // FIN / fin (common.h): the workgroup whose partials complete an image finalises its InstanceNorm statistics in this launch (a
+  // template flag, so that the instantiations without it keep their registers: the tail's loads in flight would set the count of
+  // the 64-128-register forms)
+  static_assert(!FIN || ((STATS || BST) && !F16 && !N8), "in-launch finalize: fp32 statistics / BST forms");
   // SC: conv1 of a BasicBlock AND the block's 1x1 shortcut conv in one pass (network/blocks.py:66-80: both read the block input).
   // The 1x1 conv is the centre tap with its own weights: the A fragments of tap (1,1) feed a second accumulator set (+1/9 MFMAs),
   // the epilogue stores the second result sc.y and its InstanceNorm partials sc.stats -- the separate 1x1 kernel and its re-read
@@ -755,13 +760,17 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int m = 0; m < 4; ++m) { s1 += rd[(m * CO_T + tid) * 2]; s2 += rd[(m * CO_T + tid) * 2 + 1]; }
-      *(float2*)(stats + (((size_t)en * tiles_img + ety * tiles_x + etx) * Ndim + co0 + tid) * 2) = make_float2(s1, s2);
+      float* const po = stats + (((size_t)en * tiles_img + ety * tiles_x + etx) * Ndim + co0 + tid) * 2;
+      if constexpr (FIN) st_sc1_f2(po, s1, s2);         // in-launch finalize: write-through, read by the last-arriving workgroup
+      else *(float2*)po = make_float2(s1, s2);
       if constexpr (SC) {
         const float* rs = red_sc + par * (4 * CO_T * 2);
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) { t1 += rs[(m * CO_T + tid) * 2]; t2 += rs[(m * CO_T + tid) * 2 + 1]; }
-        *(float2*)(sc.stats + (((size_t)en * tiles_img + ety * tiles_x + etx) * Ndim + co0 + tid) * 2) = make_float2(t1, t2);
+        float* const ps = sc.stats + (((size_t)en * tiles_img + ety * tiles_x + etx) * Ndim + co0 + tid) * 2;
+        if constexpr (FIN) st_sc1_f2(ps, t1, t2);
+        else *(float2*)ps = make_float2(t1, t2);
       }
     }
   };
@@ -1011,6 +1020,9 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
   for (int item = item0 + 1; item < item1; ++item) item_body(item, std::false_type{});
   epilogue(par);
   if (STATS || BST) { __syncthreads(); stats_out(par); }
+  if constexpr (FIN)                                    // the image(s) this workgroup completes: finalised here
+    fin_tail<!BST>(fin, stats, SC ? sc.stats : nullptr, item0, item1, tiles_img, tiles_img * (int)gridDim.y, Ndim, H * W,
+                   reinterpret_cast<int*>(smem + 1024), reinterpret_cast<double*>(smem));
   STAMP(11);
 }
 
@@ -1852,8 +1864,13 @@ template <int KS, int TH, int NTN, int NCH, bool K8 = false, bool N8 = false, bo
 int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                  hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr, const BstRef* bst = nullptr,
                  float* y2 = nullptr, int split = 0, const float* x2 = nullptr, const AffRef* aff = nullptr,
-                 bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr, int hs = 0) {
-  const bool o16 = (hs & 1) != 0, i16 = (hs & 2) != 0;   // half storage: bit 0 = the result (or the BST y1) is fp16, bit 1 = the input is
+                 bool f16 = false, const float* gsc = nullptr, const ScRef* sc = nullptr, int hs = 0, const FinRef* fin = nullptr) {
+  const bool o16 = (hs & 1) != 0, i16 = (hs & 2) != 0;
+  // in-launch finalize (FIN instantiations): fp32 statistics / BST forms of the fused block -- plain, input-side IN, fused shortcut
+  if (fin && (!fin->tickets || !fin->o0 || !fin->o1 || !stats || f16 || N8 || y2 || o16 || i16 || (transposed & 2) ||
+              (fin->s0 && !(sc && !(transposed & 1) && sc->stats && fin->s1)) || (!fin->s0 && sc)))
+    return -1;
+  const FinRef finv = fin ? *fin : FinRef{};   // half storage: bit 0 = the result (or the BST y1) is fp16, bit 1 = the input is
   constexpr size_t sh = fwd_p_lds<KS, TH, NTN, NCH, WINO>();
   // fused 1x1 shortcut (SC): its weight block and a second statistics scratch
   constexpr size_t sh_sc = sh + (size_t)(16 * NCH * 16 * NTN + 2 * 4 * 16 * NTN * 2 + 8) * sizeof(float);
@@ -1904,6 +1921,19 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
   // one launch site for every form; the fp16-operand twin of each form is chosen at run time (f16)
 #define P_GO(ST, AC, BS, DU, IA)                                                                                             \
   do {                                                                                                                       \
+    if constexpr ((ST || BS) && !AC) {                                                                                       \
+      if (fin) {                                      /* the same form, finalising its statistics in the launch */          \
+        if constexpr (K8) {                                                                                                  \
+          if constexpr (!BS && !DU && !IA)                                                                                   \
+            P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr, ScRef{}, finv), \
+                conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, false, false, false, false, true, false, false, false, false, false, false, true>); \
+        } else {                                                                                                             \
+          P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr, ScRef{}, finv), \
+              conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, BS, DU, IA, false, false, false, false, false, WINO, false, false, true>); \
+        }                                                                                                                    \
+        break;                                                                                                               \
+      }                                                                                                                      \
+    }                                                                                                                        \
     if constexpr (K8) {                                                                                                      \
       if constexpr (!BS && !DU && !IA)                                                                                       \
         P_K(sh, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, tr, stats, bstv, y2, split, x2, affv, nullptr), conv_mfma_fwd_p<KS, TH, NTN, NCH, ST, AC, false, false, false, false, true>);                 \
@@ -1947,6 +1977,9 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
       if (o16)
         P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc),
             conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true, false, false, false, true>);
+      else if (fin)
+        P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc, finv),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true, false, false, false, false, false, true>);
       else
         P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc),
             conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, true, true>);
@@ -1965,10 +1998,17 @@ int launch_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, 
 #undef SC16_GO
         } else return -1;
       } else if (x2) {
-        if constexpr (NCH % 2 == 0)
-          P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc),
-              conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true, false, false, WINO>);
-        else return -1;
+        if constexpr (NCH % 2 == 0) {
+          if (fin)
+            P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc, finv),
+                conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true, false, false, WINO, false, false, true>);
+          else
+            P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, x2, affv, nullptr, *sc),
+                conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, true, false, false, false, true, false, false, WINO>);
+        } else return -1;
+      } else if (fin) {
+        P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc, finv),
+            conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true, false, false, WINO, false, false, true>);
       } else {
         P_K(sh_sc, (x, w, y, N, H, W, Ndim, tiles_x, tiles_img, ipw, 0, stats, bstv, nullptr, 0, nullptr, affv, nullptr, *sc),
             conv_mfma_fwd_p<KS, TH, NTN, NCH, true, false, false, false, false, false, false, true, false, false, WINO>);
@@ -2044,8 +2084,8 @@ inline bool fwd_any_eligible(int N, int H, int W, int Kdim, int Ndim, bool f16) 
 inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int transposed,
                         hipStream_t st, float* stats, int* tiles_out, const BstRef* bst, float* y2 = nullptr, int split = 0,
                         const float* x2 = nullptr, const AffRef* aff = nullptr, bool f16 = false, const float* gsc = nullptr,
-                        const ScRef* sc = nullptr, const float* wu = nullptr, int hs = 0) {
-#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc, hs
+                        const ScRef* sc = nullptr, const float* wu = nullptr, int hs = 0, const FinRef* fin = nullptr) {
+#define PARGS x, w, y, N, H, W, Kdim, Ndim, transposed, st, stats, tiles_out, bst, y2, split, x2, aff, f16, gsc, sc, hs, fin
   // (the fused shortcut data-gradient at 64 reduction channels stays on the direct resident-weight form: 107 us vs 142 us at
   //  16 x 128^2 (32 + 32) -> 64 -- its second-half chunks are a run-time branch inside the staging parts, r03 notes)
   const bool sc2_64 = sc && (transposed & 1) && Kdim == 64 && fwd_p_eligible(N, H, W, Kdim, Ndim);
@@ -2055,7 +2095,7 @@ inline int select_fwd_p(const float* x, const float* w, float* y, int N, int H, 
     if (aff) wa = WinoAff{aff->mean, aff->rstd, aff->gamma, aff->beta, aff->slope};
     if (sc) ws = WinoSc{sc->w, sc->y, sc->stats};
     return smsut_wino_l_launch(x, x2, w, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, tiles_out, bst ? &wb : nullptr,
-                               aff ? &wa : nullptr, sc ? &ws : nullptr, st, wu);
+                               aff ? &wa : nullptr, sc ? &ws : nullptr, st, wu, fin);
   }
   if (Ndim == 8) {                                   // 8 result channels (see conv_mfma_fwd_p, N8): data-gradient forms
     if (Kdim == 16) return (H % 16 == 0) ? launch_fwd_p<3, 16, 1, 1, false, true>(PARGS) : launch_fwd_p<3, 8, 1, 1, false, true>(PARGS);
@@ -2927,6 +2967,56 @@ int smsut_conv2d_dgrad_mfma_bwdstats(const float* gy, const float* w, float* gz,
   return smsut_conv2d_dgrad_mfma_bwdstats_pre(gy, w, gz, stats, y1, mean, rstd, gamma, beta, slope, N, H, W, Kdim, Ndim, nullptr, stream);
 }
 
+// ---- `_fin` forms (r05): the same launches with the InstanceNorm statistics FINALISED INSIDE THE LAUNCH (common.h, FinRef): the
+// workgroup whose partials complete an image combines them (in_moments_final's order: same bits) -- the separate
+// smsut_in_finalize_* launch behind every statistics-producing conv of a fused BasicBlock (/root/reference/network/blocks.py:70-79:
+// conv -> InstanceNorm, three times per block forward, once more per block backward) disappears.  tickets: int [N], ZERO on entry,
+// zero again when the launch is over (the caller hands out slices of one zero-initialised pool).  wu (nullable): the caller's
+// prepared Winograd image for this call (the `_pre` argument).  fp32 operands.
+int smsut_conv2d_fwd_mfma_stats_sc_fin(const float* x, const float* xb, const float* w, const float* wsc, float* y, float* ysc,
+                                       float* stats, float* stats_sc, int* tickets, float* mean, float* rstd, float* mean_sc,
+                                       float* rstd_sc, float eps, int N, int H, int W, int Kdim, int Ndim, const float* wu,
+                                       void* stream) {
+  SMSUT_REQUIRE(x && w && wsc && y && ysc && stats && stats_sc && tickets && mean && rstd && mean_sc && rstd_sc);
+  SMSUT_REQUIRE(smsut_conv2d_fwd_sc_supported(N, H, W, Kdim, Ndim, xb != nullptr));
+  const ScRef sc{wsc, ysc, stats_sc};
+  const FinRef fin{tickets, mean, rstd, mean_sc, rstd_sc, eps};
+  const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, xb, nullptr,
+                              false, nullptr, &sc, wu, 0, &fin);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+int smsut_conv2d_fwd_mfma_stats_inaff_fin(const float* x, const float* w, float* y, float* stats, const float* mean,
+                                          const float* rstd, const float* gamma, const float* beta, float slope, int* tickets,
+                                          float* mean_out, float* rstd_out, float eps, int N, int H, int W, int Kdim, int Ndim,
+                                          const float* wu, void* stream) {
+  SMSUT_REQUIRE(x && w && y && stats && mean && rstd && gamma && beta && tickets && mean_out && rstd_out && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(fwd_any_eligible(N, H, W, Kdim, Ndim, false));
+  const AffRef a{mean, rstd, gamma, beta, slope};
+  const FinRef fin{tickets, mean_out, rstd_out, nullptr, nullptr, eps};
+  const int rc = select_fwd_p(x, w, y, N, H, W, Kdim, Ndim, 0, (hipStream_t)stream, stats, nullptr, nullptr, nullptr, 0, nullptr, &a,
+                              false, nullptr, nullptr, wu, 0, &fin);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+// ... the data-gradient with backward statistics: a_mean / b_mean [N][Ndim] = mean(gz), mean(gz * xhat) (what smsut_in_finalize_bwd writes)
+int smsut_conv2d_dgrad_mfma_bwdstats_fin(const float* gy, const float* w, float* gz, float* stats, const float* y1,
+                                         const float* mean, const float* rstd, const float* gamma, const float* beta, float slope,
+                                         int* tickets, float* a_mean, float* b_mean, int N, int H, int W, int Kdim, int Ndim,
+                                         const float* wu, void* stream) {
+  SMSUT_REQUIRE(gy && w && gz && stats && y1 && mean && rstd && gamma && beta && tickets && a_mean && b_mean && N > 0 && H > 0 && W > 0);
+  SMSUT_REQUIRE(fwd_any_eligible(N, H, W, Kdim, Ndim, false));
+  const BstRef b{y1, mean, rstd, gamma, beta, slope};
+  const FinRef fin{tickets, a_mean, b_mean, nullptr, nullptr, 0.f};
+  const int rc = select_fwd_p(gy, w, gz, N, H, W, Kdim, Ndim, 1, (hipStream_t)stream, stats, nullptr, &b, nullptr, 0, nullptr, nullptr,
+                              false, nullptr, nullptr, wu, 0, &fin);
+  SMSUT_REQUIRE(rc == 0);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
 int smsut_conv2d_fwd_mfma_cfg(const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim, int KS,
                               int transposed, int cfg, void* stream) {
   SMSUT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0 && smsut_conv2d_mfma_supported(KS, 1, (KS - 1) / 2, Kdim, Ndim));
@@ -3161,6 +3251,24 @@ int smsut_conv2d_wgrad_pair(const float* xA, const float* x2A, const float* gyA,
                     smsut_wgrad_rr_splits(NA + NB, H, W, Cin, Cout, x2A, x2A ? ca : 0, aff, gsA != nullptr), st);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+
+// Measurement entry point (bench.py's roofline leg), the paired twin of smsut_conv2d_wgrad_mfma_slabs: the register-row kernel of
+// smsut_conv2d_wgrad_pair ALONE (input-side-IN or plain form, no virtual cat / shortcut), slabs left in the workspace, no reduction.
+// Returns the number of slabs written (> 0) or a negative value.
+int smsut_conv2d_wgrad_pair_slabs(const float* xA, const float* gyA, const float* meanA, const float* rstdA, int NA, const float* xB,
+                                  const float* gyB, const float* meanB, const float* rstdB, int NB, const float* gamma,
+                                  const float* beta, float slope, float* workspace, int H, int W, int Cin, int Cout, void* stream) {
+  if (!xA || !gyA || !xB || !gyB || !workspace) return SMSUT_EINVAL;
+  const bool aff = meanA != nullptr;
+  if (aff != (rstdA != nullptr) || aff != (meanB != nullptr) || aff != (rstdB != nullptr) || (aff && !(gamma && beta))) return SMSUT_EINVAL;
+  if (!smsut_conv2d_wgrad_pair_supported(NA, NB, H, W, Cin, Cout, 0, aff, 0)) return SMSUT_EINVAL;
+  const RrAff ra{meanA, rstdA, gamma, beta, slope};
+  const RrSetB sb{xB, nullptr, gyB, nullptr, meanB, rstdB, NB};
+  if (smsut_wgrad_rr_launch(xA, nullptr, 0, gyA, nullptr, workspace, NA + NB, H, W, Cin, Cout, aff ? &ra : nullptr, (hipStream_t)stream, &sb) != 0)
+    return SMSUT_EINVAL;
+  if (hipGetLastError() != hipSuccess) return SMSUT_EINVAL;
+  return smsut_wgrad_rr_splits(NA + NB, H, W, Cin, Cout, nullptr, 0, aff, false);
 }
 
 // ---- fp16-operand entry points (BASELINE config 5; see the block comment above mfma16h) -----------------------------------

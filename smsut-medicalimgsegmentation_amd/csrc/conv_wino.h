@@ -15,10 +15,11 @@ bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim);
 // shortcut conv (sc->w, result sc->y, InstanceNorm partials sc->stats).  y2 / split: split output.  tiles_out: only report the
 // statistics tiles per image.  wu: the caller's prepared image of w for THIS form (smsut_wino_prepare with the same Kdim, Ndim and
 // transposed bit 0) or null = transform the weights on the fly; the library keeps no table of images (r03 did: SURVEY 8b rules
-// process-wide mutable state out).  Returns 0 when launched (or reported), -1 when the form is not covered (nothing launched).
+// process-wide mutable state out).  fin (statistics / BST forms): the InstanceNorm statistics are finalised inside the launch by the
+// last-arriving workgroup (common.h).  Returns 0 when launched (or reported), -1 when the form is not covered (nothing launched).
 int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W,
                         int Kdim, int Ndim, int transposed, float* stats, int* tiles_out, const WinoBst* bst, const WinoAff* aff,
-                        const WinoSc* sc, hipStream_t st, const float* wu = nullptr);
+                        const WinoSc* sc, hipStream_t st, const float* wu = nullptr, const FinRef* fin = nullptr);
 
 // ---- Winograd weight gradient F(3x3, 2x2): gw[3][3][Cin][Cout] = sum_p x[p + tap] (x) gy[p] through
 //      dg = G^T [ sum_tiles (B^T d B) (.) (A dY A^T) ] G  (16 products per 2x2 tile of gy instead of 36).

@@ -110,13 +110,14 @@ constexpr size_t wino_l_lds(bool sc, bool gli) {
   return (size_t)(2 * wino_l_buf_floats<NTN>(sc, gli) + (4 * 16 * NTN * 2 + 8) * (sc ? 2 : 1)) * sizeof(float);
 }
 
-template <int NTN, bool STATS, bool ACC, bool BST, bool DUAL, bool INAFF, bool SC, bool SC2, bool PRE>
+template <int NTN, bool STATS, bool ACC, bool BST, bool DUAL, bool INAFF, bool SC, bool SC2, bool PRE, bool FIN = false>
 __global__ void __launch_bounds__(TPB) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const float* __restrict__ w, const float* __restrict__ wu,
             float* __restrict__ y,
             float* __restrict__ y2, int split, int N, int H, int W, int nch, int Ndim, int tiles_x, int tiles_img, int items_per_wg,
-            int transposed, float* __restrict__ stats, WinoBst bst, WinoAff aff, WinoSc sc) {
+            int transposed, float* __restrict__ stats, WinoBst bst, WinoAff aff, WinoSc sc, FinRef fin) {
   static_assert(!(BST && (STATS || ACC)), "BST excludes the forward statistics and the accumulate form");
+  static_assert(!FIN || STATS || BST, "in-launch finalize (common.h): statistics / BST forms");
   static_assert(!INAFF || (STATS && !ACC && !BST && !DUAL), "input-side IN: forward statistics form only");
   static_assert(!SC || (STATS && !ACC && !BST && !INAFF && !SC2), "fused shortcut: forward statistics forms");
   static_assert(!SC2 || (DUAL && !STATS && !ACC && !BST && !INAFF && !SC), "fused shortcut data-gradient");
@@ -441,12 +442,16 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int m = 0; m < 4; ++m) { s1 += red[(m * CO_T + tid) * 2]; s2 += red[(m * CO_T + tid) * 2 + 1]; }
-      *(float2*)(stats + (((size_t)cn * tiles_img + cty * tiles_x + ctx) * Ndim + co0 + tid) * 2) = make_float2(s1, s2);
+      float* const po = stats + (((size_t)cn * tiles_img + cty * tiles_x + ctx) * Ndim + co0 + tid) * 2;
+      if constexpr (FIN) st_sc1_f2(po, s1, s2);         // in-launch finalize (common.h): write-through partials
+      else *(float2*)po = make_float2(s1, s2);
       if constexpr (SC) {
         float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int m = 0; m < 4; ++m) { t1 += red_sc[(m * CO_T + tid) * 2]; t2 += red_sc[(m * CO_T + tid) * 2 + 1]; }
-        *(float2*)(sc.stats + (((size_t)cn * tiles_img + cty * tiles_x + ctx) * Ndim + co0 + tid) * 2) = make_float2(t1, t2);
+        float* const ps = sc.stats + (((size_t)cn * tiles_img + cty * tiles_x + ctx) * Ndim + co0 + tid) * 2;
+        if constexpr (FIN) st_sc1_f2(ps, t1, t2);
+        else *(float2*)ps = make_float2(t1, t2);
       }
     }
   };
@@ -695,6 +700,9 @@ conv_wino_l(const float* __restrict__ x, const float* __restrict__ x2, const flo
     __syncthreads();
     stats_out(sn, sty, stx);
   }
+  if constexpr (FIN)                                    // the image(s) this workgroup completes: finalised here
+    fin_tail<!BST>(fin, stats, SC ? sc.stats : nullptr, item0, item1, tiles_img, tiles_img * (int)gridDim.y, Ndim, H * W,
+                   reinterpret_cast<int*>(smem + 1024), reinterpret_cast<double*>(smem));
 #ifdef SMSUT_WL_STAMPS
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
     for (int i = 0; i < 6; ++i) y[i] = (float)acc_t[i];
@@ -775,8 +783,13 @@ inline void allow_big_lds(size_t bytes) {
 
 template <int NTN>
 int launch_ntn(const float* x, const float* x2, const float* w, const float* wu, float* y, float* y2, int split, int N, int H, int W,
-               int Kdim, int Ndim, int transposed, float* stats, const WinoBst* bst, const WinoAff* aff, const WinoSc* sc, hipStream_t st) {
+               int Kdim, int Ndim, int transposed, float* stats, const WinoBst* bst, const WinoAff* aff, const WinoSc* sc, hipStream_t st,
+               const FinRef* fin) {
   const int tiles_x = W / TW, tiles_img = tiles_x * (H / TH);
+  if (fin && (!fin->tickets || !fin->o0 || !fin->o1 || !stats || y2 || (transposed & 2) ||
+              (fin->s0 && !(sc && !(transposed & 1) && sc->stats && fin->s1)) || (!fin->s0 && sc)))
+    return -1;
+  const FinRef fv = fin ? *fin : FinRef{};
   const int nz = Ndim / (16 * NTN);
   const int64_t items = (int64_t)N * tiles_img;
   const int per_cu = 1;                                 // resident workgroups per CU (one wave per SIMD: registers, 2 LDS buffers)
@@ -790,12 +803,19 @@ int launch_ntn(const float* x, const float* x2, const float* w, const float* wu,
   const WinoSc sv = sc ? *sc : WinoSc{};
   const bool sc2 = sc && (transposed & 1), scf = sc && !sc2;
   const size_t sh = wino_l_lds<NTN>(scf, !aff && SMSUT_WINO_GLDS != 0);
+#define WGO2(ST, AC, BS, DU, IA, S1, S2, PR, FI)                                                                          \
+  do {                                                                                                                     \
+    allow_big_lds<conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2, PR, FI>>(sh);                                               \
+    conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2, PR, FI><<<grid, TPB, sh, st>>>(x, x2, w, wu, y, y2, split, N, H, W, nch,  \
+                                                                                Ndim, tiles_x, tiles_img, ipw, transposed, \
+                                                                                stats, bv, av, sv, fv);                    \
+  } while (0)
 #define WGO1(ST, AC, BS, DU, IA, S1, S2, PR)                                                                              \
   do {                                                                                                                     \
-    allow_big_lds<conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2, PR>>(sh);                                                   \
-    conv_wino_l<NTN, ST, AC, BS, DU, IA, S1, S2, PR><<<grid, TPB, sh, st>>>(x, x2, w, wu, y, y2, split, N, H, W, nch, Ndim, \
-                                                                            tiles_x, tiles_img, ipw, transposed, stats, bv, \
-                                                                            av, sv);                                       \
+    if constexpr ((ST) || (BS)) {                                                                                          \
+      if (fin) { WGO2(ST, AC, BS, DU, IA, S1, S2, PR, true); break; }                                                      \
+    }                                                                                                                      \
+    WGO2(ST, AC, BS, DU, IA, S1, S2, PR, false);                                                                           \
   } while (0)
 #define WGO(ST, AC, BS, DU, IA, S1, S2)                                                                                    \
   do {                                                                                                                     \
@@ -831,6 +851,7 @@ int launch_ntn(const float* x, const float* x2, const float* w, const float* wu,
   }
 #undef WGO
 #undef WGO1
+#undef WGO2
   return 0;
 }
 
@@ -1185,7 +1206,7 @@ bool smsut_wino_l_eligible(int N, int H, int W, int Kdim, int Ndim) {
 
 int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* y, float* y2, int split, int N, int H, int W,
                         int Kdim, int Ndim, int transposed, float* stats, int* tiles_out, const WinoBst* bst, const WinoAff* aff,
-                        const WinoSc* sc, hipStream_t st, const float* wu_in) {
+                        const WinoSc* sc, hipStream_t st, const float* wu_in, const FinRef* fin) {
   if (!smsut_wino_l_eligible(N, H, W, Kdim, Ndim)) return -1;
   if (y2 && (split <= 0 || split >= Ndim || split % 16 != 0 || (Ndim - split) % 16 != 0 || stats || bst)) return -1;
   if (tiles_out) { *tiles_out = (W / TW) * (H / TH); return 0; }
@@ -1198,8 +1219,8 @@ int smsut_wino_l_launch(const float* x, const float* x2, const float* w, float* 
   // prepared weights (smsut_wino_prepare by the caller, passed with the call): copied by LDS-DMA instead of transformed per chunk
   const bool sc2 = sc && (transposed & 1);
   const float* wu = sc2 ? nullptr : wu_in;
-  if (ntn == 2) return launch_ntn<2>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
-  return launch_ntn<1>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st);
+  if (ntn == 2) return launch_ntn<2>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st, fin);
+  return launch_ntn<1>(x, x2, w, wu, y, y2, split, N, H, W, Kdim, Ndim, transposed, stats, bst, aff, sc, st, fin);
 }
 
 extern "C" {

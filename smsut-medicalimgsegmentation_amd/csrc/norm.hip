@@ -510,11 +510,13 @@ restail_fwd(TailRef t, float* __restrict__ out, int HW, int C, float slope) {
 }
 
 // partial [N][chunks][C][3] = {sum gz, sum gz*y2hat, sum gz*shat}
-template <int VEC, bool REMASK, bool HS = false>
+// FIN (r05; several chunks per image): the workgroup whose partials complete an image (agent-scope ticket per image, common.h) runs
+// in_moments_final<2>'s combine itself -- fin.o0 .. o2 then name the outputs of THAT finalize, tickets the image counters.
+template <int VEC, bool REMASK, bool HS = false, bool FIN = false>
 __global__ void __launch_bounds__(TPB)       // (a 128-VGPR cap spills here: 244 B scratch and +30 % time)
 restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
-                    int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}) {
-  const bool emit = fin.o0 != nullptr;              // one-chunk case: see fin_emit
+                    int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}, int* tickets = nullptr) {
+  const bool emit = !FIN && fin.o0 != nullptr;      // one-chunk case: see fin_emit
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
   const int CVA = C / VEC;                    // gridDim.z channel slabs, as in in_moments_partial
   const int CV = CVA / gridDim.z;
@@ -607,7 +609,8 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
             float tot = 0.f;
 #pragma unroll
             for (int w4 = 0; w4 < 4; ++w4) tot += sm[((w4 * TC + tc) * 3 + q) * VEC + j];
-            part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
+            if constexpr (FIN) st_sc1_f(part + (((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q, tot);
+            else part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
             tots[q] = tot;
           }
           if (emit) fin_emit<2>(fin, HW, n * C + cv * VEC + j, tots);
@@ -627,7 +630,8 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
           for (int q = 0; q < 3; ++q) {
             float tot = 0.f;
             for (int r = 0; r < rows; ++r) tot += sm[((r * TC + tc) * 3 + q) * VEC + j];
-            part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
+            if constexpr (FIN) st_sc1_f(part + (((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q, tot);
+            else part[(((size_t)n * chunks + chunk) * C + cv * VEC + j) * 3 + q] = tot;
             tots[q] = tot;
           }
           if (emit) fin_emit<2>(fin, HW, n * C + cv * VEC + j, tots);
@@ -635,6 +639,23 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
       }
     }
     __syncthreads();
+  }
+  if constexpr (FIN) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // every storing wave: its write-through partials have left
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(sm);
+    if (threadIdx.x == 0) {
+      const int tk = __hip_atomic_fetch_add(tickets + n, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = (tk + 1 == (int)(gridDim.x * gridDim.z)) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool last = *flag != 0;
+    __syncthreads();
+    if (last) {                                              // (sm: 12 KB = 256 x 3 doubles + slack)
+      fin_image3(part + (size_t)n * chunks * C * 3, chunks, C, HW, fin.o0 + (size_t)n * C, fin.o1 + (size_t)n * C,
+                 fin.o2 + (size_t)n * C, reinterpret_cast<double*>(sm));
+      if (threadIdx.x == 0) __hip_atomic_store(tickets + n, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -966,7 +987,7 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
                               const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
                               const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
                               float* gbs, float* workspace, float* amax, int N, int HW, int C, float slope, void* stream,
-                              bool hs = false) {
+                              bool hs = false, int* tickets = nullptr) {
   SMSUT_REQUIRE(gout && out && y2 && m2 && r2 && g2 && s && gy2 && gs && a_mean && b2_mean && bs_mean && gg2 && gb2 &&
                 workspace && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs_ && ggs && gbs)));
   TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs_, bs};
@@ -977,13 +998,19 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
   const bool remask = ms && b2 && bs;
   const FinOut fin = (chunks == 1 && fin_emit_on()) ? FinOut{a_mean, b2_mean, bs_mean, 0.f} : FinOut{};
 #define TAIL_PARTIAL(V, R) restail_bwd_partial<V, R><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin)
-  if (hs) {
+  // in-launch finalize (several chunks per image, fp32, the two-IN tail on whole float4 channel groups): the last-arriving
+  // workgroup of an image combines its partials -- no in_moments_final<2> launch
+  const bool fin_in = tickets && !fin.o0 && !hs && remask && C % 4 == 0;
+  if (fin_in) {
+    restail_bwd_partial<4, true, false, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope,
+                                                                 FinOut{a_mean, b2_mean, bs_mean, 0.f}, tickets);
+  } else if (hs) {
     SMSUT_REQUIRE(remask && C % 4 == 0);
     restail_bwd_partial<4, true, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin);
   } else if (C % 4 == 0) { if (remask) TAIL_PARTIAL(4, true); else TAIL_PARTIAL(4, false); }
   else { if (remask) TAIL_PARTIAL(1, true); else TAIL_PARTIAL(1, false); }
 #undef TAIL_PARTIAL
-  if (!fin.o0) in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
+  if (!fin.o0 && !fin_in) in_moments_final<2><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b2_mean, bs_mean);
   // the affine gradients (and the copy gbs = gb2) are written by block 0 of the apply kernel
   const int64_t total = (int64_t)N * HW * C;
   SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
@@ -1006,6 +1033,18 @@ int smsut_restail_bwd(const float* gout, const float* out, const float* y2, cons
                       float* gbs, float* workspace, int N, int HW, int C, float slope, void* stream) {
   return restail_bwd_launch(gout, out, y2, m2, r2, g2, b2, s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean, bs_mean, gg2, gb2, ggs, gbs,
                             workspace, nullptr, N, HW, C, slope, stream);
+}
+// ... with the per-image means finalised INSIDE the partial-sum launch (common.h: write-through partials, agent-scope ticket per
+// image, the last-arriving workgroup combines in in_moments_final<2>'s order: same bits) -- two launches instead of three.
+// tickets: int [N], zero on entry, zero again on exit.  Falls back to the three-launch form where the fused form does not apply
+// (one-chunk planes finalise in the partial kernel anyway; identity shortcut; C % 4 != 0).
+int smsut_restail_bwd_fin(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
+                          const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
+                          const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
+                          float* gbs, float* workspace, int* tickets, int N, int HW, int C, float slope, void* stream) {
+  SMSUT_REQUIRE(tickets);
+  return restail_bwd_launch(gout, out, y2, m2, r2, g2, b2, s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean, bs_mean, gg2, gb2, ggs, gbs,
+                            workspace, nullptr, N, HW, C, slope, stream, false, tickets);
 }
 // ... that also hands over max |gy2| (amax[0 .. B)) and max |gs| (amax[B .. 2B)), B = smsut_amax_blocks, for smsut_absmax_finish
 int smsut_restail_bwd_amax(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,

@@ -19,6 +19,7 @@ import torch.distributed
 
 
 _CAPTURING = 0           # > 0 while a GraphedPhase capture is recording on this thread
+CAPTURE_SEQ = 0          # number of GraphedPhase captures started so far (ops keys per-capture scratch on it)
 _LIVE = []               # weakrefs to the captured phases (to mark them for re-binding, see GraphedPhase)
 
 
@@ -74,7 +75,7 @@ class GraphedPhase:
     def __init__(self, fn: Callable[..., torch.Tensor], example_inputs: Sequence[torch.Tensor],
                  grad_params: Iterable[torch.nn.Parameter], warmup: int = 2,
                  rebind_params: Iterable[torch.nn.Parameter] = ()):
-        global _CAPTURING
+        global _CAPTURING, CAPTURE_SEQ
         # ``fn`` (normally a bound method of the trainer that owns this object) is used for the warm-up and the capture only and
         # is NOT kept: trainer -> GraphedPhase -> fn -> trainer was a reference cycle, so a trainer's graph execs were freed only
         # by the cyclic collector, at a moment nobody chose (r03: an abort when that moment fell into another capture).  Without
@@ -104,6 +105,7 @@ class GraphedPhase:
         gc.collect()
         gc.disable()
         _CAPTURING += 1
+        CAPTURE_SEQ += 1
         try:
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.static_out = fn(*self.static_in)

@@ -800,6 +800,61 @@ def basic_block_fusable(x, w1, ws):
             and (ws is not None or ci == co))
 
 
+# ------------------------------------------------------------------------------------------- in-launch InstanceNorm finalize
+# The three statistics-producing convs of a fused BasicBlock (conv1 + shortcut, conv2, conv2's data-gradient) can finalise their
+# InstanceNorm statistics INSIDE the launch (csrc/common.h FinRef: the workgroup whose partials complete an image combines them --
+# same order, same bits as the separate smsut_in_finalize_* launch, which disappears: ~150 launches of 4.7 us on the generator's
+# critical path per uganConsis iteration).  The kernels count arrivals in TICKETS: int32 [N], zero on entry, zero again on exit.
+# They come from here:
+#   * eager launches: slices of ONE zero-initialised ring per device (1 Mi ints; a slice is handed out again only after ~30 000
+#     later calls, long after its launch has run -- and every launch leaves its slice zeroed);
+#   * inside a GraphedPhase capture: slices of a per-capture chunk allocated (and zero-filled: one fill node, replayed first) in
+#     that graph's own pool -- a replay re-zeroes its tickets before use, and no eager launch ever shares them;
+#   * inside somebody else's stream capture: no in-launch finalize (the separate launch runs).
+# ``SMSUT_FIN=0`` switches the whole thing off (A/B).
+FIN_ON = bool(int(_os.environ.get("SMSUT_FIN", "1")))
+# which launches carry it (A/B hook): 1 = conv1 + shortcut and conv2 (forward; the two go together: conv2 reads what conv1's launch
+# finalised), 4 = conv2's data-gradient, 8 = the residual tail's backward
+FIN_MASK = int(_os.environ.get("SMSUT_FIN_MASK", "13"))
+_TICKET_RING = {}            # device index -> [tensor, position]
+_TICKET_CHUNKS = {}          # (device index, capture seq) -> [tensor, position]: the chunk being filled
+_TICKET_KEEP = []            # every chunk ever made, for the life of the process (32 KB each)
+_TICKET_RING_INTS = 1 << 20
+_TICKET_CHUNK_INTS = 1 << 13
+
+
+def _tickets(n: int, like: torch.Tensor):
+    """int32 [n] zeroed tickets for one in-launch-finalize call on ``like``'s device, or None when the call must not use them."""
+    if not FIN_ON:
+        return None
+    from . import graphs
+    dev = like.device.index or 0
+    if graphs._CAPTURING > 0:
+        key = (dev, graphs.CAPTURE_SEQ)
+        ent = _TICKET_CHUNKS.get(key)
+        if ent is None or ent[1] + n > ent[0].numel():
+            ent = _TICKET_CHUNKS[key] = [torch.zeros(max(_TICKET_CHUNK_INTS, n), dtype=torch.int32, device=like.device), 0]
+            _TICKET_KEEP.append(ent[0])              # (a full chunk stays allocated: its slices are baked into the graph)
+        t = ent[0][ent[1]:ent[1] + n]
+        ent[1] += n
+        return t
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    ent = _TICKET_RING.get(dev)
+    if ent is None:
+        ent = _TICKET_RING[dev] = [torch.zeros(_TICKET_RING_INTS, dtype=torch.int32, device=like.device), 0]
+    if ent[1] + n > _TICKET_RING_INTS:
+        ent[1] = 0
+    t = ent[0][ent[1]:ent[1] + n]
+    ent[1] += n
+    return t
+
+
+def _wu(w, transposed):
+    """The prepared Winograd image of ``w`` for this form inside a ``wino_prepared`` scope (the `_pre` argument), else None."""
+    return _WINO_ACTIVE.get((w.data_ptr(), transposed & 1)) if _WINO_ACTIVE else None
+
+
 # ------------------------------------------------------------------------------------------- paired weight gradients
 # A uganConsis iteration runs the generator twice with the same weights -- G(x_real) and the cycle pass G(x_fake) (reference
 # trainer/uganConsisTrainer.py:152,159) -- and differentiates both passes in one G-step (:179), so every 3x3 layer has its weight
@@ -948,6 +1003,12 @@ class BasicBlockFn(Function):
               and bool(H.call("smsut_conv2d_f16_hs_supported", n, h, w, co, co, 0)))
         ctx.hs = hs
         act_dt = torch.float16 if hs else torch.float32
+        # in-launch finalize of all three statistics sets of the block (fp32, fused shortcut, conv2 on the raw y1: the forms whose
+        # kernels carry it) -- decided once, so that the block never mixes the two ways for one statistics set
+        fin = (fused_sc and not (f16a or f16 or hs) and INAFF_CONV2 and co % INAFF_MIN_CO == 0
+               and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, 0)) and _tickets(0, x) is not None)
+        ctx.fin = fin
+        fin = fin and bool(FIN_MASK & 1)
         y1 = new_act(n, co, h, w, x, act_dt)
         if fused_sc:
             s = new_act(n, co, h, w, x, act_dt)
@@ -955,6 +1016,12 @@ class BasicBlockFn(Function):
             if hs:
                 H.call("smsut_conv2d_fwd_mfma_stats_sc_f16_hs", xa if virtual else x, xb if virtual else None, w1, ws, y1, s, p1, ps,
                        n, h, w, ci, co, st)
+            elif fin:
+                # statistics of y1 AND of the shortcut finalised inside the launch (no smsut_in_finalize_* behind it)
+                m1, r1 = stat(co)
+                ms, rs = stat(co)
+                H.call("smsut_conv2d_fwd_mfma_stats_sc_fin", xa if virtual else x, xb if virtual else None, w1, ws, y1, s, p1, ps,
+                       _tickets(n, x), m1, r1, ms, rs, IN_EPS, n, h, w, ci, co, _wu(w1, 0), st)
             else:
                 _conv3("smsut_conv2d_fwd_mfma_stats_sc_f16" if f16a else "smsut_conv2d_fwd_mfma_stats_sc", w1, 0, xa if virtual else x,
                        xb if virtual else None, w1, ws, y1, s, p1, ps, n, h, w, ci, co, st)
@@ -963,13 +1030,19 @@ class BasicBlockFn(Function):
                    ci, co, st)
         else:
             _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16a else "smsut_conv2d_fwd_mfma_stats", w1, 0, x, w1, y1, p1, n, h, w, ci, co, 3, st)
-        m1, r1 = stat(co)
+        if not fin:
+            m1, r1 = stat(co)
         y2 = new_act(n, co, h, w, x, act_dt)
         p2 = _ws(n * t3b * co * 2, x)
         inaff = (INAFF_CONV2 and not f16 and co % INAFF_MIN_CO == 0
                  and bool(H.call("smsut_conv2d_mfma_persistent", n, h, w, co, co, 3, 0)))
         ctx.inaff = inaff
-        if inaff:
+        if inaff and fin:
+            a1 = None
+            m2, r2 = stat(co)
+            H.call("smsut_conv2d_fwd_mfma_stats_inaff_fin", y1, w2, y2, p2, m1, r1, g1, b1, slope, _tickets(n, x), m2, r2, IN_EPS,
+                   n, h, w, co, co, _wu(w2, 0), st)
+        elif inaff:
             # conv2 (and later its weight gradient) normalise the raw conv1 output while staging their tiles: a1 is never built
             a1 = None
             H.call("smsut_in_finalize_fwd", p1, t3, m1, r1, n, hw, co, IN_EPS, st)
@@ -990,12 +1063,15 @@ class BasicBlockFn(Function):
                 a1 = new_act(n, co, h, w, x)
                 H.call("smsut_instnorm_fwd_partials", y1, g1, b1, a1, m1, r1, p1, t3, n, hw, co, IN_EPS, slope, 1, st)
                 _conv3("smsut_conv2d_fwd_mfma_stats_f16" if f16 else "smsut_conv2d_fwd_mfma_stats", w2, 0, a1, w2, y2, p2, n, h, w, co, co, 3, st)
-        m2, r2 = stat(co)
-        if fused_sc:
-            ms, rs = stat(co)                                # both sets are due now: ONE launch of the latency-bound finalize
-            H.call("smsut_in_finalize_fwd2", p2, t3b, m2, r2, ps, t1, ms, rs, n, hw, co, IN_EPS, st)
+        if fin:
+            pass                                             # (m2, r2, ms, rs: written by the conv launches themselves)
         else:
-            H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
+            m2, r2 = stat(co)
+            if fused_sc:
+                ms, rs = stat(co)                            # both sets are due now: ONE launch of the latency-bound finalize
+                H.call("smsut_in_finalize_fwd2", p2, t3b, m2, r2, ps, t1, ms, rs, n, hw, co, IN_EPS, st)
+            else:
+                H.call("smsut_in_finalize_fwd", p2, t3b, m2, r2, n, hw, co, IN_EPS, st)
         if fused_sc:
             pass
         elif has_sc:
@@ -1076,6 +1152,10 @@ class BasicBlockFn(Function):
         elif amax is not None:
             H.call("smsut_restail_bwd_amax", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
                    ggs, gbs, _ws(n * chunks * co * 3, x), amax, n, hw, co, slope, st)
+        elif ctx.has_sc and bool(FIN_MASK & 8) and _tickets(0, x) is not None:
+            # the per-image means of the tail's backward finalised inside the partial-sum launch (two launches instead of three)
+            H.call("smsut_restail_bwd_fin", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
+                   ggs, gbs, _ws(n * chunks * co * 3, x), _tickets(n, x), n, hw, co, slope, st)
         else:
             H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
                    ggs, gbs, _ws(n * chunks * co * 3, x), n, hw, co, slope, st)
@@ -1091,13 +1171,18 @@ class BasicBlockFn(Function):
             # the dgrad epilogue masks its result and emits the InstanceNorm-backward partial sums: no reduction pass
             tb = H.call("smsut_conv2d_mfma_tiles", n, h, w, co, co, 3, int(f16))
             pb = _ws(n * tb * co * 2, x)
+            fin_b = ctx.fin and bool(FIN_MASK & 4) and not (hs or f16) and _tickets(0, x) is not None      # in-launch finalize of the backward pair
             if hs:
                 H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16_hs", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, sc2, slope, n, h, w, co, co, st)
             elif f16:
                 H.call("smsut_conv2d_dgrad_mfma_bwdstats_f16", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, sc2, slope, n, h, w, co, co, st)
+            elif fin_b:
+                H.call("smsut_conv2d_dgrad_mfma_bwdstats_fin", gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, _tickets(n, x), a1m, b1m,
+                       n, h, w, co, co, _wu(w2, 1), st)
             else:
                 _conv3("smsut_conv2d_dgrad_mfma_bwdstats", w2, 1, gy2, w2, ga1, pb, y1, m1, r1, g1, b1, slope, n, h, w, co, co, st)
-            H.call("smsut_in_finalize_bwd", pb, tb, a1m, b1m, n, hw, co, st)
+            if not fin_b:                                    # (else: a1m, b1m written by the data-gradient launch itself)
+                H.call("smsut_in_finalize_bwd", pb, tb, a1m, b1m, n, hw, co, st)
             if hs:
                 H.call("smsut_in_apply_bwd_hs", ga1, y1, m1, r1, g1, a1m, b1m, gy1, gg1, gb1, amax[2 * nb:] if amax is not None else None,
                        n, hw, co, st)
@@ -1709,19 +1794,27 @@ def dice_ce_from_stats(logits, labels, stats, ce_sum, weight_ce, weight_dc, worl
 
 
 def all_reduce_dice_stats(pairs, group):
-    """ONE all-reduce for any number of (stats, ce_sum) pairs (16 floats each at 5 classes): packed into a flat buffer,
-    summed over ``group``, unpacked in place."""
+    """ONE all-reduce for any number of (stats, ce_sum) pairs (16 floats each at 5 classes), in place.  Tensors that already sit
+    back to back in one buffer (the trainers' persistent statistics buffer; a single flat tensor) are reduced where they are --
+    one collective and nothing else on the critical path between two captured phases; anything else is packed, summed, unpacked."""
     import torch.distributed as dist
     from . import graphs
     graphs.assert_no_capture("all_reduce_dice_stats (Dice-statistics all-reduce)")
-    flat = torch.cat([t.reshape(-1) for pair in pairs for t in pair])
+    ts = [t for pair in pairs for t in pair]
+    adjacent = all(t.is_contiguous() for t in ts) and all(
+        a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.storage_offset() + a.numel() == b.storage_offset()
+        for a, b in zip(ts, ts[1:]))
+    if adjacent:
+        span = ts[0].as_strided((sum(t.numel() for t in ts),), (1,), ts[0].storage_offset())
+        dist.all_reduce(span, group=group)
+        return
+    flat = torch.cat([t.reshape(-1) for t in ts])
     dist.all_reduce(flat, group=group)
     off = 0
-    for pair in pairs:
-        for t in pair:
-            n = t.numel()
-            t.copy_(flat[off:off + n].view_as(t))
-            off += n
+    for t in ts:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
 
 
 class DiceCEFn:

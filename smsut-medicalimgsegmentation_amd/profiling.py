@@ -101,9 +101,11 @@ _FORM: Dict[str, Tuple[Callable[[List[int]], Tuple[int, int, int, int, int, int]
 
 
 def _base(name: str) -> str:
-    """`_pre` entry points (same call + the caller's prepared Winograd image) and `_amax` ones (same call + the output's absolute
+    """`_pre` / `_fin` entry points (same call + the caller's prepared Winograd image / + the in-launch finalize) and `_amax` ones (same call + the output's absolute
     maximum handed to the fp16-operand consumer) count as the entry point they extend."""
     if name.endswith("_pre"):
+        return name[:-4]
+    if name.endswith("_fin"):                # (r05) the same launch, statistics finalised inside it: same integer arguments
         return name[:-4]
     return name[:-5] if name.endswith("_amax") else name
 

@@ -56,6 +56,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # gradients) is issued from the main stream in program order -- for RCCL this is the one-stream configuration; Adam and
         # D(x_fake) follow on the main stream.
         self._d_side_compute = ov == "2"
+        self._d_early = os.environ.get("SMSUT_D_EARLY_ALLREDUCE", "1") not in ("0", "")
         # The G-step's backward in THREE pieces (SMSUT_G_SPLIT; default: on whenever a side stream is in use), so that only what
         # needs the updated D waits for it:
         #   G2a  backward of the D-independent terms (cycle L1, PatchNCE, both DiceCE values) -- the whole cycle pass and the
@@ -91,6 +92,18 @@ class UGANConsisTrainer(UGANShp0Trainer):
         for f_f, f_x, crit in zip(feat_f_pool, feat_x_pool, self.criterionNCE):     # :55-64
             total = total + ops.mean_all(crit(f_f, f_x), 1.0)
         return total / len(cfg.nce_layers)
+
+    def _keep_stats(self, slot, st):
+        """The Dice statistics of the two loss terms live back to back in ONE persistent buffer (slot 0: segmentation term, phase
+        G1; slot 1: consistency term, phase G2gen): under data parallelism the exchange between the phases is then a single
+        in-place all-reduce of that buffer -- no pack, no unpack on the critical path (ops.all_reduce_dice_stats)."""
+        k = st.numel()
+        buf = self.__dict__.get("_sflat")
+        if buf is None or buf.numel() != 2 * k or buf.device != st.device:
+            buf = self._sflat = torch.zeros(2 * k, dtype=torch.float32, device=st.device)
+        view = buf[slot * k:(slot + 1) * k]
+        view.copy_(st)
+        return view
 
     def _finite_probe(self, tag, named):
         """``SMSUT_DEBUG_FINITE=1``: after each phase, record the first non-finite tensor (scalars, gradients, parameters,
@@ -138,7 +151,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
             else:
                 y_fake, x_fake, feat_x, _ = self.net(x_real, vec_ot, sample_ids=[ids])
         self._g1 = (y_fake, x_fake, feat_x)
-        return x_fake.detach(), self.loss.stats(y_fake[:y_real.size(0)], y_real)
+        return x_fake.detach(), self._keep_stats(0, self.loss.stats(y_fake[:y_real.size(0)], y_real))
 
     def _d_phase(self, x_real, x_fake, modal_org, alpha):
         """D-step forward + backward (:129-144).  Returns [D_real, D_fake, D_cls, D_gp]."""
@@ -211,7 +224,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         g_nce = self.nce_loss(feat_x, feat_f)
         if self._semi_on:
             pseudo = ops.argmax_channels(y_fake)                                     # :45-53
-            st = self.loss.stats(y_rec, pseudo)
+            st = self._keep_stats(1, self.loss.stats(y_rec, pseudo))
         else:
             pseudo, st = None, torch.zeros(1, device=self.device)
         self._g2 = (y_rec, pseudo, g_rec, g_nce) + ((cut,) if cut is not None else ())
@@ -443,12 +456,22 @@ class UGANConsisTrainer(UGANShp0Trainer):
             self.d_reducer.finish(d_work)
             self.d_optimizer.step()
 
+        d_early = [None, False]                                # [handle, started]: D's gradient all-reduce, started under G2a1 (below)
+
         def join_d():                                          # side_c: the D-step's graph is done -> all-reduce, Adam (main stream)
             cur.wait_stream(self._side)
             d_scal.record_stream(cur)
-            self.d_reducer.finish(self.d_reducer.begin())
+            self.d_reducer.finish(d_early[0] if d_early[1] else self.d_reducer.begin())
             self.d_optimizer.step()
         self.loss.reduce_stats([st_seg, st_semi] if self._semi_on else [st_seg])     # one small all-reduce (no-op at world 1)
+        if side_c and self._d_early:
+            # (r05) D's gradient all-reduce STARTS here -- pack on the side stream, right behind the captured D-step, the collective on
+            # RCCL's own stream -- and is collected at join_d(), after G2a1: the generator's cycle-pass backward runs under it.  Issued
+            # AFTER the Dice-statistics all-reduce on purpose: the communicator executes collectives in the order the host issues
+            # them, and the main stream needs the statistics before G2a1 but D's gradients only after it.  Same host order on every
+            # rank; the values are those of the synchronous form (SMSUT_D_EARLY_ALLREDUCE=0).
+            with torch.cuda.stream(self._side):
+                d_early[0], d_early[1] = self.d_reducer.begin(), True
         if self._g_split:
             # ---------------------------------------------------- G-step in three pieces (see __init__): G2a needs no D at all
             if side_c:

@@ -398,6 +398,78 @@ def test_fused_basic_block_vs_torch(ops, n, h, ci, co):
             assert rel_err(got.grad.cpu().numpy(), ref.grad.numpy()) < 5e-3, tuple(ref.shape)
 
 
+@pytest.mark.parametrize("n,h,ci,co,cat", [(8, 128, 8, 16, False), (8, 128, 16, 32, False), (9, 64, 32, 64, False), (16, 32, 64, 128, False),
+                                           (16, 16, 128, 256, False), (3, 256, 32, 16, True), (8, 128, 64, 32, True), (16, 32, 256, 128, True),
+                                           (32, 16, 128, 256, False), (2, 48, 16, 32, False)])
+def test_in_launch_finalize_is_bit_identical_to_the_separate_launch(ops, n, h, ci, co, cat):
+    """``SMSUT_FIN`` (csrc/common.h FinRef): the statistics-producing convs of a fused BasicBlock finalise their InstanceNorm
+    statistics inside the launch -- the last-arriving workgroup of an image combines the partials in the order
+    ``in_moments_final`` uses.  Forward output, input gradient(s) and every parameter gradient must be BIT-IDENTICAL to the
+    two-launch form, on every kernel family that carries the tail (8-channel, resident Winograd, streamed Winograd, direct
+    64-channel, virtual cat) and at batch / plane sizes where a workgroup spans several images and where an image spans many.
+    Run twice, so that the tickets a launch leaves behind (zero) are what the next one starts from."""
+    if not ops.FUSED_BLOCK:
+        pytest.skip("SMSUT_FUSED_BLOCK=0 in the environment")
+    slope = 0.01
+    w1, w2 = to_hwio(ops, rnd(co, ci, 3, 3, seed=2) / np.sqrt(9 * ci)), to_hwio(ops, rnd(co, co, 3, 3, seed=3) / np.sqrt(9 * co))
+    ws = to_hwio(ops, rnd(co, ci, 1, 1, seed=11) / np.sqrt(ci))
+    aff = [dev(1 + 0.1 * rnd(co, seed=4 + k)) if k % 2 == 0 else dev(0.1 * rnd(co, seed=4 + k)) for k in range(6)]
+    go = dev(rnd(n, co, h, h, seed=30))
+
+    def run(fin_on):
+        old = ops.FIN_ON
+        ops.FIN_ON = fin_on
+        try:
+            P = [t.detach().clone().requires_grad_(True) if t.dim() != 4 else to_hwio(ops, t).requires_grad_(True) for t in (w1, w2, ws, *aff)]
+            if cat:
+                xa = dev(rnd(n, ci // 2, h, h, seed=20)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                xb = dev(rnd(n, ci // 2, h, h, seed=21)).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+                parts = ops.concat_channels_deferred(xa, xb)
+                assert isinstance(parts, ops.CatParts) and ops.basic_block_cat_fusable(parts, P[0], P[2])
+                out = ops.basic_block_cat(parts, P[0], P[3], P[4], P[1], P[5], P[6], P[2], P[7], P[8], slope)
+                xs = [xa, xb]
+            else:
+                x = dev(rnd(n, ci, h, h, seed=20)).requires_grad_(True)
+                out = ops.basic_block(x, P[0], P[3], P[4], P[1], P[5], P[6], P[2], P[7], P[8], slope)
+                xs = [x]
+            out.backward(go)
+            return [out.detach()] + [t.grad for t in xs] + [t.grad for t in P]
+        finally:
+            ops.FIN_ON = old
+
+    import smsut_amd._hip as H
+    names = []
+    orig = H.call
+
+    def spy(name, *a):
+        names.append(name)
+        return orig(name, *a)
+    H.call = spy
+    try:
+        ref = run(False)
+        ref_names, names[:] = list(names), []
+        got = run(True)
+    finally:
+        H.call = orig
+    got2 = run(True)
+    base = lambda k: k[:-4] if k.endswith("_pre") else k                                                        # noqa: E731
+    fused = {"smsut_conv2d_fwd_mfma_stats_sc", "smsut_conv2d_fwd_mfma_stats_inaff", "smsut_conv2d_dgrad_mfma_bwdstats"} <= {base(k) for k in ref_names}
+    if (n, h) != (2, 48):
+        assert fused, ref_names                   # (the listed shapes take the fused forms; 2 x 48^2 is below the persistent kernels' size)
+    fins = [k for k in names if k.endswith("_fin")]
+    if fused:
+        assert sorted(fins) == ["smsut_conv2d_dgrad_mfma_bwdstats_fin", "smsut_conv2d_fwd_mfma_stats_inaff_fin", "smsut_conv2d_fwd_mfma_stats_sc_fin",
+                                "smsut_restail_bwd_fin"], names
+        assert not any(k.startswith("smsut_in_finalize") for k in names), [k for k in names if "finalize" in k]
+    else:
+        assert fins == ["smsut_restail_bwd_fin"], fins            # (the op-by-op convs finalise as before; the tail's backward still can)
+    for k, (a, b, c) in enumerate(zip(ref, got, got2)):
+        assert torch.equal(a, b), k
+        assert torch.equal(a, c), k
+    pool = ops._TICKET_RING[0][0]
+    assert int(pool.abs().sum()) == 0              # every launch left its tickets zeroed
+
+
 @pytest.mark.parametrize("n,h,ci,co", [(8, 128, 16, 32), (4, 64, 32, 64), (8, 32, 64, 128), (2, 32, 16, 16), (8, 128, 8, 16)])
 def test_paired_weight_gradients_of_two_passes_through_one_block(ops, n, h, ci, co):
     """``ops.pair_wgrads()``: two passes through ONE fused BasicBlock (the generator's G(x_real) and cycle pass, reference
