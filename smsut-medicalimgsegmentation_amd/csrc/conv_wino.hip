@@ -792,7 +792,10 @@ int launch_ntn(const float* x, const float* x2, const float* w, const float* wu,
   const FinRef fv = fin ? *fin : FinRef{};
   const int nz = Ndim / (16 * NTN);
   const int64_t items = (int64_t)N * tiles_img;
-  const int per_cu = 1;                                 // resident workgroups per CU (one wave per SIMD: registers, 2 LDS buffers)
+  // resident workgroups per CU: ONE (one wave per SIMD: registers, 2 LDS buffers).  SMSUT_WINO_WGS_PER_CU > 1 sizes the grid for that
+  // many ROUNDS of smaller workgroups instead (tuning hook: with the discriminator's small kernels on a second queue a CU may be
+  // taken when the grid launches, and a workgroup that waits for it holds the whole launch back by its own length)
+  static const int per_cu = [] { const char* e = getenv("SMSUT_WINO_WGS_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
   const int64_t slots = (int64_t)device_cus() * per_cu;
   int ipw = (int)((items * nz + slots - 1) / slots);
   if (ipw < 1) ipw = 1;

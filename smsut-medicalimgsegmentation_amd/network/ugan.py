@@ -82,16 +82,25 @@ class _UGANBase(nn.Module):
         # matches nn.Conv2d / nn.ConvTranspose2d / norms, so netF keeps init_weights('normal', 0.02).
         init_conv_kaiming(self, "leaky_relu")
 
-    def _trunk(self, x, m):
+    # The generator is two independent branches that share only the ``enc5`` module (ugan.py:156-170): the TRANSLATION branch
+    # (x + modality planes -> tsl_encoder -> enc5 -> tsl_decoder) and the SEGMENTATION branch (x -> seg_encoder -> enc5 ->
+    # seg_decoder).  ``_trunk`` is the reference's forward; the trainers may run the branches separately (the segmentation branch
+    # of the two generator passes of an iteration as ONE batched pass: InstanceNorm is per sample, so the values are the same).
+    def _tsl_branch(self, x, m):
         if m is None:
             m = torch.zeros(x.size(0), self.n_modal, device=x.device)
         tsl_in = ops.modal_planes(x, m.to(x.device))            # ugan.py:156-159
         t_bot, t_sk = self.tsl_encoder(tsl_in)
         t_e5 = self.enc5(t_bot)                                 # shared enc5 (ugan.py:163,168)
-        tsl = self.tsl_decoder(t_e5, t_sk)
+        return self.tsl_decoder(t_e5, t_sk), t_e5
+
+    def _seg_branch(self, x):
         s_bot, s_sk = self.seg_encoder(x)
-        seg = self.seg_decoder(self.enc5(s_bot), s_sk)
-        return seg, tsl, t_e5
+        return self.seg_decoder(self.enc5(s_bot), s_sk)
+
+    def _trunk(self, x, m):
+        tsl, t_e5 = self._tsl_branch(x, m)
+        return self._seg_branch(x), tsl, t_e5
 
 
 class UGAN(_UGANBase):
@@ -110,7 +119,17 @@ class UGANnce(_UGANBase):
         self.val_phase = val_phase
         self._build(in_ch, out_ch, n_modal, base_width, with_nce=True)
 
-    def forward(self, x, m=None, sample_ids=None, val_phase=False):
+    def forward(self, x, m=None, sample_ids=None, val_phase=False, branch=None):
+        """Reference contract (ugan.py:153-195) for ``branch=None``.  ``branch`` (this package's trainers only): "tsl" -> the
+        translation branch alone, ``(tsl, feat_pool, sample_ids, t_e5)``; "seg" -> the segmentation branch alone, ``seg``."""
+        if branch == "seg":
+            return self._seg_branch(x)
+        if branch == "tsl":
+            tsl, t_e5 = self._tsl_branch(x, m)
+            if sample_ids is None:
+                return tsl, None, None, t_e5
+            feat_pool, _ = self.netF([t_e5], patch_ids=sample_ids)
+            return tsl, feat_pool, sample_ids, t_e5
         seg, tsl, t_e5 = self._trunk(x, m)
         if val_phase:
             return seg, tsl

@@ -1705,6 +1705,43 @@ def concat_channels(a, b):
     return y
 
 
+class RowSegmentsFn(Function):
+    """(y[a0:b0], y[a1:b1], ...) along the batch dimension as views, with ONE gradient buffer assembled in the backward (rows no
+    segment covers are zero; a segment without a gradient too) -- instead of autograd's zeros + copy + add per slice and a layout
+    conversion behind them.  The segments must not overlap."""
+
+    @staticmethod
+    def forward(ctx, y, *bounds):
+        y = nhwc(y)
+        ctx.shape, ctx.bounds = tuple(y.shape), tuple(int(b) for b in bounds)
+        ctx.set_materialize_grads(False)
+        return tuple(y[ctx.bounds[2 * i]:ctx.bounds[2 * i + 1]] for i in range(len(bounds) // 2))
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gs):
+        n, c, h, w = ctx.shape
+        ref = next(g for g in gs if g is not None)
+        out = new_act(n, c, h, w, ref)
+        pos = 0
+        segs = sorted((ctx.bounds[2 * i], ctx.bounds[2 * i + 1], gs[i]) for i in range(len(gs)))
+        for a, b, g in segs:
+            if a > pos:
+                out[pos:a].zero_()
+            if g is None:
+                out[a:b].zero_()
+            else:
+                out[a:b].copy_(g)
+            pos = b
+        if pos < n:
+            out[pos:].zero_()
+        return (out,) + (None,) * len(ctx.bounds)
+
+
+def row_segments(y, *bounds):
+    return RowSegmentsFn.apply(y, *bounds)
+
+
 class ModalPlanesFn(Function):
     """cat([x, m.view(B,n,1,1).repeat(1,1,H,W)], 1) (network/ugan.py:156-159)."""
 

@@ -56,7 +56,18 @@ class UGANConsisTrainer(UGANShp0Trainer):
         # gradients) is issued from the main stream in program order -- for RCCL this is the one-stream configuration; Adam and
         # D(x_fake) follow on the main stream.
         self._d_side_compute = ov == "2"
-        self._d_early = os.environ.get("SMSUT_D_EARLY_ALLREDUCE", "1") not in ("0", "")
+        # SMSUT_SEG_BATCH (r05, default on): the SEGMENTATION branch of the two generator passes of an iteration -- seg_encoder, enc5,
+        # seg_decoder on x_real (uganConsisTrainer.py:152) and on x_fake (the cycle pass, :159) -- runs as ONE pass over the batch
+        # [x_real | x_fake]: the branch does not depend on the translation branch of its own pass, only on its input, and InstanceNorm
+        # is per sample, so every value is the one the two passes produce -- but every kernel of that half of the generator runs
+        # once on 32 slices instead of twice on 16 (forward, data- and weight-gradient).  The translation branches stay two passes
+        # (the second one reads the first one's output); their 3x3 weight gradients are paired (ops.pair_wgrads).
+        self._seg_batch = os.environ.get("SMSUT_SEG_BATCH", "1") not in ("0", "")
+        # SMSUT_D_EARLY_ALLREDUCE=1 (mode 2 only): D's gradient all-reduce is STARTED (pack on the side stream, collective on RCCL's own)
+        # before G2a1 and collected after it.  Off by default: at ONE rank it measured slower (21.25 vs 20.85 ms per iteration over a
+        # one-rank RCCL communicator, profiles/r05_notes.md) -- there is no wire time to hide there, only one more stream to
+        # synchronise with; an A/B switch for the first multi-GPU run, where the 9.7 MB ring all-reduce is what it would hide.
+        self._d_early = os.environ.get("SMSUT_D_EARLY_ALLREDUCE", "0") not in ("0", "")
         # The G-step's backward in THREE pieces (SMSUT_G_SPLIT; default: on whenever a side stream is in use), so that only what
         # needs the updated D waits for it:
         #   G2a  backward of the D-independent terms (cycle L1, PatchNCE, both DiceCE values) -- the whole cycle pass and the
@@ -145,6 +156,15 @@ class UGANConsisTrainer(UGANShp0Trainer):
         """G(x_real -> x_fake) with the autograd graph retained for the G-step; returns (x_fake detached, seg statistics)."""
         # (scopes: the weights move in the optimizer steps only; pair_wgrads: this pass and the cycle pass of phase G2gen go through
         #  every generator layer with the same weights -- their 3x3 weight gradients are computed by ONE launch per layer, ops.py)
+        if self._seg_batch:
+            # translation branch only; the segmentation branch of x_real runs batched with the cycle pass' in phase G2gen
+            with ops.wino_prepared(self.net, forms="f"), ops.pair_wgrads():
+                if self._g_split:
+                    x_fake, _, _, feat_x = self.net(x_real, vec_ot, branch="tsl")             # feat_x: the raw bottleneck features t_e5
+                else:
+                    x_fake, feat_x, _, _ = self.net(x_real, vec_ot, sample_ids=[ids], branch="tsl")
+            self._g1 = (None, x_fake, feat_x)
+            return x_fake.detach(), torch.zeros(1, device=self.device)
         with ops.wino_prepared(self.net, forms="f"), ops.pair_wgrads():
             if self._g_split:
                 y_fake, x_fake, feat_x = self.net._trunk(x_real, vec_ot)          # feat_x: the raw bottleneck features t_e5
@@ -205,11 +225,13 @@ class UGANConsisTrainer(UGANShp0Trainer):
                 torch._foreach_add_(main, extra)
         return torch.stack([t.detach().float() for t in (d_real, d_fake, d_cls, d_gp)])
 
-    def _g2gen_phase(self, x_real, vec_to, ids):
+    def _g2gen_phase(self, x_real, vec_to, ids, y_real=None):
         """The cycle pass of the G-step (:159-168) -- everything that does not need the updated D: G(x_fake -> x_rec) on
         parameter ALIASES (same storage, separate ``.grad``, so the two passes' weight gradients are summed by one
         multi-tensor add instead of one add kernel per parameter), L1, PatchNCE, the pseudo labels and the consistency
-        term's Dice statistics.  Leaves its autograd graph for phase G2; returns the (local) statistics."""
+        term's Dice statistics.  Leaves its autograd graph for phase G2; returns the (local) statistics.
+        SMSUT_SEG_BATCH: the segmentation branch of BOTH passes runs here, once, on [x_real | x_fake] (main parameters), and the
+        cycle pass on the aliases is its translation branch only; returns both statistics sets (one buffer: [seg | semi])."""
         y_fake, x_fake, feat_x = self._g1
         cut = None
         if self._g_split:
@@ -217,9 +239,22 @@ class UGANConsisTrainer(UGANShp0Trainer):
             xd, td = x_fake.detach().requires_grad_(True), feat_x.detach().requires_grad_(True)
             feat_x, _ = self.net.netF([td], patch_ids=[ids])
             cut, x_fake = (xd, td), xd
-        with ops.wino_prepared(self.net, forms="f"), ops.pair_wgrads():
-            y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
-                                                                 {"sample_ids": [ids]})
+        if self._seg_batch:
+            b, bs = x_real.size(0), y_real.size(0)
+            with ops.wino_prepared(self.net, forms="f"):
+                y_all = self.net(torch.cat([x_real, x_fake], 0), branch="seg")
+                with ops.pair_wgrads():
+                    x_rec, feat_f, _, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
+                                                                     {"sample_ids": [ids], "branch": "tsl"})
+            # the rows the losses read: the labeled half of G(x_real)'s segmentation, the whole of the cycle pass' (one gradient buffer)
+            y_seg, y_rec = ops.row_segments(y_all, 0, bs, b, 2 * b)
+            self._g1 = (y_seg, self._g1[1], self._g1[2])
+            st_seg = self._keep_stats(0, self.loss.stats(y_seg, y_real))
+            y_fake = y_all[:b].detach()
+        else:
+            with ops.wino_prepared(self.net, forms="f"), ops.pair_wgrads():
+                y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
+                                                                     {"sample_ids": [ids]})
         g_rec = ops.l1_mean(x_real, x_rec)
         g_nce = self.nce_loss(feat_x, feat_f)
         if self._semi_on:
@@ -228,6 +263,8 @@ class UGANConsisTrainer(UGANShp0Trainer):
         else:
             pseudo, st = None, torch.zeros(1, device=self.device)
         self._g2 = (y_rec, pseudo, g_rec, g_nce) + ((cut,) if cut is not None else ())
+        if self._seg_batch:
+            return self._sflat                       # [seg statistics | consistency statistics]: back to back, reduced in place
         return st
 
     def _g2a_phase(self, y_real, st_seg, st_semi, lambda_semi):
@@ -236,7 +273,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         bs = y_real.size(0)
         y_fake = self._g1[0]
         y_rec, pseudo, g_rec, g_nce, _ = self._g2
-        g_seg = self.loss.from_stats(y_fake[:bs], y_real, st_seg)
+        g_seg = self.loss.from_stats(y_fake if y_fake.size(0) == bs else y_fake[:bs], y_real, st_seg)
         if self._semi_on:
             g_semi = self.loss.from_stats(y_rec, pseudo, st_semi)
         else:
@@ -249,8 +286,14 @@ class UGANConsisTrainer(UGANShp0Trainer):
     # main stream's time line -- still has generator work to run beside: G2a1 = the cycle pass' terms, G2a2 = the segmentation
     # term of G(x_real) (disjoint graphs and parameters: two backward calls, same values).
     def _g2a1_phase(self, st_semi, lambda_semi):
-        """[G_rec, G_semi, G_nce] and their backward (cycle pass on the aliases, netF, down to the cut points)."""
+        """[G_rec, G_semi, G_nce] and their backward (cycle pass on the aliases, netF, down to the cut points).
+        SMSUT_SEG_BATCH: the segmentation branch is ONE graph over both passes, so its two terms go together (phase G2a2) and this
+        phase holds the cycle pass' translation branch only: [G_rec, G_nce]."""
         y_rec, pseudo, g_rec, g_nce, _ = self._g2
+        if self._seg_batch:
+            with ops.wino_prepared(self.net, forms="b"):
+                (self.lambda_rec * g_rec + 1.0 * g_nce).backward()
+            return torch.stack([t.detach().float() for t in (g_rec, g_nce)])
         if self._semi_on:
             g_semi = self.loss.from_stats(y_rec, pseudo, st_semi)
         else:
@@ -259,9 +302,17 @@ class UGANConsisTrainer(UGANShp0Trainer):
             (self.lambda_rec * g_rec + lambda_semi * g_semi + 1.0 * g_nce).backward()
         return torch.stack([t.detach().float() for t in (g_rec, g_semi, g_nce)])
 
-    def _g2a2_phase(self, y_real, st_seg):
-        """[G_seg] and its backward (segmentation branch of G(x_real))."""
-        g_seg = self.loss.from_stats(self._g1[0][:y_real.size(0)], y_real, st_seg)
+    def _g2a2_phase(self, y_real, st_seg, st_semi=None, lambda_semi=None):
+        """[G_seg] and its backward (segmentation branch of G(x_real)).  SMSUT_SEG_BATCH: [G_seg, G_semi] -- both terms of the batched
+        segmentation branch, one backward through it."""
+        y_fake = self._g1[0]
+        g_seg = self.loss.from_stats(y_fake if y_fake.size(0) == y_real.size(0) else y_fake[:y_real.size(0)], y_real, st_seg)
+        if self._seg_batch:
+            y_rec, pseudo = self._g2[0], self._g2[1]
+            g_semi = self.loss.from_stats(y_rec, pseudo, st_semi) if self._semi_on else torch.zeros((), device=self.device)
+            with ops.wino_prepared(self.net, forms="b"):
+                (self.lambda_seg * g_seg + lambda_semi * g_semi).backward()
+            return torch.stack([t.detach().float() for t in (g_seg, g_semi)])
         with ops.wino_prepared(self.net, forms="b"):
             (self.lambda_seg * g_seg).backward()
         return g_seg.detach().float().reshape(1)
@@ -330,7 +381,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
                 g_fake, g_cls = d_pass()
         else:
             g_fake, g_cls = d_pass()
-        g_seg = self.loss.from_stats(y_fake[:bs], y_real, st_seg)
+        g_seg = self.loss.from_stats(y_fake if y_fake.size(0) == bs else y_fake[:bs], y_real, st_seg)
         if self._semi_on:
             g_semi = self.loss.from_stats(y_rec, pseudo, st_semi)
         else:
@@ -451,7 +502,11 @@ class UGANConsisTrainer(UGANShp0Trainer):
                     self.d_reducer.finish(d_work)
                     self.d_optimizer.step()
                     d_work = None
-        st_semi = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids), list(self._alias.values()))
+        if self._seg_batch:
+            sf = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids, y_real), list(self._alias.values()))
+            st_seg, st_semi = sf[:sf.numel() // 2], sf[sf.numel() // 2:]
+        else:
+            st_semi = self._run_phase("G2gen", self._g2gen_phase, (x_real, vec_to, ids), list(self._alias.values()))
         if d_work is not None:
             self.d_reducer.finish(d_work)
             self.d_optimizer.step()
@@ -487,7 +542,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
                 gb = self._run_phase("G2d", self._g2d_phase, (modal_trg,), [])
             for p in d_params:
                 p.requires_grad_(True)
-            if side_c:
+            if side_c and self._seg_batch:
+                ga2 = self._run_phase("G2a2", self._g2a2_phase, (y_real, st_seg, st_semi, lam_t), [], rebind=g_params)
+            elif side_c:
                 ga2 = self._run_phase("G2a2", self._g2a2_phase, (y_real, st_seg), [], rebind=g_params)
             if overlap or side_c:
                 cur.wait_stream(self._side)
@@ -498,7 +555,9 @@ class UGANConsisTrainer(UGANShp0Trainer):
             if self._probe:
                 self._finite_probe("D.step", list(self.D.named_parameters()))
             self._run_phase("G2c", self._g2c_phase, (), [], rebind=g_params)
-            if side_c:                           # [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]
+            if side_c and self._seg_batch:       # [G_fake, G_rec, G_cls, G_seg, G_semi, G_nce]; ga1 = [rec, nce], ga2 = [seg, semi]
+                g_scal = torch.cat([gb[0:1], ga1[0:1], gb[1:2], ga2, ga1[1:2]])
+            elif side_c:
                 g_scal = torch.cat([gb[0:1], ga1[0:1], gb[1:2], ga2, ga1[1:3]])
             else:
                 g_scal = torch.cat([gb[0:1], ga[0:1], gb[1:2], ga[1:4]])
