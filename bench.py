@@ -12,7 +12,7 @@ config 3); N>1 is pure data parallel, one process per GPU, flat RCCL all-reduce 
 
 Rank 0 prints ONE JSON line.  ``roofline`` is measured live with HIP events on the launch stream around the
 dominant kernel -- the device kernel with the largest total time in the committed rocprofv3 summary of the iteration
-(profiles/r04_ugan_kernel_stats.csv: the register-row 3x3 weight gradient, input-side-IN form), launched through the
+(profiles/r05_ugan_kernel_stats.csv: the register-row 3x3 weight gradient, input-side-IN form), launched through the
 entry point and with the arguments ops.py uses; ``roofline_fwd`` is the Winograd forward conv of r03's line, in the form
 the step launches it; ``cpu_baseline`` times the CPU oracle (``oracle/``, kind "port") on a bounded sample of the same
 workload on this host's cores (rank 0, N=1 only).
@@ -37,7 +37,7 @@ FP16_MFMA_PEAK_TFLOPS = 2500.0     # dense fp16 / bf16 MFMA peak (MI355X_MICROAR
 HBM_PEAK_GBS = 8000.0
 EXECUTED_GFLOP_PER_SLICE_UGAN = 1475.4 / 16     # conv FLOPs one uganConsis iteration of THIS build executes (census, 8 + 8 slices)
 REFERENCE_GFLOP_PER_SLICE_UGAN = 1710.0 / 16    # the reference's iteration: G(x_real) twice
-PMC_FILE = "r04_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
+PMC_FILE = "r05_pmc_dominant.json"   # FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only` (profiles/collect.sh)
 
 
 def host_cores():

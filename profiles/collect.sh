@@ -4,10 +4,14 @@
 # 1. rocprofv3 --kernel-trace --stats of the two bench workloads and of the roofline leg alone
 # 2. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the roofline leg, as MI355X_MICROARCH.md prescribes
 # Raw output goes under gpurun_out/<tag>_*; profiles/summarize.py turns it into the files committed in profiles/.
+# Optional second argument: 1 = parts 1-3 only (kernel stats of the three workloads, roofline legs + their counter passes),
+# 2 = parts 3b-4 only (byte census, whole-step counters per layer class) -- one gpurun call each (20-minute limit).
 set -e
 tag=${1:-r01}
+part=${2:-all}
 out=gpurun_out
 common="--output-format csv"
+if [ "$part" != "2" ]; then
 rm -rf $out/${tag}_ugan $out/${tag}_unet $out/${tag}_roof $out/${tag}_pmc_fetch $out/${tag}_pmc_write
 rocprofv3 --kernel-trace --stats $common -d $out/${tag}_ugan -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-unet-step --no-dist-leg > $out/${tag}_ugan.log 2>&1
 tail -1 $out/${tag}_ugan.log | cut -c1-160
@@ -28,7 +32,9 @@ rm -rf $out/${tag}_c5roof $out/${tag}_c5pmc_fetch $out/${tag}_c5pmc_write
 rocprofv3 --kernel-trace --stats $common -d $out/${tag}_c5roof -- python3 bench.py --roofline-only --dtype f16 --size 512 > $out/${tag}_c5roof.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace $common -d $out/${tag}_c5pmc_fetch -- python3 bench.py --roofline-only --dtype f16 --size 512 > $out/${tag}_c5pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace $common -d $out/${tag}_c5pmc_write -- python3 bench.py --roofline-only --dtype f16 --size 512 > $out/${tag}_c5pmc_write.log 2>&1
-python3 profiles/summarize.py $tag
+python3 profiles/summarize.py $tag || true
+fi
+if [ "$part" = "1" ]; then exit 0; fi
 # 3b. algorithmic bytes of the step's launches (bench.py's per-shape census: every tensor of every conv / InstanceNorm / tail / pooling
 #     call read once + written once), un-profiled: the floor the PMC traffic below stands against
 python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-unet-step --no-dist-leg --no-config5 > $out/${tag}_bytes_ugan.log 2>/dev/null

@@ -17,7 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 OUT, PROF = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 DOMINANT = None   # instantiation of conv_mfma_fwd the roofline leg launches, read from its own stats below
-STEPS = 12    # 2 warm-up + 5 timed + 5 end-to-end (scalar fetch every step) iterations in collect.sh
+STEPS = 17    # 2 warm-up + 5 timed + 5 end-to-end (blocking scalar fetch) + 5 end-to-end (pipelined fetch) iterations in collect.sh
+              # (r01-r04 divided by 12: their per-step launch counts and ms/step in the kernel tables are 17/12 too high)
 
 
 def one(pattern):
@@ -98,7 +99,7 @@ for nm, rows in (("fetch", frows), ("write", wrows)):
         w = csv.DictWriter(f, fieldnames=cols)
         w.writeheader()
         w.writerows(rows)
-batch = int(live["shape"].split()[0][1:])
+batch = sum(int(v) for v in live["shape"].split()[0][1:].split("+"))      # "N16+16 ...": the paired launch covers both sets
 fetch_kb, write_kb = sum(fetch) / len(fetch), sum(write) / len(write)
 hbm = (2.0 * fetch_kb + write_kb) * 1024.0         # FETCH_SIZE/WRITE_SIZE are in KB; FETCH_SIZE x2 on gfx950
 dom = {"kernel": DOMINANT, "shape": live["shape"], "dispatches": len(fetch),
@@ -166,7 +167,7 @@ for key, leg in (("resident", "roofline_fwd"), ("wino_l", "roofline_wino_l")):
             continue
         fkb, wkb = sum(fv) / len(fv), sum(wv) / len(wv)
         hb = (2.0 * fkb + wkb) * 1024.0
-        nb = int(lv["shape"].split()[0][1:])
+        nb = sum(int(v) for v in lv["shape"].split()[0][1:].split("+"))
         ent = {"kernel_match": m, "shape": lv["shape"], "dispatches": len(fv), "FETCH_SIZE_kb_per_launch": round(fkb, 1),
                "WRITE_SIZE_kb_per_launch": round(wkb, 1), "fetch_correction": 2.0, "hbm_bytes_per_launch": round(hb),
                "hbm_bytes_per_slice": round(hb / nb), "algorithmic_bytes_per_launch": round(lv["algorithmic_gbytes_per_launch"] * 1e9),

@@ -1830,6 +1830,9 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
 
 inline int device_cus() {
   static const int cus = [] {
+    // SMSUT_CUS: the number of CUs the persistent grids are sized for, when the launch stream owns fewer than the device has (a CU
+    // mask: trainer SMSUT_CU_SPLIT keeps a few CUs for the discriminator's side stream) -- tuning hook
+    if (const char* e = getenv("SMSUT_CUS")) { const int v = atoi(e); if (v > 0) return v; }
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)

@@ -766,6 +766,7 @@ __global__ void __launch_bounds__(TPB) wino_u_prepare(PrepTable t) {
 
 inline int device_cus() {
   static const int cus = [] {
+    if (const char* e = getenv("SMSUT_CUS")) { const int v = atoi(e); if (v > 0) return v; }      // (tuning hook: see conv_mfma.hip)
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
     return n > 0 ? n : 256;
