@@ -73,6 +73,24 @@ constexpr int WROWH = 24;    // halves between consecutive output channels of th
 __device__ __forceinline__ f32x4 mfma16h(h4 a, h4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4 mfmak(h4 a, h4 b, f32x4 c) { return mfma16h(a, b, c); }
+// gfx950's double-depth instruction (r05): v_mfma_f32_16x16x32_f16, 32 k-slots per issue.  A 16-channel chunk fills 16 of them, so the
+// forward kernels feed it TWO TAPS at a time: k-slots 0..15 = the chunk's channels under tap 2p, 16..31 = under tap 2p+1.  Lane
+// (lm, kq) holds k = 8kq .. 8kq+7, i.e. eight consecutive channels of ITS tap (kq >> 1): one ds_read_b128 per fragment instead of two
+// ds_read_b64, one MFMA issue instead of two; the 48-B pixel stride keeps eight consecutive lanes on 32 distinct banks.  A lone tap
+// (the ninth of a 3x3 conv, a 1x1 conv, the centre tap of the fused shortcut data-gradient's second half) runs the SAME instruction
+// with the upper sixteen k-slots multiplying zeros -- it holds the pipe as long as the 16-deep one, and the two must not be mixed on one
+// accumulator: a v_mfma_f32_16x16x16_f16 accumulating onto a register a v_mfma_f32_16x16x32_f16 had just written DROPPED that
+// contribution (statistics form, 16 -> 16, rows 4r+2 / columns 4q, 4q+1 of every tile: scratch/x32_debug.py; the dependent issue came
+// too early).  The weight gradient pairs two tile ROWS per issue.  SMSUT_F16_X32=0 at compile time: 16-deep instructions throughout.
+#ifndef SMSUT_F16_X32
+#define SMSUT_F16_X32 1
+#endif
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma32h(h8 a, h8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfmak(h8 a, h8 b, f32x4 c) { return mfma32h(a, b, c); }
 __device__ __forceinline__ h4 to_h4(float4 v) { return (h4){(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w}; }
 __device__ __forceinline__ h4 to_h4s(float4 v, float s) {
   return (h4){(_Float16)(v.x * s), (_Float16)(v.y * s), (_Float16)(v.z * s), (_Float16)(v.w * s)};
@@ -221,7 +239,34 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     if (step + 1 < nsteps) prefetch(step + 1);
     if (step < 2) { STAMP(4 + 4 * step); }
     // ---- MFMA over taps
-    if constexpr (F16) {
+    if constexpr (F16 && SMSUT_F16_X32) {
+      // tap pairs on the 32-deep instruction (comment at mfma32h); a lone last tap multiplies zeros in the upper k-slots
+      const bool hi = kq >= 2;
+      const int ko = 8 * (kq & 1);
+      const h8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+      for (int p = 0; p < (KK + 1) / 2; ++p) {
+        const bool solo = 2 * p + 1 >= KK;
+        const int tlo = 2 * p, thi = solo ? 2 * p : 2 * p + 1;
+        const int tap = hi ? thi : tlo;
+        const int kh = hi ? thi / KS : tlo / KS, kw = hi ? thi % KS : tlo % KS;
+        h8 a[MR], b[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          a[i] = *(const h8*)(in_h + (((wm * MR + i) * RPT + a_row + kh) * IW + a_col + kw) * SPIXH + ko);
+          if (solo && hi) a[i] = zero8;
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          b[j] = *(const h8*)(w_h + ((size_t)tap * CO_T + (wn * NR + j) * 16 + lm) * WROWH + ko);
+          if (solo && hi) b[j] = zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma32h(a[i], b[j], acc[i][j]);
+      }
+    } else if constexpr (F16) {
 #pragma unroll
       for (int tap = 0; tap < KK; ++tap) {
         const int kh = tap / KS, kw = tap % KS;
@@ -901,6 +946,52 @@ conv_mfma_fwd_p(const float* __restrict__ x, const float* __restrict__ w, float*
               for (int i = 0; i < MR; ++i)
 #pragma unroll
                 for (int j = 0; j < NR; ++j) acs[i][j] = mfma16(a[i][s], bs[j][s], acs[i][j]);
+          }
+        }
+      }
+      return;
+    }
+    if constexpr (F16 && SMSUT_F16_X32) {
+      // tap pairs on the 32-deep instruction (comment at mfma32h); lone taps multiply zeros in the upper sixteen k-slots
+      const bool sc2_half = SC2 && c >= NCH / 2;
+      const bool hi = kq >= 2;
+      const int ko = 8 * (kq & 1);
+      const h8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+      for (int p = 0; p < (KK + 1) / 2; ++p) {
+        if (sc2_half && p != (KK / 2) / 2) continue;            // the shortcut's gradient: centre tap only
+        const bool solo = 2 * p + 1 >= KK || sc2_half;          // no second tap in this issue
+        const int tlo = sc2_half ? KK / 2 : 2 * p, thi = (2 * p + 1 < KK) ? 2 * p + 1 : 2 * p;
+        const int tap = hi ? thi : tlo;
+        const int kh = hi ? thi / KS : tlo / KS, kw = hi ? thi % KS : tlo % KS;
+        h8 a[MR], b[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          a[i] = *(const h8*)(in_h + ((wave * MR + i + kh) * IW + lm + kw) * SPIXH + ko);
+          if (solo && hi) a[i] = zero8;
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          b[j] = *(const h8*)(w_h + ((size_t)(tap * NCH + c) * CO_T + j * 16 + lm) * WROWH + ko);
+          if (solo && hi) b[j] = zero8;
+        }
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma32h(a[i], b[j], acc[i][j]);
+        if constexpr (SC) {
+          if (2 * p == KK / 2 || 2 * p + 1 == KK / 2) {    // the pair that holds the centre tap: the 1x1 shortcut rides on that half
+            const bool mine = hi == (2 * p + 1 == KK / 2); // (the other half's k-slots multiply zeros)
+            h8 bs[NR];
+#pragma unroll
+            for (int j = 0; j < NR; ++j) {
+              bs[j] = *(const h8*)(wsc_h + ((size_t)c * CO_T + j * 16 + lm) * WROWH + ko);
+              if (!mine) bs[j] = zero8;
+            }
+#pragma unroll
+            for (int i = 0; i < MR; ++i)
+#pragma unroll
+              for (int j = 0; j < NR; ++j) acs[i][j] = mfma32h(a[i], bs[j], acs[i][j]);
           }
         }
       }
@@ -1598,6 +1689,19 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
     const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(plane_pix + tr_off));
     return __builtin_bit_cast(h4, v);
   };
+  // RS tile rows per MFMA issue: 2 on v_mfma_f32_16x16x32_f16 (comment at mfma32h: k-slots 0..15 = the 16-pixel segment of row r,
+  // 16..31 = that of row r + 1 -- the same transposed reads, concatenated; x and gy agree on the order), 1 on the 16-deep instruction
+  constexpr int RS = SMSUT_F16_X32 ? 2 : 1;
+  static_assert(WTH % 8 == 0, "whole row pairs per wave");
+  auto tr_rows = [&](const _Float16* plane_pix, int row_halves) {            // row_halves: halves between the two rows' segments
+    if constexpr (RS == 2) {
+      const h4 lo = tr_read(plane_pix), up = tr_read(plane_pix + row_halves);
+      return (h8)__builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7);
+    } else {
+      (void)row_halves;
+      return tr_read(plane_pix);
+    }
+  };
 
   if (t_begin < t_end) prefetch();
   for (int t = t_begin; t < t_end; ++t) {
@@ -1632,45 +1736,45 @@ conv_f16_wgrad(const float* __restrict__ x, const float* __restrict__ gy, float*
     if constexpr (TS) {
       const int jt = wave & 1;
 #pragma unroll
-      for (int r = 0; r < WTH; ++r) {
-        const h4 b = tr_read(g_h + (jt * NPG + r * TW) * 16);
+      for (int r = 0; r < WTH; r += RS) {
+        const auto b = tr_rows(g_h + (jt * NPG + r * TW) * 16, TW * 16);
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
           const int ti = (wave + 4 * k) >> 1;                  // tap * CIT + i   (wave-uniform)
           const int tap = ti >> 1, i = ti & 1;
-          const h4 a = tr_read(x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16);
-          acc[k] = mfma16h(a, b, acc[k]);
+          const auto a = tr_rows(x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16, IW * 16);
+          acc[k] = mfmak(a, b, acc[k]);
         }
         if constexpr (SC) {                                    // k = 9 is tap row 9 on every wave: (wave + 36) >> 1 = 18 | 19
-          const h4 bs = tr_read(s_h + (jt * NPG + r * TW) * 16);
-          const h4 a = tr_read(x_h + ((wave >> 1) * NPX + (r + 1) * IW + 1) * 16);
-          acc[9] = mfma16h(a, bs, acc[9]);
+          const auto bs = tr_rows(s_h + (jt * NPG + r * TW) * 16, TW * 16);
+          const auto a = tr_rows(x_h + ((wave >> 1) * NPX + (r + 1) * IW + 1) * 16, IW * 16);
+          acc[9] = mfmak(a, bs, acc[9]);
         }
       }
     } else {
 #pragma unroll
-      for (int rr = 0; rr < WTH / 4; ++rr) {
+      for (int rr = 0; rr < WTH / 4; rr += RS) {
         const int r = wave * (WTH / 4) + rr;
-        h4 b[COT];
+        decltype(tr_rows(g_h, 0)) b[COT];
 #pragma unroll
-        for (int j = 0; j < COT; ++j) b[j] = tr_read(g_h + (j * NPG + r * TW) * 16);
+        for (int j = 0; j < COT; ++j) b[j] = tr_rows(g_h + (j * NPG + r * TW) * 16, TW * 16);
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap)
 #pragma unroll
           for (int i = 0; i < CIT; ++i) {
-            const h4 a = tr_read(x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16);
+            const auto a = tr_rows(x_h + (i * NPX + (r + tap / KS) * IW + tap % KS) * 16, IW * 16);
 #pragma unroll
-            for (int j = 0; j < COT; ++j) acc[(tap * CIT + i) * COT + j] = mfma16h(a, b[j], acc[(tap * CIT + i) * COT + j]);
+            for (int j = 0; j < COT; ++j) acc[(tap * CIT + i) * COT + j] = mfmak(a, b[j], acc[(tap * CIT + i) * COT + j]);
           }
         if constexpr (SC) {
-          h4 bs[COT];
+          decltype(tr_rows(s_h, 0)) bs[COT];
 #pragma unroll
-          for (int j = 0; j < COT; ++j) bs[j] = tr_read(s_h + (j * NPG + r * TW) * 16);
+          for (int j = 0; j < COT; ++j) bs[j] = tr_rows(s_h + (j * NPG + r * TW) * 16, TW * 16);
 #pragma unroll
           for (int i = 0; i < CIT; ++i) {
-            const h4 a = tr_read(x_h + (i * NPX + (r + 1) * IW + 1) * 16);
+            const auto a = tr_rows(x_h + (i * NPX + (r + 1) * IW + 1) * 16, IW * 16);
 #pragma unroll
-            for (int j = 0; j < COT; ++j) acc[(9 * CIT + i) * COT + j] = mfma16h(a, bs[j], acc[(9 * CIT + i) * COT + j]);
+            for (int j = 0; j < COT; ++j) acc[(9 * CIT + i) * COT + j] = mfmak(a, bs[j], acc[(9 * CIT + i) * COT + j]);
           }
         }
       }
