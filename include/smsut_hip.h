@@ -421,6 +421,17 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta /*null
                        const float* rstd, const float* gamma, float* gx, float* a_mean, float* b_mean,
                        float* ggamma /*nullable*/, float* gbeta /*nullable*/, float* workspace, int N, int HW, int C,
                        float slope, void* stream);
+/* InstanceNorm + LeakyReLU + AvgPool2d(2) as ONE op (r05): bn1 -> relu -> avgpool of a stride-2 BottleBlock
+ * (/root/reference/network/blocks.py:99-107), for passes differentiated once.  Forward from a conv epilogue's statistics partials
+ * (as smsut_instnorm_fwd_partials): x [N,H,W,C] raw conv output -> y [N,H/2,W/2,C]; mean / rstd [N,C] are outputs; H, W even.
+ * Backward: gyp [N,H/2,W/2,C] = gradient of the POOLED output; other arguments as smsut_instnorm_bwd.  Both are bit-identical to
+ * the two-op compositions (instnorm + avgpool2; avgpool2_bwd + instnorm_bwd) without the full-resolution intermediate. */
+int smsut_instnorm_pool_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                     const float* partials, int chunks, int N, int H, int W, int C, float eps, float slope,
+                                     void* stream);
+int smsut_instnorm_pool_bwd(const float* gyp, const float* x, const float* beta, const float* mean, const float* rstd,
+                            const float* gamma, float* gx, float* a_mean, float* b_mean, float* ggamma /*nullable*/,
+                            float* gbeta /*nullable*/, float* workspace, int N, int H, int W, int C, float slope, void* stream);
 int smsut_instnorm_bwd2(const float* v, const float* ug /*nullable*/, const float* ub /*nullable*/, const float* gy,
                         const float* x, const float* beta /*nullable: no activation*/, const float* mean, const float* rstd,
                         const float* gamma, const float* a_mean, const float* b_mean, float* d_gy, float* d_x,

@@ -47,7 +47,9 @@ __device__ __forceinline__ void fin_emit(const FinOut& f, int HW, int k, const f
   }
 }
 
-template <int MODE, int VEC>
+// POOLG (MODE 1, r05): t0 is the gradient of the 2x2-AVERAGE-POOLED activation, [N, H/2, W/2, C]; the full-resolution gradient
+// 0.25 * t0[h/2][w/2] (what k_avgpool_bwd, pointwise.hip, would have written) is formed while loading -- pw = W.
+template <int MODE, int VEC, bool POOLG = false>
 __global__ void __launch_bounds__(TPB, 4)   // <= 128 VGPRs: 4 waves per SIMD (it sat at 172 = 2 waves)
 in_moments_partial(const float* __restrict__ t0,   // x | gy | v
                    const float* __restrict__ t1,   // - | x  | x
@@ -55,7 +57,8 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
                    const float* __restrict__ gamma, const float* __restrict__ beta,   // beta == null: no activation
                    const float* __restrict__ mean, const float* __restrict__ rstd,
                    float* __restrict__ part,        // [N][chunks][C][NS]
-                   int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}) {
+                   int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}, int pw = 0) {
+  static_assert(!POOLG || MODE == 1, "pooled gradient: first-order backward sums only");
   constexpr int NS = NSums<MODE>::n;
   const bool emit = fin.o0 != nullptr;              // (host: only with gridDim.x == 1)
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
@@ -94,7 +97,14 @@ in_moments_partial(const float* __restrict__ t0,   // x | gy | v
       constexpr int U = (MODE == 0) ? 4 : 2;
       auto load = [&](int p, float* a0, float* a1, float* a2) {
         const size_t off = base + (size_t)p * C + cv * VEC;
-        if constexpr (VEC == 4) {
+        if constexpr (POOLG) {
+          const int ph = p / pw, pc = p - ph * pw;
+          const size_t goff = ((size_t)n * (HW >> 2) + (size_t)(ph >> 1) * (pw >> 1) + (pc >> 1)) * C + cv * VEC;
+          if constexpr (VEC == 4) { *(float4*)a0 = *(const float4*)(t0 + goff); *(float4*)a1 = *(const float4*)(t1 + off); }
+          else { a0[0] = t0[goff]; a1[0] = t1[off]; }
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) a0[j] *= 0.25f;
+        } else if constexpr (VEC == 4) {
           *(float4*)a0 = *(const float4*)(t0 + off);
           if (MODE >= 1) *(float4*)a1 = *(const float4*)(t1 + off);
           if (MODE == 2) *(float4*)a2 = *(const float4*)(t2 + off);
@@ -356,6 +366,49 @@ in_apply_fwd(const float* __restrict__ x, const float* __restrict__ mean, const 
     });
 }
 
+// InstanceNorm + LeakyReLU + AvgPool2d(2) in ONE pass (r05): y[n, ho, wo, c] = mean over the 2x2 window of lrelu(IN(x)) -- bn1 -> relu ->
+// avgpool of a stride-2 BottleBlock (reference network/blocks.py:99-107) without writing the activated full-resolution tensor (one
+// read of x + a quarter-size write instead of read + write + read + quarter write).  Arithmetic = in_apply_fwd followed by
+// k_avgpool_fwd (pointwise.hip): (a00 + a01 + a10 + a11) * 0.25f in that order -- bit-identical to the two kernels.
+template <int VEC>
+__global__ void __launch_bounds__(TPB)
+in_apply_pool_fwd(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+                  const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y, int H, int W, int C,
+                  float slope) {
+  struct Prm { float mu[VEC], rs[VEC], gm[VEC], bt[VEC]; };
+  const int Wo = W >> 1, CV = C / VEC, HWo = (H >> 1) * Wo;
+  const float* xin = x + (size_t)blockIdx.y * H * W * C;
+  img_walk(HWo, CV,
+    [&](int n, int cv) {
+      Prm p;
+      ldv<VEC>(mean, n * C + cv * VEC, p.mu); ldv<VEC>(rstd, n * C + cv * VEC, p.rs);
+      ldv<VEC>(gamma, cv * VEC, p.gm); ldv<VEC>(beta, cv * VEC, p.bt);
+      return p;
+    },
+    [&](int64_t i, const Prm& p) {
+      const int li = (int)(i - (int64_t)blockIdx.y * HWo * CV);
+      const int pp = li / CV, cv = li - pp * CV;
+      const int ho = pp / Wo, wo = pp - ho * Wo;
+      const float* b = xin + ((size_t)(2 * ho) * W + 2 * wo) * C + cv * VEC;
+      float a[4][VEC];
+      if constexpr (VEC == 4) {
+        *(float4*)a[0] = *(const float4*)b; *(float4*)a[1] = *(const float4*)(b + C);
+        *(float4*)a[2] = *(const float4*)(b + (size_t)W * C); *(float4*)a[3] = *(const float4*)(b + (size_t)W * C + C);
+      } else {
+        a[0][0] = b[0]; a[1][0] = b[C]; a[2][0] = b[(size_t)W * C]; a[3][0] = b[(size_t)W * C + C];
+      }
+      float v[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = lrelu_f(in_affine(a[k][j], p.mu[j], p.rs[j], p.gm[j], p.bt[j]), slope);
+        v[j] = (q[0] + q[1] + q[2] + q[3]) * 0.25f;
+      }
+      if constexpr (VEC == 4) *(float4*)(y + i * 4) = *(float4*)v; else y[i] = v[0];
+    });
+}
+
 // fp16-operand convolutions scale a gradient operand by a power of two derived from its absolute maximum (smsut_absmax_scale).
 // The kernels that WRITE such a gradient hand the maximum over (amax, nullable): every workgroup stores the maximum of what it
 // wrote in its own slot amax[block] -- no atomics (a first version with one atomicMax per wave on a single float cost 3 ms per
@@ -374,13 +427,14 @@ __device__ __forceinline__ void amax_emit(float m, float* slots) {
   __syncthreads();
 }
 
-template <int VEC, bool HS = false, bool AMAX = false>      // AMAX: hand max|gx| over (amax non-null); compile-time, so that the
-__global__ void __launch_bounds__(TPB)                       // fp32 path's instantiation carries nothing of it
-in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
+template <int VEC, bool HS = false, bool AMAX = false, bool POOLG = false>   // AMAX: hand max|gx| over (amax non-null); compile-time, so
+__global__ void __launch_bounds__(TPB)                       // that the fp32 path's instantiation carries nothing of it.  POOLG: gy is the
+in_apply_bwd(                                                // gradient of the 2x2-average-pooled output (see in_moments_partial), pw = W
+const float* __restrict__ gy, const float* __restrict__ x, const float* __restrict__ beta,
              const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma,
              const float* __restrict__ am, const float* __restrict__ bm, float* __restrict__ gx,
              int HW, int C, float slope, int N, float* __restrict__ ggamma, float* __restrict__ gbeta,
-             float* __restrict__ amax = nullptr) {
+             float* __restrict__ amax = nullptr, int pw = 0) {
   float mx = 0.f;
   if (ggamma && blockIdx.x == 0 && blockIdx.y == 0) {   // affine gradients ride along in one block: ggamma = sum_n M*b, gbeta = sum_n M*a
     for (int c = threadIdx.x; c < C; c += TPB) {
@@ -402,7 +456,16 @@ in_apply_bwd(const float* __restrict__ gy, const float* __restrict__ x, const fl
     },
     [&](int64_t i, const Prm& p) {
       float g[VEC], xv[VEC];
-      if constexpr (VEC == 4) *(float4*)g = *(const float4*)(gy + i * 4); else g[0] = gy[i];
+      if constexpr (POOLG) {
+        const int CV = C / VEC;
+        const int li = (int)(i - (int64_t)blockIdx.y * HW * CV);          // unit inside the image: pixel * CV + channel group
+        const int pix = li / CV, cv = li - pix * CV;
+        const int ph = pix / pw, pc = pix - ph * pw;
+        const size_t goff = ((size_t)blockIdx.y * (HW >> 2) + (size_t)(ph >> 1) * (pw >> 1) + (pc >> 1)) * C + cv * VEC;
+        if constexpr (VEC == 4) *(float4*)g = *(const float4*)(gy + goff); else g[0] = gy[goff];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) g[j] *= 0.25f;
+      } else if constexpr (VEC == 4) *(float4*)g = *(const float4*)(gy + i * 4); else g[0] = gy[i];
       ld_act<VEC, HS>(x, (size_t)i * VEC, xv);
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -839,6 +902,53 @@ int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta, const
   else
     in_apply_bwd<1><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(gy, x, beta, mean, rstd, gamma, a_mean, b_mean, gx, HW, C, slope,
                                                     N, gg, gbeta);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+
+// InstanceNorm + LeakyReLU + AvgPool2d(2) as one op (r05; bn1 -> relu -> avgpool of a stride-2 BottleBlock, reference
+// network/blocks.py:99-107; passes differentiated once).  Forward from the conv epilogue's statistics partials (as
+// smsut_instnorm_fwd_partials): x [N,H,W,C] raw conv output -> y [N,H/2,W/2,C]; mean / rstd [N,C] are outputs.  H, W even.
+int smsut_instnorm_pool_fwd_partials(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                     const float* partials, int chunks, int N, int H, int W, int C, float eps, float slope,
+                                     void* stream) {
+  SMSUT_REQUIRE(x && gamma && beta && y && mean && rstd && partials && chunks > 0 && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) &&
+                !(W & 1) && (int64_t)H * W * C < (1ll << 31));
+  hipStream_t st = (hipStream_t)stream;
+  in_moments_final<0><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(partials, chunks, C, H * W, eps, mean, rstd, nullptr);
+  const int64_t units = (int64_t)(H / 2) * (W / 2);
+  if (C % 4 == 0) in_apply_pool_fwd<4><<<img_grid(units * (C / 4), N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, H, W, C, slope);
+  else in_apply_pool_fwd<1><<<img_grid(units * C, N), TPB, 0, st>>>(x, mean, rstd, gamma, beta, y, H, W, C, slope);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+// ... its backward: gyp [N,H/2,W/2,C] is the gradient of the POOLED output; everything else as smsut_instnorm_bwd (beta non-null:
+// the mask is recomputed from x).  The full-resolution gradient 0.25 * gyp[h/2][w/2] is formed while loading, in both passes --
+// bit-identical to smsut_avgpool2_bwd followed by smsut_instnorm_bwd, without the full-resolution gradient tensor.
+int smsut_instnorm_pool_bwd(const float* gyp, const float* x, const float* beta, const float* mean, const float* rstd,
+                            const float* gamma, float* gx, float* a_mean, float* b_mean, float* ggamma, float* gbeta,
+                            float* workspace, int N, int H, int W, int C, float slope, void* stream) {
+  SMSUT_REQUIRE(gyp && x && beta && mean && rstd && gamma && gx && a_mean && b_mean && workspace && N > 0 && H > 0 && W > 0 && C > 0 &&
+                !(H & 1) && !(W & 1));
+  hipStream_t st = (hipStream_t)stream;
+  const int HW = H * W;
+  const int ppc = pick_chunk(HW, C, N);
+  const int chunks = (int)cdiv64(HW, ppc);
+  dim3 g(chunks, N, slab_count(N, chunks, C, C % 4 == 0 ? 4 : 1));
+  const FinOut fin = (chunks == 1 && fin_emit_on()) ? FinOut{a_mean, b_mean, nullptr, 0.f} : FinOut{};
+  if (C % 4 == 0)
+    in_moments_partial<1, 4, true><<<g, TPB, 0, st>>>(gyp, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope, fin, W);
+  else
+    in_moments_partial<1, 1, true><<<g, TPB, 0, st>>>(gyp, x, nullptr, gamma, beta, mean, rstd, workspace, HW, C, ppc, slope, fin, W);
+  if (!fin.o0) in_moments_final<1><<<dim3((C + 15) / 16, N), TPB, 0, st>>>(workspace, chunks, C, HW, 0.f, a_mean, b_mean, nullptr);
+  float* gg = (ggamma && gbeta) ? ggamma : nullptr;
+  SMSUT_REQUIRE((int64_t)HW * C < (1ll << 31));       // per-image walks index in 32 bits
+  if (C % 4 == 0)
+    in_apply_bwd<4, false, false, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gyp, x, beta, mean, rstd, gamma, a_mean, b_mean,
+                                                                                         gx, HW, C, slope, N, gg, gbeta, nullptr, W);
+  else
+    in_apply_bwd<1, false, false, true><<<img_grid((int64_t)HW * C, N), TPB, 0, st>>>(gyp, x, beta, mean, rstd, gamma, a_mean, b_mean, gx,
+                                                                                   HW, C, slope, N, gg, gbeta, nullptr, W);
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }

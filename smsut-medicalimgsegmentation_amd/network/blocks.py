@@ -227,9 +227,13 @@ class BottleBlock(nn.Module):
     def forward(self, x):
         s = self.relu.slope
         idn = ops.avg_pool2(x) if self.stride == 2 else x
-        y = self.bn1(self.conv1(x, stats=True), slope=s)
-        if self.stride == 2:
-            y = ops.avg_pool2(y)
+        y1 = self.conv1(x, stats=True)
+        if self.stride == 2 and isinstance(self.bn1, InstanceNorm2d) and ops.instnorm_act_pool_fusable(y1):
+            y = ops.instnorm_act_pool(y1, self.bn1.weight, self.bn1.bias, s)      # first-order passes: IN + act + pool in one pass (r05)
+        else:
+            y = self.bn1(y1, slope=s)
+            if self.stride == 2:
+                y = ops.avg_pool2(y)
         y2 = self.conv2(y, stats=True)
         if self.downsample is not None:
             sc = self.downsample[0](idn, stats=True)

@@ -708,6 +708,58 @@ class InstNormActBwdFn(Function):
         return d_gy, d_x, None, None, None, d_gamma, None, None, None
 
 
+class InstNormActPoolFn(Function):
+    """avg_pool2(lrelu(InstanceNorm(x) * gamma + beta)) as ONE op -- bn1 -> relu -> avgpool of a stride-2 BottleBlock
+    (reference network/blocks.py:99-107) for passes that are differentiated once (the discriminator's real | fake pass and D(x_fake);
+    the WGAN-GP x_hat pass keeps the twice-differentiable InstNormActFn + AvgPool2Fn).  x is a raw conv output that carries the
+    statistics partials of the conv epilogue.  Forward: one read of x, a quarter-size write; backward: the full-resolution gradient
+    0.25 * g[h/2][w/2] is formed while loading in both passes.  Bit-identical to the two-op composition."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, slope):
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        part, tiles = x._smsut_in_partials
+        del x._smsut_in_partials
+        y = new_act(n, c, h // 2, w // 2, x)
+        mean = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        H.call("smsut_instnorm_pool_fwd_partials", x, gamma, beta, y, mean, rstd, part, tiles, n, h, w, c, IN_EPS, float(slope), _s())
+        ctx.save_for_backward(x, mean, rstd, gamma, beta)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, mean, rstd, gamma, beta = ctx.saved_tensors
+        gy = nhwc(gy)
+        n, c, h, w = x.shape
+        want_affine = (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and not _INPUT_GRADS_ONLY
+        gx = new_act(n, c, h, w, x)
+        a = torch.empty(n, c, dtype=torch.float32, device=x.device)
+        b = torch.empty_like(a)
+        gg = torch.empty(c, dtype=torch.float32, device=x.device) if want_affine else None
+        gb = torch.empty_like(gg) if want_affine else None
+        chunks = H.call("smsut_in_chunks", n, h * w, c)
+        H.call("smsut_instnorm_pool_bwd", gy, x, beta, mean, rstd, gamma, gx, a, b, gg, gb, _ws(n * chunks * c * 3, x), n, h, w, c,
+               ctx.slope, _s())
+        return gx, gg, gb, None
+
+
+IN_ACT_POOL = bool(int(_os.environ.get("SMSUT_IN_ACT_POOL", "1")))       # stride-2 BottleBlock, first-order passes: IN + act + pool as one op
+
+
+def instnorm_act_pool_fusable(x):
+    """x carries conv-epilogue statistics, even plane, whole channel quads, and the pass is differentiated at most once."""
+    return (IN_ACT_POOL and first_order_only() and hasattr(x, "_smsut_in_partials") and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+            and x.shape[1] % 4 == 0 and x.dtype == torch.float32)
+
+
+def instnorm_act_pool(x, gamma, beta, slope: float):
+    return InstNormActPoolFn.apply(cl(x), gamma, beta, float(slope))
+
+
 def instnorm_act(x, gamma, beta, slope: Optional[float]):
     """slope=None -> no activation."""
     y, _, _ = InstNormActFn.apply(cl(x), gamma, beta, 0.0 if slope is None else slope, slope is not None)

@@ -31,6 +31,9 @@ _CONV_FLOPS: Dict[str, Tuple[Callable[[List[int]], float], str]] = {
     "smsut_conv2d_dgrad_generic": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * a[7] * a[8], "direct"),
     "smsut_conv2d_wgrad_generic": (lambda a: 2.0 * a[0] * a[4] * a[5] * a[3] * a[6] * a[7] * a[8], "direct"),
     "smsut_conv2d_fwd_mfma": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
+    # two image sets of one layer in one launch (ints: NA, NB, ca, H, W, Cin, Cout); conv_flops_of counts the fused-shortcut row too
+    "smsut_conv2d_wgrad_pair": (lambda a: 2.0 * (a[0] + a[1]) * a[3] * a[4] * a[5] * a[6] * 9, "mfma"),
+    "smsut_conv2d_wgrad_pair_slabs": (lambda a: 2.0 * (a[0] + a[1]) * a[2] * a[3] * a[4] * a[5] * 9, "mfma"),
     "smsut_conv2d_fwd_mfma_stats": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
     "smsut_conv2d_dgrad_mfma_bwdstats": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * 9, "mfma"),
     "smsut_conv2d_wgrad_mfma": (lambda a: 2.0 * a[0] * a[1] * a[2] * a[3] * a[4] * _k2(a, 5), "mfma"),
@@ -292,7 +295,7 @@ def summarize(rows: List[Row], peak_tflops: float) -> dict:
     DEFINES (what the contract's ``achieved`` is made of); ``*_executed`` count the products the MFMA pipes actually run (Winograd
     forms: 16 / 36 of them) -- the figure to hold against the 157.3 TFLOP/s the pipes can do."""
     conv = [r for r in rows if r.flops > 0]
-    mfma = [r for r in conv if r.name == "smsut_conv2d_wgrad_pair" or _CONV_FLOPS[_base(r.name)][1] == "mfma"]
+    mfma = [r for r in conv if _CONV_FLOPS[_base(r.name)][1] == "mfma"]
     t_all = sum(r.total_us for r in rows)
     t_conv = sum(r.total_us for r in conv)
     f_conv = sum(r.flops * r.calls for r in conv)

@@ -40,7 +40,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         self._d_alias = None
         self._use_d_alias = os.environ.get("SMSUT_D_ALIAS", "1") not in ("0", "")
         self._d_async = os.environ.get("SMSUT_D_ASYNC_ALLREDUCE", "0") not in ("0", "")
-        self._g1 = self._g2 = None
+        self._g1 = self._g2 = self._seg_real = None
         self._side = None
         # SMSUT_D_OVERLAP = 1: D-step (graph, gradient all-reduce, Adam) and D(x_fake) on a side stream beside the generator's
         # cycle pass and D-independent backward -- the default at ONE GPU.  Under data parallelism (world > 1, any backend) that
@@ -251,6 +251,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
             self._g1 = (y_seg, self._g1[1], self._g1[2])
             st_seg = self._keep_stats(0, self.loss.stats(y_seg, y_real))
             y_fake = y_all[:b].detach()
+            self._seg_real = y_fake                  # (segmentation logits of G(x_real), all rows: read by tests / tools only)
         else:
             with ops.wino_prepared(self.net, forms="f"), ops.pair_wgrads():
                 y_rec, x_rec, feat_f, _ = torch.func.functional_call(self.net, self._alias, (x_fake, vec_to),
@@ -338,7 +339,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
         with ops.wino_prepared(self.net, forms="b"):
             torch.autograd.backward([x_fake, t_e5], [xd.grad + self._gx_d, td.grad])
             ops.pair_flush()                     # sets parked without a partner (consistency term off): computed alone, here
-        self._g1 = self._g2 = self._gx_d = None
+        self._g1 = self._g2 = self._gx_d = self._seg_real = None
         main, extra = [], []
         for name, p in self.net.named_parameters():
             a = self._alias[name]

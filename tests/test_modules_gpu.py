@@ -238,6 +238,45 @@ def test_discriminator_first_order_pass_matches_default(pkg, golden):
         dydx.square().sum().backward()
 
 
+@pytest.mark.parametrize("n,ci,co,h", [(3, 16, 32, 32), (2, 32, 64, 64), (5, 64, 64, 16), (2, 8, 16, 128)])
+def test_bottleblock_in_act_pool_is_bit_identical_to_the_two_ops(pkg, n, ci, co, h):
+    """r05: a stride-2 BottleBlock (reference network/blocks.py:83-117) runs bn1 -> LeakyReLU -> avg_pool2 as ONE op in passes that are
+    differentiated once (``ops.InstNormActPoolFn``: the activated full-resolution tensor and its gradient are never written).  Same
+    arithmetic in the same order as ``InstNormActFn`` + ``AvgPool2Fn``: output, input gradient and every parameter gradient are the
+    same bits with the fusion on and off."""
+    from smsut_amd.network.blocks import BottleBlock
+    from smsut_amd import ops, profiling
+    torch.manual_seed(n * 100 + ci)
+    blk = BottleBlock(ci, co, norm_type="instance", act_type="lrelu", stride=2).cuda().train()
+    for p in blk.parameters():
+        p.data.add_(0.1 * torch.randn_like(p))
+    x = torch.randn(n, ci, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+    gout = torch.randn(n, co, h // 2, h // 2, device="cuda").contiguous(memory_format=torch.channels_last)
+    res = {}
+    prev = ops.IN_ACT_POOL
+    try:
+        for on in (False, True):
+            ops.IN_ACT_POOL = on
+            blk.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            box = {}
+
+            def step():
+                with ops.first_order_pass():
+                    box["out"] = blk(xin)
+                    box["out"].backward(gout)
+            calls = [name for name, _ in profiling.record_step(step)]
+            out = box["out"]
+            res[on] = (out.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+            assert (sum(c.startswith("smsut_instnorm_pool") for c in calls) == 2) == on, calls
+            assert calls.count("smsut_avgpool2_bwd") == (1 if on else 2), calls           # (the shortcut's pooling stays a separate op)
+    finally:
+        ops.IN_ACT_POOL = prev
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    for k in res[False][2]:
+        assert torch.equal(res[True][2][k], res[False][2][k]), k
+
+
 def test_ugannce_forward(pkg, golden):
     from smsut_amd.network.ugan import UGANnce
     g = golden("ugan_small")

@@ -79,11 +79,22 @@ def run_hip(path):
     stash = {}
     g1_phase = tr._g1_phase
 
-    def g1_spy(*a):                                           # forward of G(x_real): segmentation logits and translated images
-        r = g1_phase(*a)
-        stash["seg"], stash["x_fake"] = tr._g1[0].detach().clone(), tr._g1[1].detach().clone()
+    g2gen_phase = tr._g2gen_phase
+
+    def g1_spy(*a):                                           # forward of G(x_real): translated images (+ segmentation logits, unless
+        r = g1_phase(*a)                                      # the segmentation branch of both passes runs batched inside G2gen: r05)
+        stash["x_fake"] = tr._g1[1].detach().clone()
+        if tr._g1[0] is not None:
+            stash["seg"] = tr._g1[0].detach().clone()
+        return r
+
+    def g2gen_spy(*a, **k):
+        r = g2gen_phase(*a, **k)
+        seg = getattr(tr, "_seg_real", None) if tr._seg_batch else tr._g1[0]
+        stash["seg"] = seg.detach().clone()                   # logits of G(x_real)'s segmentation branch, all rows (either schedule)
         return r
     tr._g1_phase = g1_spy
+    tr._g2gen_phase = g2gen_spy
     for step in STEPS:
         x4, y2, modal, mj, alpha, ids = inputs(step)
         tr.train_iteration(x4.cuda(), y2.cuda(), modal, mj=mj, alpha=alpha.cuda(), sample_ids=[ids.cuda()])
