@@ -417,6 +417,20 @@ int smsut_restail_bwd_amax(const float* gout, const float* out, const float* y2,
                            const float* rs, const float* gs_, const float* bs /*nullable*/, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2,
                            float* ggs /*nullable*/, float* gbs /*nullable*/, float* workspace, float* amax, int N, int HW,
                            int C, float slope, void* stream);
+/* The tail of an ENCODER level's block together with the level's MaxPool2d(2, 2) (r05; /root/reference/network/blocks.py:74-79 +
+ * 131-133, network/ugan.py:36-39).  Forward: out [N,H,W,C] (the skip connection), pooled [N,H/2,W/2,C] and idx (one byte per pooled
+ * element: where the maximum sat in its window) in ONE pass -- bit-identical to smsut_restail_fwd + smsut_maxpool2_fwd.  Backward:
+ * gout = gradient of out through the skip connection, gp = gradient of pooled; the block output's total gradient (what
+ * smsut_maxpool2_bwd_add writes) is formed while loading -- bit-identical to that call followed by smsut_restail_bwd / _fin (tickets
+ * non-null) / _amax (amax non-null) / _hs (hs != 0: y2, s are _Float16).  Conv shortcut only (ms, b2, bs non-null), C % 4 == 0, H, W even. */
+int smsut_restail_fwd_pool(const void* y2, const float* m2, const float* r2, const float* g2, const float* b2, const void* s,
+                           const float* ms, const float* rs, const float* gs, const float* bs, float* out, float* pooled,
+                           void* idx, int N, int H, int W, int C, float slope, int hs, void* stream);
+int smsut_restail_bwd_pool(const float* gout, const float* gp, const void* idx, const void* y2, const float* m2, const float* r2,
+                           const float* g2, const float* b2, const void* s, const float* ms, const float* rs, const float* gs_,
+                           const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2,
+                           float* gb2, float* ggs, float* gbs, float* workspace, int* tickets /*nullable*/, float* amax /*nullable*/,
+                           int N, int H, int W, int C, float slope, int hs, void* stream);
 int smsut_instnorm_bwd(const float* gy, const float* x, const float* beta /*nullable: no activation*/, const float* mean,
                        const float* rstd, const float* gamma, float* gx, float* a_mean, float* b_mean,
                        float* ggamma /*nullable*/, float* gbeta /*nullable*/, float* workspace, int N, int HW, int C,

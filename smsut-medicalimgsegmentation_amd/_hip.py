@@ -38,6 +38,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_absmax_finish": "p i p s",
     "smsut_amax_blocks": "iii",
     "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
+    "smsut_restail_fwd_pool": "pppppppppp ppp iiii f i s",
+    "smsut_restail_bwd_pool": "ppp pppppppppp pp ppp pppp p pp iiii f i s",
     "smsut_instnorm_pool_fwd_partials": "ppppppp iiiii ff s",
     "smsut_instnorm_pool_bwd": "pppppp ppppp p iiii f s",
     "smsut_instnorm_bwd2": "ppppppppppp ppp pp iii f s",

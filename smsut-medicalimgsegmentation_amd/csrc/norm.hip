@@ -572,13 +572,87 @@ restail_fwd(TailRef t, float* __restrict__ out, int HW, int C, float slope) {
     });
 }
 
+// The tail of an ENCODER level's block and the level's MaxPool2d(2, 2) in ONE pass (r05; reference network/blocks.py:74-79 +
+// 131-133): a thread owns a pooled unit = the 2x2 window of one channel quad, computes the four outputs as restail_fwd does, stores
+// them (the skip connection reads `out`), their maximum in k_maxpool_fwd's scan order (pointwise.hip; NaN propagates) and WHERE the
+// maximum sat (one byte per channel: 0..3 = (0,0),(0,1),(1,0),(1,1)) -- the pooling pass over `out` disappears, and the backward
+// needs neither `out` nor a pass of its own to route the pooled gradient (MaxRef below).
+template <bool HS>
+__global__ void __launch_bounds__(TPB)
+restail_fwd_pool(TailRef t, float* __restrict__ out, float* __restrict__ pooled, unsigned int* __restrict__ idx, int H, int W, int C,
+                 float slope) {
+  constexpr int VEC = 4;
+  struct Prm { float m2[VEC], r2[VEC], g2[VEC], b2[VEC], ms[VEC], rs[VEC], gs[VEC], bs[VEC]; };
+  const int Wo = W >> 1, CV = C / VEC, HWo = (H >> 1) * Wo;
+  const size_t ibase = (size_t)blockIdx.y * H * W * C;
+  img_walk(HWo, CV,
+    [&](int n, int cv) {
+      Prm p;
+      const int c0 = cv * VEC, k0 = n * C + c0;
+      ldv<VEC>(t.m2, k0, p.m2); ldv<VEC>(t.r2, k0, p.r2); ldv<VEC>(t.g2, c0, p.g2); ldv<VEC>(t.b2, c0, p.b2);
+      if (t.ms) { ldv<VEC>(t.ms, k0, p.ms); ldv<VEC>(t.rs, k0, p.rs); ldv<VEC>(t.gs, c0, p.gs); ldv<VEC>(t.bs, c0, p.bs); }
+      return p;
+    },
+    [&](int64_t i, const Prm& p) {
+      const int li = (int)(i - (int64_t)blockIdx.y * HWo * CV);
+      const int pp = li / CV, cv = li - pp * CV;
+      const int ho = pp / Wo, wo = pp - ho * Wo;
+      const size_t o0 = ibase + ((size_t)(2 * ho) * W + 2 * wo) * C + cv * VEC;
+      const size_t offs[4] = {o0, o0 + C, o0 + (size_t)W * C, o0 + (size_t)W * C + C};
+      float a[4][VEC], b[4][VEC];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { ld_act<VEC, HS>(t.y2, offs[k], a[k]); ld_act<VEC, HS>(t.s, offs[k], b[k]); }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float u = in_affine(a[k][j], p.m2[j], p.r2[j], p.g2[j], p.b2[j]);
+          const float v = t.ms ? in_affine(b[k][j], p.ms[j], p.rs[j], p.gs[j], p.bs[j]) : b[k][j];
+          a[k][j] = lrelu_f(u + v, slope);
+        }
+        *(float4*)(out + offs[k]) = *(float4*)a[k];
+      }
+      float m[VEC];
+      unsigned int where = 0;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        int kk = 0; float mv = a[0][j];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) if (a[k][j] > mv || a[k][j] != a[k][j]) { mv = a[k][j]; kk = k; }
+        m[j] = mv; where |= (unsigned int)kk << (8 * j);
+      }
+      *(float4*)(pooled + i * 4) = *(float4*)m;
+      idx[i] = where;
+    });
+}
+
+// MaxRef (r05): the gradient of a block output that went into MaxPool2d(2, 2) AND a skip connection, never materialised:
+// g[n,h,w,c] = (idx[n,h/2,w/2,c] == 2 (h & 1) + (w & 1) ? gp[n,h/2,w/2,c] : 0) + gout[n,h,w,c] -- exactly what k_maxpool_bwd with
+// `add` (pointwise.hip) would have written (idx from restail_fwd_pool).  gp == null: the plain tensor gout.
+struct MaxRef { const float* gp; const unsigned int* idx; int W; };
+__device__ __forceinline__ void add_pooled_grad(const MaxRef& mr, int n, int HW, int C, int p, int cv, float* g) {
+  // n: image, p: pixel inside the image (h * W + w), cv: float4 channel group; g[4] holds gout's values on entry
+  const int h = p / mr.W, w = p - h * mr.W;
+  const size_t u = ((size_t)n * (HW >> 2) + (size_t)(h >> 1) * (mr.W >> 1) + (w >> 1)) * (C >> 2) + cv;      // pooled unit
+  const float4 gp = *(const float4*)(mr.gp + u * 4);
+  const unsigned int wh = mr.idx[u];
+  const unsigned int pos = ((h & 1) << 1) | (w & 1);
+  g[0] = (((wh) & 0xffu) == pos ? gp.x : 0.f) + g[0];
+  g[1] = (((wh >> 8) & 0xffu) == pos ? gp.y : 0.f) + g[1];
+  g[2] = (((wh >> 16) & 0xffu) == pos ? gp.z : 0.f) + g[2];
+  g[3] = (((wh >> 24) & 0xffu) == pos ? gp.w : 0.f) + g[3];
+}
+
 // partial [N][chunks][C][3] = {sum gz, sum gz*y2hat, sum gz*shat}
 // FIN (r05; several chunks per image): the workgroup whose partials complete an image (agent-scope ticket per image, common.h) runs
 // in_moments_final<2>'s combine itself -- fin.o0 .. o2 then name the outputs of THAT finalize, tickets the image counters.
-template <int VEC, bool REMASK, bool HS = false, bool FIN = false>
+// MPG (r05): gout is the skip connection's gradient only; the pooled path's is routed in while loading (MaxRef above).
+template <int VEC, bool REMASK, bool HS = false, bool FIN = false, bool MPG = false>
 __global__ void __launch_bounds__(TPB)       // (a 128-VGPR cap spills here: 244 B scratch and +30 % time)
 restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, float* __restrict__ part,
-                    int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}, int* tickets = nullptr) {
+                    int HW, int C, int pix_per_chunk, float slope, FinOut fin = FinOut{}, int* tickets = nullptr,
+                    MaxRef mr = MaxRef{nullptr, nullptr, 0}) {
+  static_assert(!MPG || VEC == 4, "routed pooled gradient: whole channel quads");
   const bool emit = !FIN && fin.o0 != nullptr;      // one-chunk case: see fin_emit
   const int n = blockIdx.y, chunk = blockIdx.x, chunks = gridDim.x;
   const int CVA = C / VEC;                    // gridDim.z channel slabs, as in in_moments_partial
@@ -621,6 +695,7 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
           g[0] = gout[off];
           if (!remask) o[0] = out[off];
         }
+        if constexpr (MPG) add_pooled_grad(mr, n, HW, C, p, cv, g);
         ld_act<VEC, HS>(t.y2, off, y);
         if (t.ms) ld_act<VEC, HS>(t.s, off, sv);
       };
@@ -722,12 +797,14 @@ restail_bwd_partial(const float* __restrict__ gout, const float* __restrict__ ou
   }
 }
 
-template <int VEC, bool REMASK, bool HS = false, bool AMAX = false>
+template <int VEC, bool REMASK, bool HS = false, bool AMAX = false, bool MPG = false>
 __global__ void __launch_bounds__(TPB)
 restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out, TailRef t, const float* __restrict__ am,
                   const float* __restrict__ b2m, const float* __restrict__ bsm, float* __restrict__ gy2,
                   float* __restrict__ gs, int HW, int C, float slope, int N, float* __restrict__ gg2,
-                  float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs, float* __restrict__ amax = nullptr) {
+                  float* __restrict__ gb2, float* __restrict__ ggs, float* __restrict__ gbs, float* __restrict__ amax = nullptr,
+                  MaxRef mr = MaxRef{nullptr, nullptr, 0}) {
+  static_assert(!MPG || VEC == 4, "routed pooled gradient: whole channel quads");
   constexpr bool remask = REMASK;             // see restail_bwd_partial
   float mx1 = 0.f, mx2 = 0.f;                 // amax: {max |gy2|, max |gs|}
   if (blockIdx.x == 0 && blockIdx.y == 0) {   // affine gradients of the tail: gg2 = sum_n M*b2, gb = sum_n M*a (both norms), ggs = sum_n M*bs
@@ -756,6 +833,12 @@ restail_bwd_apply(const float* __restrict__ gout, const float* __restrict__ out,
       } else {
         g[0] = gout[i];
         if (!remask) o[0] = out[i];
+      }
+      if constexpr (MPG) {
+        const int CV = C / VEC;
+        const int li = (int)(i - (int64_t)blockIdx.y * HW * CV);
+        const int pix = li / CV;
+        add_pooled_grad(mr, blockIdx.y, HW, C, pix, li - pix * CV, g);
       }
       ld_act<VEC, HS>(t.y2, (size_t)i * VEC, y);
       if (t.ms) ld_act<VEC, HS>(t.s, (size_t)i * VEC, sv);
@@ -1097,9 +1180,12 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
                               const float* g2, const float* b2, const float* s, const float* ms, const float* rs,
                               const float* gs_, const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2, float* gb2, float* ggs,
                               float* gbs, float* workspace, float* amax, int N, int HW, int C, float slope, void* stream,
-                              bool hs = false, int* tickets = nullptr) {
+                              bool hs = false, int* tickets = nullptr, const MaxRef* mr = nullptr) {
   SMSUT_REQUIRE(gout && out && y2 && m2 && r2 && g2 && s && gy2 && gs && a_mean && b2_mean && bs_mean && gg2 && gb2 &&
                 workspace && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs_ && ggs && gbs)));
+  // mr (r05): gout is the skip connection's gradient, the pooled path's is routed in while loading (two-IN tail, channel quads)
+  SMSUT_REQUIRE(!mr || (mr->gp && mr->idx && mr->W > 0 && HW % mr->W == 0 && ms && b2 && bs && C % 4 == 0));
+  const MaxRef mrv = mr ? *mr : MaxRef{nullptr, nullptr, 0};
   TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs_, bs};
   hipStream_t st = (hipStream_t)stream;
   const int ppc = pick_chunk(HW, C, N);
@@ -1111,12 +1197,18 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
   // in-launch finalize (several chunks per image, fp32, the two-IN tail on whole float4 channel groups): the last-arriving
   // workgroup of an image combines its partials -- no in_moments_final<2> launch
   const bool fin_in = tickets && !fin.o0 && !hs && remask && C % 4 == 0;
-  if (fin_in) {
+  if (fin_in && mr) {
+    restail_bwd_partial<4, true, false, true, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope,
+                                                                       FinOut{a_mean, b2_mean, bs_mean, 0.f}, tickets, mrv);
+  } else if (fin_in) {
     restail_bwd_partial<4, true, false, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope,
                                                                  FinOut{a_mean, b2_mean, bs_mean, 0.f}, tickets);
   } else if (hs) {
     SMSUT_REQUIRE(remask && C % 4 == 0);
-    restail_bwd_partial<4, true, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin);
+    if (mr) restail_bwd_partial<4, true, true, false, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin, nullptr, mrv);
+    else restail_bwd_partial<4, true, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin);
+  } else if (mr) {
+    restail_bwd_partial<4, true, false, false, true><<<g, TPB, 0, st>>>(gout, out, t, workspace, HW, C, ppc, slope, fin, nullptr, mrv);
   } else if (C % 4 == 0) { if (remask) TAIL_PARTIAL(4, true); else TAIL_PARTIAL(4, false); }
   else { if (remask) TAIL_PARTIAL(1, true); else TAIL_PARTIAL(1, false); }
 #undef TAIL_PARTIAL
@@ -1129,13 +1221,53 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
                                                                                HW, C, slope, N, gg2, gb2, ms ? ggs : nullptr,  \
                                                                                ms ? gbs : nullptr, amax)
 #define TAIL_APPLY_AM(V, R, HSF) do { if (amax) TAIL_APPLY(V, R, HSF, true); else TAIL_APPLY(V, R, HSF, false); } while (0)
+#define TAIL_APPLY_MP(HSF, AM)                                                                                              \
+  restail_bwd_apply<4, true, HSF, AM, true><<<img_grid((int64_t)HW * (C / 4), N), TPB, 0, st>>>(gout, out, t, a_mean, b2_mean, bs_mean, gy2, \
+                                                                                             gs, HW, C, slope, N, gg2, gb2, ggs, gbs, amax, mrv)
+  if (mr) {
+    if (hs) { if (amax) TAIL_APPLY_MP(true, true); else TAIL_APPLY_MP(true, false); }
+    else { if (amax) TAIL_APPLY_MP(false, true); else TAIL_APPLY_MP(false, false); }
+  } else
   if (hs) TAIL_APPLY_AM(4, true, true);
   else if (C % 4 == 0) { if (remask) TAIL_APPLY_AM(4, true, false); else TAIL_APPLY_AM(4, false, false); }
   else { if (remask) TAIL_APPLY_AM(1, true, false); else TAIL_APPLY_AM(1, false, false); }
+#undef TAIL_APPLY_MP
 #undef TAIL_APPLY_AM
 #undef TAIL_APPLY
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
+}
+// The tail of an encoder level's block + the level's MaxPool2d(2, 2) (r05, reference network/blocks.py:74-79 + 131-133 / network/ugan.py:36-39).
+// Forward: out [N,H,W,C] (the skip connection), pooled [N,H/2,W/2,C] and idx [N,H/2,W/2,C] bytes (position of the maximum in its
+// window) in one pass -- bit-identical to smsut_restail_fwd + smsut_maxpool2_fwd.  hs: y2 / s are fp16 (smsut_restail_fwd_hs).
+// Conv shortcut (ms != null), C % 4 == 0, H and W even.
+int smsut_restail_fwd_pool(const void* y2, const float* m2, const float* r2, const float* g2, const float* b2, const void* s,
+                           const float* ms, const float* rs, const float* gs, const float* bs, float* out, float* pooled,
+                           void* idx, int N, int H, int W, int C, float slope, int hs, void* stream) {
+  SMSUT_REQUIRE(y2 && m2 && r2 && g2 && b2 && s && ms && rs && gs && bs && out && pooled && idx && N > 0 && H > 0 && W > 0 && C > 0 &&
+                C % 4 == 0 && !(H & 1) && !(W & 1) && (int64_t)H * W * C < (1ll << 31));
+  TailRef t{(const float*)y2, m2, r2, g2, b2, (const float*)s, ms, rs, gs, bs};
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g = img_grid((int64_t)(H / 2) * (W / 2) * (C / 4), N);
+  if (hs) restail_fwd_pool<true><<<g, TPB, 0, st>>>(t, out, pooled, (unsigned int*)idx, H, W, C, slope);
+  else restail_fwd_pool<false><<<g, TPB, 0, st>>>(t, out, pooled, (unsigned int*)idx, H, W, C, slope);
+  SMSUT_LAUNCH_CHECK();
+  return SMSUT_OK;
+}
+// Backward of that pair: gout = gradient of `out` through the skip connection, gp [N,H/2,W/2,C] = gradient of `pooled`; the block
+// output's total gradient (what smsut_maxpool2_bwd_add would write) is formed while loading, in both passes of the tail backward --
+// no pooling-backward pass, no full-resolution gradient tensor.  tickets (nullable): in-launch finalize as smsut_restail_bwd_fin;
+// amax (nullable): as smsut_restail_bwd_amax; hs: y2 / s fp16 as smsut_restail_bwd_hs.  Results bit-identical to
+// smsut_maxpool2_bwd_add followed by the corresponding smsut_restail_bwd* call.
+int smsut_restail_bwd_pool(const float* gout, const float* gp, const void* idx, const void* y2, const float* m2, const float* r2,
+                           const float* g2, const float* b2, const void* s, const float* ms, const float* rs, const float* gs_,
+                           const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2,
+                           float* gb2, float* ggs, float* gbs, float* workspace, int* tickets, float* amax, int N, int H, int W, int C,
+                           float slope, int hs, void* stream) {
+  SMSUT_REQUIRE(gp && idx && H > 0 && W > 0 && !(H & 1) && !(W & 1));
+  const MaxRef mr{gp, (const unsigned int*)idx, W};
+  return restail_bwd_launch(gout, gout, (const float*)y2, m2, r2, g2, b2, (const float*)s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean,
+                            bs_mean, gg2, gb2, ggs, gbs, workspace, amax, N, H * W, C, slope, stream, hs != 0, tickets, &mr);
 }
 int smsut_restail_bwd(const float* gout, const float* out, const float* y2, const float* m2, const float* r2,
                       const float* g2, const float* b2, const float* s, const float* ms, const float* rs,

@@ -209,6 +209,18 @@ class BasicBlock(nn.Module):
         idn = self.shortcut2(self.shortcut1(x, stats=True)) if self.downsample else x
         return ops.add_act(y, idn, s)
 
+    def forward_pool(self, x):
+        """(max_pool2(out), out) of an encoder level (blocks.py:131-133, ugan.py:36-39) with the block's residual tail and the pooling
+        as ONE pass (r05, ``ops.basic_block_pool``) -- or None where that form does not apply (the caller then runs block + pooling)."""
+        if not (self.downsample and isinstance(self.bn1, InstanceNorm2d)) or isinstance(x, ops.CatParts):
+            return None
+        ws = self.shortcut1.weight
+        if not ops.basic_block_pool_fusable(x, self.conv1.weight, ws):
+            return None
+        out, pooled = ops.basic_block_pool(x, self.conv1.weight, self.bn1.weight, self.bn1.bias, self.conv2.weight, self.bn2.weight,
+                                           self.bn2.bias, ws, self.shortcut2.weight, self.shortcut2.bias, self.relu.slope)
+        return pooled, out
+
 
 class BottleBlock(nn.Module):
     def __init__(self, in_channels, out_channels, norm_type="batch", act_type="relu", stride=1):
@@ -260,10 +272,17 @@ class Encoder(nn.Module):
         skips = []
         x = self.pre_bn(self.pre_conv(x, stats=True), slope=self.pre_relu.slope)
         for i in range(1, 5):
-            x = getattr(self, f"layer{i}")(x)
-            x, skip = getattr(self, f"pool{i}").pool_skip(x)
+            x, skip = encoder_level(getattr(self, f"layer{i}"), getattr(self, f"pool{i}"), x)
             skips.append(skip)
         return self.layer5(x), skips
+
+
+def encoder_level(block, pool, x):
+    """(pooled, skip) of one encoder level: block -> MaxPool2d(2, 2), the block output also being the skip connection."""
+    fused = block.forward_pool(x) if isinstance(block, BasicBlock) else None
+    if fused is not None:
+        return fused
+    return pool.pool_skip(block(x))
 
 
 class MaxPool2x2(nn.Module):

@@ -8,7 +8,7 @@ import torch.nn as nn
 from .. import config as cfg
 from .. import ops
 from . import networks
-from .blocks import (Act, BasicBlock, BottleBlock, Conv2d, MaxPool2x2, UpSampleAndConcat, get_act, get_norm,
+from .blocks import (Act, BasicBlock, BottleBlock, Conv2d, MaxPool2x2, UpSampleAndConcat, encoder_level, get_act, get_norm,
                      init_conv_kaiming)
 
 
@@ -34,8 +34,7 @@ class Encoder(nn.Module):
         skips = []
         x = self.pre(x)
         for i in range(1, 5):
-            x = getattr(self, f"enc{i}")(x)
-            x, skip = getattr(self, f"pool{i}").pool_skip(x)
+            x, skip = encoder_level(getattr(self, f"enc{i}"), getattr(self, f"pool{i}"), x)
             skips.append(skip)
         skips.reverse()                    # deepest first (ugan.py:54)
         return x, skips

@@ -1005,7 +1005,9 @@ class BasicBlockFn(Function):
     VGPRs, cost the MFMA kernels more than the memory passes they remove.)  First-order only (generator / U-Net)."""
 
     @staticmethod
-    def forward(ctx, x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, xa=None, xb=None):
+    def forward(ctx, x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, xa=None, xb=None, pool=False):
+        # pool (r05): the block closes an encoder level -- returns (out, max_pool2(out)); the residual tail writes both in one pass and
+        # the backward takes the two gradients (skip connection, pooled path) without a pooling-backward pass (smsut_restail_*_pool)
         # xa, xb (optional): x is cat([xa, xb], 1), already materialised and passed detached; the backward then writes the
         # block-input gradient straight into the two parts (split-output data-gradients) instead of returning d/dx
         # x None (with xa, xb): the cat is never materialised -- conv1, the shortcut and their weight gradients read the two
@@ -1144,7 +1146,13 @@ class BasicBlockFn(Function):
         else:
             s, ms, rs = x, None, None
         out = new_act(n, co, h, w, x)
-        H.call("smsut_restail_fwd_hs" if hs else "smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, co, slope, st)
+        ctx.pool = bool(pool)
+        if pool:
+            pooled = new_act(n, co, h // 2, w // 2, x)
+            ctx.pool_idx = torch.empty(n * (h // 2) * (w // 2) * co, dtype=torch.uint8, device=dev)
+            H.call("smsut_restail_fwd_pool", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, pooled, ctx.pool_idx, n, h, w, co, slope, int(hs), st)
+        else:
+            H.call("smsut_restail_fwd_hs" if hs else "smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, co, slope, st)
         ctx.has_sc = has_sc
         ctx.slope = slope
         ctx.pair = _PAIR_FWD and not CONV_F16
@@ -1155,11 +1163,11 @@ class BasicBlockFn(Function):
             ctx.save_for_backward(x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs)
         else:
             ctx.save_for_backward(x, w1, w2, y1, a1, y2, out, m1, r1, m2, r2, g1, b1, g2)
-        return out
+        return (out, pooled) if pool else out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_pooled=None):
         xb_part = None
         if ctx.virtual:
             x, w1, w2, ws, y1, a1, y2, s, out, m1, r1, m2, r2, ms, rs, g1, b1, g2, gs, b2, bs, xb_part = ctx.saved_tensors
@@ -1174,8 +1182,15 @@ class BasicBlockFn(Function):
             ws = ms = rs = gs = b2 = bs = None
             s = x
         slope = ctx.slope
-        g_out = nhwc(g_out)
         n, ci, h, w = x.shape
+        if ctx.pool and g_out is None:                   # (no skip gradient: the pooled path's alone, through the plain pooling backward)
+            g_out = new_act(n, w1.shape[0], h, w, x)
+            H.call("smsut_maxpool2_bwd", nhwc(g_pooled), out, g_out, n, h, w, w1.shape[0], _s())
+            g_pooled = None
+        g_out = nhwc(g_out)
+        mp = ctx.pool and g_pooled is not None           # two gradients: routed together inside the tail backward's loads
+        if mp:
+            g_pooled = nhwc(g_pooled)
         if ctx.virtual:
             ci = x.shape[1] + xb_part.shape[1]           # x is the first part here
         co = w1.shape[0]
@@ -1198,7 +1213,11 @@ class BasicBlockFn(Function):
         nb = H.call("smsut_amax_blocks", n, hw, co) if (f16 or f16a) and AMAX_HANDOVER else 0
         amax = torch.empty(3 * nb, dtype=torch.float32, device=dev) if nb else None
         hs = ctx.hs
-        if hs:
+        if mp:
+            tk = _tickets(n, x) if (not hs and amax is None and bool(FIN_MASK & 8) and _tickets(0, x) is not None) else None
+            H.call("smsut_restail_bwd_pool", g_out, g_pooled, ctx.pool_idx, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t,
+                   bs_t, gg2, gb2, ggs, gbs, _ws(n * chunks * co * 3, x), tk, amax, n, h, w, co, slope, int(hs), st)
+        elif hs:
             H.call("smsut_restail_bwd_hs", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
                    ggs, gbs, _ws(n * chunks * co * 3, x), amax, n, hw, co, slope, st)
         elif amax is not None:
@@ -1381,18 +1400,18 @@ class BasicBlockFn(Function):
                     else:
                         _conv3("smsut_conv2d_fwd_mfma", w1, 1, gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
                     H.call("smsut_concat2", ga, ca, gb, cb, gx, n * hw, 1, st)
-            return None, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, ga, gb
+            return None, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, ga, gb, None
         if ctx.needs_input_grad[0]:
             # the shortcut's gradient lands in gx first; the 3x3 data-gradient then accumulates into it in its store
             # epilogue (transposed | 2), which replaces a separate 3-pass add
             if fused_dsc16:
                 gx = new_act(n, ci, h, w, x)
                 H.call("smsut_conv2d_dgrad_mfma_sc_f16", gy1, gs_t, w1, ws, gx, None, sc1, 0, n, h, w, co, ci, st)
-                return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
+                return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None, None
             if ctx.has_sc and not f16a and H.call("smsut_conv2d_dgrad_sc_supported", n, h, w, co, ci, 0):
                 gx = new_act(n, ci, h, w, x)
                 H.call("smsut_conv2d_dgrad_mfma_sc", gy1, gs_t, w1, ws, gx, None, 0, n, h, w, co, ci, st)
-                return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
+                return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None, None
             if ctx.has_sc:
                 gx = new_act(n, ci, h, w, x)
                 if H.call("smsut_conv1x1_supported", co, ci):
@@ -1405,7 +1424,7 @@ class BasicBlockFn(Function):
                 H.call("smsut_conv2d_fwd_mfma_f16", gy1, w1, gx, sc1, n, h, w, co, ci, 3, 3, st)
             else:
                 _conv3("smsut_conv2d_fwd_mfma", w1, 1, gy1, w1, gx, n, h, w, co, ci, 3, 3, st)
-        return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None
+        return gx, gw1, gg1, gb1, gw2, gg2, gb2, gws, ggs, gbs, None, None, None, None
 
 
 class CatParts:
@@ -1448,6 +1467,22 @@ def basic_block_cat_fusable(parts, w1, ws):
 
 def basic_block_cat(parts, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):
     return BasicBlockFn.apply(None, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, cl(parts.a), cl(parts.b))
+
+
+BLOCK_POOL = bool(int(_os.environ.get("SMSUT_BLOCK_POOL", "1")))     # encoder level: the block's tail and the level's max-pool as one pass
+
+
+def basic_block_pool_fusable(x, w1, ws):
+    """The fused block applies, it has a conv shortcut (two-IN tail), whole channel quads, an even plane -- and a gradient is wanted
+    (the inference path keeps block + pooling)."""
+    return (BLOCK_POOL and POOL_SKIP and ws is not None and REMASK_TAIL and basic_block_fusable(x, w1, ws) and w1.shape[0] % 4 == 0
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and torch.is_grad_enabled() and (x.requires_grad or w1.requires_grad)
+            and getattr(x, "_smsut_cat_parts", None) is None)
+
+
+def basic_block_pool(x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):
+    """(skip, pooled) of an encoder level whose block is fused with its MaxPool2d(2, 2)."""
+    return BasicBlockFn.apply(cl(x), w1, g1, b1, w2, g2, b2, ws, gs, bs, slope, None, None, True)
 
 
 def basic_block(x, w1, g1, b1, w2, g2, b2, ws, gs, bs, slope):

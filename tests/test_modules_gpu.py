@@ -277,6 +277,79 @@ def test_bottleblock_in_act_pool_is_bit_identical_to_the_two_ops(pkg, n, ci, co,
         assert torch.equal(res[True][2][k], res[False][2][k]), k
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+@pytest.mark.parametrize("n,ci,co,h", [(3, 8, 16, 64), (2, 16, 32, 128), (4, 32, 64, 32), (2, 64, 128, 16), (2, 16, 32, 256)])
+def test_encoder_level_tail_and_maxpool_as_one_pass_is_bit_identical(pkg, n, ci, co, h, dtype):
+    """r05: an encoder level = BasicBlock -> MaxPool2d(2, 2), the block output also feeding the skip connection (reference
+    network/blocks.py:128-134, network/ugan.py:36-39).  ``ops.basic_block_pool`` writes the block output, the pooled tensor and the
+    position of every window's maximum in ONE pass of the residual tail, and its backward routes the pooled gradient + the skip
+    gradient into the tail backward's loads (no pooling-backward pass, no summed full-resolution gradient).  Against the two-node form
+    (``BasicBlockFn`` + ``MaxPool2SkipFn``): both outputs, the input gradient and every parameter gradient are the same bits -- with
+    fp32 operands and with config 5's fp16 operands + half storage."""
+    from smsut_amd.network.blocks import BasicBlock, MaxPool2x2, encoder_level
+    from smsut_amd import ops, profiling
+    torch.manual_seed(n * 1000 + ci + h)
+    blk = BasicBlock(ci, co, "instance", "lrelu").cuda().train()
+    for p in blk.parameters():
+        p.data.add_(0.1 * torch.randn_like(p))
+    pool = MaxPool2x2()
+    x = torch.randn(n, ci, h, h, device="cuda").contiguous(memory_format=torch.channels_last)
+    g_skip = (torch.randn(n, co, h, h, device="cuda") * 1e-3).contiguous(memory_format=torch.channels_last)
+    g_pool = (torch.randn(n, co, h // 2, h // 2, device="cuda") * 1e-3).contiguous(memory_format=torch.channels_last)
+    res = {}
+    prev, prev_dt = ops.BLOCK_POOL, ops.conv_dtype()
+    ops.set_conv_dtype(dtype)
+    try:
+        for on in (False, True):
+            ops.BLOCK_POOL = on
+            blk.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            box = {}
+
+            def step():
+                box["o"] = encoder_level(blk, pool, xin)
+                torch.autograd.backward(box["o"], (g_pool, g_skip))
+            calls = [name for name, _ in profiling.record_step(step)]
+            pooled, skip = box["o"]
+            res[on] = (pooled.detach().clone(), skip.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+            assert ("smsut_restail_fwd_pool" in calls and "smsut_restail_bwd_pool" in calls) == on, calls
+            assert ("smsut_maxpool2_bwd_add" in calls) == (not on), calls
+    finally:
+        ops.BLOCK_POOL = prev
+        ops.set_conv_dtype(prev_dt)
+    for a, b in zip(res[True][:3], res[False][:3]):
+        assert torch.equal(a, b)
+    for k in res[False][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), k
+
+
+def test_encoder_level_with_one_gradient_missing(pkg):
+    """... and when only ONE of the two outputs gets a gradient (pooled path alone / skip connection alone) the fused node equals the
+    two-node form as well."""
+    from smsut_amd.network.blocks import BasicBlock, MaxPool2x2, encoder_level
+    from smsut_amd import ops
+    torch.manual_seed(5)
+    blk = BasicBlock(16, 32, "instance", "lrelu").cuda().train()
+    pool = MaxPool2x2()
+    x = torch.randn(2, 16, 64, 64, device="cuda").contiguous(memory_format=torch.channels_last)
+    prev = ops.BLOCK_POOL
+    try:
+        for which in (0, 1):
+            got = {}
+            for on in (False, True):
+                ops.BLOCK_POOL = on
+                blk.zero_grad(set_to_none=True)
+                xin = x.clone().requires_grad_(True)
+                o = encoder_level(blk, pool, xin)[which]
+                o.square().sum().backward()
+                got[on] = (xin.grad.clone(), {k: p.grad.clone() for k, p in blk.named_parameters()})
+            assert torch.equal(got[True][0], got[False][0])
+            for k in got[False][1]:
+                assert torch.equal(got[True][1][k], got[False][1][k]), (which, k)
+    finally:
+        ops.BLOCK_POOL = prev
+
+
 def test_ugannce_forward(pkg, golden):
     from smsut_amd.network.ugan import UGANnce
     g = golden("ugan_small")
