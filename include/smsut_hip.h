@@ -422,11 +422,13 @@ int smsut_restail_bwd_amax(const float* gout, const float* out, const float* y2,
  * element: where the maximum sat in its window) in ONE pass -- bit-identical to smsut_restail_fwd + smsut_maxpool2_fwd.  Backward:
  * gout = gradient of out through the skip connection, gp = gradient of pooled; the block output's total gradient (what
  * smsut_maxpool2_bwd_add writes) is formed while loading -- bit-identical to that call followed by smsut_restail_bwd / _fin (tickets
- * non-null) / _amax (amax non-null) / _hs (hs != 0: y2, s are _Float16).  Conv shortcut only (ms, b2, bs non-null), C % 4 == 0, H, W even. */
+ * non-null) / _amax (amax non-null) / _hs (hs != 0: y2, s are _Float16).  Conv shortcut only (ms, b2, bs non-null), C % 4 == 0, H, W even.
+ * idx == NULL in both calls: AVERAGE pooling instead (a stride-2 BottleBlock feeding the next one, blocks.py:99-107: its output goes to
+ * conv1 and to F.avg_pool2d) -- smsut_avgpool2_fwd's arithmetic forward, gout + 0.25 gp per window pixel backward. */
 int smsut_restail_fwd_pool(const void* y2, const float* m2, const float* r2, const float* g2, const float* b2, const void* s,
                            const float* ms, const float* rs, const float* gs, const float* bs, float* out, float* pooled,
-                           void* idx, int N, int H, int W, int C, float slope, int hs, void* stream);
-int smsut_restail_bwd_pool(const float* gout, const float* gp, const void* idx, const void* y2, const float* m2, const float* r2,
+                           void* idx /*nullable*/, int N, int H, int W, int C, float slope, int hs, void* stream);
+int smsut_restail_bwd_pool(const float* gout, const float* gp, const void* idx /*nullable*/, const void* y2, const float* m2, const float* r2,
                            const float* g2, const float* b2, const void* s, const float* ms, const float* rs, const float* gs_,
                            const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2,
                            float* gb2, float* ggs, float* gbs, float* workspace, int* tickets /*nullable*/, float* amax /*nullable*/,

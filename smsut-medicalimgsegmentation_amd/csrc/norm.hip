@@ -613,6 +613,12 @@ restail_fwd_pool(TailRef t, float* __restrict__ out, float* __restrict__ pooled,
         *(float4*)(out + offs[k]) = *(float4*)a[k];
       }
       float m[VEC];
+      if (!idx) {                                     // AVERAGE pooling (the discriminator's stride-2 blocks): k_avgpool_fwd's order
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) m[j] = (a[0][j] + a[1][j] + a[2][j] + a[3][j]) * 0.25f;
+        *(float4*)(pooled + i * 4) = *(float4*)m;
+        return;
+      }
       unsigned int where = 0;
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
@@ -635,6 +641,10 @@ __device__ __forceinline__ void add_pooled_grad(const MaxRef& mr, int n, int HW,
   const int h = p / mr.W, w = p - h * mr.W;
   const size_t u = ((size_t)n * (HW >> 2) + (size_t)(h >> 1) * (mr.W >> 1) + (w >> 1)) * (C >> 2) + cv;      // pooled unit
   const float4 gp = *(const float4*)(mr.gp + u * 4);
+  if (!mr.idx) {                                      // average pooling: every pixel of the window gets a quarter (k_avgpool_bwd)
+    g[0] = gp.x * 0.25f + g[0]; g[1] = gp.y * 0.25f + g[1]; g[2] = gp.z * 0.25f + g[2]; g[3] = gp.w * 0.25f + g[3];
+    return;
+  }
   const unsigned int wh = mr.idx[u];
   const unsigned int pos = ((h & 1) << 1) | (w & 1);
   g[0] = (((wh) & 0xffu) == pos ? gp.x : 0.f) + g[0];
@@ -1184,7 +1194,7 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
   SMSUT_REQUIRE(gout && out && y2 && m2 && r2 && g2 && s && gy2 && gs && a_mean && b2_mean && bs_mean && gg2 && gb2 &&
                 workspace && N > 0 && HW > 0 && C > 0 && (!ms || (rs && gs_ && ggs && gbs)));
   // mr (r05): gout is the skip connection's gradient, the pooled path's is routed in while loading (two-IN tail, channel quads)
-  SMSUT_REQUIRE(!mr || (mr->gp && mr->idx && mr->W > 0 && HW % mr->W == 0 && ms && b2 && bs && C % 4 == 0));
+  SMSUT_REQUIRE(!mr || (mr->gp && mr->W > 0 && HW % mr->W == 0 && ms && b2 && bs && C % 4 == 0));
   const MaxRef mrv = mr ? *mr : MaxRef{nullptr, nullptr, 0};
   TailRef t{y2, m2, r2, g2, b2, s, ms, rs, gs_, bs};
   hipStream_t st = (hipStream_t)stream;
@@ -1240,11 +1250,13 @@ static int restail_bwd_launch(const float* gout, const float* out, const float* 
 // The tail of an encoder level's block + the level's MaxPool2d(2, 2) (r05, reference network/blocks.py:74-79 + 131-133 / network/ugan.py:36-39).
 // Forward: out [N,H,W,C] (the skip connection), pooled [N,H/2,W/2,C] and idx [N,H/2,W/2,C] bytes (position of the maximum in its
 // window) in one pass -- bit-identical to smsut_restail_fwd + smsut_maxpool2_fwd.  hs: y2 / s are fp16 (smsut_restail_fwd_hs).
-// Conv shortcut (ms != null), C % 4 == 0, H and W even.
+// Conv shortcut (ms != null), C % 4 == 0, H and W even.  idx == null (both calls): AVERAGE pooling instead -- a stride-2 BottleBlock of the
+// discriminator feeding the next one (blocks.py:83-117: its output goes to conv1 and to F.avg_pool2d): smsut_avgpool2_fwd's arithmetic
+// forward; backward every window pixel gets gout + 0.25 gp, i.e. smsut_avgpool2_bwd + autograd's accumulation, bit for bit.
 int smsut_restail_fwd_pool(const void* y2, const float* m2, const float* r2, const float* g2, const float* b2, const void* s,
                            const float* ms, const float* rs, const float* gs, const float* bs, float* out, float* pooled,
                            void* idx, int N, int H, int W, int C, float slope, int hs, void* stream) {
-  SMSUT_REQUIRE(y2 && m2 && r2 && g2 && b2 && s && ms && rs && gs && bs && out && pooled && idx && N > 0 && H > 0 && W > 0 && C > 0 &&
+  SMSUT_REQUIRE(y2 && m2 && r2 && g2 && b2 && s && ms && rs && gs && bs && out && pooled && N > 0 && H > 0 && W > 0 && C > 0 &&
                 C % 4 == 0 && !(H & 1) && !(W & 1) && (int64_t)H * W * C < (1ll << 31));
   TailRef t{(const float*)y2, m2, r2, g2, b2, (const float*)s, ms, rs, gs, bs};
   hipStream_t st = (hipStream_t)stream;
@@ -1264,7 +1276,7 @@ int smsut_restail_bwd_pool(const float* gout, const float* gp, const void* idx, 
                            const float* bs, float* gy2, float* gs, float* a_mean, float* b2_mean, float* bs_mean, float* gg2,
                            float* gb2, float* ggs, float* gbs, float* workspace, int* tickets, float* amax, int N, int H, int W, int C,
                            float slope, int hs, void* stream) {
-  SMSUT_REQUIRE(gp && idx && H > 0 && W > 0 && !(H & 1) && !(W & 1));
+  SMSUT_REQUIRE(gp && H > 0 && W > 0 && !(H & 1) && !(W & 1));
   const MaxRef mr{gp, (const unsigned int*)idx, W};
   return restail_bwd_launch(gout, gout, (const float*)y2, m2, r2, g2, b2, (const float*)s, ms, rs, gs_, bs, gy2, gs, a_mean, b2_mean,
                             bs_mean, gg2, gb2, ggs, gbs, workspace, amax, N, H * W, C, slope, stream, hs != 0, tickets, &mr);

@@ -232,13 +232,18 @@ class BottleBlock(nn.Module):
         self.conv2 = conv3x3(out_channels, out_channels)
         self.bn2 = get_norm(out_channels, norm_type)
         self.stride = stride
+        self.feeds_stride2 = False           # set by the owner: the output goes into ANOTHER stride-2 BottleBlock (conv1 + pooled shortcut)
         self.downsample = None
         if in_channels != out_channels:
             self.downsample = nn.Sequential(conv1x1(in_channels, out_channels), get_norm(out_channels, norm_type))
 
     def forward(self, x):
         s = self.relu.slope
-        idn = ops.avg_pool2(x) if self.stride == 2 else x
+        idn = x
+        if self.stride == 2:
+            idn = getattr(x, "_smsut_avg_pooled", None)        # written by the previous block's residual tail (r05, first-order passes)
+            if idn is None:
+                idn = ops.avg_pool2(x)
         y1 = self.conv1(x, stats=True)
         if self.stride == 2 and isinstance(self.bn1, InstanceNorm2d) and ops.instnorm_act_pool_fusable(y1):
             y = ops.instnorm_act_pool(y1, self.bn1.weight, self.bn1.bias, s)      # first-order passes: IN + act + pool in one pass (r05)
@@ -250,6 +255,11 @@ class BottleBlock(nn.Module):
         if self.downsample is not None:
             sc = self.downsample[0](idn, stats=True)
             if isinstance(self.bn2, InstanceNorm2d) and ops.res_tail_fusable(y2, sc):          # first-order passes: IN2 + IN(shortcut) + add + act in one kernel
+                if self.feeds_stride2 and ops.res_tail_pool_fusable(y2):
+                    out, pooled = ops.res_tail_pool(y2, self.bn2.weight, self.bn2.bias, sc, self.downsample[1].weight,
+                                                    self.downsample[1].bias, s)
+                    out._smsut_avg_pooled = pooled                # the next block's shortcut input, from the same pass
+                    return out
                 return ops.res_tail(y2, self.bn2.weight, self.bn2.bias, sc, self.downsample[1].weight,
                                     self.downsample[1].bias, s)
             idn = self.downsample[1](sc)

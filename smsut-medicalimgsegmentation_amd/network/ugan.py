@@ -151,6 +151,9 @@ class Discriminator(nn.Module):
             out_w = min(in_w * 2, max_width)
             layers.append(BottleBlock(in_w, out_w, norm_type="instance", act_type="lrelu", stride=2))
             in_w = out_w
+        blocks_ = [m for m in layers if isinstance(m, BottleBlock)]
+        for a, b in zip(blocks_[:-1], blocks_[1:]):          # consecutive stride-2 blocks: the first one's tail also writes the pooled
+            a.feeds_stride2 = b.stride == 2                  # shortcut input of the second (ops.res_tail_pool)
         self.main = nn.Sequential(*layers)
         k = int(input_size / np.power(2, repeat_num))
         self.conv_src = Conv2d(out_w, 1, 3, stride=1, padding=1, bias=False)

@@ -774,7 +774,10 @@ class ResTailFn(Function):
     of the conv epilogue that produced them (``_smsut_in_partials``)."""
 
     @staticmethod
-    def forward(ctx, y2, g2, b2, s, gs, bs, slope):
+    def forward(ctx, y2, g2, b2, s, gs, bs, slope, pool=False):
+        # pool (r05): also returns avg_pool2(out) -- the next stride-2 BottleBlock's shortcut input -- written by the same pass; the backward
+        # then takes the two gradients (through conv1 of the next block, through its pooled shortcut) without a pooling-backward pass
+        # and without autograd's accumulation kernel (smsut_restail_*_pool with idx = null)
         y2, s = nhwc(y2), nhwc(s)
         n, c, h, w = y2.shape
         hw = h * w
@@ -790,19 +793,29 @@ class ResTailFn(Function):
         m2, r2 = stats(y2)
         ms, rs = stats(s)
         out = new_act(n, c, h, w, y2)
-        H.call("smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, c, float(slope), st)
+        ctx.pool = bool(pool)
+        if pool:
+            pooled = new_act(n, c, h // 2, w // 2, y2)
+            H.call("smsut_restail_fwd_pool", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, pooled, None, n, h, w, c, float(slope), 0, st)
+        else:
+            H.call("smsut_restail_fwd", y2, m2, r2, g2, b2, s, ms, rs, gs, bs, out, n, hw, c, float(slope), st)
         ctx.save_for_backward(y2, s, out, m2, r2, ms, rs, g2, gs, b2, bs)
         ctx.slope = float(slope)
-        return out
+        return (out, pooled) if pool else out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, g_out):
+    def backward(ctx, g_out, g_pooled=None):
         y2, s, out, m2, r2, ms, rs, g2, gs, b2, bs = ctx.saved_tensors
-        if not REMASK_TAIL:
+        n, c, h, w = y2.shape
+        if ctx.pool and g_out is None:                   # (pooled path alone)
+            g_out = new_act(n, c, h, w, y2)
+            H.call("smsut_avgpool2_bwd", nhwc(g_pooled), g_out, n, h, w, c, _s())
+            g_pooled = None
+        mp = ctx.pool and g_pooled is not None
+        if not REMASK_TAIL and not mp:
             b2 = bs = None
         g_out = nhwc(g_out)
-        n, c, h, w = y2.shape
         hw = h * w
         dev = y2.device
         vec = lambda *sh: torch.empty(*sh, dtype=torch.float32, device=dev)
@@ -810,9 +823,13 @@ class ResTailFn(Function):
         a_t, b2_t, bs_t = vec(n, c), vec(n, c), vec(n, c)
         gg2, gb2, ggs, gbs = vec(c), vec(c), vec(c), vec(c)
         chunks = H.call("smsut_in_chunks", n, hw, c)
-        H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
-               ggs, gbs, _ws(n * chunks * c * 3, y2), n, hw, c, ctx.slope, _s())
-        return gy2, gg2, gb2, gs_t, ggs, gbs, None
+        if mp:
+            H.call("smsut_restail_bwd_pool", g_out, nhwc(g_pooled), None, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t,
+                   bs_t, gg2, gb2, ggs, gbs, _ws(n * chunks * c * 3, y2), None, None, n, h, w, c, ctx.slope, 0, _s())
+        else:
+            H.call("smsut_restail_bwd", g_out, out, y2, m2, r2, g2, b2, s, ms, rs, gs, bs, gy2, gs_t, a_t, b2_t, bs_t, gg2, gb2,
+                   ggs, gbs, _ws(n * chunks * c * 3, y2), n, hw, c, ctx.slope, _s())
+        return gy2, gg2, gb2, gs_t, ggs, gbs, None, None
 
 
 def res_tail_fusable(y2, s):
@@ -824,6 +841,18 @@ def res_tail_fusable(y2, s):
 
 def res_tail(y2, g2, b2, s, gs, bs, slope):
     return ResTailFn.apply(y2, g2, b2, s, gs, bs, slope)
+
+
+TAIL_AVGPOOL = bool(int(_os.environ.get("SMSUT_TAIL_AVGPOOL", "1")))     # BottleBlock -> stride-2 BottleBlock: tail + the next shortcut's pooling
+
+
+def res_tail_pool_fusable(y2):
+    return TAIL_AVGPOOL and REMASK_TAIL and y2.shape[1] % 4 == 0 and y2.shape[2] % 2 == 0 and y2.shape[3] % 2 == 0
+
+
+def res_tail_pool(y2, g2, b2, s, gs, bs, slope):
+    """(out, avg_pool2(out)) of a BottleBlock whose output feeds a stride-2 BottleBlock (one pass; see ResTailFn)."""
+    return ResTailFn.apply(y2, g2, b2, s, gs, bs, slope, True)
 
 
 # ------------------------------------------------------------------------------------------- fused BasicBlock

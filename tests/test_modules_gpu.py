@@ -350,6 +350,42 @@ def test_encoder_level_with_one_gradient_missing(pkg):
         ops.BLOCK_POOL = prev
 
 
+@pytest.mark.parametrize("size,width,n", [(64, 16, 3), (128, 8, 2)])
+def test_discriminator_tail_writes_the_next_blocks_pooled_shortcut_input(pkg, size, width, n):
+    """r05: between two stride-2 BottleBlocks of the discriminator (reference network/ugan.py:205-215, blocks.py:83-117) the first
+    block's residual tail also writes avg_pool2(out) -- the second block's shortcut input -- and its backward takes the gradient through
+    conv1 and the gradient through the pooled shortcut in its loads (``ops.res_tail_pool``: no pooling pass either way, no accumulation
+    kernel).  First-order passes only.  Same bits as the op-by-op form: both outputs, the input gradient, every parameter gradient."""
+    from smsut_amd.network.ugan import Discriminator
+    from smsut_amd import ops, profiling
+    torch.manual_seed(size + width)
+    D = Discriminator(size, 4, width, max_width=8 * width).cuda().train()
+    x = torch.randn(n, 1, size, size, device="cuda")
+    res = {}
+    prev = ops.TAIL_AVGPOOL
+    try:
+        for on in (False, True):
+            ops.TAIL_AVGPOOL = on
+            D.zero_grad(set_to_none=True)
+            xin = x.clone().requires_grad_(True)
+            box = {}
+
+            def step():
+                with ops.first_order_pass():
+                    box["o"] = D(xin)
+                (box["o"][0].square().mean() + box["o"][1].square().mean()).backward()
+            calls = [name for name, _ in profiling.record_step(step)]
+            src, cls = box["o"]
+            res[on] = (src.detach().clone(), cls.detach().clone(), xin.grad.clone(), {k: p.grad.clone() for k, p in D.named_parameters()})
+            assert ("smsut_restail_fwd_pool" in calls and "smsut_restail_bwd_pool" in calls) == on, calls
+    finally:
+        ops.TAIL_AVGPOOL = prev
+    for a, b in zip(res[True][:3], res[False][:3]):
+        assert torch.equal(a, b)
+    for k in res[False][3]:
+        assert torch.equal(res[True][3][k], res[False][3][k]), k
+
+
 def test_ugannce_forward(pkg, golden):
     from smsut_amd.network.ugan import UGANnce
     g = golden("ugan_small")
