@@ -188,6 +188,11 @@ _BYTES: Dict[str, Callable[[List[int]], float]] = {
     "smsut_instnorm_fwd_partials": lambda a: 4.0 * a[1] * a[2] * a[3] * 2,
     "smsut_instnorm_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * 3,
     "smsut_instnorm_bwd2": lambda a: 4.0 * a[0] * a[1] * a[2] * 5,
+    # pooling folded into the neighbouring node (r05): (n, h, w, c[, hs]); idx = one byte per pooled element
+    "smsut_restail_fwd_pool": lambda a: a[0] * a[1] * a[2] * a[3] * ((2.0 * 2 if a[4] else 4.0 * 2) + 4.0 * 1.25 + 0.25),
+    "smsut_restail_bwd_pool": lambda a: a[0] * a[1] * a[2] * a[3] * ((2.0 * 2 if a[4] else 4.0 * 2) + 4.0 * 3.25 + 0.25),
+    "smsut_instnorm_pool_fwd_partials": lambda a: 4.0 * a[1] * a[2] * a[3] * a[4] * 1.25,      # x -> pooled
+    "smsut_instnorm_pool_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 2.25,               # gp, x -> gx
     "smsut_maxpool2_fwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 1.25,
     "smsut_maxpool2_bwd": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 2.25,
     "smsut_maxpool2_bwd_add": lambda a: 4.0 * a[0] * a[1] * a[2] * a[3] * 3.25,
