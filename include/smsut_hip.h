@@ -467,6 +467,14 @@ int smsut_row_lerp(const float* a, const float* b, const float* alpha, float* ou
                    void* stream);
 int smsut_fill(float* out, float v, int64_t n, void* stream);
 int smsut_scale(const float* x, const float* scale_dev /*nullable*/, float mul, float* out, int64_t n, void* stream);
+/* SGD with momentum + weight decay over many tensors in ONE launch (r05): torch.optim.SGD's rule (dampening 0, no Nesterov; the
+ * reference's optimizer, /root/reference/trainer/baseTrainer.py) -- g' = g + wd p; buf = momentum buf + g'; p -= lr buf.  ents: device
+ * array of {float* p; const float* g; float* buf; long long n;} (parameter, gradient, momentum buffer: same dense layout); blk_ent /
+ * blk_chunk: per block its entry and its chunk (of smsut_sgd_chunk() elements) inside that tensor.  Not for the first step (the buffers
+ * must exist). */
+int smsut_sgd_momentum_multi(const void* ents, const int* blk_ent, const int* blk_chunk, int nblocks, float lr, float momentum, float wd,
+                             void* stream);
+int smsut_sgd_chunk(void);
 int smsut_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int smsut_maxpool2_bwd(const float* gy, const float* x, float* gx, int N, int H, int W, int C, void* stream);
 /* gx = maxpool2_bwd(gy; x) + add: pooled-path and skip-connection gradients of an encoder level (blocks.py:131-133) in one pass */

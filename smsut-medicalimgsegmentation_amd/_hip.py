@@ -38,6 +38,8 @@ SIGNATURES: Dict[str, str] = {
     "smsut_absmax_finish": "p i p s",
     "smsut_amax_blocks": "iii",
     "smsut_instnorm_bwd": "pppppp ppppp p iii f s",
+    "smsut_sgd_momentum_multi": "ppp i fff s",
+    "smsut_sgd_chunk": "",
     "smsut_restail_fwd_pool": "pppppppppp ppp iiii f i s",
     "smsut_restail_bwd_pool": "ppp pppppppppp pp ppp pppp p pp iiii f i s",
     "smsut_instnorm_pool_fwd_partials": "ppppppp iiiii ff s",
@@ -213,7 +215,7 @@ _NO_STATUS = _RET_I64 | {"smsut_conv2d_k4_supported", "smsut_conv2d_f16_supporte
                          "smsut_conv2d_fwd_sc_supported", "smsut_conv2d_fwd_sc_f16_supported", "smsut_conv2d_dgrad_sc_supported",
                          "smsut_conv2d_dgrad_sc_f16_supported", "smsut_conv2d_wgrad_sc_f16_supported", "smsut_conv2d_f16_hs_supported",
                          "smsut_conv2d_wgrad_sc_supported", "smsut_convT2x2_ps_supported", "smsut_conv2d_wgrad_pair_supported",
-                         "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_wgrad_pair_slabs", "smsut_conv2d_mfma_form"}     # (return a count / a form id, not a status)
+                         "smsut_conv2d_wgrad_mfma_slabs", "smsut_conv2d_wgrad_pair_slabs", "smsut_conv2d_mfma_form", "smsut_sgd_chunk"}     # (return a count / a form id, not a status)
 
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_int64, "f": ctypes.c_float, "d": ctypes.c_double,
        "s": ctypes.c_void_p}

@@ -584,6 +584,36 @@ int smsut_scale(const float* x, const float* scale_dev, float mul, float* out, i
   k_scale<<<ew_grid(n), TPB, 0, ST>>>(x, scale_dev, mul, out, n);
   SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
 }
+// ---- SGD with momentum + weight decay over MANY tensors in one launch (r05).  The update rule of torch.optim.SGD(momentum, weight_decay,
+// dampening 0, no Nesterov) -- the reference's optimizer (/root/reference/trainer/baseTrainer.py: SGD(lr, momentum=0.9, weight_decay)) --
+// g' = g + wd p; buf = momentum buf + g'; p -= lr buf, element-wise, so a parameter, its gradient and its momentum buffer only need the SAME
+// dense layout (they share the HWIO strides).  torch's own multi-tensor kernel launches ~48 blocks four times for the 12.6 MB of the
+// generator (28 us each, latency-bound); here one block per 8192-element chunk of one tensor: ~1500 blocks, one launch.
+struct SgdEnt { float* p; const float* g; float* buf; long long n; };
+constexpr int SGD_CHUNK = 8192;
+__global__ void __launch_bounds__(TPB)
+k_sgd_multi(const SgdEnt* __restrict__ ents, const int* __restrict__ blk_ent, const int* __restrict__ blk_chunk, float lr, float momentum,
+            float wd) {
+  const SgdEnt e = ents[blk_ent[blockIdx.x]];
+  const long long base = (long long)blk_chunk[blockIdx.x] * SGD_CHUNK;
+  const long long end = base + SGD_CHUNK < e.n ? base + SGD_CHUNK : e.n;
+  for (long long i = base + threadIdx.x; i < end; i += TPB) {
+    const float pv = e.p[i];
+    const float g = e.g[i] + pv * wd;
+    const float b = momentum * e.buf[i] + g;
+    e.buf[i] = b;
+    e.p[i] = pv - lr * b;
+  }
+}
+// ents: device array of `SgdEnt` {p, g, buf, n} (4 x 8 bytes each); blk_ent / blk_chunk: for every block its entry and its chunk index
+// inside that entry's tensor (host-built: sum over entries of ceil(n / 8192) blocks).  All momentum buffers must exist (not the first step).
+int smsut_sgd_momentum_multi(const void* ents, const int* blk_ent, const int* blk_chunk, int nblocks, float lr, float momentum, float wd,
+                             void* stream) {
+  SMSUT_REQUIRE(ents && blk_ent && blk_chunk && nblocks > 0);
+  k_sgd_multi<<<nblocks, TPB, 0, ST>>>((const SgdEnt*)ents, blk_ent, blk_chunk, lr, momentum, wd);
+  SMSUT_LAUNCH_CHECK(); return SMSUT_OK;
+}
+int smsut_sgd_chunk(void) { return SGD_CHUNK; }
 int smsut_maxpool2_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
   SMSUT_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && !(H & 1) && !(W & 1));
   if (C % 4 == 0) k_maxpool_fwd<4><<<ew_grid(((int64_t)N * H * W * C / 4) / 4), TPB, 0, ST>>>(x, y, N, H, W, C);

@@ -42,7 +42,96 @@ def make_sgd(params, lr, momentum, weight_decay):
     """torch.optim.SGD with the single-kernel ("fused") multi-tensor step: same update rule as the reference's optimizer
     (baseline trainers: SGD(lr, momentum=0.9, weight_decay)), ~3 launches instead of ~12 per step.  The parameters, their
     gradients and the momentum buffers share the HWIO strides, which is all the fused kernel needs (dense, same layout)."""
-    return torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=True)
+    opt = torch.optim.SGD(params, lr=lr, momentum=momentum, weight_decay=weight_decay, fused=True)
+    opt._smsut_stepper = SgdStepper(opt)         # (class below; used by the trainers through ``sgd_step``)
+    return opt
+
+
+class SgdStepper:
+    """``optimizer.step()`` of a ``torch.optim.SGD(momentum, weight_decay)`` as ONE launch over all parameters
+    (``smsut_sgd_momentum_multi``, csrc/pointwise.hip: same update rule; torch's fused multi-tensor kernel needs four under-filled
+    launches for the generator's 12.6 MB: 113 us against ~10).  The optimizer object stays the owner of the state (``momentum_buffer``
+    per parameter: checkpoints and ``resume`` see what they always saw); this class only keeps a device table of {parameter, gradient,
+    buffer} pointers, rebuilt when a pointer changes (under hipGraph replay and with the data-parallel bucket they never do).  Falls
+    back to ``optimizer.step()`` for the first step (the buffers are created there), for an option this kernel does not implement,
+    for a tensor whose layout differs from its parameter's, and -- permanently -- when the pointers keep changing (eager mode)."""
+
+    def __init__(self, optimizer):
+        self.opt = optimizer
+        self._params = None          # [(parameter, momentum buffer)] of the table in use
+        self._gptrs = None           # the gradient pointers that table was built for
+        self._tab = None
+        self._misses = 0
+        self.enabled = os.environ.get("SMSUT_SGD_ONE_LAUNCH", "1") not in ("0", "")
+        self.launched = 0
+
+    def _hyper(self):
+        hyper = None
+        for grp in self.opt.param_groups:
+            if grp.get("nesterov") or grp.get("dampening", 0) != 0 or grp.get("maximize") or grp.get("momentum", 0) == 0:
+                return None
+            h = (float(grp["lr"]), float(grp["momentum"]), float(grp["weight_decay"]))
+            if hyper is not None and h != hyper:
+                return None
+            hyper = h
+        return hyper
+
+    def _build(self):
+        """Validate every (parameter, gradient, buffer) triple and upload the pointer table; False: this step goes to torch."""
+        from .. import _hip as H
+        params, ents = [], []
+        for grp in self.opt.param_groups:
+            for p in grp["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                buf = self.opt.state.get(p, {}).get("momentum_buffer")
+                if (buf is None or not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or g.is_sparse
+                        or g.stride() != p.stride() or buf.stride() != p.stride()):
+                    return False
+                params.append((p, buf))
+                ents.append((p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel()))
+        if not ents:
+            return False
+        chunk = H.call("smsut_sgd_chunk")
+        dev = params[0][0].device
+        blk_ent, blk_chunk = [], []
+        for i, e in enumerate(ents):
+            nb = (e[3] + chunk - 1) // chunk
+            blk_ent += [i] * nb
+            blk_chunk += list(range(nb))
+        self._tab = (torch.tensor(ents, dtype=torch.int64, device=dev), torch.tensor(blk_ent, dtype=torch.int32, device=dev),
+                     torch.tensor(blk_chunk, dtype=torch.int32, device=dev), len(blk_ent))
+        self._params = params
+        self._gptrs = [e[1] for e in ents]
+        return True
+
+    def step(self):
+        from .. import _hip as H
+        hyper = self._hyper() if self.enabled and self._misses <= 8 else None
+        if hyper is None:
+            return self.opt.step()
+        same = False
+        if self._params is not None:
+            n_with_grad = sum(1 for grp in self.opt.param_groups for p in grp["params"] if p.grad is not None)
+            if n_with_grad == len(self._params):
+                same = all(p.grad is not None and p.grad.data_ptr() == gp and self.opt.state[p].get("momentum_buffer") is buf
+                           for (p, buf), gp in zip(self._params, self._gptrs))
+        if same:
+            self._misses = 0
+        else:
+            self._misses += 1
+            if not self._build():
+                return self.opt.step()
+        t, be, bc, nb = self._tab
+        H.call("smsut_sgd_momentum_multi", t, be, bc, nb, hyper[0], hyper[1], hyper[2], torch.cuda.current_stream().cuda_stream)
+        self.launched += 1
+
+
+def sgd_step(optimizer):
+    """``optimizer.step()`` through the optimizer's one-launch stepper (``make_sgd`` attaches it); any other optimizer: its own step."""
+    st = getattr(optimizer, "_smsut_stepper", None)
+    return st.step() if st is not None else optimizer.step()
 
 
 def make_adam(params, lr, betas, weight_decay):

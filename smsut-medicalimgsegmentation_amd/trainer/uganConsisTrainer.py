@@ -23,7 +23,7 @@ import torch
 
 from .. import config as cfg
 from .. import graphs, ops
-from .baseTrainer import seed_all
+from .baseTrainer import seed_all, sgd_step
 from .uganShp0Trainer import UGANShp0Trainer
 
 SCALARS = ("D_real", "D_fake", "D_cls", "D_gp", "G_fake", "G_rec", "G_cls", "G_seg", "G_semi", "G_nce")
@@ -582,7 +582,7 @@ class UGANConsisTrainer(UGANShp0Trainer):
             self._finite_probe("G2", [("g_scalars", g_scal)] + [("grad " + k, p.grad) for k, p in self.net.named_parameters()])
         ops.pair_assert_empty()                # every parked operand set of the cycle pass met its G(x_real) partner
         self.g_reducer.reduce()
-        self.optimizer.step()
+        sgd_step(self.optimizer)
         if self._probe:
             self._finite_probe("G.step", list(self.net.named_parameters()))
 

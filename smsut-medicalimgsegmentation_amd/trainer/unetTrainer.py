@@ -10,7 +10,7 @@ import torch
 from .. import config as cfg
 from .. import graphs, ops, parallel
 from ..network.unet import UNet
-from .baseTrainer import seed_all, BaseTrainer, make_sgd
+from .baseTrainer import seed_all, BaseTrainer, make_sgd, sgd_step
 
 
 class UnetTrainer(BaseTrainer):
@@ -74,7 +74,7 @@ class UnetTrainer(BaseTrainer):
             self.loss.reduce_stats([stats])
             loss = self._bwd_phase(msk, stats)
         self.reducer.reduce()
-        self.optimizer.step()
+        sgd_step(self.optimizer)
         lr_ = self.poly_lr()
         for g in self.optimizer.param_groups:
             g["lr"] = lr_

@@ -896,3 +896,42 @@ def test_convT2x2_pixel_shuffle_forms(ops, n, h, w, ci, co):
     gref = torch.stack([torch.einsum("nhwc,nhwo->co", x.double(), gyd[:, a::2, b::2]) for a in range(2) for b in range(2)]).view(2, 2, ci, co)
     e1 = (g1.double().view(2, 2, ci, co) - gref).abs().max(); e0 = (g0.double().view(2, 2, ci, co) - gref).abs().max()
     assert torch.isfinite(g1).all() and e1 <= 2 * e0 + 1e-6 * float(gref.abs().max()), (float(e1), float(e0))
+
+
+def test_one_launch_sgd_matches_torch_sgd():
+    """r05: ``baseTrainer.SgdStepper`` (smsut_sgd_momentum_multi: momentum + weight decay over all parameters in one launch) against
+    ``torch.optim.SGD`` on a copy of the same parameters: five steps with changing learning rate, tensors of odd sizes and the
+    HWIO-strided weight layout; parameters and momentum buffers agree to fp32 rounding (fma contraction may differ by an ulp), the
+    optimizer's own state_dict holds the buffers, and the stepper really launched (steps 2..5; the first creates the buffers)."""
+    from smsut_amd import ops as O
+    from smsut_amd.trainer.baseTrainer import make_sgd, sgd_step
+    torch.manual_seed(3)
+    shapes = [(16, 8, 3, 3), (5,), (33, 7, 1, 1), (64, 64, 3, 3), (1,), (12345,)]
+    pa, pb = [], []
+    for sh in shapes:
+        t = O.new_weight(*sh, device="cuda") if len(sh) == 4 else torch.empty(*sh, device="cuda")
+        t.copy_(torch.randn(*sh, device="cuda"))
+        pa.append(torch.nn.Parameter(t))
+        u = O.new_weight(*sh, device="cuda") if len(sh) == 4 else torch.empty(*sh, device="cuda")
+        u.copy_(t)
+        pb.append(torch.nn.Parameter(u))
+    oa = make_sgd(pa, 0.05, 0.9, 1e-3)
+    ob = torch.optim.SGD(pb, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    grads = [[torch.empty_like(p).copy_(torch.randn(*p.shape, device="cuda")) for p in pa] for _ in range(5)]
+    gkeep = [torch.empty_like(p) for p in pa]                       # stable gradient tensors, as under hipGraph replay
+    for it in range(5):
+        lr = 0.05 * (1 - it / 10) ** 0.9
+        for o in (oa, ob):
+            for grp in o.param_groups:
+                grp["lr"] = lr
+        for p, q, k, g in zip(pa, pb, gkeep, grads[it]):
+            k.copy_(g)
+            p.grad = k
+            q.grad = g.clone()
+        sgd_step(oa)
+        ob.step()
+        for p, q in zip(pa, pb):
+            assert torch.allclose(p, q, rtol=2e-6, atol=1e-7), it
+            assert torch.allclose(oa.state[p]["momentum_buffer"], ob.state[q]["momentum_buffer"], rtol=2e-6, atol=1e-7), it
+    assert oa._smsut_stepper.launched == 4
+    assert len(oa.state_dict()["state"]) == len(shapes)
