@@ -37,7 +37,7 @@ CLASSES = [
     ("InstanceNorm (in_*)", r"in_moments|in_apply|in_affine|in_bwd|instnorm|in_slab"),
     ("pooling / upsample / pointwise", r"maxpool|avgpool|pool|bilinear|k_add_act|k_concat|concat|k_window|blur|planes|k_act|lerp|tanh"),
     ("losses", r"dicece|k_nce|k_gp|k_ce_rows|k_l1|k_sum|k_mean|gather_rows|scatter_rows|l2norm|argmax|softmax"),
-    ("optimizer / ATen", r"at::native|multi_tensor|fused_sgd|fused_adam|elementwise|vectorized|CatArray|reduce_kernel|cumsum|scan"),
+    ("optimizer / ATen", r"at::native|multi_tensor|fused_sgd|fused_adam|k_sgd_multi|elementwise|vectorized|CatArray|reduce_kernel|cumsum|scan"),
 ]
 
 

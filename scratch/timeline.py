@@ -9,7 +9,9 @@ with open(path) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), r["Kernel_Name"], int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))))
 rows.sort()
 # the steady region: last N launches of the per-step marker kernel (multi_tensor SGD step = once per iteration on the main queue)
-mark = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r[3] and "FusedSgd" in r[3]]
+mark = [i for i, r in enumerate(rows) if "k_sgd_multi" in r[3]]          # r05: the one-launch SGD step, once per iteration
+if not mark:
+    mark = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r[3] and "FusedSgd" in r[3]]
 if not mark:
     mark = [i for i, r in enumerate(rows) if "FusedSgd" in r[3] or "fused_sgd" in r[3].lower()]
 print("rows", len(rows), "sgd marks", len(mark))

@@ -2289,7 +2289,9 @@ int dispatch_fwd(const float* x, const float* w, float* y, int N, int H, int W, 
 template <int KS>
 int dispatch_fwd_cfg(int cfg, const float* x, const float* w, float* y, int N, int H, int W, int Kdim, int Ndim,
                      int transposed, hipStream_t st) {
-#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st
+  // (SMSUT_CFG_F16=1: the fp16-operand instantiations of the same tile shapes -- the sweep behind dispatch_fwd's fp16 table)
+  static const bool cfg_f16 = [] { const char* e = getenv("SMSUT_CFG_F16"); return e && atoi(e) != 0; }();
+#define ARGS x, w, y, N, H, W, Kdim, Ndim, transposed, 1, 1, 1, 1, st, nullptr, nullptr, nullptr, nullptr, 0, cfg_f16
   switch (cfg) {
     case 0: return launch_fwd<KS, 16, 4, 1, 1>(ARGS);
     case 1: return launch_fwd<KS, 8, 4, 1, 1>(ARGS);
