@@ -165,7 +165,7 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   const int nsteps = G * nchunk;
   // per-thread unit descriptors, computed once (integer div/mod is ~40 VALU instructions each on CDNA)
   int in_off[NI], in_q[NI];        // element offset of the pixel inside one image (tap group 0), or -1; channel quad
-  int w_off[NW], w_k[NW];          // element offset inside one tap-group chunk (c0 = 0), or -1; k of the unit
+  int w_off[NW], w_k[NW], w_dst[NW];   // element offset inside one tap-group chunk (c0 = 0), or -1; k of the unit; its LDS offset
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int u = tid + i * TPB;
@@ -179,12 +179,17 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 #pragma unroll
   for (int i = 0; i < NW; ++i) {
     const int u = tid + i * TPB;
-    const int n = u % CO_T;
-    const int k4 = (u / CO_T) & 3;
+    // unit u = (tap, k quad, n).  Forward: n fastest -- consecutive lanes read consecutive output channels of one k row (Cout-contiguous
+    // memory).  Data-gradient (weights read transposed: [ng][k] rows of Kdim floats): the k quad fastest -- four lanes cover the 64
+    // contiguous bytes a chunk takes from one row; with n fastest every lane of a wave touched its own cache line (r05: the fp16-operand
+    // data-gradients of the 128 / 256-channel levels ran at 130-240 TF against 350-490 TF forward, scratch/cfg_f16_probe.py).
+    const int n = transposed ? (u >> 2) % CO_T : u % CO_T;
+    const int k4 = transposed ? (u & 3) : (u / CO_T) & 3;
     const int tap = u / (4 * CO_T);
     const int ng = co0 + n;
     const bool ok = u < KK * 4 * CO_T && ng < Ndim;
     w_k[i] = 4 * k4;
+    w_dst[i] = F16 ? (tap * CO_T + n) * WROWH + 4 * k4 : ((tap * 4 + k4) * CO_T + n) * 4;
     w_off[i] = !ok ? -1 : (!transposed ? (tap * Kdim + 4 * k4) * Ndim + ng : ((KK - 1 - tap) * Ndim + ng) * Kdim + 4 * k4);
   }
 
@@ -229,9 +234,9 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     for (int i = 0; i < NW; ++i) {
       const int u = tid + i * TPB;
       if (u < KK * 4 * CO_T) {
-        // unit u = (tap, k4, n): four consecutive k of output channel n
-        if (F16) *(h4*)(w_h + ((size_t)(u / (4 * CO_T)) * CO_T + u % CO_T) * WROWH + 4 * ((u / CO_T) & 3)) = to_h4(rw[i]);
-        else *(float4*)(w_s + (size_t)u * 4) = rw[i];
+        // four consecutive k of output channel n of one tap, at the unit's place in [tap][k quad][n][4] (fp16: [tap][n][16 k + pad])
+        if (F16) *(h4*)(w_h + w_dst[i]) = to_h4(rw[i]);
+        else *(float4*)(w_s + w_dst[i]) = rw[i];
       }
     }
     __syncthreads();

@@ -103,7 +103,7 @@ class SgdStepper:
         self._tab = (torch.tensor(ents, dtype=torch.int64, device=dev), torch.tensor(blk_ent, dtype=torch.int32, device=dev),
                      torch.tensor(blk_chunk, dtype=torch.int32, device=dev), len(blk_ent))
         self._params = params
-        self._gptrs = [e[1] for e in ents]
+        self._gptrs = [(e[0], e[1]) for e in ents]                 # (parameter, gradient) addresses the table was built for
         return True
 
     def step(self):
@@ -115,8 +115,8 @@ class SgdStepper:
         if self._params is not None:
             n_with_grad = sum(1 for grp in self.opt.param_groups for p in grp["params"] if p.grad is not None)
             if n_with_grad == len(self._params):
-                same = all(p.grad is not None and p.grad.data_ptr() == gp and self.opt.state[p].get("momentum_buffer") is buf
-                           for (p, buf), gp in zip(self._params, self._gptrs))
+                same = all(p.grad is not None and (p.data_ptr(), p.grad.data_ptr()) == pg
+                           and self.opt.state[p].get("momentum_buffer") is buf for (p, buf), pg in zip(self._params, self._gptrs))
         if same:
             self._misses = 0
         else:
