@@ -96,7 +96,11 @@ __device__ __forceinline__ h4 to_h4s(float4 v, float s) {
   return (h4){(_Float16)(v.x * s), (_Float16)(v.y * s), (_Float16)(v.z * s), (_Float16)(v.w * s)};
 }
 
-template <int KS, int TH, int WM, int WN, int NTN, bool F16 = false, int MW = TW>
+// CKW (fp16 operands only; r05): channels staged per LDS pass.  32: one pass moves 128 contiguous bytes per pixel and per weight row --
+// whole cache lines, where the 16-channel pass takes half of each line (the vector-memory path bounds these kernels: the data-gradient
+// form, whose weight rows are read along k, ran at half the forward form's rate on the 128 / 256-channel levels) -- and the 32-deep MFMA
+// takes the 32 channels of ONE tap per issue: 9 issues per chunk and tile pair instead of 2 x 5.  Kdim % 32 == 0 (host).
+template <int KS, int TH, int WM, int WN, int NTN, bool F16 = false, int MW = TW, int CKW = 16>
 __global__ void __launch_bounds__(TPB)
 conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y, int H, int W, int Kdim,
               int Ndim, int tiles_x, int transposed, int isc, int osc, int G, int nz, float* __restrict__ stats,
@@ -122,11 +126,15 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
   constexpr int MR = MT / WM, NR = NTN / WN;
   static_assert(WM * WN == 4 && TH % RPT == 0 && MT % WM == 0 && MR >= 1 && NTN % WN == 0, "wave grid");
   static_assert(MW == 16 || MW == 8 || MW == 4, "M-tile width");
+  static_assert(CKW == 16 || (CKW == 32 && F16 && SMSUT_F16_X32), "32-channel passes: fp16 operands on the 32-deep instruction");
+  constexpr int Q = CKW / 4;                   // float4 units per pixel / per weight row of one pass
+  constexpr int PXH = CKW == 32 ? 40 : SPIXH;  // halves between pixels / weight rows of the fp16 images (80 B: eight lanes' 16-byte
+  constexpr int WRH = CKW == 32 ? 40 : WROWH;  // reads 20 banks apart -> 32 distinct banks, as the 48-B stride of the 16-channel image)
   extern __shared__ float smem[];
   float* in_s = smem;                        // [IH][IW][SPIX]
   float* w_s = smem + IH * IW * SPIX;        // [KK][4][CO_T][4]
-  [[maybe_unused]] _Float16* in_h = reinterpret_cast<_Float16*>(smem);      // F16: [IH][IW][SPIXH]
-  [[maybe_unused]] _Float16* w_h = reinterpret_cast<_Float16*>(w_s);        // F16: [KK][CO_T][WROWH]
+  [[maybe_unused]] _Float16* in_h = reinterpret_cast<_Float16*>(smem);      // F16: [IH][IW][PXH]
+  [[maybe_unused]] _Float16* w_h = reinterpret_cast<_Float16*>(w_s);        // F16: [KK][CO_T][WRH]
   [[maybe_unused]] const float gs = (F16 && gsc) ? gsc[0] : 1.f, gi = (F16 && gsc) ? gsc[1] : 1.f;
 
   const bool accum = (transposed & 2) != 0;     // y += conv(x) instead of y = conv(x) (second gradient path of a block)
@@ -158,10 +166,10 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 
   // Software pipeline over (tap group g, 16-channel chunk c0): the NEXT chunk's global loads are issued into
   // registers right after the current chunk has been published to LDS, so their latency hides under the MFMAs.
-  constexpr int NI = (IH * IW * 4 + TPB - 1) / TPB;       // float4 units of the input tile per thread
-  constexpr int NW = (KK * 4 * CO_T + TPB - 1) / TPB;     // float4 units of the weight chunk per thread
+  constexpr int NI = (IH * IW * Q + TPB - 1) / TPB;       // float4 units of the input tile per thread
+  constexpr int NW = (KK * Q * CO_T + TPB - 1) / TPB;     // float4 units of the weight chunk per thread
   float4 rin[NI], rw[NW];
-  const int nchunk = (Kdim + CK - 1) / CK;
+  const int nchunk = (Kdim + CKW - 1) / CKW;
   const int nsteps = G * nchunk;
   // per-thread unit descriptors, computed once (integer div/mod is ~40 VALU instructions each on CDNA)
   int in_off[NI], in_q[NI];        // element offset of the pixel inside one image (tap group 0), or -1; channel quad
@@ -169,10 +177,10 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int u = tid + i * TPB;
-    const int q = u & 3, pix = u >> 2;
+    const int q = u % Q, pix = u / Q;
     const int iy = pix / IW, ix = pix % IW;
     const int gy_ = y0 + iy - PAD, gx_ = x0 + ix - PAD;
-    const bool ok = u < IH * IW * 4 && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
+    const bool ok = u < IH * IW * Q && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;
     in_off[i] = ok ? ((gy_ * isc) * Wi + gx_ * isc) * KSTR + 4 * q : -1;
     in_q[i] = 4 * q;
   }
@@ -183,18 +191,18 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     // memory).  Data-gradient (weights read transposed: [ng][k] rows of Kdim floats): the k quad fastest -- four lanes cover the 64
     // contiguous bytes a chunk takes from one row; with n fastest every lane of a wave touched its own cache line (r05: the fp16-operand
     // data-gradients of the 128 / 256-channel levels ran at 130-240 TF against 350-490 TF forward, scratch/cfg_f16_probe.py).
-    const int n = transposed ? (u >> 2) % CO_T : u % CO_T;
-    const int k4 = transposed ? (u & 3) : (u / CO_T) & 3;
-    const int tap = u / (4 * CO_T);
+    const int n = transposed ? (u / Q) % CO_T : u % CO_T;
+    const int k4 = transposed ? (u % Q) : (u / CO_T) % Q;
+    const int tap = u / (Q * CO_T);
     const int ng = co0 + n;
-    const bool ok = u < KK * 4 * CO_T && ng < Ndim;
+    const bool ok = u < KK * Q * CO_T && ng < Ndim;
     w_k[i] = 4 * k4;
-    w_dst[i] = F16 ? (tap * CO_T + n) * WROWH + 4 * k4 : ((tap * 4 + k4) * CO_T + n) * 4;
+    w_dst[i] = F16 ? (tap * CO_T + n) * WRH + 4 * k4 : ((tap * 4 + k4) * CO_T + n) * 4;
     w_off[i] = !ok ? -1 : (!transposed ? (tap * Kdim + 4 * k4) * Ndim + ng : ((KK - 1 - tap) * Ndim + ng) * Kdim + 4 * k4);
   }
 
   auto prefetch = [&](int step) {
-    const int g = step / nchunk, c0 = (step % nchunk) * CK;
+    const int g = step / nchunk, c0 = (step % nchunk) * CKW;
     const float* wg = w + (size_t)g * KK * Kdim * Ndim + (transposed ? c0 : c0 * Ndim);
     const bool second = x2 && c0 >= KSTR;
     const float* xg = (second ? xin2 : xin) + ((size_t)(g >> 1) * Wi + (g & 1)) * KSTR + (second ? c0 - KSTR : c0);
@@ -225,15 +233,15 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int u = tid + i * TPB;
-      if (u < IH * IW * 4) {
-        if (F16) *(h4*)(in_h + (u >> 2) * SPIXH + 4 * (u & 3)) = to_h4s(rin[i], gs);
+      if (u < IH * IW * Q) {
+        if (F16) *(h4*)(in_h + (u / Q) * PXH + 4 * (u % Q)) = to_h4s(rin[i], gs);
         else *(float4*)(in_s + (u >> 2) * SPIX + 4 * (u & 3)) = rin[i];
       }
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       const int u = tid + i * TPB;
-      if (u < KK * 4 * CO_T) {
+      if (u < KK * Q * CO_T) {
         // four consecutive k of output channel n of one tap, at the unit's place in [tap][k quad][n][4] (fp16: [tap][n][16 k + pad])
         if (F16) *(h4*)(w_h + w_dst[i]) = to_h4(rw[i]);
         else *(float4*)(w_s + w_dst[i]) = rw[i];
@@ -244,7 +252,24 @@ conv_mfma_fwd(const float* __restrict__ x, const float* __restrict__ w, float* _
     if (step + 1 < nsteps) prefetch(step + 1);
     if (step < 2) { STAMP(4 + 4 * step); }
     // ---- MFMA over taps
-    if constexpr (F16 && SMSUT_F16_X32) {
+    if constexpr (CKW == 32) {
+      // the 32 channels of one tap per issue: lane (lm, kq) holds channels 8kq .. 8kq+7 of its pixel / its output channel
+#pragma unroll
+      for (int tap = 0; tap < KK; ++tap) {
+        const int kh = tap / KS, kw = tap % KS;
+        h8 a[MR], b[NR];
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+          a[i] = *(const h8*)(in_h + (((wm * MR + i) * RPT + a_row + kh) * IW + a_col + kw) * PXH + 8 * kq);
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          b[j] = *(const h8*)(w_h + ((size_t)tap * CO_T + (wn * NR + j) * 16 + lm) * WRH + 8 * kq);
+#pragma unroll
+        for (int i = 0; i < MR; ++i)
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] = mfma32h(a[i], b[j], acc[i][j]);
+      }
+    } else if constexpr (F16 && SMSUT_F16_X32) {
       // tap pairs on the 32-deep instruction (comment at mfma32h); a lone last tap multiplies zeros in the upper k-slots
       const bool hi = kq >= 2;
       const int ko = 8 * (kq & 1);
@@ -1918,8 +1943,11 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
                int isc, int osc, int G, int ntap_out, hipStream_t st, float* stats = nullptr, int* tiles_out = nullptr,
                const float* x2 = nullptr, float* y2 = nullptr, int split = 0, bool f16 = false, const float* gsc = nullptr) {
   constexpr int IH = TH + KS - 1, IW = MW + KS - 1;
-  constexpr size_t sh = (size_t)(IH * IW * SPIX + KS * KS * CK * 16 * NTN) * sizeof(float);
-  static_assert(sh <= 64 * 1024, "LDS budget");
+  constexpr size_t sh16 = (size_t)(IH * IW * SPIX + KS * KS * CK * 16 * NTN) * sizeof(float);
+  // (fp16 operands in 32-channel passes: the weight image [taps][16 NTN][40 halves] starts where the fp32 one would)
+  constexpr size_t sh32 = (size_t)(IH * IW * SPIX) * sizeof(float) + (size_t)(KS * KS * 16 * NTN * 40) * sizeof(_Float16);
+  constexpr size_t sh = sh16;
+  static_assert(sh16 <= 64 * 1024 && (KS != 3 || MW != TW || sh32 <= 64 * 1024), "LDS budget");
   const int tiles_x = (W + MW - 1) / MW, tiles_y = (H + TH - 1) / TH;
   if (MW != TW && (isc != 1 || osc != 1 || G != 1 || ntap_out != 1)) return -1;
   const int nz = (Ndim + 16 * NTN - 1) / (16 * NTN);
@@ -1928,6 +1956,16 @@ int launch_fwd(const float* x, const float* w, float* y, int N, int H, int W, in
   if ((x2 && (isc != 1 || osc != 1 || G != 1 || ntap_out != 1 || (transposed & 1) || Kdim % 32 != 0)) ||
       (y2 && (osc != 1 || ntap_out != 1 || stats || split <= 0 || split >= Ndim || split % 16 != 0)))
     return -1;
+  if constexpr (KS == 3 && MW == TW && SMSUT_F16_X32) {
+    // SMSUT_F16_CK32=0: 16-channel passes (A/B; config 5 49.50 -> 48.56 ms with 32-channel passes on every tile shape, 48.95 with
+    // them on the 16-row tiles only)
+    static const bool ck32 = [] { const char* e = getenv("SMSUT_F16_CK32"); return !e || atoi(e) != 0; }();
+    if (f16 && ck32 && Kdim % 32 == 0 && Kdim >= 32 && (!x2 || (Kdim / 2) % 32 == 0) && isc == 1 && osc == 1 && G == 1) {
+      conv_mfma_fwd<KS, TH, WM, WN, NTN, true, MW, 32><<<grid, TPB, sh32, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc,
+                                                                              osc, G, nz, stats, x2, y2, split, gsc);
+      return 0;
+    }
+  }
   if (f16)
     conv_mfma_fwd<KS, TH, WM, WN, NTN, true, MW><<<grid, TPB, sh, st>>>(x, w, y, H, W, Kdim, Ndim, tiles_x, transposed, isc,
                                                                         osc, G, nz, stats, x2, y2, split, gsc);
