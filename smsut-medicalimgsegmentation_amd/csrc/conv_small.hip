@@ -62,7 +62,10 @@ small_fwd(const float* __restrict__ x, const float* __restrict__ w, const float*
 }
 
 // gx[n,hi,wi,ci] = sum_{kh,kw,co} gy[n,ho,wo,co] * w[kh][kw][ci][co],  ho*s - p + kh = hi      (Cin <= 8)
-template <int CQ>
+// S1: stride 1 (the 5x5 stems, reference network/blocks.py:123: the cycle pass differentiates them w.r.t. x_fake) -- without the
+// per-tap `% stride` / `/ stride` of the general form (r05: 68 -> 64.6 us per launch; issuing a whole tap row's loads at once was tried
+// and measured 2.5x SLOWER -- the kernel is bound by the latency chain of its L1 hits, not by instruction count).
+template <int CQ, bool S1 = false>
 __global__ void __launch_bounds__(TPB)
 small_dgrad(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, SmallGeom g,
             int64_t npix) {
@@ -81,13 +84,13 @@ small_dgrad(const float* __restrict__ gy, const float* __restrict__ w, float* __
     const float* gn = gy + (size_t)n * g.Ho * g.Wo * (4 * CQ);
     for (int kh = 0; kh < g.KS; ++kh) {
       const int hn = hi + g.pad - kh;
-      if (hn < 0 || hn % g.stride) continue;
-      const int ho = hn / g.stride;
+      if (hn < 0 || (!S1 && hn % g.stride)) continue;
+      const int ho = S1 ? hn : hn / g.stride;
       if (ho >= g.Ho) continue;
       for (int kw = 0; kw < g.KS; ++kw) {
         const int wn = wi + g.pad - kw;
-        if (wn < 0 || wn % g.stride) continue;
-        const int wo = wn / g.stride;
+        if (wn < 0 || (!S1 && wn % g.stride)) continue;
+        const int wo = S1 ? wn : wn / g.stride;
         if (wo >= g.Wo) continue;
         const float4* gp = (const float4*)(gn + ((size_t)ho * g.Wo + wo) * (4 * CQ));
         float4 gv[CQ];
@@ -447,12 +450,15 @@ int smsut_conv2d_small_dgrad(const float* gy, const float* w, float* gx, int N, 
   const int64_t npix = (int64_t)N * H * W;
   const int grid = ew_grid(npix) * 2;
   hipStream_t st = (hipStream_t)stream;
+#define SMALL_DG(Q) do { if (stride == 1) small_dgrad<Q, true><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix);  \
+                         else small_dgrad<Q, false><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); } while (0)
   switch (Cout / 4) {
-    case 1: small_dgrad<1><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
-    case 2: small_dgrad<2><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
-    case 3: small_dgrad<3><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
-    default: small_dgrad<4><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); break;
+    case 1: SMALL_DG(1); break;
+    case 2: SMALL_DG(2); break;
+    case 3: SMALL_DG(3); break;
+    default: SMALL_DG(4); break;
   }
+#undef SMALL_DG
   SMSUT_LAUNCH_CHECK();
   return SMSUT_OK;
 }
