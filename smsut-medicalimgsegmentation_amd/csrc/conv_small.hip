@@ -304,6 +304,52 @@ stem_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* 
   }
 }
 
+// data-gradient of the ONE-channel stems (r05; the cycle pass differentiates G's stems w.r.t. x_fake, reference
+// trainer/uganConsisTrainer.py:159): gx[y][x] = sum_{kh,kw,co} gy[y + 2 - kh][x + 2 - kw][co] * w[kh][kw][0][co].  The mirror of
+// stem_fwd: the gy tile with its halo staged once as channel planes [co][20][68], a thread computes 4 consecutive pixels; per (kernel
+// row, output channel) two 16-byte LDS reads + five broadcast weight reads for 20 FMAs.  The general kernel (small_dgrad) walks 25 taps
+// of dependent L1 hits per pixel: 65 us for tensors that stream in 10.
+__global__ void __launch_bounds__(TPB)
+stem_dgrad1(const float* __restrict__ gy, const float* __restrict__ w, float* __restrict__ gx, int N, int H, int W) {
+  __shared__ __attribute__((aligned(16))) float g_s[SCO * SIH * SIW];
+  __shared__ __attribute__((aligned(16))) float w_s[SKS * SKS * SCO];
+  const int tiles_x = W / STX, tiles_y = H / STY;
+  const int t = blockIdx.x;
+  const int n = t / (tiles_x * tiles_y), rem = t % (tiles_x * tiles_y);
+  const int y0 = (rem / tiles_x) * STY, x0 = (rem % tiles_x) * STX;
+  for (int u = threadIdx.x; u < SKS * SKS * SCO; u += TPB) w_s[u] = w[u];            // [kh][kw][ci = 0][co]
+  // global [y][x][co] (two float4 per pixel) -> LDS planes [co][SIH][SIW], zero outside the image
+  for (int u = threadIdx.x; u < SIH * SIW * 2; u += TPB) {
+    const int h = u & 1, pix = u >> 1;
+    const int iy = pix / SIW, ix = pix % SIW;
+    const int gy_ = y0 + iy - SPD, gx_ = x0 + ix - SPD;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W) v = *(const float4*)(gy + (((size_t)n * H + gy_) * W + gx_) * SCO + 4 * h);
+    float* d = g_s + ((4 * h) * SIH + iy) * SIW + ix;
+    d[0] = v.x; d[SIH * SIW] = v.y; d[2 * SIH * SIW] = v.z; d[3 * SIH * SIW] = v.w;
+  }
+  __syncthreads();
+  const int row = threadIdx.x >> 4, cg = threadIdx.x & 15;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  // output pixel (row, 4cg + p) takes gy at tile coordinates (row + 4 - kh, 4cg + p + 4 - kw): with jh = 4 - kh, jw = 4 - kw the window
+  // is the forward kernel's, read against the flipped weights
+#pragma unroll
+  for (int jh = 0; jh < SKS; ++jh)
+#pragma unroll
+    for (int co = 0; co < SCO; ++co) {
+      float v[8];
+      const float* ip = g_s + (co * SIH + row + jh) * SIW + 4 * cg;
+      *(float4*)v = *(const float4*)ip; *(float4*)(v + 4) = *(const float4*)(ip + 4);
+#pragma unroll
+      for (int jw = 0; jw < SKS; ++jw) {
+        const float wv = w_s[((SKS - 1 - jh) * SKS + (SKS - 1 - jw)) * SCO + co];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) acc[p] = fmaf(v[p + jw], wv, acc[p]);
+      }
+    }
+  *(float4*)(gx + ((size_t)n * H + y0 + row) * W + x0 + 4 * cg) = *(float4*)acc;
+}
+
 // weight gradient: gw[kh][kw][ci][co] = sum over pixels of x[y + kh - 2][x + kw - 2][ci] * gy[y][x][co].  5 * CIN "pairs"
 // q = (kh, ci); TPP threads share a pair (8 for CIN = 5: 200 live threads, 32 for CIN = 1: 160) and split the tile's 256 pixel
 // quads; a thread keeps its pair's 5 kw x 8 co accumulators in registers ACROSS the tiles of its workgroup (two 16-byte input
@@ -450,6 +496,11 @@ int smsut_conv2d_small_dgrad(const float* gy, const float* w, float* gx, int N, 
   const int64_t npix = (int64_t)N * H * W;
   const int grid = ew_grid(npix) * 2;
   hipStream_t st = (hipStream_t)stream;
+  if (stem_shape(g) && Cin == 1) {                       // the one-channel 5x5 stems: tiled kernel (see stem_dgrad1)
+    stem_dgrad1<<<N * (H / STY) * (W / STX), TPB, 0, st>>>(gy, w, gx, N, H, W);
+    SMSUT_LAUNCH_CHECK();
+    return SMSUT_OK;
+  }
 #define SMALL_DG(Q) do { if (stride == 1) small_dgrad<Q, true><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix);  \
                          else small_dgrad<Q, false><<<grid, TPB, 0, st>>>(gy, w, gx, g, npix); } while (0)
   switch (Cout / 4) {

@@ -868,6 +868,12 @@ def test_stem_5x5_kernels(ops, n, h, w, ci):
             gref[kh, kw] = torch.einsum("nchw,nhwo->co", xp[:, :, kh:kh + h, kw:kw + w], gyd)
     err = (gw.double().view(5, 5, ci, co) - gref).abs().max()
     assert err < 2e-5 * float(gref.abs().max()) + 1e-3, float(err)
+    # data-gradient (r05: the one-channel stems on a tiled kernel, stem_dgrad1; the 5-channel stems on the general one)
+    gx = torch.full((n, h, w, ci), float("nan"), device="cuda")
+    H.call("smsut_conv2d_small_dgrad", gy, wt, gx, n, h, w, ci, h, w, co, 5, 1, 2, st)
+    dref = torch.nn.functional.conv_transpose2d(gy[:k].double().permute(0, 3, 1, 2), wd, padding=2).permute(0, 2, 3, 1)
+    assert torch.isfinite(gx).all()
+    assert (gx[:k].double() - dref).abs().max() < 1e-5 * max(1.0, float(dref.abs().max()))
 
 
 @pytest.mark.parametrize("n,h,w,ci,co", [(4, 32, 32, 32, 16), (2, 16, 24, 64, 16), (3, 8, 8, 256, 16), (1, 64, 64, 32, 16), (5, 12, 20, 128, 16)])
